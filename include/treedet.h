@@ -1,0 +1,148 @@
+/*
+ * treedet.h — C ABI of libtreedet_hip.so, the MI355X (gfx950) tile-inference engine that
+ * stands behind the reference's model seam:
+ *
+ *     batch_predictions = self.model(batch_tensors)      TreeDetection/prediction.py:182-183
+ *
+ * (a Python call into detectron2's GeneralizedRCNN configured by TreeDetection/config.py:25-66;
+ * the reference itself has no FFI — this header is the FFI a maintainer would bind instead, see
+ * INTEGRATION.md). Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns td_status: 0 = ok, < 0 = error; the message is td_last_error().
+ *   - "dev" pointers are device (HBM) addresses on the engine's GPU; "host" pointers are host.
+ *   - activations are NHWC float32 (or float16 when precision = 1) inside the engine.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - the engine is NOT thread-safe; one engine per device and stream.
+ */
+#ifndef TREEDET_H
+#define TREEDET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int td_status;
+typedef struct td_engine td_engine;
+
+enum {
+    TD_OK = 0,
+    TD_ERR_INVALID = -1,   /* bad argument / shape */
+    TD_ERR_HIP = -2,       /* a HIP runtime call failed */
+    TD_ERR_WEIGHTS = -3,   /* missing or mis-shaped tensor in load_weights */
+    TD_ERR_CAPACITY = -4,  /* forward() exceeds what reserve() sized */
+    TD_ERR_STATE = -5      /* call order (forward before load/reserve) */
+};
+
+enum { TD_PRECISION_FP32 = 0, TD_PRECISION_FP16 = 1 };
+enum { TD_INPUT_F32_CHW = 0,  /* float32 [B,3,Hp,Wp], BGR 0..255 — what prediction.py:170 builds   */
+       TD_INPUT_U8_HWC = 1 }; /* uint8   [B,Hp,Wp,3],  BGR        — the same values before astype() */
+
+/* Model hyper-parameters. Defaults (td_model_desc_default) = detectron2 defaults + the overrides
+ * of TreeDetection/config.py:35,59-61 (NUM_CLASSES=1, SCORE_THRESH_TEST=0.3, NMS_THRESH_TEST=0.5). */
+typedef struct td_model_desc {
+    int32_t num_classes;           /* 1 */
+    int32_t precision;             /* TD_PRECISION_* */
+    int32_t pre_nms_topk;          /* 1000 per FPN level */
+    int32_t post_nms_topk;         /* 1000 per image */
+    int32_t detections_per_image;  /* 100 */
+    float rpn_nms_thresh;          /* 0.7 */
+    float score_thresh;            /* 0.3 (strict >) */
+    float nms_thresh;              /* 0.5 */
+    float mask_thresh;             /* 0.5 (>=) */
+} td_model_desc;
+
+/* One named fp32 host tensor; names are detectron2 state-dict keys
+ * (e.g. "backbone.bottom_up.res2.0.conv1.norm.running_var"). */
+typedef struct td_tensor_desc {
+    const char* name;
+    const float* data;   /* host, contiguous, torch layout ([Cout,Cin,kh,kw] / [out,in]) */
+    int32_t ndim;
+    int64_t shape[4];
+} td_tensor_desc;
+
+#define TD_MASK_SIDE 28
+
+/* Caller-allocated device output of one forward(). D = detections_per_image.
+ * Fields may be NULL to skip that output (mask_bits == NULL skips the paste). */
+typedef struct td_detections {
+    float* boxes;          /* dev [B, D, 4]  x1,y1,x2,y2 in OUTPUT (pre-resize tile) pixels, score-descending */
+    float* scores;         /* dev [B, D] */
+    int32_t* classes;      /* dev [B, D] */
+    int32_t* count;        /* dev [B]    number of valid rows */
+    float* mask_probs;     /* dev [B, D, 28, 28] sigmoid probabilities */
+    int32_t* mask_region;  /* dev [B, D, 4] x0,y0,x1,y1: the integer region the CPU paste evaluates */
+    int64_t* mask_offset;  /* dev [B, D]   offset (in 32-bit words) of detection's bit rows from mask_bits of image b */
+    uint32_t* mask_bits;   /* dev [B, mask_words_per_image]; row r of a region starts at offset + r*ceil((x1-x0)/32);
+                              bit (x-x0)&31 of word (x-x0)>>5 = pasted mask >= mask_thresh */
+    int64_t mask_words_per_image;
+} td_detections;
+
+/* ---- engine life cycle ------------------------------------------------------------------- */
+void td_model_desc_default(td_model_desc* desc);
+td_status td_engine_create(const td_model_desc* desc, int device, td_engine** out);
+td_status td_engine_load_weights(td_engine* e, const td_tensor_desc* tensors, size_t n);
+/* Size the workspace for forward() calls of up to max_batch images of padded size max_hp x max_wp
+ * (multiples of 32). May be called again to grow. */
+td_status td_engine_reserve(td_engine* e, int max_batch, int max_hp, int max_wp);
+/* images: dev, format per `input_format`, B images padded to Hp x Wp (multiples of 32);
+ * hw_valid: host int32 [B,2] un-padded (H', W') of each image (detectron2 image_sizes);
+ * hw_out:   host int32 [B,2] output (height, width) = the tile's pre-resize size (prediction.py:168,182).
+ * Asynchronous on `stream`; results are complete once the stream has drained. */
+td_status td_engine_forward(td_engine* e, const void* images, int input_format, const int32_t* hw_valid,
+                            const int32_t* hw_out, int B, int Hp, int Wp, void* stream, td_detections* out);
+/* Expose an internal activation of the last forward() for stage-wise parity tests: names
+ * "stem","pool","res2".."res5","p2".."p6","rpn_logits","rpn_deltas","proposals","proposal_scores",
+ * "proposal_count","pooled7","cls_logits","box_deltas","det_boxes_net","pooled14","mask_logits".
+ * dims is filled with up to 4 extents (0-padded); *elem_size with the element size in bytes. */
+td_status td_engine_tensor(td_engine* e, const char* name, void** dev_ptr, int64_t dims[4], int* elem_size);
+const char* td_last_error(void);
+void td_engine_destroy(td_engine* e);
+
+/* ---- tile preprocessing (reference Predictor._process_tile, prediction.py:159-176) ---------- */
+/* Pillow-exact 8-bit bilinear resize (two fixed-point passes) of one tile, fused with the
+ * band pick (2,1,0)=BGR of prediction.py:166: src dev uint8 [h, w, C] (pixel-interleaved, C >= 3),
+ * dst dev uint8 [dst_pitch_rows.., 3] written at dst[(y*dst_pitch_px + x)*3 + c] for y<out_h, x<out_w. */
+td_status td_resize_tile_u8(const uint8_t* src, int h, int w, int c, uint8_t* dst, int out_h, int out_w,
+                            int dst_pitch_px, void* tmp_dev /* >= h*out_w*3 bytes */, void* stream);
+/* ResizeShortestEdge(800, 1333) output shape for an h x w tile (Appendix A item 2). */
+void td_resize_shape(int h, int w, int short_edge, int max_size, int* out_h, int* out_w);
+
+/* ---- op-level entry points (parity tests; each is the kernel the engine itself launches) ---- */
+/* NHWC convolution: y = act(conv(x, w) * scale + bias [+ residual]).
+ * x [B,H,W,Cin], w [Cout,KH,KW,Cin], scale/bias [Cout] (NULL = 1 / 0), residual [B,Ho>>rs,Wo>>rs,Cout]
+ * (rs = res_shift: 1 = nearest-2x upsampled add, the FPN top-down path), y [B,Ho,Wo,Cout].
+ * Cin must be a multiple of 32. precision selects float32 or float16 tensors (weights follow). */
+td_status td_conv2d_nhwc(const void* x, const void* w, const float* scale, const float* bias,
+                         const void* residual, int res_shift, void* y, int B, int H, int W, int Cin,
+                         int Cout, int KH, int KW, int stride, int pad, int relu, int precision,
+                         void* stream);
+/* Greedy NMS of n boxes (dev [n,4], scores dev [n]); keep_idx dev int32 [n] receives the kept
+ * indices in descending-score order (ties: lower index first), *keep_count (dev) their number. */
+td_status td_nms(const float* boxes, const float* scores, int n, float iou_thresh, int32_t* keep_idx,
+                 int32_t* keep_count, void* stream);
+/* RoIAlign (aligned, adaptive sampling) over one NHWC level: feat [H,W,C], rois dev [R,4],
+ * out [R,pooled,pooled,C]. */
+td_status td_roi_align(const void* feat, int H, int W, int C, const float* rois, int R, float spatial_scale,
+                       int pooled, void* out, int precision, void* stream);
+/* Paste N 28x28 probability masks into out_h x out_w at `boxes` (output units): fills
+ * mask_region/mask_offset/mask_bits exactly like forward() does for one image. */
+td_status td_paste_masks(const float* mask_probs, const float* boxes, int n, int out_h, int out_w,
+                         float thresh, int32_t* mask_region, int64_t* mask_offset, uint32_t* mask_bits,
+                         int64_t mask_words_cap, void* stream);
+
+/* ---- host-side epilogue (reference prediction.py:232-245, utilities.py:182-207) ------------- */
+/* Border following on a binary image (row-major uint8, non-zero = foreground) equivalent to
+ * cv2.findContours(RETR_TREE / RETR_LIST ordering, CHAIN_APPROX_SIMPLE): writes contour points as
+ * int32 (x,y) pairs into `points` (capacity max_points pairs) and contour start offsets into
+ * `starts` (capacity max_contours+1). Returns the number of contours, or < 0 on overflow/error. */
+int td_find_contours(const uint8_t* img, int h, int w, int32_t* points, int max_points, int32_t* starts,
+                     int max_contours);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TREEDET_H */

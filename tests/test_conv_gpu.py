@@ -1,0 +1,56 @@
+"""GPU parity: td_conv2d_nhwc (MFMA implicit GEMM) vs torch CPU F.conv2d on the same seeded inputs.
+
+fp32 tolerance: the MFMA accumulates an exact f32 fmaf chain in a different order than the CPU
+library, so |err| <= 2e-5 * sum|a*b| (stated here, checked per case)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.gpu_util import conv2d_hip
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, scale, bias, res(0 none,1 same,2 upsample), relu
+    (1, 32, 8, 8, 16, 1, 1, 0, False, False, 0, False),
+    (2, 64, 20, 24, 64, 3, 1, 1, True, True, 0, True),
+    (2, 64, 33, 17, 256, 1, 1, 0, True, True, 1, True),
+    (1, 256, 40, 40, 128, 1, 2, 0, True, True, 0, True),
+    (1, 128, 25, 25, 128, 3, 1, 1, True, True, 0, True),
+    (3, 96, 14, 14, 100, 3, 1, 1, False, True, 0, True),
+    (1, 512, 16, 16, 256, 1, 1, 0, False, True, 2, False),
+    (1, 256, 120, 120, 15, 1, 1, 0, False, True, 0, False),
+    (1, 64, 200, 200, 64, 3, 1, 1, True, True, 0, True),
+    (2, 1024, 13, 13, 2048, 1, 1, 0, True, True, 1, True),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_matches_torch(case):
+    B, Cin, H, W, Cout, k, stride, pad, use_scale, use_bias, res, relu = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, Cin, H, W), dtype=np.float32)
+    w = rng.standard_normal((Cout, Cin, k, k), dtype=np.float32) / np.float32(np.sqrt(Cin * k * k))
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32) if use_scale else None
+    bias = rng.standard_normal(Cout).astype(np.float32) if use_bias else None
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), None, stride=stride, padding=pad)
+    if use_scale:
+        ref = ref * torch.from_numpy(scale).reshape(1, -1, 1, 1)
+    if use_bias:
+        ref = ref + torch.from_numpy(bias).reshape(1, -1, 1, 1)
+    r = None
+    if res == 1:
+        r = rng.standard_normal(tuple(ref.shape), dtype=np.float32)
+        ref = ref + torch.from_numpy(r)
+    elif res == 2:
+        Ho, Wo = ref.shape[-2:]
+        r = rng.standard_normal((B, Cout, Ho // 2, Wo // 2), dtype=np.float32)
+        ref = ref + F.interpolate(torch.from_numpy(r), scale_factor=2.0, mode="nearest")
+    if relu:
+        ref = F.relu(ref)
+    got = conv2d_hip(x, w, scale, bias, r, res_shift=1 if res == 2 else 0, stride=stride, pad=pad, relu=relu)
+    ref = ref.numpy()
+    assert got.shape == ref.shape
+    err = np.abs(got - ref).max()
+    assert err <= 5e-5 * max(1.0, np.abs(ref).max()), f"max abs err {err}"

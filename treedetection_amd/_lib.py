@@ -1,0 +1,95 @@
+"""ctypes binding of libtreedet_hip.so (C ABI declared in include/treedet.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C treedetection_amd/csrc``.
+There is no CPU fallback: if the shared object is missing, or a call is made without a GPU, the
+product path raises (SURVEY.md §8b — the oracle under ``oracle/`` is test infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtreedet_hip.so")
+
+_lib: Optional[C.CDLL] = None
+
+
+class TdError(RuntimeError):
+    """A libtreedet_hip call returned a negative status (message from td_last_error)."""
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("num_classes", C.c_int32), ("precision", C.c_int32), ("pre_nms_topk", C.c_int32),
+                ("post_nms_topk", C.c_int32), ("detections_per_image", C.c_int32),
+                ("rpn_nms_thresh", C.c_float), ("score_thresh", C.c_float), ("nms_thresh", C.c_float),
+                ("mask_thresh", C.c_float)]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+class Detections(C.Structure):
+    _fields_ = [("boxes", C.c_void_p), ("scores", C.c_void_p), ("classes", C.c_void_p), ("count", C.c_void_p),
+                ("mask_probs", C.c_void_p), ("mask_region", C.c_void_p), ("mask_offset", C.c_void_p),
+                ("mask_bits", C.c_void_p), ("mask_words_per_image", C.c_int64)]
+
+
+# name -> (restype, argtypes); every symbol include/treedet.h declares
+SIGNATURES = {
+    "td_model_desc_default": (None, [C.POINTER(ModelDesc)]),
+    "td_engine_create": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(C.c_void_p)]),
+    "td_engine_load_weights": (C.c_int, [C.c_void_p, C.POINTER(TensorDesc), C.c_size_t]),
+    "td_engine_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "td_engine_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Detections)]),
+    "td_engine_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int)]),
+    "td_last_error": (C.c_char_p, []),
+    "td_engine_destroy": (None, [C.c_void_p]),
+    "td_resize_tile_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p]),
+    "td_resize_shape": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "td_conv2d_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+                       + [C.c_int] * 11 + [C.c_void_p]),
+    "td_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "td_roi_align": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int,
+                               C.c_void_p, C.c_int, C.c_void_p]),
+    "td_paste_masks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "td_find_contours": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+}
+
+
+def load() -> C.CDLL:
+    """Load the shared object (after torch, so both share one HIP runtime) and bind signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TdError(f"{LIB_PATH} not found — build it first: python -c 'import __graft_entry__ as g; g.build()' "
+                      f"(or make -C treedetection_amd/csrc). There is no CPU fallback.")
+    import torch  # noqa: F401  (loads libamdhip64 first; our .so then binds to the same runtime)
+
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status < 0:
+        msg = load().td_last_error().decode("utf-8", "replace")
+        raise TdError(f"{what or 'libtreedet_hip'} failed ({status}): {msg}")
+
+
+def stream_ptr() -> int:
+    """Raw hipStream_t of torch's current stream on the current device."""
+    import torch
+
+    return int(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,62 @@
+// Shared declarations of libtreedet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdint>
+#include <cstddef>
+#include "../../include/treedet.h"
+
+void td_set_error(const char* fmt, ...);
+
+#define TD_HIP_CHECK(expr)                                                                         \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            td_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return TD_ERR_HIP;                                                                     \
+        }                                                                                          \
+    } while (0)
+
+#define TD_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            td_set_error(__VA_ARGS__);   \
+            return TD_ERR_INVALID;       \
+        }                                \
+    } while (0)
+
+#define TD_KERNEL_CHECK() TD_HIP_CHECK(hipGetLastError())
+
+static inline int td_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- convolution (conv_igemm.hip) -------------------------------------------------------------
+struct ConvArgs {
+    const void* x;        // NHWC [B,H,W,Cin]
+    const void* w;        // [Cout][KH][KW][Cin]
+    const float* scale;   // [Cout] or nullptr
+    const float* bias;    // [Cout] or nullptr
+    const void* res;      // residual or nullptr
+    void* y;              // NHWC [B,Ho,Wo,Cout] (out_mode 0) / [B,2Ho,2Wo,Cout/4] (out_mode 1)
+    int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+    int res_shift;        // 0: residual same size; 1: residual at half resolution (nearest 2x upsample)
+    int relu;
+    int out_mode;         // 0 plain, 1 deconv2x2 pixel shuffle: n = (dy*2+dx)*Cq + co, Cq = Cout/4
+    int M;                // B*Ho*Wo
+    const int* m_dyn;     // optional device scalar: effective rows = min(M, *m_dyn * m_mul)
+    int m_mul;
+};
+td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
+
+// ---- stem / pooling / resize (stem.hip) ---------------------------------------------------------
+struct ImgSizes {           // per-image valid sizes, passed by value (B <= TD_MAX_BATCH)
+    int h[64];
+    int w[64];
+};
+#define TD_MAX_BATCH 64
+td_status stem_launch(const void* images, int input_format, const ImgSizes& valid, int B, int Hp, int Wp,
+                      const float* w_kc /*[147][cout]*/, const float* scale, const float* bias, void* y,
+                      int cout, int precision, hipStream_t stream);
+td_status maxpool3x3s2_launch(const void* x, void* y, int B, int H, int W, int C, int precision, hipStream_t stream);
+td_status subsample2_launch(const void* x, void* y, int B, int H, int W, int C, int precision, hipStream_t stream);
+td_status resize_tile_u8_launch(const uint8_t* src, int h, int w, int c, uint8_t* dst, int out_h, int out_w,
+                                int dst_pitch_px, void* tmp, hipStream_t stream);

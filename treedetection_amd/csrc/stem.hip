@@ -1,0 +1,307 @@
+// Input side of the forward: Pillow-exact tile resize, normalise + 7x7/s2 stem conv + FrozenBN + ReLU,
+// 3x3/s2 max-pool, and the stride-2 subsample that makes p6.
+//
+// Reference: Predictor._process_tile (TreeDetection/prediction.py:159-176: bands (2,1,0) = BGR, PIL
+// bilinear via ResizeShortestEdge for uint8 tiles) and detectron2's preprocess_image + BasicStem
+// (SURVEY.md Appendix A items 1-3). These are HBM-bound byte / float streams: coalesced 16-B
+// accesses, LDS-staged input patches, no MFMA (Cin = 3 is not GEMM-shaped).
+#include "common.h"
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+constexpr int PIL_PRECISION_BITS = 32 - 8 - 2;
+
+// ---- Pillow resample coefficients (libImaging Resample.c precompute_coeffs, bilinear filter) ----
+struct CoeffTable {
+    int ksize = 0;
+    int* d_bounds = nullptr;   // [out] xmin
+    int* d_kk = nullptr;       // [out][ksize] fixed-point weights
+};
+
+static std::mutex g_coeff_mu;
+static std::map<std::pair<long long, int>, CoeffTable> g_coeff_cache;   // ((in<<32|out), device) -> table
+
+static void host_coeffs(int in_size, int out_size, std::vector<int>& bounds, std::vector<int>& kk, int& ksize) {
+    const double scale = (double)in_size / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 1.0 * filterscale;
+    ksize = (int)std::ceil(support) * 2 + 1;
+    bounds.assign(out_size, 0);
+    kk.assign((size_t)out_size * ksize, 0);
+    std::vector<double> k(ksize);
+    const double ss = 1.0 / filterscale;
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = (xx + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        double ww = 0.0;
+        for (int x = 0; x < ksize; ++x) k[x] = 0.0;
+        for (int x = 0; x < xmax; ++x) {
+            double a = (x + xmin - center + 0.5) * ss;
+            if (a < 0) a = -a;
+            const double w = a < 1.0 ? 1.0 - a : 0.0;
+            k[x] = w;
+            ww += w;
+        }
+        for (int x = 0; x < xmax; ++x)
+            if (ww != 0.0) k[x] /= ww;
+        bounds[xx] = xmin;
+        for (int x = 0; x < ksize; ++x) {
+            const double v = k[x] * (double)(1 << PIL_PRECISION_BITS);
+            kk[(size_t)xx * ksize + x] = k[x] < 0 ? (int)(-0.5 + v) : (int)(0.5 + v);
+        }
+    }
+}
+
+static td_status get_coeffs(int in_size, int out_size, CoeffTable& out) {
+    int device = 0;
+    TD_HIP_CHECK(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lock(g_coeff_mu);
+    const auto key = std::make_pair(((long long)in_size << 32) | (unsigned)out_size, device);
+    auto it = g_coeff_cache.find(key);
+    if (it != g_coeff_cache.end()) {
+        out = it->second;
+        return TD_OK;
+    }
+    std::vector<int> bounds, kk;
+    CoeffTable t;
+    host_coeffs(in_size, out_size, bounds, kk, t.ksize);
+    TD_HIP_CHECK(hipMalloc(&t.d_bounds, bounds.size() * sizeof(int)));
+    TD_HIP_CHECK(hipMalloc(&t.d_kk, kk.size() * sizeof(int)));
+    TD_HIP_CHECK(hipMemcpy(t.d_bounds, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice));
+    TD_HIP_CHECK(hipMemcpy(t.d_kk, kk.data(), kk.size() * sizeof(int), hipMemcpyHostToDevice));
+    g_coeff_cache[key] = t;
+    out = t;
+    return TD_OK;
+}
+
+__device__ __forceinline__ uint8_t clip8(int v) {
+    v >>= PIL_PRECISION_BITS;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// horizontal pass + band pick: tmp[y][x][j] = sum_t src[y][xmin+t][2-j] * kk[x][t]
+__global__ void resize_h_u8(const uint8_t* __restrict__ src, int h, int w, int c, uint8_t* __restrict__ tmp,
+                            int out_w, const int* __restrict__ bounds, const int* __restrict__ kk, int ksize) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= out_w) return;
+    const int xmin = bounds[x];
+    int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0;
+    const uint8_t* row = src + (size_t)y * w * c;
+    for (int t = 0; t < ksize; ++t) {
+        const int k = kk[x * ksize + t];
+        int xs = xmin + t;
+        xs = xs < w ? xs : w - 1;      // weights beyond xmax are 0
+        const uint8_t* p = row + (size_t)xs * c;
+        s0 += p[2] * k;
+        s1 += p[1] * k;
+        s2 += p[0] * k;
+    }
+    uint8_t* o = tmp + ((size_t)y * out_w + x) * 3;
+    o[0] = clip8(s0);
+    o[1] = clip8(s1);
+    o[2] = clip8(s2);
+}
+
+// vertical pass over the 3-channel intermediate
+__global__ void resize_v_u8(const uint8_t* __restrict__ tmp, int h, int row_bytes, uint8_t* __restrict__ dst,
+                            int out_h, int dst_pitch_bytes, const int* __restrict__ bounds,
+                            const int* __restrict__ kk, int ksize) {
+    const int xb = blockIdx.x * blockDim.x + threadIdx.x;   // byte column (x*3 + j)
+    const int y = blockIdx.y;
+    if (xb >= row_bytes) return;
+    const int ymin = bounds[y];
+    int s = 1 << (PIL_PRECISION_BITS - 1);
+    for (int t = 0; t < ksize; ++t) {
+        int ys = ymin + t;
+        ys = ys < h ? ys : h - 1;
+        s += tmp[(size_t)ys * row_bytes + xb] * kk[y * ksize + t];
+    }
+    dst[(size_t)y * dst_pitch_bytes + xb] = clip8(s);
+}
+
+// ---- stem: (x - mean) → conv 7x7 / s2 / p3 (3 → 64) → *scale + bias → ReLU -------------------------
+// One block = 16x16 output pixels; the 37x37x3 normalised input patch sits in LDS; each thread owns
+// one pixel and all 64 output channels (weights are wave-uniform → scalar loads).
+constexpr int ST = 16;                 // output tile side
+constexpr int SP = 2 * ST + 5;         // input patch side (37)
+constexpr int SPW = SP * 3 + 1;        // patch row stride in floats (padded)
+
+template <int FORMAT, int COUT>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const void* __restrict__ images, ImgSizes valid, int Hp, int Wp,
+                                                        const float* __restrict__ w_kc, const float* __restrict__ scale,
+                                                        const float* __restrict__ bias, float* __restrict__ y) {
+    __shared__ float patch[SP * SPW];
+    const int b = blockIdx.z;
+    const int oy0 = blockIdx.y * ST, ox0 = blockIdx.x * ST;
+    const int Ho = Hp >> 1, Wo = Wp >> 1;
+    const int vh = valid.h[b], vw = valid.w[b];
+    const float mean[3] = {103.530f, 116.280f, 123.675f};
+    for (int i = threadIdx.x; i < SP * SP * 3; i += 256) {
+        const int py = i / (SP * 3);
+        const int r = i - py * (SP * 3);
+        const int px = r / 3, c = r - px * 3;
+        const int iy = 2 * oy0 - 3 + py, ix = 2 * ox0 - 3 + px;
+        float v = 0.f;
+        if (iy >= 0 && iy < vh && ix >= 0 && ix < vw) {
+            if (FORMAT == TD_INPUT_U8_HWC)
+                v = (float)static_cast<const uint8_t*>(images)[((size_t)(b * Hp + iy) * Wp + ix) * 3 + c];
+            else
+                v = static_cast<const float*>(images)[((size_t)(b * 3 + c) * Hp + iy) * Wp + ix];
+            v = __fsub_rn(v, mean[c]);
+        }
+        patch[py * SPW + r] = v;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & (ST - 1), ty = threadIdx.x >> 4;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+    for (int ky = 0; ky < 7; ++ky) {
+        const float* prow = &patch[(2 * ty + ky) * SPW + 2 * tx * 3];
+        for (int kx = 0; kx < 7; ++kx) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float a = prow[kx * 3 + c];
+                const float* wk = w_kc + (size_t)((ky * 7 + kx) * 3 + c) * COUT;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] = __fmaf_rn(a, wk[co], acc[co]);
+            }
+        }
+    }
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy < Ho && ox < Wo) {
+        float* o = y + ((size_t)(b * Ho + oy) * Wo + ox) * COUT;
+#pragma unroll
+        for (int co = 0; co < COUT; co += 4) {
+            float4 v;
+            float* pv = reinterpret_cast<float*>(&v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float t = __fadd_rn(__fmul_rn(acc[co + q], scale[co + q]), bias[co + q]);
+                pv[q] = t > 0.f ? t : 0.f;
+            }
+            *reinterpret_cast<float4*>(o + co) = v;
+        }
+    }
+}
+
+// ---- max-pool 3x3 / s2 / p1 over NHWC (float4 of channels per thread) ------------------------------
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C,
+                                    int Ho, int Wo) {
+    const int c4 = C >> 2;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * Ho * Wo * c4;
+    if (idx >= total) return;
+    const int c = (int)(idx % c4);
+    size_t p = idx / c4;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int iy = 2 * oy + dy;
+        if (iy < 0 || iy >= H) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int ix = 2 * ox + dx;
+            if (ix < 0 || ix >= W) continue;
+            const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)(b * H + iy) * W + ix) * C + c * 4);
+            m.x = fmaxf(m.x, v.x);
+            m.y = fmaxf(m.y, v.y);
+            m.z = fmaxf(m.z, v.z);
+            m.w = fmaxf(m.w, v.w);
+        }
+    }
+    *reinterpret_cast<float4*>(y + ((size_t)(b * Ho + oy) * Wo + ox) * C + c * 4) = m;
+}
+
+// ---- p6 = max_pool2d(p5, kernel 1, stride 2) = p5[::2, ::2] ------------------------------------------
+__global__ void subsample2_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C,
+                                  int Ho, int Wo) {
+    const int c4 = C >> 2;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * Ho * Wo * c4;
+    if (idx >= total) return;
+    const int c = (int)(idx % c4);
+    size_t p = idx / c4;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    *reinterpret_cast<float4*>(y + ((size_t)(b * Ho + oy) * Wo + ox) * C + c * 4) =
+        *reinterpret_cast<const float4*>(x + ((size_t)(b * H + 2 * oy) * W + 2 * ox) * C + c * 4);
+}
+
+}  // namespace
+
+td_status resize_tile_u8_launch(const uint8_t* src, int h, int w, int c, uint8_t* dst, int out_h, int out_w,
+                                int dst_pitch_px, void* tmp, hipStream_t stream) {
+    TD_REQUIRE(src && dst && tmp, "resize: null pointer");
+    TD_REQUIRE(h > 0 && w > 0 && c >= 3 && out_h > 0 && out_w > 0 && dst_pitch_px >= out_w, "resize: bad geometry");
+    CoeffTable th, tv;
+    td_status st = get_coeffs(w, out_w, th);
+    if (st < 0) return st;
+    st = get_coeffs(h, out_h, tv);
+    if (st < 0) return st;
+    hipLaunchKernelGGL(resize_h_u8, dim3(td_cdiv(out_w, 256), h), dim3(256), 0, stream, src, h, w, c,
+                       static_cast<uint8_t*>(tmp), out_w, th.d_bounds, th.d_kk, th.ksize);
+    TD_KERNEL_CHECK();
+    hipLaunchKernelGGL(resize_v_u8, dim3(td_cdiv(out_w * 3, 256), out_h), dim3(256), 0, stream,
+                       static_cast<const uint8_t*>(tmp), h, out_w * 3, dst, out_h, dst_pitch_px * 3, tv.d_bounds,
+                       tv.d_kk, tv.ksize);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
+td_status stem_launch(const void* images, int input_format, const ImgSizes& valid, int B, int Hp, int Wp,
+                      const float* w_kc, const float* scale, const float* bias, void* y, int cout, int precision,
+                      hipStream_t stream) {
+    TD_REQUIRE(precision == TD_PRECISION_FP32, "stem: precision %d not built", precision);
+    TD_REQUIRE(Hp % 2 == 0 && Wp % 2 == 0 && B <= TD_MAX_BATCH, "stem: bad geometry");
+    const dim3 grid(td_cdiv(Wp / 2, ST), td_cdiv(Hp / 2, ST), B);
+#define TD_STEM_CASE(F, C)                                                                                          \
+    hipLaunchKernelGGL((stem_conv_kernel<F, C>), grid, dim3(256), 0, stream, images, valid, Hp, Wp, w_kc, scale, \
+                       bias, static_cast<float*>(y))
+    if (cout == 64) {
+        if (input_format == TD_INPUT_U8_HWC) TD_STEM_CASE(TD_INPUT_U8_HWC, 64);
+        else TD_STEM_CASE(TD_INPUT_F32_CHW, 64);
+    } else if (cout == 32) {
+        if (input_format == TD_INPUT_U8_HWC) TD_STEM_CASE(TD_INPUT_U8_HWC, 32);
+        else TD_STEM_CASE(TD_INPUT_F32_CHW, 32);
+    } else {
+        td_set_error("stem: %d output channels not built (32 or 64)", cout);
+        return TD_ERR_INVALID;
+    }
+#undef TD_STEM_CASE
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
+td_status maxpool3x3s2_launch(const void* x, void* y, int B, int H, int W, int C, int precision, hipStream_t stream) {
+    TD_REQUIRE(precision == TD_PRECISION_FP32 && C % 4 == 0, "maxpool: unsupported configuration");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       static_cast<const float*>(x), static_cast<float*>(y), B, H, W, C, Ho, Wo);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
+td_status subsample2_launch(const void* x, void* y, int B, int H, int W, int C, int precision, hipStream_t stream) {
+    TD_REQUIRE(precision == TD_PRECISION_FP32 && C % 4 == 0, "subsample: unsupported configuration");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(subsample2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       static_cast<const float*>(x), static_cast<float*>(y), B, H, W, C, Ho, Wo);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}

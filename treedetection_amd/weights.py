@@ -1,0 +1,190 @@
+"""Model weights for the Mask R-CNN R50/R101-FPN tile predictor.
+
+Two sources of a state dict, both keyed exactly like a detectron2 checkpoint so that a
+real ``model_combined.pth`` (reference ``README.md:14``, loaded by ``DefaultPredictor`` via
+``cfg.MODEL.WEIGHTS`` — reference ``TreeDetection/config.py:39``) drops in unchanged:
+
+* :func:`load_checkpoint` — read a ``.pth`` (``{"model": state_dict, ...}`` or a flat dict).
+* :func:`make_synthetic_state_dict` — seeded random weights of the same architecture
+  (there is no network, and the trained weights are not shipped with the reference). The
+  generator keeps activations O(1) through the trunk and biases the heads so that a few
+  dozen detections per tile pass the 0.3 score threshold (``config.py:60``).
+
+Key names follow detectron2 v0.6.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+RES_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+RES_MID = (64, 128, 256, 512)
+RES_OUT = (256, 512, 1024, 2048)
+FPN_CH = 256
+NUM_ANCHORS = 3
+FC_DIM = 1024
+POOL_BOX = 7
+POOL_MASK = 14
+
+
+def conv_specs(depth: int = 50, num_classes: int = 1) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """List of (key prefix, weight shape, kind) for every learnable layer.
+
+    kind: "conv_bn" (conv without bias followed by FrozenBN), "conv_bias", "fc", "deconv".
+    """
+    specs: List[Tuple[str, Tuple[int, ...], str]] = []
+    specs.append(("backbone.bottom_up.stem.conv1", (64, 3, 7, 7), "conv_bn"))
+    cin = 64
+    for si, nblk in enumerate(RES_BLOCKS[depth]):
+        mid, cout = RES_MID[si], RES_OUT[si]
+        for bi in range(nblk):
+            p = f"backbone.bottom_up.res{si + 2}.{bi}"
+            if bi == 0:
+                specs.append((p + ".shortcut", (cout, cin, 1, 1), "conv_bn"))
+            specs.append((p + ".conv1", (mid, cin, 1, 1), "conv_bn"))
+            specs.append((p + ".conv2", (mid, mid, 3, 3), "conv_bn"))
+            specs.append((p + ".conv3", (cout, mid, 1, 1), "conv_bn"))
+            cin = cout
+    for lvl, c in zip((2, 3, 4, 5), RES_OUT):
+        specs.append((f"backbone.fpn_lateral{lvl}", (FPN_CH, c, 1, 1), "conv_bias"))
+        specs.append((f"backbone.fpn_output{lvl}", (FPN_CH, FPN_CH, 3, 3), "conv_bias"))
+    specs.append(("proposal_generator.rpn_head.conv", (FPN_CH, FPN_CH, 3, 3), "conv_bias"))
+    specs.append(("proposal_generator.rpn_head.objectness_logits", (NUM_ANCHORS, FPN_CH, 1, 1), "conv_bias"))
+    specs.append(("proposal_generator.rpn_head.anchor_deltas", (4 * NUM_ANCHORS, FPN_CH, 1, 1), "conv_bias"))
+    specs.append(("roi_heads.box_head.fc1", (FC_DIM, FPN_CH * POOL_BOX * POOL_BOX), "fc"))
+    specs.append(("roi_heads.box_head.fc2", (FC_DIM, FC_DIM), "fc"))
+    specs.append(("roi_heads.box_predictor.cls_score", (num_classes + 1, FC_DIM), "fc"))
+    specs.append(("roi_heads.box_predictor.bbox_pred", (4 * num_classes, FC_DIM), "fc"))
+    for i in range(1, 5):
+        specs.append((f"roi_heads.mask_head.mask_fcn{i}", (FPN_CH, FPN_CH, 3, 3), "conv_bias"))
+    specs.append(("roi_heads.mask_head.deconv", (FPN_CH, FPN_CH, 2, 2), "deconv"))
+    specs.append(("roi_heads.mask_head.predictor", (num_classes, FPN_CH, 1, 1), "conv_bias"))
+    return specs
+
+
+def make_synthetic_state_dict(depth: int = 50, seed: int = 0, num_classes: int = 1,
+                              width_div: int = 1) -> Dict[str, np.ndarray]:
+    """Seeded random weights in detectron2 key naming (float32 numpy arrays).
+
+    ``width_div`` > 1 shrinks every channel count by that factor (test-size models; the
+    engine and the oracle both read channel counts from the tensor shapes).
+    """
+    if depth not in RES_BLOCKS:
+        raise ValueError(f"unsupported ResNet depth {depth}")
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+
+    def shrink(shape, kind, name):
+        if width_div == 1:
+            return shape
+        s = list(shape)
+        keep_in = name.endswith("stem.conv1")
+        if kind == "fc":
+            if name.endswith("fc1"):
+                s[1] = (FPN_CH // width_div) * POOL_BOX * POOL_BOX
+                s[0] = FC_DIM // width_div
+            elif name.endswith("fc2"):
+                s[0] = s[1] = FC_DIM // width_div
+            else:
+                s[1] = FC_DIM // width_div
+            return tuple(s)
+        if kind == "deconv":
+            s[0] //= width_div
+            s[1] //= width_div
+            return tuple(s)
+        head_out = name.endswith(("objectness_logits", "anchor_deltas", "mask_head.predictor"))
+        if not head_out:
+            s[0] //= width_div
+        if not keep_in:
+            s[1] //= width_div
+        return tuple(s)
+
+    for name, shape, kind in conv_specs(depth, num_classes):
+        shape = shrink(shape, kind, name)
+        if kind == "fc":
+            fan_in = shape[1]
+        elif kind == "deconv":
+            fan_in = shape[0]  # ConvTranspose2d weight is [Cin, Cout, kh, kw]; each output sees Cin taps
+        else:
+            fan_in = shape[1] * shape[2] * shape[3]
+        std = math.sqrt(2.0 / fan_in)
+        w = rng.standard_normal(shape, dtype=np.float32) * np.float32(std)
+        if kind != "deconv" and not name.endswith("stem.conv1"):
+            # zero-mean filters: post-ReLU inputs have a large positive mean; cancelling the DC
+            # gain keeps every layer's output centred and O(1) without data-dependent calibration
+            w -= w.reshape(shape[0], -1).mean(axis=1).reshape((shape[0],) + (1,) * (len(shape) - 1))
+        if kind == "conv_bn":
+            c = shape[0]
+            gamma = rng.uniform(0.9, 1.1, c).astype(np.float32)
+            beta = (rng.standard_normal(c) * 0.1).astype(np.float32)
+            mean = (rng.standard_normal(c) * 0.1).astype(np.float32)
+            var = rng.uniform(0.9, 1.1, c).astype(np.float32)
+            if name.endswith("stem.conv1"):
+                # inputs are 0..255 minus the pixel mean: bring the stem output back to O(1)
+                var *= np.float32(70.0 * 70.0)
+                mean *= np.float32(70.0)
+            if name.endswith(".conv3"):
+                gamma *= np.float32(0.5)   # damp the residual branch so depth does not blow up
+            if name.endswith(".shortcut"):
+                gamma *= np.float32(0.7)
+            sd[name + ".weight"] = w
+            sd[name + ".norm.weight"] = gamma
+            sd[name + ".norm.bias"] = beta
+            sd[name + ".norm.running_mean"] = mean
+            sd[name + ".norm.running_var"] = var
+        else:
+            b = (rng.standard_normal(shape[1] if kind == "deconv" else shape[0]) * 0.02).astype(np.float32)
+            if "fpn_lateral" in name or "fpn_output" in name:
+                w *= np.float32(1.0 / math.sqrt(2.0))
+            if name.endswith("anchor_deltas"):
+                w *= np.float32(0.25)
+            if name.endswith("objectness_logits"):
+                w *= np.float32(1.5)
+            if name.endswith("cls_score"):
+                w *= np.float32(1.0)
+                b[:] = 0.0
+                b[-1] = 2.6       # background logit bias: most proposals stay below 0.3
+            if name.endswith("bbox_pred"):
+                w *= np.float32(0.6)
+            if name.endswith("mask_head.predictor"):
+                w *= np.float32(2.0)
+            sd[name + ".weight"] = w
+            sd[name + ".bias"] = b
+    return sd
+
+
+def load_checkpoint(path: str) -> Dict[str, np.ndarray]:
+    """Read a detectron2 ``.pth`` (torch.save of ``{"model": state_dict, ...}``) into numpy fp32.
+
+    A ``.npz`` with the same key names is accepted as well (used by the plumbing tests,
+    which must not depend on a multi-hundred-MB pickle).
+    """
+    if path.endswith(".npz"):
+        with np.load(path) as z:
+            return {k: np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}
+    import torch
+
+    obj = torch.load(path, map_location="cpu", weights_only=False)
+    if isinstance(obj, dict) and "model" in obj and isinstance(obj["model"], dict):
+        obj = obj["model"]
+    out: Dict[str, np.ndarray] = {}
+    for k, v in obj.items():
+        if hasattr(v, "detach"):
+            v = v.detach().cpu().numpy()
+        v = np.asarray(v)
+        if v.dtype.kind == "f":
+            out[k] = np.ascontiguousarray(v, dtype=np.float32)
+    return out
+
+
+def infer_depth(sd: Dict[str, np.ndarray]) -> int:
+    """ResNet depth from the number of res4 blocks present in a state dict."""
+    n = 0
+    while f"backbone.bottom_up.res4.{n}.conv1.weight" in sd:
+        n += 1
+    for d, blocks in RES_BLOCKS.items():
+        if blocks[2] == n:
+            return d
+    raise ValueError(f"cannot infer ResNet depth from {n} res4 blocks")
