@@ -99,6 +99,8 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
  * "proposal_count","pooled7","cls_logits","box_deltas","det_boxes_net","pooled14","mask_logits".
  * dims is filled with up to 4 extents (0-padded); *elem_size with the element size in bytes. */
 td_status td_engine_tensor(td_engine* e, const char* name, void** dev_ptr, int64_t dims[4], int* elem_size);
+/* Copy that activation into a caller-owned device buffer of `bytes` bytes (asynchronous on `stream`). */
+td_status td_engine_read_tensor(td_engine* e, const char* name, void* dst_dev, int64_t bytes, void* stream);
 const char* td_last_error(void);
 void td_engine_destroy(td_engine* e);
 

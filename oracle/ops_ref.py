@@ -304,10 +304,11 @@ def paste_mask_values(mask: np.ndarray, box: np.ndarray, img_h: int, img_w: int,
         return out, region
     iy0 = np.floor(iy)
     ix0 = np.floor(ix)
+    # torch grid_sampler: west/north weight = (floor + 1) - coord, east/south weight = coord - floor
     wy1 = (iy - iy0).astype(F32)
     wx1 = (ix - ix0).astype(F32)
-    wy0 = (F32(1) - wy1).astype(F32)
-    wx0 = (F32(1) - wx1).astype(F32)
+    wy0 = ((iy0 + F32(1)) - iy).astype(F32)
+    wx0 = ((ix0 + F32(1)) - ix).astype(F32)
     pad = np.zeros((M + 2, M + 2), dtype=F32)
     pad[1:-1, 1:-1] = m
 

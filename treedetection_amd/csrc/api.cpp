@@ -1,5 +1,7 @@
 // extern "C" surface of libtreedet_hip.so (include/treedet.h): error channel + op-level entry points.
+// (The engine entry points live in engine.cpp, the host contour tracer in contours.cpp.)
 #include "common.h"
+#include "detect.h"
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
@@ -12,6 +14,14 @@ void td_set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+namespace {
+// scratch for the op-level NMS / paste entry points (tests only; the engine owns its own workspace)
+td_status scratch(void** p, size_t bytes) {
+    TD_HIP_CHECK(hipMalloc(p, bytes ? bytes : 16));
+    return TD_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -34,7 +44,7 @@ td_status td_conv2d_nhwc(const void* x, const void* w, const float* scale, const
                          int Cout, int KH, int KW, int stride, int pad, int relu, int precision,
                          void* stream) {
     TD_REQUIRE(x && w && y, "td_conv2d_nhwc: null pointer");
-    TD_REQUIRE(stride >= 1 && KH >= 1 && KW >= 1, "td_conv2d_nhwc: bad geometry");
+    TD_REQUIRE(stride >= 1 && KH >= 1 && KW >= 1 && B >= 1, "td_conv2d_nhwc: bad geometry");
     ConvArgs a{};
     a.x = x; a.w = w; a.scale = scale; a.bias = bias; a.res = residual; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW;
@@ -46,20 +56,88 @@ td_status td_conv2d_nhwc(const void* x, const void* w, const float* scale, const
     return conv2d_launch(a, precision, static_cast<hipStream_t>(stream));
 }
 
+td_status td_resize_tile_u8(const uint8_t* src, int h, int w, int c, uint8_t* dst, int out_h, int out_w,
+                            int dst_pitch_px, void* tmp_dev, void* stream) {
+    return resize_tile_u8_launch(src, h, w, c, dst, out_h, out_w, dst_pitch_px, tmp_dev, static_cast<hipStream_t>(stream));
+}
 
-// ---- not built yet (replaced as the engine grows) ---------------------------------------------
-#define TD_STUB(...) { td_set_error("%s: not built yet", __func__); return TD_ERR_STATE; }
-td_status td_engine_create(const td_model_desc*, int, td_engine**) TD_STUB()
-td_status td_engine_load_weights(td_engine*, const td_tensor_desc*, size_t) TD_STUB()
-td_status td_engine_reserve(td_engine*, int, int, int) TD_STUB()
-td_status td_engine_forward(td_engine*, const void*, int, const int32_t*, const int32_t*, int, int, int, void*, td_detections*) TD_STUB()
-td_status td_engine_tensor(td_engine*, const char*, void**, int64_t*, int*) TD_STUB()
-void td_engine_destroy(td_engine*) {}
-td_status td_resize_tile_u8(const uint8_t*, int, int, int, uint8_t*, int, int, int, void*, void*) TD_STUB()
-void td_resize_shape(int, int, int, int, int*, int*) {}
-td_status td_nms(const float*, const float*, int, float, int32_t*, int32_t*, void*) TD_STUB()
-td_status td_roi_align(const void*, int, int, int, const float*, int, float, int, void*, int, void*) TD_STUB()
-td_status td_paste_masks(const float*, const float*, int, int, int, float, int32_t*, int64_t*, uint32_t*, int64_t, void*) TD_STUB()
-int td_find_contours(const uint8_t*, int, int, int32_t*, int, int32_t*, int) TD_STUB()
+void td_resize_shape(int h, int w, int short_edge, int max_size, int* out_h, int* out_w) {
+    // detectron2 ResizeShortestEdge.get_output_shape (python doubles; int(x + 0.5)) — Appendix A item 2
+    const double scale = (double)short_edge / (double)(h < w ? h : w);
+    double newh, neww;
+    if (h < w) { newh = short_edge; neww = scale * w; }
+    else { newh = scale * h; neww = short_edge; }
+    const double mx = newh > neww ? newh : neww;
+    if (mx > max_size) {
+        const double s2 = (double)max_size / mx;
+        newh *= s2;
+        neww *= s2;
+    }
+    *out_h = (int)(newh + 0.5);
+    *out_w = (int)(neww + 0.5);
+}
+
+td_status td_nms(const float* boxes, const float* scores, int n, float iou_thresh, int32_t* keep_idx,
+                 int32_t* keep_count, void* stream) {
+    TD_REQUIRE(boxes && scores && keep_idx && keep_count, "td_nms: null pointer");
+    TD_REQUIRE(n >= 0 && n <= 1024, "td_nms: n=%d must be in [0, 1024]", n);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n == 0) {
+        TD_HIP_CHECK(hipMemsetAsync(keep_count, 0, sizeof(int32_t), s));
+        return TD_OK;
+    }
+    void *sb = nullptr, *ss = nullptr, *si = nullptr, *sc = nullptr, *mk = nullptr, *kp = nullptr;
+    td_status st;
+    if ((st = scratch(&sb, sizeof(float) * 4 * n)) < 0) return st;
+    if ((st = scratch(&ss, sizeof(float) * n)) < 0) return st;
+    if ((st = scratch(&si, sizeof(int) * n)) < 0) return st;
+    if ((st = scratch(&sc, sizeof(int))) < 0) return st;
+    if ((st = scratch(&mk, sizeof(unsigned long long) * n * td_cdiv(n, 64))) < 0) return st;
+    if ((st = scratch(&kp, sizeof(int) * n)) < 0) return st;
+    st = sort_boxes_launch(boxes, scores, nullptr, nullptr, 1, n, (float*)sb, (float*)ss, (int*)si, (int*)sc, s);
+    if (st >= 0) st = nms_launch((float*)sb, (int*)sc, nullptr, 1, n, iou_thresh, (unsigned long long*)mk, (int*)kp, keep_count, n, s);
+    if (st >= 0) st = gather_keep_launch((int*)si, (int*)kp, keep_count, n, keep_idx, s);
+    hipError_t herr = hipStreamSynchronize(s);
+    (void)hipFree(sb); (void)hipFree(ss); (void)hipFree(si); (void)hipFree(sc); (void)hipFree(mk); (void)hipFree(kp);
+    if (st < 0) return st;
+    TD_HIP_CHECK(herr);
+    return TD_OK;
+}
+
+td_status td_roi_align(const void* feat, int H, int W, int C, const float* rois, int R, float spatial_scale,
+                       int pooled, void* out, int precision, void* stream) {
+    TD_REQUIRE(feat && rois && out, "td_roi_align: null pointer");
+    TD_REQUIRE(H >= 1 && W >= 1 && pooled >= 1 && R >= 0, "td_roi_align: bad geometry");
+    if (R == 0) return TD_OK;
+    return roi_align_single_launch(feat, H, W, C, rois, R, spatial_scale, pooled, out, precision, static_cast<hipStream_t>(stream));
+}
+
+td_status td_paste_masks(const float* mask_probs, const float* boxes, int n, int out_h, int out_w, float thresh,
+                         int32_t* mask_region, int64_t* mask_offset, uint32_t* mask_bits, int64_t mask_words_cap,
+                         void* stream) {
+    TD_REQUIRE(mask_probs && boxes && mask_region && mask_offset && mask_bits, "td_paste_masks: null pointer");
+    TD_REQUIRE(n >= 0 && n <= 1024 && out_h >= 1 && out_w >= 1, "td_paste_masks: bad shape");
+    if (n == 0) return TD_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    void* cnt = nullptr;
+    td_status st = scratch(&cnt, sizeof(int));
+    if (st < 0) return st;
+    TD_HIP_CHECK(hipMemcpy(cnt, &n, sizeof(int), hipMemcpyHostToDevice));
+    ImgSizes outsz{};
+    outsz.h[0] = out_h;
+    outsz.w[0] = out_w;
+    st = paste_masks_launch(mask_probs, boxes, (int*)cnt, outsz, 1, n, thresh, mask_region,
+                            reinterpret_cast<long long*>(mask_offset), mask_bits, mask_words_cap, s);
+    hipError_t herr = hipStreamSynchronize(s);
+    (void)hipFree(cnt);
+    if (st < 0) return st;
+    TD_HIP_CHECK(herr);
+    return TD_OK;
+}
+
+int td_find_contours(const uint8_t*, int, int, int32_t*, int, int32_t*, int) {
+    td_set_error("td_find_contours: not built yet");
+    return TD_ERR_STATE;
+}
 
 }  // extern "C"

@@ -1,0 +1,720 @@
+// td_engine: weights, workspace plan and the forward schedule of the Mask R-CNN R50/R101-FPN tile predictor.
+//
+// Stands behind `self.model(batch_tensors)` (TreeDetection/prediction.py:182-183) with the model that
+// TreeDetection/config.py:25-66 configures. Layer order and hyper-parameters follow SURVEY.md Appendix A; every
+// contraction runs through conv2d_launch (MFMA implicit GEMM), everything else through the kernels of
+// stem.hip / rpn.hip / roi.hip. The whole forward is asynchronous on one HIP stream: dynamic counts
+// (proposals, detections) stay on the device and bound the later kernels, so there is no host sync inside.
+#include "common.h"
+#include "detect.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct HostTensor {
+    const float* data = nullptr;
+    std::vector<int64_t> shape;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+struct ConvLayer {
+    int cout = 0, cin = 0, kh = 1, kw = 1;
+    float* w = nullptr;       // [cout][kh][kw][cin]
+    float* scale = nullptr;   // [cout] or null
+    float* bias = nullptr;    // [cout] or null
+};
+
+struct Block {
+    ConvLayer c1, c2, c3, sc;
+    bool has_sc = false;
+    int stride = 1;
+};
+
+struct NamedTensor {
+    void* p = nullptr;
+    int64_t dims[4] = {0, 0, 0, 0};
+    int elem = 4;
+};
+
+}  // namespace
+
+struct td_engine {
+    td_model_desc desc{};
+    int device = 0;
+    bool loaded = false;
+    std::vector<void*> weight_allocs;
+    std::vector<void*> ws_allocs;
+
+    // weights
+    float* stem_w = nullptr;  // [147][stem_c]
+    float* stem_scale = nullptr;
+    float* stem_bias = nullptr;
+    int stem_c = 64;
+    std::vector<Block> stages[4];
+    ConvLayer lateral[4], fpn_out[4];
+    ConvLayer rpn_conv, rpn_head;   // head: fused 3 + 12 rows
+    ConvLayer fc1, fc2, pred;       // pred: fused 2 + 4 rows
+    ConvLayer mask_fcn[4], deconv;  // deconv packed [4*C][C]
+    float* mask_pred_w = nullptr;
+    float mask_pred_b = 0.f;
+    int fpn_c = 256, fc_dim = 1024;
+
+    // workspace (sized by reserve)
+    int rB = 0, rHp = 0, rWp = 0;
+    float *stem_out = nullptr, *pool_out = nullptr;
+    float *t1[4] = {}, *t2[4] = {}, *scb[4] = {}, *res[4] = {}, *xtmp[4] = {};
+    float *inner[4] = {}, *pfeat[5] = {};
+    float *rpn_t = nullptr, *rpn_headbuf[5] = {};
+    uint32_t* key_ws = nullptr;
+    float *cand_boxes = nullptr, *cand_scores = nullptr;
+    int *cand_valid = nullptr, *cand_idx = nullptr;
+    unsigned long long* nms_mask = nullptr;
+    int *rpn_keep = nullptr, *rpn_keep_count = nullptr;
+    float *props = nullptr, *prop_scores = nullptr;
+    int* prop_count = nullptr;
+    float *pooled7 = nullptr, *fc1_out = nullptr, *fc2_out = nullptr, *pred_out = nullptr;
+    float *dboxes = nullptr, *dscores = nullptr;
+    int* dflags = nullptr;
+    float *sboxes = nullptr, *sscores = nullptr;
+    int *sidx = nullptr, *scount = nullptr, *det_keep = nullptr, *det_keep_count = nullptr;
+    float* det_boxes_net = nullptr;
+    float *pooled14 = nullptr, *mbuf0 = nullptr, *mbuf1 = nullptr, *deconv_out = nullptr;
+    float *mask_logits = nullptr, *mask_probs_compact = nullptr;
+    int* total_rows = nullptr;
+    // fallback outputs when the caller passes NULL fields
+    float *o_boxes = nullptr, *o_scores = nullptr, *o_mask_probs = nullptr;
+    int *o_classes = nullptr, *o_count = nullptr;
+
+    std::map<std::string, NamedTensor> named;
+};
+
+namespace {
+
+td_status dev_alloc(std::vector<void*>& pool, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    TD_HIP_CHECK(hipMalloc(p, bytes));
+    pool.push_back(*p);
+    return TD_OK;
+}
+
+template <typename T>
+td_status upload(td_engine* e, const std::vector<T>& h, T** d) {
+    void* p = nullptr;
+    td_status st = dev_alloc(e->weight_allocs, &p, h.size() * sizeof(T));
+    if (st < 0) return st;
+    TD_HIP_CHECK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *d = static_cast<T*>(p);
+    return TD_OK;
+}
+
+using TensorMap = std::map<std::string, HostTensor>;
+
+td_status need(const TensorMap& tm, const std::string& name, int ndim, const HostTensor** out) {
+    auto it = tm.find(name);
+    if (it == tm.end()) {
+        td_set_error("load_weights: tensor '%s' missing", name.c_str());
+        return TD_ERR_WEIGHTS;
+    }
+    if ((int)it->second.shape.size() != ndim) {
+        td_set_error("load_weights: tensor '%s' has %d dims, expected %d", name.c_str(), (int)it->second.shape.size(), ndim);
+        return TD_ERR_WEIGHTS;
+    }
+    *out = &it->second;
+    return TD_OK;
+}
+
+// [Cout,Cin,KH,KW] → [Cout][KH][KW][Cin]
+std::vector<float> pack_ohwi(const HostTensor& t) {
+    const int co = (int)t.shape[0], ci = (int)t.shape[1], kh = (int)t.shape[2], kw = (int)t.shape[3];
+    std::vector<float> out((size_t)co * ci * kh * kw);
+    for (int o = 0; o < co; ++o)
+        for (int c = 0; c < ci; ++c)
+            for (int y = 0; y < kh; ++y)
+                for (int x = 0; x < kw; ++x)
+                    out[(((size_t)o * kh + y) * kw + x) * ci + c] = t.data[(((size_t)o * ci + c) * kh + y) * kw + x];
+    return out;
+}
+
+// FrozenBN fold: scale = gamma * (1/sqrt(var + eps)), bias = beta - mean * scale (float32, like the oracle)
+td_status bn_fold(const TensorMap& tm, const std::string& p, int c, std::vector<float>& scale, std::vector<float>& bias) {
+    const HostTensor *g, *b, *m, *v;
+    td_status st;
+    if ((st = need(tm, p + ".norm.weight", 1, &g)) < 0) return st;
+    if ((st = need(tm, p + ".norm.bias", 1, &b)) < 0) return st;
+    if ((st = need(tm, p + ".norm.running_mean", 1, &m)) < 0) return st;
+    if ((st = need(tm, p + ".norm.running_var", 1, &v)) < 0) return st;
+    if (g->shape[0] != c || b->shape[0] != c || m->shape[0] != c || v->shape[0] != c) {
+        td_set_error("load_weights: norm tensors of '%s' do not have %d channels", p.c_str(), c);
+        return TD_ERR_WEIGHTS;
+    }
+    scale.resize(c);
+    bias.resize(c);
+    for (int i = 0; i < c; ++i) {
+        const float r = 1.0f / std::sqrt(v->data[i] + 1e-5f);
+        const float s = g->data[i] * r;
+        const float ms = m->data[i] * s;
+        scale[i] = s;
+        bias[i] = b->data[i] - ms;
+    }
+    return TD_OK;
+}
+
+td_status load_conv_bn(td_engine* e, const TensorMap& tm, const std::string& p, ConvLayer& L) {
+    const HostTensor* w;
+    td_status st = need(tm, p + ".weight", 4, &w);
+    if (st < 0) return st;
+    L.cout = (int)w->shape[0];
+    L.cin = (int)w->shape[1];
+    L.kh = (int)w->shape[2];
+    L.kw = (int)w->shape[3];
+    if ((st = upload(e, pack_ohwi(*w), &L.w)) < 0) return st;
+    std::vector<float> s, b;
+    if ((st = bn_fold(tm, p, L.cout, s, b)) < 0) return st;
+    if ((st = upload(e, s, &L.scale)) < 0) return st;
+    return upload(e, b, &L.bias);
+}
+
+td_status load_conv_bias(td_engine* e, const TensorMap& tm, const std::string& p, ConvLayer& L) {
+    const HostTensor *w, *b;
+    td_status st = need(tm, p + ".weight", 4, &w);
+    if (st < 0) return st;
+    if ((st = need(tm, p + ".bias", 1, &b)) < 0) return st;
+    L.cout = (int)w->shape[0];
+    L.cin = (int)w->shape[1];
+    L.kh = (int)w->shape[2];
+    L.kw = (int)w->shape[3];
+    if (b->shape[0] != L.cout) {
+        td_set_error("load_weights: bias of '%s' has wrong length", p.c_str());
+        return TD_ERR_WEIGHTS;
+    }
+    if ((st = upload(e, pack_ohwi(*w), &L.w)) < 0) return st;
+    L.scale = nullptr;
+    return upload(e, std::vector<float>(b->data, b->data + L.cout), &L.bias);
+}
+
+td_status run_conv(const ConvLayer& L, const float* x, int B, int H, int W, int stride, int pad, bool relu, float* y,
+                   const float* res, int res_shift, hipStream_t s, int precision, const int* m_dyn = nullptr,
+                   int m_mul = 1, int out_mode = 0) {
+    ConvArgs a{};
+    a.x = x; a.w = L.w; a.scale = L.scale; a.bias = L.bias; a.res = res; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.Cin = L.cin; a.Cout = L.cout; a.KH = L.kh; a.KW = L.kw;
+    a.stride = stride; a.pad = pad;
+    a.Ho = (H + 2 * pad - L.kh) / stride + 1;
+    a.Wo = (W + 2 * pad - L.kw) / stride + 1;
+    a.res_shift = res_shift; a.relu = relu ? 1 : 0; a.out_mode = out_mode;
+    a.M = B * a.Ho * a.Wo; a.m_dyn = m_dyn; a.m_mul = m_mul;
+    return conv2d_launch(a, precision, s);
+}
+
+void set_named(td_engine* e, const char* name, void* p, int64_t d0, int64_t d1 = 0, int64_t d2 = 0, int64_t d3 = 0,
+               int elem = 4) {
+    NamedTensor t;
+    t.p = p;
+    t.dims[0] = d0; t.dims[1] = d1; t.dims[2] = d2; t.dims[3] = d3;
+    t.elem = elem;
+    e->named[name] = t;
+}
+
+void free_pool(std::vector<void*>& pool) {
+    for (void* p : pool) (void)hipFree(p);
+    pool.clear();
+}
+
+}  // namespace
+
+extern "C" {
+
+td_status td_engine_create(const td_model_desc* desc, int device, td_engine** out) {
+    TD_REQUIRE(out, "td_engine_create: out is NULL");
+    td_model_desc d;
+    if (desc) d = *desc; else td_model_desc_default(&d);
+    TD_REQUIRE(d.num_classes == 1, "td_engine_create: num_classes=%d (the reference configures exactly 1, config.py:35)", d.num_classes);
+    TD_REQUIRE(d.precision == TD_PRECISION_FP32, "td_engine_create: precision %d not built in this round (fp32 only)", d.precision);
+    TD_REQUIRE(d.pre_nms_topk >= 1 && d.pre_nms_topk <= RPN_CAND, "td_engine_create: pre_nms_topk must be in [1,%d]", RPN_CAND);
+    TD_REQUIRE(d.post_nms_topk >= 1 && d.post_nms_topk <= 1024, "td_engine_create: post_nms_topk must be in [1,1024]");
+    TD_REQUIRE(d.detections_per_image >= 1 && d.detections_per_image <= 1024, "td_engine_create: detections_per_image must be in [1,1024]");
+    int ndev = 0;
+    TD_HIP_CHECK(hipGetDeviceCount(&ndev));
+    TD_REQUIRE(device >= 0 && device < ndev, "td_engine_create: device %d of %d", device, ndev);
+    TD_HIP_CHECK(hipSetDevice(device));
+    td_engine* e = new td_engine();
+    e->desc = d;
+    e->device = device;
+    *out = e;
+    return TD_OK;
+}
+
+void td_engine_destroy(td_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    free_pool(e->weight_allocs);
+    free_pool(e->ws_allocs);
+    delete e;
+}
+
+td_status td_engine_load_weights(td_engine* e, const td_tensor_desc* tensors, size_t n) {
+    TD_REQUIRE(e && tensors, "td_engine_load_weights: null argument");
+    TD_HIP_CHECK(hipSetDevice(e->device));
+    TensorMap tm;
+    for (size_t i = 0; i < n; ++i) {
+        TD_REQUIRE(tensors[i].name && tensors[i].data && tensors[i].ndim >= 1 && tensors[i].ndim <= 4,
+                   "td_engine_load_weights: bad tensor descriptor %zu", i);
+        HostTensor t;
+        t.data = tensors[i].data;
+        t.shape.assign(tensors[i].shape, tensors[i].shape + tensors[i].ndim);
+        tm[tensors[i].name] = t;
+    }
+    free_pool(e->weight_allocs);
+    e->loaded = false;
+    td_status st;
+    // stem: [C,3,7,7] → [k = (ky*7+kx)*3 + c][C]
+    {
+        const HostTensor* w;
+        if ((st = need(tm, "backbone.bottom_up.stem.conv1.weight", 4, &w)) < 0) return st;
+        if (w->shape[1] != 3 || w->shape[2] != 7 || w->shape[3] != 7) {
+            td_set_error("load_weights: stem conv must be [C,3,7,7] (RGB+nDSM tiles still feed 3 channels, prediction.py:166)");
+            return TD_ERR_WEIGHTS;
+        }
+        e->stem_c = (int)w->shape[0];
+        std::vector<float> p((size_t)147 * e->stem_c);
+        for (int co = 0; co < e->stem_c; ++co)
+            for (int c = 0; c < 3; ++c)
+                for (int ky = 0; ky < 7; ++ky)
+                    for (int kx = 0; kx < 7; ++kx)
+                        p[(size_t)((ky * 7 + kx) * 3 + c) * e->stem_c + co] = w->data[(((size_t)co * 3 + c) * 7 + ky) * 7 + kx];
+        if ((st = upload(e, p, &e->stem_w)) < 0) return st;
+        std::vector<float> s, b;
+        if ((st = bn_fold(tm, "backbone.bottom_up.stem.conv1", e->stem_c, s, b)) < 0) return st;
+        if ((st = upload(e, s, &e->stem_scale)) < 0) return st;
+        if ((st = upload(e, b, &e->stem_bias)) < 0) return st;
+    }
+    for (int si = 0; si < 4; ++si) {
+        e->stages[si].clear();
+        for (int bi = 0;; ++bi) {
+            const std::string p = "backbone.bottom_up.res" + std::to_string(si + 2) + "." + std::to_string(bi);
+            if (tm.find(p + ".conv1.weight") == tm.end()) break;
+            Block blk;
+            blk.stride = (bi == 0 && si > 0) ? 2 : 1;
+            if ((st = load_conv_bn(e, tm, p + ".conv1", blk.c1)) < 0) return st;
+            if ((st = load_conv_bn(e, tm, p + ".conv2", blk.c2)) < 0) return st;
+            if ((st = load_conv_bn(e, tm, p + ".conv3", blk.c3)) < 0) return st;
+            blk.has_sc = tm.find(p + ".shortcut.weight") != tm.end();
+            if (blk.has_sc && (st = load_conv_bn(e, tm, p + ".shortcut", blk.sc)) < 0) return st;
+            e->stages[si].push_back(blk);
+        }
+        if (e->stages[si].empty()) {
+            td_set_error("load_weights: no blocks found for res%d", si + 2);
+            return TD_ERR_WEIGHTS;
+        }
+    }
+    for (int l = 0; l < 4; ++l) {
+        if ((st = load_conv_bias(e, tm, "backbone.fpn_lateral" + std::to_string(l + 2), e->lateral[l])) < 0) return st;
+        if ((st = load_conv_bias(e, tm, "backbone.fpn_output" + std::to_string(l + 2), e->fpn_out[l])) < 0) return st;
+    }
+    e->fpn_c = e->lateral[0].cout;
+    if ((st = load_conv_bias(e, tm, "proposal_generator.rpn_head.conv", e->rpn_conv)) < 0) return st;
+    {
+        const HostTensor *wo, *bo, *wd, *bd;
+        if ((st = need(tm, "proposal_generator.rpn_head.objectness_logits.weight", 4, &wo)) < 0) return st;
+        if ((st = need(tm, "proposal_generator.rpn_head.objectness_logits.bias", 1, &bo)) < 0) return st;
+        if ((st = need(tm, "proposal_generator.rpn_head.anchor_deltas.weight", 4, &wd)) < 0) return st;
+        if ((st = need(tm, "proposal_generator.rpn_head.anchor_deltas.bias", 1, &bd)) < 0) return st;
+        if (wo->shape[0] != RPN_A || wd->shape[0] != 4 * RPN_A || wo->shape[1] != e->fpn_c || wd->shape[1] != e->fpn_c) {
+            td_set_error("load_weights: RPN head must have %d anchors per position", RPN_A);
+            return TD_ERR_WEIGHTS;
+        }
+        const int c = e->fpn_c;
+        std::vector<float> w((size_t)RPN_HEAD_C * c), b(RPN_HEAD_C);
+        std::memcpy(w.data(), wo->data, sizeof(float) * RPN_A * c);
+        std::memcpy(w.data() + (size_t)RPN_A * c, wd->data, sizeof(float) * 4 * RPN_A * c);
+        std::memcpy(b.data(), bo->data, sizeof(float) * RPN_A);
+        std::memcpy(b.data() + RPN_A, bd->data, sizeof(float) * 4 * RPN_A);
+        e->rpn_head.cout = RPN_HEAD_C; e->rpn_head.cin = c; e->rpn_head.kh = e->rpn_head.kw = 1;
+        if ((st = upload(e, w, &e->rpn_head.w)) < 0) return st;
+        if ((st = upload(e, b, &e->rpn_head.bias)) < 0) return st;
+    }
+    {   // fc1: input index c*49 + y*7 + x → (y*7 + x)*C + c (RoIAlign writes NHWC rows)
+        const HostTensor *w, *b;
+        if ((st = need(tm, "roi_heads.box_head.fc1.weight", 2, &w)) < 0) return st;
+        if ((st = need(tm, "roi_heads.box_head.fc1.bias", 1, &b)) < 0) return st;
+        const int c = e->fpn_c, o = (int)w->shape[0];
+        if (w->shape[1] != (int64_t)c * 49) {
+            td_set_error("load_weights: fc1 expects %d inputs", c * 49);
+            return TD_ERR_WEIGHTS;
+        }
+        std::vector<float> p((size_t)o * c * 49);
+        for (int r = 0; r < o; ++r)
+            for (int ch = 0; ch < c; ++ch)
+                for (int q = 0; q < 49; ++q) p[(size_t)r * c * 49 + (size_t)q * c + ch] = w->data[(size_t)r * c * 49 + (size_t)ch * 49 + q];
+        e->fc1.cout = o; e->fc1.cin = c * 49; e->fc1.kh = e->fc1.kw = 1;
+        e->fc_dim = o;
+        if ((st = upload(e, p, &e->fc1.w)) < 0) return st;
+        if ((st = upload(e, std::vector<float>(b->data, b->data + o), &e->fc1.bias)) < 0) return st;
+    }
+    {
+        const HostTensor *w, *b;
+        if ((st = need(tm, "roi_heads.box_head.fc2.weight", 2, &w)) < 0) return st;
+        if ((st = need(tm, "roi_heads.box_head.fc2.bias", 1, &b)) < 0) return st;
+        e->fc2.cout = (int)w->shape[0]; e->fc2.cin = (int)w->shape[1]; e->fc2.kh = e->fc2.kw = 1;
+        if ((st = upload(e, std::vector<float>(w->data, w->data + w->numel()), &e->fc2.w)) < 0) return st;
+        if ((st = upload(e, std::vector<float>(b->data, b->data + e->fc2.cout), &e->fc2.bias)) < 0) return st;
+    }
+    {
+        const HostTensor *wc, *bc, *wr, *br;
+        if ((st = need(tm, "roi_heads.box_predictor.cls_score.weight", 2, &wc)) < 0) return st;
+        if ((st = need(tm, "roi_heads.box_predictor.cls_score.bias", 1, &bc)) < 0) return st;
+        if ((st = need(tm, "roi_heads.box_predictor.bbox_pred.weight", 2, &wr)) < 0) return st;
+        if ((st = need(tm, "roi_heads.box_predictor.bbox_pred.bias", 1, &br)) < 0) return st;
+        if (wc->shape[0] != 2 || wr->shape[0] != 4) {
+            td_set_error("load_weights: box predictor must be 1 class (+background), got cls %lld / reg %lld rows",
+                         (long long)wc->shape[0], (long long)wr->shape[0]);
+            return TD_ERR_WEIGHTS;
+        }
+        const int k = (int)wc->shape[1];
+        std::vector<float> w((size_t)6 * k), b(6);
+        std::memcpy(w.data(), wc->data, sizeof(float) * 2 * k);
+        std::memcpy(w.data() + (size_t)2 * k, wr->data, sizeof(float) * 4 * k);
+        std::memcpy(b.data(), bc->data, sizeof(float) * 2);
+        std::memcpy(b.data() + 2, br->data, sizeof(float) * 4);
+        e->pred.cout = 6; e->pred.cin = k; e->pred.kh = e->pred.kw = 1;
+        if ((st = upload(e, w, &e->pred.w)) < 0) return st;
+        if ((st = upload(e, b, &e->pred.bias)) < 0) return st;
+    }
+    for (int i = 0; i < 4; ++i)
+        if ((st = load_conv_bias(e, tm, "roi_heads.mask_head.mask_fcn" + std::to_string(i + 1), e->mask_fcn[i])) < 0) return st;
+    {   // ConvTranspose2d weight [Cin,Cout,2,2] → rows n = (dy*2+dx)*Cout + co over Cin
+        const HostTensor *w, *b;
+        if ((st = need(tm, "roi_heads.mask_head.deconv.weight", 4, &w)) < 0) return st;
+        if ((st = need(tm, "roi_heads.mask_head.deconv.bias", 1, &b)) < 0) return st;
+        const int ci = (int)w->shape[0], co = (int)w->shape[1];
+        if (w->shape[2] != 2 || w->shape[3] != 2) {
+            td_set_error("load_weights: mask deconv must be 2x2");
+            return TD_ERR_WEIGHTS;
+        }
+        std::vector<float> p((size_t)4 * co * ci);
+        for (int i = 0; i < ci; ++i)
+            for (int o = 0; o < co; ++o)
+                for (int q = 0; q < 4; ++q) p[((size_t)q * co + o) * ci + i] = w->data[((size_t)i * co + o) * 4 + q];
+        e->deconv.cout = 4 * co; e->deconv.cin = ci; e->deconv.kh = e->deconv.kw = 1;
+        if ((st = upload(e, p, &e->deconv.w)) < 0) return st;
+        if ((st = upload(e, std::vector<float>(b->data, b->data + co), &e->deconv.bias)) < 0) return st;
+    }
+    {
+        const HostTensor *w, *b;
+        if ((st = need(tm, "roi_heads.mask_head.predictor.weight", 4, &w)) < 0) return st;
+        if ((st = need(tm, "roi_heads.mask_head.predictor.bias", 1, &b)) < 0) return st;
+        if (w->shape[0] != 1) {
+            td_set_error("load_weights: mask predictor must have 1 output channel");
+            return TD_ERR_WEIGHTS;
+        }
+        if ((st = upload(e, std::vector<float>(w->data, w->data + w->shape[1]), &e->mask_pred_w)) < 0) return st;
+        e->mask_pred_b = b->data[0];
+    }
+    e->loaded = true;
+    return TD_OK;
+}
+
+td_status td_engine_reserve(td_engine* e, int B, int Hp, int Wp) {
+    TD_REQUIRE(e, "td_engine_reserve: null engine");
+    TD_REQUIRE(e->loaded, "td_engine_reserve: load weights first");
+    TD_REQUIRE(B >= 1 && B <= TD_MAX_BATCH, "td_engine_reserve: batch %d not in [1,%d]", B, TD_MAX_BATCH);
+    TD_REQUIRE(Hp >= 64 && Wp >= 64 && Hp % 32 == 0 && Wp % 32 == 0, "td_engine_reserve: padded size %dx%d must be multiples of 32 (>= 64)", Hp, Wp);
+    if (B <= e->rB && Hp <= e->rHp && Wp <= e->rWp) return TD_OK;   // current plan already covers it
+    B = B > e->rB ? B : e->rB;
+    Hp = Hp > e->rHp ? Hp : e->rHp;
+    Wp = Wp > e->rWp ? Wp : e->rWp;
+    TD_HIP_CHECK(hipSetDevice(e->device));
+    free_pool(e->ws_allocs);
+    e->rB = e->rHp = e->rWp = 0;
+    auto A = [&](auto** p, size_t elems) -> td_status {
+        void* q = nullptr;
+        td_status st = dev_alloc(e->ws_allocs, &q, elems * sizeof(**p));
+        *p = static_cast<std::remove_reference_t<decltype(*p)>>(q);
+        return st;
+    };
+    td_status st;
+    const size_t b = B;
+    const int H2 = Hp / 4, W2 = Wp / 4;
+    if ((st = A(&e->stem_out, b * (Hp / 2) * (Wp / 2) * e->stem_c)) < 0) return st;
+    if ((st = A(&e->pool_out, b * H2 * W2 * e->stem_c)) < 0) return st;
+    int hs[5], wsz[5];
+    for (int l = 0; l < 4; ++l) {
+        hs[l] = Hp >> (l + 2);
+        wsz[l] = Wp >> (l + 2);
+    }
+    hs[4] = (hs[3] - 1) / 2 + 1;
+    wsz[4] = (wsz[3] - 1) / 2 + 1;
+    for (int s = 0; s < 4; ++s) {
+        const size_t px = b * hs[s] * wsz[s];
+        const int mid = e->stages[s][0].c1.cout, co = e->stages[s][0].c3.cout;
+        if ((st = A(&e->t1[s], px * mid)) < 0) return st;
+        if ((st = A(&e->t2[s], px * mid)) < 0) return st;
+        if ((st = A(&e->scb[s], px * co)) < 0) return st;
+        if ((st = A(&e->res[s], px * co)) < 0) return st;
+        if ((st = A(&e->xtmp[s], px * co)) < 0) return st;
+        if ((st = A(&e->inner[s], px * e->fpn_c)) < 0) return st;
+    }
+    size_t total_anchors = 0;
+    for (int l = 0; l < 5; ++l) {
+        const size_t px = b * hs[l] * wsz[l];
+        if ((st = A(&e->pfeat[l], px * e->fpn_c)) < 0) return st;
+        if ((st = A(&e->rpn_headbuf[l], px * RPN_HEAD_C)) < 0) return st;
+        total_anchors += (size_t)hs[l] * wsz[l] * RPN_A;
+    }
+    if ((st = A(&e->rpn_t, b * hs[0] * wsz[0] * e->fpn_c)) < 0) return st;
+    if ((st = A(&e->key_ws, b * total_anchors)) < 0) return st;
+    const size_t nc = b * RPN_LEVELS * RPN_CAND;
+    if ((st = A(&e->cand_boxes, nc * 4)) < 0) return st;
+    if ((st = A(&e->cand_scores, nc)) < 0) return st;
+    if ((st = A(&e->cand_valid, nc)) < 0) return st;
+    if ((st = A(&e->cand_idx, nc)) < 0) return st;
+    if ((st = A(&e->nms_mask, nc * (RPN_CAND / 64))) < 0) return st;
+    if ((st = A(&e->rpn_keep, nc)) < 0) return st;
+    if ((st = A(&e->rpn_keep_count, b * RPN_LEVELS)) < 0) return st;
+    const int P = e->desc.post_nms_topk, D = e->desc.detections_per_image;
+    if ((st = A(&e->props, b * P * 4)) < 0) return st;
+    if ((st = A(&e->prop_scores, b * P)) < 0) return st;
+    if ((st = A(&e->prop_count, b)) < 0) return st;
+    if ((st = A(&e->pooled7, b * P * 49 * e->fpn_c)) < 0) return st;
+    if ((st = A(&e->fc1_out, b * P * e->fc_dim)) < 0) return st;
+    if ((st = A(&e->fc2_out, b * P * e->fc_dim)) < 0) return st;
+    if ((st = A(&e->pred_out, b * P * 6)) < 0) return st;
+    if ((st = A(&e->dboxes, b * P * 4)) < 0) return st;
+    if ((st = A(&e->dscores, b * P)) < 0) return st;
+    if ((st = A(&e->dflags, b * P)) < 0) return st;
+    if ((st = A(&e->sboxes, b * P * 4)) < 0) return st;
+    if ((st = A(&e->sscores, b * P)) < 0) return st;
+    if ((st = A(&e->sidx, b * P)) < 0) return st;
+    if ((st = A(&e->scount, b)) < 0) return st;
+    if ((st = A(&e->det_keep, b * D)) < 0) return st;
+    if ((st = A(&e->det_keep_count, b)) < 0) return st;
+    if ((st = A(&e->det_boxes_net, b * D * 4)) < 0) return st;
+    const size_t mrows = b * D;
+    if ((st = A(&e->pooled14, mrows * 196 * e->fpn_c)) < 0) return st;
+    if ((st = A(&e->mbuf0, mrows * 196 * e->fpn_c)) < 0) return st;
+    if ((st = A(&e->mbuf1, mrows * 196 * e->fpn_c)) < 0) return st;
+    if ((st = A(&e->deconv_out, mrows * 784 * (e->deconv.cout / 4))) < 0) return st;
+    if ((st = A(&e->mask_logits, mrows * 784)) < 0) return st;
+    if ((st = A(&e->mask_probs_compact, mrows * 784)) < 0) return st;
+    if ((st = A(&e->total_rows, 4)) < 0) return st;
+    if ((st = A(&e->o_boxes, b * D * 4)) < 0) return st;
+    if ((st = A(&e->o_scores, b * D)) < 0) return st;
+    if ((st = A(&e->o_classes, b * D)) < 0) return st;
+    if ((st = A(&e->o_count, b)) < 0) return st;
+    if ((st = A(&e->o_mask_probs, mrows * 784)) < 0) return st;
+    e->rB = B;
+    e->rHp = Hp;
+    e->rWp = Wp;
+    return TD_OK;
+}
+
+td_status td_engine_forward(td_engine* e, const void* images, int input_format, const int32_t* hw_valid,
+                            const int32_t* hw_out, int B, int Hp, int Wp, void* stream_v, td_detections* out) {
+    TD_REQUIRE(e && images && hw_valid && hw_out && out, "td_engine_forward: null argument");
+    TD_REQUIRE(e->loaded, "td_engine_forward: load weights first");
+    TD_REQUIRE(input_format == TD_INPUT_F32_CHW || input_format == TD_INPUT_U8_HWC, "td_engine_forward: bad input format %d", input_format);
+    TD_REQUIRE(B >= 1 && Hp % 32 == 0 && Wp % 32 == 0 && Hp >= 64 && Wp >= 64, "td_engine_forward: bad batch geometry B=%d %dx%d", B, Hp, Wp);
+    if (B > e->rB || Hp > e->rHp || Wp > e->rWp) {
+        td_set_error("td_engine_forward: B=%d %dx%d exceeds the reserved B=%d %dx%d", B, Hp, Wp, e->rB, e->rHp, e->rWp);
+        return TD_ERR_CAPACITY;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream_v);
+    const int prec = e->desc.precision;
+    ImgSizes valid{}, outsz{};
+    for (int i = 0; i < B; ++i) {
+        valid.h[i] = hw_valid[2 * i];
+        valid.w[i] = hw_valid[2 * i + 1];
+        outsz.h[i] = hw_out[2 * i];
+        outsz.w[i] = hw_out[2 * i + 1];
+        TD_REQUIRE(valid.h[i] >= 1 && valid.h[i] <= Hp && valid.w[i] >= 1 && valid.w[i] <= Wp, "td_engine_forward: image %d valid size %dx%d outside %dx%d", i, valid.h[i], valid.w[i], Hp, Wp);
+        TD_REQUIRE(outsz.h[i] >= 1 && outsz.w[i] >= 1, "td_engine_forward: image %d has an empty output size", i);
+    }
+    e->named.clear();
+    td_status st;
+    // ---- backbone ------------------------------------------------------------------------------------------
+    if ((st = stem_launch(images, input_format, valid, B, Hp, Wp, e->stem_w, e->stem_scale, e->stem_bias, e->stem_out,
+                          e->stem_c, prec, s)) < 0) return st;
+    set_named(e, "stem", e->stem_out, B, Hp / 2, Wp / 2, e->stem_c);
+    if ((st = maxpool3x3s2_launch(e->stem_out, e->pool_out, B, Hp / 2, Wp / 2, e->stem_c, prec, s)) < 0) return st;
+    set_named(e, "pool", e->pool_out, B, Hp / 4, Wp / 4, e->stem_c);
+    int hs[5], wsz[5];
+    for (int l = 0; l < 4; ++l) {
+        hs[l] = Hp >> (l + 2);
+        wsz[l] = Wp >> (l + 2);
+    }
+    hs[4] = (hs[3] - 1) / 2 + 1;
+    wsz[4] = (wsz[3] - 1) / 2 + 1;
+    const float* x = e->pool_out;
+    int xh = hs[0], xw = wsz[0];
+    for (int si = 0; si < 4; ++si) {
+        const int nb = (int)e->stages[si].size();
+        const int oh = hs[si], ow = wsz[si];
+        for (int bi = 0; bi < nb; ++bi) {
+            const Block& blk = e->stages[si][bi];
+            // the last block must land in res[si]: alternate so that block nb-1 writes res
+            float* y = ((nb - 1 - bi) % 2 == 0) ? e->res[si] : e->xtmp[si];
+            const float* shortcut = x;
+            if (blk.has_sc) {
+                if ((st = run_conv(blk.sc, x, B, xh, xw, blk.stride, 0, false, e->scb[si], nullptr, 0, s, prec)) < 0) return st;
+                shortcut = e->scb[si];
+            }
+            if ((st = run_conv(blk.c1, x, B, xh, xw, blk.stride, 0, true, e->t1[si], nullptr, 0, s, prec)) < 0) return st;
+            if ((st = run_conv(blk.c2, e->t1[si], B, oh, ow, 1, 1, true, e->t2[si], nullptr, 0, s, prec)) < 0) return st;
+            if ((st = run_conv(blk.c3, e->t2[si], B, oh, ow, 1, 0, true, y, shortcut, 0, s, prec)) < 0) return st;
+            x = y;
+            xh = oh;
+            xw = ow;
+        }
+        const std::string nm = "res" + std::to_string(si + 2);
+        set_named(e, nm.c_str(), e->res[si], B, oh, ow, e->stages[si][0].c3.cout);
+    }
+    // ---- FPN (top-down; the nearest-2x upsampled add rides in the lateral conv's epilogue) ---------------------
+    for (int l = 3; l >= 0; --l) {
+        const float* td_res = l == 3 ? nullptr : e->inner[l + 1];
+        if ((st = run_conv(e->lateral[l], e->res[l], B, hs[l], wsz[l], 1, 0, false, e->inner[l], td_res, td_res ? 1 : 0, s, prec)) < 0) return st;
+        if ((st = run_conv(e->fpn_out[l], e->inner[l], B, hs[l], wsz[l], 1, 1, false, e->pfeat[l], nullptr, 0, s, prec)) < 0) return st;
+    }
+    if ((st = subsample2_launch(e->pfeat[3], e->pfeat[4], B, hs[3], wsz[3], e->fpn_c, prec, s)) < 0) return st;
+    for (int l = 0; l < 5; ++l) {
+        const std::string nm = "p" + std::to_string(l + 2);
+        set_named(e, nm.c_str(), e->pfeat[l], B, hs[l], wsz[l], e->fpn_c);
+    }
+    // ---- RPN -----------------------------------------------------------------------------------------------------
+    RpnLevels lv{};
+    {
+        static const int sizes[5] = {32, 64, 128, 256, 512};
+        static const double ratios[3] = {0.5, 1.0, 2.0};
+        int off = 0;
+        for (int l = 0; l < 5; ++l) {
+            if ((st = run_conv(e->rpn_conv, e->pfeat[l], B, hs[l], wsz[l], 1, 1, true, e->rpn_t, nullptr, 0, s, prec)) < 0) return st;
+            if ((st = run_conv(e->rpn_head, e->rpn_t, B, hs[l], wsz[l], 1, 0, false, e->rpn_headbuf[l], nullptr, 0, s, prec)) < 0) return st;
+            lv.head[l] = e->rpn_headbuf[l];
+            lv.h[l] = hs[l];
+            lv.w[l] = wsz[l];
+            lv.stride[l] = 4 << l;
+            lv.anchor_off[l] = off;
+            off += hs[l] * wsz[l] * RPN_A;
+            const double area = (double)sizes[l] * sizes[l];
+            for (int a = 0; a < 3; ++a) {
+                const double w = std::sqrt(area / ratios[a]);
+                const double h = ratios[a] * w;
+                lv.base[l][a][0] = (float)(-w / 2.0);
+                lv.base[l][a][1] = (float)(-h / 2.0);
+                lv.base[l][a][2] = (float)(w / 2.0);
+                lv.base[l][a][3] = (float)(h / 2.0);
+            }
+            const std::string nm = "rpn_head" + std::to_string(l + 2);
+            set_named(e, nm.c_str(), e->rpn_headbuf[l], B, hs[l], wsz[l], RPN_HEAD_C);
+        }
+        lv.total_anchors = off;
+    }
+    if ((st = rpn_topk_decode_launch(lv, valid, B, e->desc.pre_nms_topk, e->key_ws, e->cand_boxes, e->cand_scores,
+                                     e->cand_valid, e->cand_idx, s)) < 0) return st;
+    set_named(e, "rpn_cand_boxes", e->cand_boxes, B, RPN_LEVELS, RPN_CAND, 4);
+    set_named(e, "rpn_cand_scores", e->cand_scores, B, RPN_LEVELS, RPN_CAND);
+    set_named(e, "rpn_cand_valid", e->cand_valid, B, RPN_LEVELS, RPN_CAND);
+    set_named(e, "rpn_cand_idx", e->cand_idx, B, RPN_LEVELS, RPN_CAND);
+    if ((st = nms_launch(e->cand_boxes, nullptr, e->cand_valid, B * RPN_LEVELS, RPN_CAND, e->desc.rpn_nms_thresh,
+                         e->nms_mask, e->rpn_keep, e->rpn_keep_count, RPN_CAND, s)) < 0) return st;
+    set_named(e, "rpn_keep", e->rpn_keep, B, RPN_LEVELS, RPN_CAND);
+    set_named(e, "rpn_keep_count", e->rpn_keep_count, B, RPN_LEVELS);
+    const int P = e->desc.post_nms_topk, D = e->desc.detections_per_image;
+    if ((st = rpn_merge_launch(e->cand_boxes, e->cand_scores, e->rpn_keep, e->rpn_keep_count, B, P, e->props,
+                               e->prop_scores, e->prop_count, P, s)) < 0) return st;
+    set_named(e, "proposals", e->props, B, P, 4);
+    set_named(e, "proposal_scores", e->prop_scores, B, P);
+    set_named(e, "proposal_count", e->prop_count, B);
+    // ---- box head -----------------------------------------------------------------------------------------------
+    FeatLevels fl{};
+    for (int l = 0; l < 4; ++l) {
+        fl.feat[l] = e->pfeat[l];
+        fl.h[l] = hs[l];
+        fl.w[l] = wsz[l];
+        fl.scale[l] = 1.0f / (float)(4 << l);
+    }
+    fl.C = e->fpn_c;
+    if ((st = roi_align_launch(fl, e->props, e->prop_count, B, P, 7, 0, e->pooled7, nullptr, prec, s)) < 0) return st;
+    set_named(e, "pooled7", e->pooled7, (int64_t)B * P, 7, 7, e->fpn_c);
+    if ((st = run_conv(e->fc1, e->pooled7, B * P, 1, 1, 1, 0, true, e->fc1_out, nullptr, 0, s, prec)) < 0) return st;
+    if ((st = run_conv(e->fc2, e->fc1_out, B * P, 1, 1, 1, 0, true, e->fc2_out, nullptr, 0, s, prec)) < 0) return st;
+    if ((st = run_conv(e->pred, e->fc2_out, B * P, 1, 1, 1, 0, false, e->pred_out, nullptr, 0, s, prec)) < 0) return st;
+    set_named(e, "box_pred", e->pred_out, (int64_t)B * P, 6);
+    if ((st = det_decode_launch(e->pred_out, 6, e->props, e->prop_count, valid, B, P, e->desc.score_thresh, e->dboxes,
+                                e->dscores, e->dflags, s)) < 0) return st;
+    set_named(e, "det_all_boxes", e->dboxes, B, P, 4);
+    set_named(e, "det_all_scores", e->dscores, B, P);
+    set_named(e, "det_flags", e->dflags, B, P);
+    if ((st = sort_boxes_launch(e->dboxes, e->dscores, e->dflags, e->prop_count, B, P, e->sboxes, e->sscores, e->sidx,
+                                e->scount, s)) < 0) return st;
+    if ((st = nms_launch(e->sboxes, e->scount, nullptr, B, P, e->desc.nms_thresh, e->nms_mask, e->det_keep,
+                         e->det_keep_count, D, s)) < 0) return st;
+    float* o_boxes = out->boxes ? out->boxes : e->o_boxes;
+    float* o_scores = out->scores ? out->scores : e->o_scores;
+    int* o_classes = out->classes ? out->classes : e->o_classes;
+    int* o_count = out->count ? out->count : e->o_count;
+    if ((st = det_finalize_launch(e->sboxes, e->sscores, e->det_keep, e->det_keep_count, valid, outsz, B, P, D,
+                                  e->det_boxes_net, o_boxes, o_scores, o_classes, o_count, s)) < 0) return st;
+    set_named(e, "det_boxes_net", e->det_boxes_net, B, D, 4);
+    // ---- mask head (compact rows: only live detections are computed) ------------------------------------------
+    const int mrows = B * D;
+    if ((st = roi_align_launch(fl, e->det_boxes_net, o_count, B, D, 14, 1, e->pooled14, e->total_rows, prec, s)) < 0) return st;
+    set_named(e, "pooled14", e->pooled14, mrows, 14, 14, e->fpn_c);
+    const float* mx = e->pooled14;
+    float* mbuf[2] = {e->mbuf0, e->mbuf1};
+    for (int i = 0; i < 4; ++i) {
+        if ((st = run_conv(e->mask_fcn[i], mx, mrows, 14, 14, 1, 1, true, mbuf[i & 1], nullptr, 0, s, prec, e->total_rows, 196)) < 0) return st;
+        mx = mbuf[i & 1];
+    }
+    if ((st = run_conv(e->deconv, mx, mrows, 14, 14, 1, 0, true, e->deconv_out, nullptr, 0, s, prec, e->total_rows, 196, 1)) < 0) return st;
+    if ((st = mask_predict_launch(e->deconv_out, e->mask_pred_w, e->mask_pred_b, e->deconv.cout / 4, mrows * 784,
+                                  e->total_rows, 784, e->mask_logits, e->mask_probs_compact, prec, s)) < 0) return st;
+    set_named(e, "mask_logits", e->mask_logits, mrows, 28, 28);
+    float* o_probs = out->mask_probs ? out->mask_probs : e->o_mask_probs;
+    if ((st = mask_scatter_launch(e->mask_probs_compact, o_count, B, D, o_probs, s)) < 0) return st;
+    if (out->mask_bits) {
+        TD_REQUIRE(out->mask_region && out->mask_offset && out->mask_words_per_image > 0, "td_engine_forward: mask_bits needs mask_region, mask_offset and mask_words_per_image");
+        if ((st = paste_masks_launch(o_probs, o_boxes, o_count, outsz, B, D, e->desc.mask_thresh, out->mask_region,
+                                     reinterpret_cast<long long*>(out->mask_offset), out->mask_bits,
+                                     out->mask_words_per_image, s)) < 0) return st;
+    }
+    return TD_OK;
+}
+
+td_status td_engine_tensor(td_engine* e, const char* name, void** dev_ptr, int64_t dims[4], int* elem_size) {
+    TD_REQUIRE(e && name && dev_ptr && dims, "td_engine_tensor: null argument");
+    auto it = e->named.find(name);
+    if (it == e->named.end()) {
+        td_set_error("td_engine_tensor: no tensor named '%s' (run forward first)", name);
+        return TD_ERR_INVALID;
+    }
+    *dev_ptr = it->second.p;
+    for (int i = 0; i < 4; ++i) dims[i] = it->second.dims[i];
+    if (elem_size) *elem_size = it->second.elem;
+    return TD_OK;
+}
+
+td_status td_engine_read_tensor(td_engine* e, const char* name, void* dst_dev, int64_t bytes, void* stream) {
+    TD_REQUIRE(e && name && dst_dev, "td_engine_read_tensor: null argument");
+    auto it = e->named.find(name);
+    if (it == e->named.end()) {
+        td_set_error("td_engine_read_tensor: no tensor named '%s' (run forward first)", name);
+        return TD_ERR_INVALID;
+    }
+    int64_t n = it->second.elem;
+    for (int i = 0; i < 4; ++i)
+        if (it->second.dims[i] > 0) n *= it->second.dims[i];
+    TD_REQUIRE(bytes == n, "td_engine_read_tensor: '%s' is %lld bytes, caller passed %lld", name, (long long)n, (long long)bytes);
+    TD_HIP_CHECK(hipMemcpyAsync(dst_dev, it->second.p, (size_t)n, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return TD_OK;
+}
+
+}  // extern "C"

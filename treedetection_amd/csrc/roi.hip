@@ -1,0 +1,359 @@
+// RoI side of the forward: FPN level assignment + RoIAlign (aligned, adaptive sampling), detection decoding,
+// output-space finalisation, the mask predictor (1x1 → sigmoid) and the box-region mask paste.
+// detectron2 semantics: SURVEY.md Appendix A items 9, 11, 12, 13 (reached from TreeDetection/prediction.py:183);
+// operation order mirrors oracle/ops_ref.py so results agree to float32 rounding.
+// HBM-gather bound (RoIAlign reads whole 1-KB channel rows per bilinear corner) or trivially small: no MFMA.
+#include "common.h"
+#include "detect.h"
+
+namespace {
+
+__device__ __forceinline__ int fpn_level(float x1, float y1, float x2, float y2) {
+    const float area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+    const float s = sqrtf(area);
+    float lv = floorf(__fadd_rn(4.f, log2f(__fadd_rn(__fdiv_rn(s, 224.f), 1e-8f))));
+    lv = fminf(fmaxf(lv, 2.f), 5.f);
+    if (!(lv >= 2.f)) lv = 2.f;   // NaN area → lowest level (detectron2 casts NaN to int64 min, then clamps)
+    return (int)lv - 2;
+}
+
+// One block (256 threads = 4 waves) per RoI; each wave walks bins w, w+4, ...; lane = channel quad.
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_kernel(FeatLevels fl, const float* __restrict__ rois,
+                                                        const int* __restrict__ counts, int items, int roi_stride,
+                                                        int pooled, int compact, T* __restrict__ out,
+                                                        int* __restrict__ total_rows, int single_level) {
+    const int item = blockIdx.y, r = blockIdx.x;
+    const int cnt = counts ? counts[item] : roi_stride;
+    int prefix = 0;
+    if (compact) {
+        for (int i = 0; i < item; ++i) prefix += counts[i];
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && total_rows) {
+            int t = 0;
+            for (int i = 0; i < items; ++i) t += counts[i];
+            *total_rows = t;
+        }
+    }
+    if (r >= cnt) return;
+    const size_t row = compact ? (size_t)(prefix + r) : (size_t)item * roi_stride + r;
+    const float4 bx = *reinterpret_cast<const float4*>(rois + ((size_t)item * roi_stride + r) * 4);
+    const int lvl = single_level ? 0 : fpn_level(bx.x, bx.y, bx.z, bx.w);
+    const int H = fl.h[lvl], W = fl.w[lvl], C = fl.C;
+    const float sc = fl.scale[lvl];
+    const float* __restrict__ feat = static_cast<const float*>(fl.feat[lvl]) + (single_level ? 0 : (size_t)item * H * W * C);
+
+    const float sw = __fsub_rn(__fmul_rn(bx.x, sc), 0.5f), sh = __fsub_rn(__fmul_rn(bx.y, sc), 0.5f);
+    const float ew = __fsub_rn(__fmul_rn(bx.z, sc), 0.5f), eh = __fsub_rn(__fmul_rn(bx.w, sc), 0.5f);
+    const float rw = __fsub_rn(ew, sw), rh = __fsub_rn(eh, sh);
+    const float bh = __fdiv_rn(rh, (float)pooled), bw = __fdiv_rn(rw, (float)pooled);
+    int gh = (int)ceilf(__fdiv_rn(rh, (float)pooled)), gw = (int)ceilf(__fdiv_rn(rw, (float)pooled));
+    gh = gh > 0 ? gh : 0;
+    gw = gw > 0 ? gw : 0;
+    const int ghw = gh * gw;
+    const float count = (float)(ghw > 1 ? ghw : 1);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nbins = pooled * pooled;
+    for (int bin = wave; bin < nbins; bin += 4) {
+        const int ph = bin / pooled, pw = bin - ph * pooled;
+        for (int c0 = lane * 4; c0 < C; c0 += 256) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int iy = 0; iy < gh; ++iy) {
+                const float y = __fadd_rn(__fadd_rn(sh, __fmul_rn((float)ph, bh)),
+                                          __fdiv_rn(__fmul_rn(__fadd_rn((float)iy, 0.5f), bh), (float)gh));
+                for (int ix = 0; ix < gw; ++ix) {
+                    const float x = __fadd_rn(__fadd_rn(sw, __fmul_rn((float)pw, bw)),
+                                              __fdiv_rn(__fmul_rn(__fadd_rn((float)ix, 0.5f), bw), (float)gw));
+                    if (y < -1.f || y > (float)H || x < -1.f || x > (float)W) continue;
+                    float yy = y <= 0.f ? 0.f : y, xx = x <= 0.f ? 0.f : x;
+                    int yl = (int)yy, xl = (int)xx, yh, xh;
+                    if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
+                    if (xl >= W - 1) { xh = xl = W - 1; xx = (float)xl; } else xh = xl + 1;
+                    const float ly = __fsub_rn(yy, (float)yl), lx = __fsub_rn(xx, (float)xl);
+                    const float hy = __fsub_rn(1.f, ly), hx = __fsub_rn(1.f, lx);
+                    const float w1 = __fmul_rn(hy, hx), w2 = __fmul_rn(hy, lx), w3 = __fmul_rn(ly, hx), w4 = __fmul_rn(ly, lx);
+                    const float4 v1 = *reinterpret_cast<const float4*>(feat + ((size_t)yl * W + xl) * C + c0);
+                    const float4 v2 = *reinterpret_cast<const float4*>(feat + ((size_t)yl * W + xh) * C + c0);
+                    const float4 v3 = *reinterpret_cast<const float4*>(feat + ((size_t)yh * W + xl) * C + c0);
+                    const float4 v4 = *reinterpret_cast<const float4*>(feat + ((size_t)yh * W + xh) * C + c0);
+#define TD_RA(f) acc.f = __fadd_rn(acc.f, __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w1, v1.f), __fmul_rn(w2, v2.f)), __fmul_rn(w3, v3.f)), __fmul_rn(w4, v4.f)))
+                    TD_RA(x); TD_RA(y); TD_RA(z); TD_RA(w);
+#undef TD_RA
+                }
+            }
+            acc.x = __fdiv_rn(acc.x, count);
+            acc.y = __fdiv_rn(acc.y, count);
+            acc.z = __fdiv_rn(acc.z, count);
+            acc.w = __fdiv_rn(acc.w, count);
+            *reinterpret_cast<float4*>(out + (row * nbins + bin) * C + c0) = acc;
+        }
+    }
+}
+
+// softmax (2 logits, foreground first) + apply_deltas (10,10,5,5) + clip + score > thresh
+__global__ void det_decode_kernel(const float* __restrict__ cls_reg, int cr_stride, const float* __restrict__ props,
+                                  const int* __restrict__ prop_count, ImgSizes valid, int B, int prop_stride,
+                                  float score_thresh, float* __restrict__ boxes, float* __restrict__ scores,
+                                  int* __restrict__ flags) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * prop_stride) return;
+    const int b = idx / prop_stride, r = idx - b * prop_stride;
+    float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, score = 0.f;
+    int ok = 0;
+    if (r < prop_count[b]) {
+        const float* cr = cls_reg + (size_t)idx * cr_stride;
+        const float l0 = cr[0], l1 = cr[1];
+        const float m = fmaxf(l0, l1);
+        const float e0 = expf(__fsub_rn(l0, m)), e1 = expf(__fsub_rn(l1, m));
+        score = __fdiv_rn(e0, __fadd_rn(e0, e1));
+        const float4 p = *reinterpret_cast<const float4*>(props + (size_t)idx * 4);
+        decode_box(p.x, p.y, p.z, p.w, cr[2], cr[3], cr[4], cr[5], 10.f, 10.f, 5.f, 5.f, x1, y1, x2, y2);
+        const bool fin = isfinite(x1) && isfinite(y1) && isfinite(x2) && isfinite(y2) && isfinite(score) &&
+                         isfinite(__fsub_rn(1.f, score));
+        const float ih = (float)valid.h[b], iw = (float)valid.w[b];
+        x1 = fminf(fmaxf(x1, 0.f), iw);
+        y1 = fminf(fmaxf(y1, 0.f), ih);
+        x2 = fminf(fmaxf(x2, 0.f), iw);
+        y2 = fminf(fmaxf(y2, 0.f), ih);
+        ok = fin && score > score_thresh;
+    }
+    *reinterpret_cast<float4*>(boxes + (size_t)idx * 4) = make_float4(x1, y1, x2, y2);
+    scores[idx] = score;
+    flags[idx] = ok;
+}
+
+// detector_postprocess for the kept detections of one image (block per image, serial over <= max_det rows)
+__global__ void det_finalize_kernel(const float* __restrict__ sboxes, const float* __restrict__ sscores,
+                                    const int* __restrict__ keep_pos, const int* __restrict__ keep_count,
+                                    ImgSizes valid, ImgSizes outsz, int stride_items, int max_det,
+                                    float* __restrict__ det_boxes_net, float* __restrict__ out_boxes,
+                                    float* __restrict__ out_scores, int* __restrict__ out_classes,
+                                    int* __restrict__ out_count) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    int n = keep_count[b];
+    n = n < max_det ? n : max_det;
+    const float sx = (float)((double)outsz.w[b] / (double)valid.w[b]);
+    const float sy = (float)((double)outsz.h[b] / (double)valid.h[b]);
+    const float ow = (float)outsz.w[b], oh = (float)outsz.h[b];
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        const int pos = keep_pos[(size_t)b * max_det + i];
+        const float4 bx = *reinterpret_cast<const float4*>(sboxes + ((size_t)b * stride_items + pos) * 4);
+        float x1 = fminf(fmaxf(__fmul_rn(bx.x, sx), 0.f), ow), y1 = fminf(fmaxf(__fmul_rn(bx.y, sy), 0.f), oh);
+        float x2 = fminf(fmaxf(__fmul_rn(bx.z, sx), 0.f), ow), y2 = fminf(fmaxf(__fmul_rn(bx.w, sy), 0.f), oh);
+        if (__fsub_rn(x2, x1) > 0.f && __fsub_rn(y2, y1) > 0.f) {
+            const size_t o = (size_t)b * max_det + m;
+            *reinterpret_cast<float4*>(det_boxes_net + o * 4) = bx;
+            *reinterpret_cast<float4*>(out_boxes + o * 4) = make_float4(x1, y1, x2, y2);
+            out_scores[o] = sscores[(size_t)b * stride_items + pos];
+            out_classes[o] = 0;
+            ++m;
+        }
+    }
+    for (int i = m; i < max_det; ++i) {
+        const size_t o = (size_t)b * max_det + i;
+        *reinterpret_cast<float4*>(det_boxes_net + o * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(out_boxes + o * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        out_scores[o] = 0.f;
+        out_classes[o] = 0;
+    }
+    out_count[b] = m;
+}
+
+// mask predictor: one wave per pixel, dot over C channels, + bias, sigmoid
+__global__ __launch_bounds__(256) void mask_predict_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           float bias, int C, int rows_max, const int* __restrict__ rows_dyn,
+                                                           int rows_mul, float* __restrict__ logits,
+                                                           float* __restrict__ probs) {
+    int rows = rows_max;
+    if (rows_dyn) {
+        const int rd = *rows_dyn * rows_mul;
+        rows = rd < rows ? rd : rows;
+    }
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float acc = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * C + c);
+        const float4 k = *reinterpret_cast<const float4*>(w + c);
+        acc = __fmaf_rn(v.x, k.x, acc);
+        acc = __fmaf_rn(v.y, k.y, acc);
+        acc = __fmaf_rn(v.z, k.z, acc);
+        acc = __fmaf_rn(v.w, k.w, acc);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) {
+        const float l = __fadd_rn(acc, bias);
+        if (logits) logits[row] = l;
+        probs[row] = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-l)));
+    }
+}
+
+__global__ void mask_scatter_kernel(const float* __restrict__ compact, const int* __restrict__ counts, int B, int D,
+                                    float* __restrict__ out) {
+    const int b = blockIdx.y, d = blockIdx.x;
+    int prefix = 0;
+    for (int i = 0; i < b; ++i) prefix += counts[i];
+    float* o = out + ((size_t)b * D + d) * (TD_MASK_SIDE * TD_MASK_SIDE);
+    const bool live = d < counts[b];
+    const float* s = compact + (size_t)(prefix + d) * (TD_MASK_SIDE * TD_MASK_SIDE);
+    for (int i = threadIdx.x; i < TD_MASK_SIDE * TD_MASK_SIDE; i += blockDim.x) o[i] = live ? s[i] : 0.f;
+}
+
+// paste step 1: integer regions + word offsets per image (CPU-path region: floor(x0)-1 .. ceil(x1)+1, clamped)
+__global__ void paste_plan_kernel(const float* __restrict__ boxes, const int* __restrict__ counts, ImgSizes outsz, int D,
+                                  int* __restrict__ region, long long* __restrict__ offset, long long words_cap) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const int n = counts[b];
+    long long off = 0;
+    for (int d = 0; d < D; ++d) {
+        int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+        long long o = 0;
+        if (d < n) {
+            const float4 bx = *reinterpret_cast<const float4*>(boxes + ((size_t)b * D + d) * 4);
+            x0 = (int)fmaxf(__fsub_rn(floorf(bx.x), 1.f), 0.f);
+            y0 = (int)fmaxf(__fsub_rn(floorf(bx.y), 1.f), 0.f);
+            x1 = (int)fminf(__fadd_rn(ceilf(bx.z), 1.f), (float)outsz.w[b]);
+            y1 = (int)fminf(__fadd_rn(ceilf(bx.w), 1.f), (float)outsz.h[b]);
+            if (x1 < x0) x1 = x0;
+            if (y1 < y0) y1 = y0;
+            const long long sz = (long long)((x1 - x0 + 31) >> 5) * (y1 - y0);
+            if (off + sz > words_cap) { x1 = x0; y1 = y0; }   // out of room: empty region (caller sized the buffer)
+            else { o = off; off += sz; }
+        }
+        int* rg = region + ((size_t)b * D + d) * 4;
+        rg[0] = x0; rg[1] = y0; rg[2] = x1; rg[3] = y1;
+        offset[(size_t)b * D + d] = o;
+    }
+}
+
+// paste step 2: one block per detection; thread per 32-pixel word
+__global__ __launch_bounds__(256) void paste_fill_kernel(const float* __restrict__ probs, const float* __restrict__ boxes,
+                                                         const int* __restrict__ counts, int D, float thresh,
+                                                         const int* __restrict__ region,
+                                                         const long long* __restrict__ offset, uint32_t* __restrict__ bits,
+                                                         long long words_per_image) {
+    const int b = blockIdx.y, d = blockIdx.x;
+    if (d >= counts[b]) return;
+    constexpr int MS = TD_MASK_SIDE;
+    __shared__ float m[MS * MS];
+    const float* src = probs + ((size_t)b * D + d) * (MS * MS);
+    for (int i = threadIdx.x; i < MS * MS; i += blockDim.x) m[i] = src[i];
+    __syncthreads();
+    const int* rg = region + ((size_t)b * D + d) * 4;
+    const int x0 = rg[0], y0 = rg[1], x1 = rg[2], y1 = rg[3];
+    const int wpr = (x1 - x0 + 31) >> 5, rows = y1 - y0;
+    if (wpr <= 0 || rows <= 0) return;
+    const float4 bx = *reinterpret_cast<const float4*>(boxes + ((size_t)b * D + d) * 4);
+    const float bw = __fsub_rn(bx.z, bx.x), bh = __fsub_rn(bx.w, bx.y);
+    uint32_t* out = bits + (size_t)b * words_per_image + offset[(size_t)b * D + d];
+    for (int wi = threadIdx.x; wi < wpr * rows; wi += blockDim.x) {
+        const int ry = wi / wpr, wx = wi - ry * wpr;
+        const float py = __fadd_rn((float)(y0 + ry), 0.5f);
+        const float gy = __fsub_rn(__fmul_rn(__fdiv_rn(__fsub_rn(py, bx.y), bh), 2.f), 1.f);
+        const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), (float)MS), 1.f), 2.f);
+        const float iy0f = floorf(iy);
+        const float wn = __fsub_rn(__fadd_rn(iy0f, 1.f), iy), ws = __fsub_rn(iy, iy0f);
+        const int iy0 = (int)iy0f, iy1 = iy0 + 1;
+        const bool yok0 = iy0 >= 0 && iy0 < MS, yok1 = iy1 >= 0 && iy1 < MS;
+        uint32_t word = 0u;
+        for (int bit = 0; bit < 32; ++bit) {
+            const int x = x0 + wx * 32 + bit;
+            if (x >= x1) break;
+            const float px = __fadd_rn((float)x, 0.5f);
+            const float gx = __fsub_rn(__fmul_rn(__fdiv_rn(__fsub_rn(px, bx.x), bw), 2.f), 1.f);
+            const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), (float)MS), 1.f), 2.f);
+            const float ix0f = floorf(ix);
+            const float ww = __fsub_rn(__fadd_rn(ix0f, 1.f), ix), we = __fsub_rn(ix, ix0f);
+            float v = 0.f;
+            if (isfinite(ix) && isfinite(iy)) {
+                const int ix0 = (int)ix0f, ix1 = ix0 + 1;
+                const bool xok0 = ix0 >= 0 && ix0 < MS, xok1 = ix1 >= 0 && ix1 < MS;
+                const float nw = (yok0 && xok0) ? m[iy0 * MS + ix0] : 0.f;
+                const float ne = (yok0 && xok1) ? m[iy0 * MS + ix1] : 0.f;
+                const float sw = (yok1 && xok0) ? m[iy1 * MS + ix0] : 0.f;
+                const float se = (yok1 && xok1) ? m[iy1 * MS + ix1] : 0.f;
+                v = __fmul_rn(nw, __fmul_rn(wn, ww));
+                v = __fadd_rn(v, __fmul_rn(ne, __fmul_rn(wn, we)));
+                v = __fadd_rn(v, __fmul_rn(sw, __fmul_rn(ws, ww)));
+                v = __fadd_rn(v, __fmul_rn(se, __fmul_rn(ws, we)));
+            }
+            if (v >= thresh) word |= 1u << bit;
+        }
+        out[(size_t)ry * wpr + wx] = word;
+    }
+}
+
+}  // namespace
+
+td_status roi_align_launch(const FeatLevels& fl, const float* rois, const int* counts, int items, int roi_stride,
+                           int pooled, int compact, void* out, int* total_rows, int precision, hipStream_t stream) {
+    TD_REQUIRE(precision == TD_PRECISION_FP32, "roi_align: precision %d not built", precision);
+    TD_REQUIRE(fl.C % 4 == 0, "roi_align: C must be a multiple of 4");
+    hipLaunchKernelGGL((roi_align_kernel<float>), dim3(roi_stride, items), dim3(256), 0, stream, fl, rois, counts, items,
+                       roi_stride, pooled, compact, static_cast<float*>(out), total_rows, 0);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
+td_status roi_align_single_launch(const void* feat, int H, int W, int C, const float* rois, int R, float scale,
+                                  int pooled, void* out, int precision, hipStream_t stream) {
+    TD_REQUIRE(precision == TD_PRECISION_FP32, "roi_align: precision %d not built", precision);
+    TD_REQUIRE(C % 4 == 0 && R >= 1, "roi_align: bad shape");
+    FeatLevels fl{};
+    fl.feat[0] = feat; fl.h[0] = H; fl.w[0] = W; fl.scale[0] = scale; fl.C = C;
+    hipLaunchKernelGGL((roi_align_kernel<float>), dim3(R, 1), dim3(256), 0, stream, fl, rois, (const int*)nullptr, 1, R,
+                       pooled, 0, static_cast<float*>(out), (int*)nullptr, 1);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
+td_status det_decode_launch(const float* cls_reg, int cr_stride, const float* props, const int* prop_count,
+                            const ImgSizes& valid, int B, int prop_stride, float score_thresh, float* boxes,
+                            float* scores, int* flags, hipStream_t stream) {
+    hipLaunchKernelGGL(det_decode_kernel, dim3(td_cdiv(B * prop_stride, 256)), dim3(256), 0, stream, cls_reg, cr_stride,
+                       props, prop_count, valid, B, prop_stride, score_thresh, boxes, scores, flags);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
+td_status det_finalize_launch(const float* sboxes, const float* sscores, const int* keep_pos, const int* keep_count,
+                              const ImgSizes& valid, const ImgSizes& outsz, int B, int stride_items, int max_det,
+                              float* det_boxes_net, float* out_boxes, float* out_scores, int* out_classes,
+                              int* out_count, hipStream_t stream) {
+    hipLaunchKernelGGL(det_finalize_kernel, dim3(B), dim3(64), 0, stream, sboxes, sscores, keep_pos, keep_count, valid,
+                       outsz, stride_items, max_det, det_boxes_net, out_boxes, out_scores, out_classes, out_count);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
+td_status mask_predict_launch(const void* x, const float* w, float bias, int C, int rows_max, const int* rows_dyn,
+                              int rows_mul, float* logits_out, float* probs_out, int precision, hipStream_t stream) {
+    TD_REQUIRE(precision == TD_PRECISION_FP32 && C % 4 == 0, "mask_predict: unsupported configuration");
+    if (rows_max <= 0) return TD_OK;
+    hipLaunchKernelGGL(mask_predict_kernel, dim3(td_cdiv(rows_max, 4)), dim3(256), 0, stream,
+                       static_cast<const float*>(x), w, bias, C, rows_max, rows_dyn, rows_mul, logits_out, probs_out);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
+td_status mask_scatter_launch(const float* compact, const int* counts, int B, int D, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(mask_scatter_kernel, dim3(D, B), dim3(256), 0, stream, compact, counts, B, D, out);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
+td_status paste_masks_launch(const float* probs, const float* boxes, const int* counts, const ImgSizes& outsz, int B,
+                             int D, float thresh, int* region, long long* offset, uint32_t* bits,
+                             long long words_per_image, hipStream_t stream) {
+    hipLaunchKernelGGL(paste_plan_kernel, dim3(B), dim3(64), 0, stream, boxes, counts, outsz, D, region, offset,
+                       words_per_image);
+    TD_KERNEL_CHECK();
+    hipLaunchKernelGGL(paste_fill_kernel, dim3(D, B), dim3(256), 0, stream, probs, boxes, counts, D, thresh, region,
+                       offset, bits, words_per_image);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}

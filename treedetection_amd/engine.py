@@ -1,0 +1,212 @@
+"""Python handle of the HIP tile-inference engine (``td_engine`` in include/treedet.h).
+
+This is the object that replaces ``self.model`` of the reference's ``Predictor``
+(TreeDetection/prediction.py:182-183): it takes a batch of model-input tensors and returns the
+``Instances`` fields the reference consumes (``pred_boxes``, ``scores``, ``pred_classes``,
+``pred_masks``) — computed by libtreedet_hip.so on an MI355X. torch tensors are used only as
+device-buffer containers (``data_ptr()``); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Detections, ModelDesc, TensorDesc
+
+MASK_SIDE = 28
+INPUT_F32_CHW = 0
+INPUT_U8_HWC = 1
+PRECISIONS = {"fp32": 0, "fp16": 1}
+
+
+def _round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+class Engine:
+    def __init__(self, state_dict: Dict[str, np.ndarray], device: int = 0, precision: str = "fp32",
+                 score_thresh: float = 0.3, nms_thresh: float = 0.5, rpn_nms_thresh: float = 0.7,
+                 pre_nms_topk: int = 1000, post_nms_topk: int = 1000, detections_per_image: int = 100,
+                 mask_thresh: float = 0.5):
+        if not torch.cuda.is_available():
+            raise _lib.TdError("treedetection_amd.Engine needs a GPU (no CPU fallback; the oracle under oracle/ "
+                               "is test infrastructure only)")
+        self.lib = _lib.load()
+        self.device = int(device)
+        torch.cuda.set_device(self.device)
+        desc = ModelDesc()
+        self.lib.td_model_desc_default(C.byref(desc))
+        desc.precision = PRECISIONS[precision]
+        desc.score_thresh = score_thresh
+        desc.nms_thresh = nms_thresh
+        desc.rpn_nms_thresh = rpn_nms_thresh
+        desc.pre_nms_topk = pre_nms_topk
+        desc.post_nms_topk = post_nms_topk
+        desc.detections_per_image = detections_per_image
+        desc.mask_thresh = mask_thresh
+        self.desc = desc
+        self.D = detections_per_image
+        self.P = post_nms_topk
+        handle = C.c_void_p()
+        _lib.check(self.lib.td_engine_create(C.byref(desc), self.device, C.byref(handle)), "td_engine_create")
+        self._h = handle
+        self._load(state_dict)
+        self._reserved = (0, 0, 0)
+
+    # -- life cycle -------------------------------------------------------------------------------
+    def _load(self, sd: Dict[str, np.ndarray]) -> None:
+        keep = []   # host arrays must outlive the call
+        descs = (TensorDesc * len(sd))()
+        for i, (k, v) in enumerate(sd.items()):
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            keep.append(a)
+            descs[i].name = k.encode()
+            descs[i].data = a.ctypes.data
+            descs[i].ndim = a.ndim
+            for j, s in enumerate(a.shape):
+                descs[i].shape[j] = s
+        _lib.check(self.lib.td_engine_load_weights(self._h, descs, len(sd)), "td_engine_load_weights")
+
+    def reserve(self, batch: int, hp: int, wp: int) -> None:
+        b, h, w = self._reserved
+        if batch <= b and hp <= h and wp <= w:
+            return
+        batch, hp, wp = max(batch, b), max(hp, h), max(wp, w)
+        _lib.check(self.lib.td_engine_reserve(self._h, batch, hp, wp), "td_engine_reserve")
+        self._reserved = (batch, hp, wp)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.lib.td_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- forward ------------------------------------------------------------------------------------
+    def alloc_outputs(self, B: int, max_out_h: int, max_out_w: int, paste: bool = True) -> Dict[str, torch.Tensor]:
+        D = self.D
+        dev = torch.device("cuda", self.device)
+        out = {
+            "boxes": torch.empty((B, D, 4), dtype=torch.float32, device=dev),
+            "scores": torch.empty((B, D), dtype=torch.float32, device=dev),
+            "classes": torch.empty((B, D), dtype=torch.int32, device=dev),
+            "count": torch.zeros((B,), dtype=torch.int32, device=dev),
+            "mask_probs": torch.empty((B, D, MASK_SIDE, MASK_SIDE), dtype=torch.float32, device=dev),
+        }
+        if paste:
+            words = D * ((max_out_w + 2 + 31) // 32) * max_out_h
+            out["mask_region"] = torch.empty((B, D, 4), dtype=torch.int32, device=dev)
+            out["mask_offset"] = torch.empty((B, D), dtype=torch.int64, device=dev)
+            out["mask_bits"] = torch.empty((B, words), dtype=torch.int32, device=dev)
+        return out
+
+    def forward_raw(self, images: torch.Tensor, input_format: int, hw_valid: Sequence[Sequence[int]],
+                    hw_out: Sequence[Sequence[int]], out: Dict[str, torch.Tensor]) -> None:
+        """Asynchronous launch on torch's current stream; ``out`` from :meth:`alloc_outputs`."""
+        if input_format == INPUT_F32_CHW:
+            B, c, Hp, Wp = images.shape
+            assert c == 3 and images.dtype == torch.float32
+        else:
+            B, Hp, Wp, c = images.shape
+            assert c == 3 and images.dtype == torch.uint8
+        assert images.is_cuda and images.is_contiguous()
+        self.reserve(B, Hp, Wp)
+        hv = (C.c_int32 * (2 * B))(*[int(v) for p in hw_valid for v in p])
+        ho = (C.c_int32 * (2 * B))(*[int(v) for p in hw_out for v in p])
+        det = Detections()
+        det.boxes = out["boxes"].data_ptr()
+        det.scores = out["scores"].data_ptr()
+        det.classes = out["classes"].data_ptr()
+        det.count = out["count"].data_ptr()
+        det.mask_probs = out["mask_probs"].data_ptr()
+        if "mask_bits" in out:
+            det.mask_region = out["mask_region"].data_ptr()
+            det.mask_offset = out["mask_offset"].data_ptr()
+            det.mask_bits = out["mask_bits"].data_ptr()
+            det.mask_words_per_image = out["mask_bits"].shape[1]
+        st = self.lib.td_engine_forward(self._h, images.data_ptr(), input_format, hv, ho, B, Hp, Wp,
+                                        _lib.stream_ptr(), C.byref(det))
+        _lib.check(st, "td_engine_forward")
+
+    def tensor(self, name: str) -> torch.Tensor:
+        """Copy of an internal activation of the last forward (stage-wise parity tests)."""
+        ptr = C.c_void_p()
+        dims = (C.c_int64 * 4)()
+        elem = C.c_int()
+        _lib.check(self.lib.td_engine_tensor(self._h, name.encode(), C.byref(ptr), dims, C.byref(elem)), "td_engine_tensor")
+        shape = [int(d) for d in dims if d > 0]
+        integer = name in ("rpn_cand_valid", "rpn_cand_idx", "rpn_keep", "rpn_keep_count", "proposal_count", "det_flags")
+        dt = torch.int32 if integer else (torch.float32 if elem.value == 4 else torch.float16)
+        t = torch.empty(shape, dtype=dt, device=torch.device("cuda", self.device))
+        _lib.check(self.lib.td_engine_read_tensor(self._h, name.encode(), t.data_ptr(), t.numel() * t.element_size(),
+                                                  _lib.stream_ptr()), "td_engine_read_tensor")
+        torch.cuda.synchronize()
+        return t
+
+    # -- the reference's model seam ---------------------------------------------------------------------
+    def __call__(self, batched_inputs: List[dict], paste: bool = True) -> List[dict]:
+        """Same contract as ``self.model(batch_tensors)`` (prediction.py:182-183).
+
+        batched_inputs: list of {"image": float32 [3,H',W'] BGR 0..255 (CPU or CUDA tensor / ndarray),
+        "height": h, "width": w}. Returns per image {"pred_boxes" [N,4], "scores" [N], "pred_classes" [N],
+        "pred_masks" bool [N,h,w], "mask_probs" [N,28,28]} as numpy arrays.
+        """
+        B = len(batched_inputs)
+        sizes = [(int(b["image"].shape[1]), int(b["image"].shape[2])) for b in batched_inputs]
+        Hp = _round_up(max(s[0] for s in sizes), 32)
+        Wp = _round_up(max(s[1] for s in sizes), 32)
+        dev = torch.device("cuda", self.device)
+        x = torch.zeros((B, 3, Hp, Wp), dtype=torch.float32, device=dev)
+        for i, b in enumerate(batched_inputs):
+            t = torch.as_tensor(b["image"], dtype=torch.float32)
+            x[i, :, : sizes[i][0], : sizes[i][1]] = t.to(dev)
+        hw_out = [(int(b.get("height", s[0])), int(b.get("width", s[1]))) for b, s in zip(batched_inputs, sizes)]
+        out = self.alloc_outputs(B, max(h for h, _ in hw_out), max(w for _, w in hw_out), paste)
+        self.forward_raw(x, INPUT_F32_CHW, sizes, hw_out, out)
+        torch.cuda.synchronize()
+        return unpack_outputs(out, hw_out, paste)
+
+
+def unpack_masks(region: np.ndarray, offset: np.ndarray, bits: np.ndarray, n: int, h: int, w: int) -> np.ndarray:
+    """Packed bit rows of one image → bool [n, h, w] (what detectron2's paste_masks_in_image returns)."""
+    masks = np.zeros((n, h, w), dtype=bool)
+    bits = bits.view(np.uint32)
+    for d in range(n):
+        x0, y0, x1, y1 = (int(v) for v in region[d])
+        if x1 <= x0 or y1 <= y0:
+            continue
+        wpr = (x1 - x0 + 31) // 32
+        words = bits[int(offset[d]): int(offset[d]) + wpr * (y1 - y0)].reshape(y1 - y0, wpr)
+        row_bits = np.unpackbits(words.view(np.uint8).reshape(y1 - y0, wpr * 4), axis=1, bitorder="little")
+        masks[d, y0:y1, x0:x1] = row_bits[:, : x1 - x0].astype(bool)
+    return masks
+
+
+def unpack_outputs(out: Dict[str, torch.Tensor], hw_out, paste: bool = True) -> List[dict]:
+    cnt = out["count"].cpu().numpy()
+    boxes = out["boxes"].cpu().numpy()
+    scores = out["scores"].cpu().numpy()
+    classes = out["classes"].cpu().numpy()
+    probs = out["mask_probs"].cpu().numpy()
+    res = []
+    if paste and "mask_bits" in out:
+        region = out["mask_region"].cpu().numpy()
+        offset = out["mask_offset"].cpu().numpy()
+        bits = out["mask_bits"].cpu().numpy()
+    for i, (h, w) in enumerate(hw_out):
+        n = int(cnt[i])
+        r = {"pred_boxes": boxes[i, :n].copy(), "scores": scores[i, :n].copy(),
+             "pred_classes": classes[i, :n].astype(np.int64), "mask_probs": probs[i, :n].copy(), "pred_masks": None}
+        if paste and "mask_bits" in out:
+            r["pred_masks"] = unpack_masks(region[i], offset[i], bits[i], n, h, w)
+            r["mask_region"] = region[i, :n].copy()
+        res.append(r)
+    return res
