@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Throughput bench of the predict_tiles hot path (BASELINE.json metric: tiles/sec on a fixed 1000x1000 RGB+nDSM
+tile stream at 1/2/4/8 MI355X).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one batch of `--batch` (8) synthetic 1000x1000 tiles, already resident in HBM as uint8 RGB (+ float32
+nDSM side band), through the whole device path of the reference's model stage (TreeDetection/prediction.py:159-183):
+band pick + Pillow-exact resize to 800x800 → Mask R-CNN R50-FPN forward (fp32 MFMA) → detections + 28x28 mask
+probabilities + pasted bit masks in HBM. Tiles shard across ranks (weak scaling: every rank runs K steps of its own
+batches); each step ends with the RCCL gather of the per-tile detections to rank 0 (the hand-off to stitching).
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel family =
+conv_igemm, MFMA-bound, timed live with HIP events on the forward's stream) and `cpu_baseline` (the torch-CPU oracle
+on a bounded sample of the same stream, rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MATRIX_TFLOPS = 2500.0
+MASK_HEAD_GFLOP_PER_DET = 1.028
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)     # 32 x 8 = the 256-tile stream of BASELINE config #2
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--depth", type=int, default=50, choices=(50, 101))
+    ap.add_argument("--precision", default="fp32", choices=("fp32", "fp16"))
+    ap.add_argument("--tile", type=int, default=1000)
+    ap.add_argument("--stream-tiles", type=int, default=256)
+    ap.add_argument("--distinct", type=int, default=16, help="distinct seeds generated (cycled over the stream)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tiles", type=int, default=6)
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    return ap.parse_args()
+
+
+T_START = time.perf_counter()
+
+
+def log(msg):
+    """Progress on stderr (the JSON line on stdout stays alone)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """Threads this process may really use: affinity, capped by the cgroup CPU quota and by 16 (the GPU box's share)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(sd, rgb_np, n_tiles):
+    """The torch-CPU oracle (oracle/ = test infrastructure, used here only as the timed CPU baseline) on the first
+    n_tiles of the same stream: Pillow-restated resize + forward + paste, batch 1, all host cores."""
+    from oracle import ops_ref as R
+    from oracle.maskrcnn_ref import MaskRCNNOracle
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    oracle = MaskRCNNOracle(sd)
+    img, h, w = R.preprocess_tile_u8(rgb_np[0].transpose(2, 0, 1))
+    oracle.forward([{"image": img, "height": h, "width": w}])          # warm-up (thread pools, allocator)
+    t0 = time.perf_counter()
+    dets = 0
+    for i in range(n_tiles):
+        img, h, w = R.preprocess_tile_u8(rgb_np[i % len(rgb_np)].transpose(2, 0, 1))
+        out = oracle.forward([{"image": img, "height": h, "width": w}])
+        dets += len(out[0]["scores"])
+        log(f"cpu baseline tile {i + 1}/{n_tiles}")
+    dt = time.perf_counter() - t0
+    return {"value": n_tiles / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"first {n_tiles} tiles of the same synthetic stream, batch 1, torch {torch.__version__} CPU fp32 "
+                      f"restatement (oracle/), resize+forward+paste, {dt:.1f} s, {dets} detections"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs a launcher: python -m torch.distributed.run --nproc-per-node "
+                             f"{args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from treedetection_amd.engine import Engine, INPUT_U8_HWC
+    from treedetection_amd.synth import make_stream
+    from treedetection_amd.weights import make_synthetic_state_dict
+
+    torch.set_num_threads(host_cores())
+    log("generating weights")
+    sd = make_synthetic_state_dict(args.depth, seed=0)
+    log("creating engine")
+    eng = Engine(sd, device=local_rank, precision=args.precision)
+    log("generating tile stream")
+    B, S = args.batch, args.tile
+    # every rank gets its own shard of the stream: tile t of the global stream goes to rank t % world
+    n_local = min(args.stream_tiles, B * (args.steps + args.warmup))
+    rgb_np, ndsm_np = make_stream(n_local, S, distinct=args.distinct)
+    if world > 1:   # different ranks see different tiles (shifted seeds would cost start-up; rotate instead)
+        rgb_np = np.roll(rgb_np, rank, axis=0)
+        ndsm_np = np.roll(ndsm_np, rank, axis=0)
+    dev = torch.device("cuda", local_rank)
+    rgb = torch.from_numpy(rgb_np).to(dev)            # [n,S,S,3] uint8, resident in HBM before the timed region
+    ndsm = torch.from_numpy(ndsm_np).to(dev)          # side band: travels with the tile, not a network input
+    out = eng.alloc_outputs(B, S, S, paste=True)
+    gather_keys = ("boxes", "scores", "count", "mask_probs")
+    gl = None
+    if world > 1 and rank == 0:
+        gl = {k: [torch.empty_like(out[k]) for _ in range(world)] for k in gather_keys}
+
+    def step(i):
+        tiles = [rgb[(i * B + j) % n_local] for j in range(B)]
+        batch, hw_valid, hw_out = eng.preprocess_tiles_u8(tiles)
+        eng.forward_raw(batch, INPUT_U8_HWC, hw_valid, hw_out, out)
+        if world > 1:
+            for k in gather_keys:   # RCCL gather of the per-tile detections to rank 0 (hand-off to stitching)
+                dist.gather(out[k], gl[k] if rank == 0 else None, dst=0)
+
+    log("warm-up")
+    for i in range(args.warmup):
+        step(i)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i + 1}/{args.warmup} done")
+    if not args.no_profile:
+        eng.profile_enable(True)
+        eng.profile_read(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ndet = 0
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    log(f"timed region done: {dt:.3f} s")
+    prof = eng.profile_read(reset=True) if not args.no_profile else None
+    eng.profile_enable(False)
+    ndet = int(out["count"].sum().item())     # detections of the last batch (for the mask-head FLOP estimate)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        tiles_total = args.steps * B * world
+        line = {
+            "metric": "tiles/sec (1000x1000 RGB+nDSM) predict_tiles model stage",
+            "value": tiles_total / dt,
+            "unit": "tiles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1000.0 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f16",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: single model ResNet{args.depth}-FPN Mask R-CNN, "
+                                   f"{args.stream_tiles}-tile synthetic {S}x{S} RGB(+nDSM side band) stream, batch={B} per GPU, "
+                                   f"resize 800x800 + forward + paste on device, inputs resident in HBM",
+                       "depth": args.depth, "batch_per_gpu": B, "tile": S, "net_input": "3x800x800",
+                       "parallelism": f"tile-shard x{world} (replicated weights, RCCL gather of detections to rank 0)",
+                       "detections_last_batch": ndet},
+        }
+        if prof is not None:
+            conv = prof["conv_igemm"]
+            peak = PEAK_F32_MATRIX_TFLOPS if args.precision == "fp32" else PEAK_F16_MATRIX_TFLOPS
+            ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+            line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                                "traffic": None,
+                                "kernel": "conv_igemm_f32 (all trunk/FPN/RPN/box-head contractions)",
+                                "launches_per_step": conv["launches"] / args.steps,
+                                "avg_launch_us": 1e3 * conv["ms"] / max(conv["launches"], 1),
+                                "gflop_per_step": conv["flops"] / args.steps / 1e9,
+                                "algorithmic_gbytes_per_step": conv["bytes"] / args.steps / 1e9}
+            line["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd, rgb_np, args.cpu_tiles)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

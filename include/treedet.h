@@ -101,6 +101,15 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
 td_status td_engine_tensor(td_engine* e, const char* name, void** dev_ptr, int64_t dims[4], int* elem_size);
 /* Copy that activation into a caller-owned device buffer of `bytes` bytes (asynchronous on `stream`). */
 td_status td_engine_read_tensor(td_engine* e, const char* name, void* dst_dev, int64_t bytes, void* stream);
+/* Per-category device timing of forward(): when enabled, every kernel launch is bracketed by HIP events on the
+ * forward's stream. Categories: 0 conv_igemm (all MFMA contractions), 1 stem, 2 pool/subsample, 3 rpn_select
+ * (top-k, decode, NMS, merge), 4 roi_align, 5 detect (decode/sort/NMS/finalize), 6 mask_tail (predictor, scatter,
+ * paste), 7 mask-head contractions (row count lives on the device: flops/bytes are left 0 for the caller to fill). td_engine_profile_read synchronises the recorded events and ACCUMULATES since the last reset:
+ * ms[c] device milliseconds, launches[c], flops[c] algorithmic FLOPs (2*M*N*K, conv only), bytes[c] algorithmic
+ * HBM bytes (inputs read once + outputs written once). Arrays hold TD_PROF_CATEGORIES entries. */
+#define TD_PROF_CATEGORIES 8
+td_status td_engine_profile_enable(td_engine* e, int enable);
+td_status td_engine_profile_read(td_engine* e, double* ms, int64_t* launches, double* flops, double* bytes, int reset);
 const char* td_last_error(void);
 void td_engine_destroy(td_engine* e);
 

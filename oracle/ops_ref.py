@@ -208,15 +208,16 @@ def roi_align(feat: np.ndarray, rois: np.ndarray, spatial_scale: float, pooled: 
 
 
 def roi_align_fast(feat, rois, spatial_scale: float, pooled: int):
-    """Vectorised (torch) form of :func:`roi_align`; same operation order per element."""
+    """Vectorised (torch) form of :func:`roi_align`: RoIs that share a sample grid (gh, gw) are evaluated
+    together; per element the operation order is identical to the scalar version."""
     import torch
 
     feat = torch.as_tensor(feat, dtype=torch.float32)
     C, H, W = feat.shape
     rois = torch.as_tensor(np.asarray(rois, dtype=F32)).reshape(-1, 4)
-    R = rois.shape[0]
-    out = torch.zeros((R, C, pooled, pooled), dtype=torch.float32)
-    if R == 0:
+    Rn = rois.shape[0]
+    out = torch.zeros((Rn, C, pooled, pooled), dtype=torch.float32)
+    if Rn == 0:
         return out.numpy()
     sc = torch.tensor(spatial_scale, dtype=torch.float32)
     sw = rois[:, 0] * sc - 0.5
@@ -227,20 +228,24 @@ def roi_align_fast(feat, rois, spatial_scale: float, pooled: int):
     rh = eh - sh
     bh = rh / pooled
     bw = rw / pooled
-    gh = torch.ceil(rh / pooled).to(torch.int64)
-    gw = torch.ceil(rw / pooled).to(torch.int64)
+    gh = torch.clamp(torch.ceil(rh / pooled), min=0).to(torch.int64)
+    gw = torch.clamp(torch.ceil(rw / pooled), min=0).to(torch.int64)
     flat = feat.reshape(C, H * W)
     p = torch.arange(pooled, dtype=torch.float32)
-    for r in range(R):
-        ghr, gwr = int(gh[r]), int(gw[r])
+    keys = gh * 100000 + gw
+    for key in torch.unique(keys).tolist():
+        sel = torch.nonzero(keys == key).flatten()
+        ghr, gwr = int(key // 100000), int(key % 100000)
         count = float(max(ghr * gwr, 1))
-        acc = torch.zeros((C, pooled, pooled), dtype=torch.float32)
+        G = sel.numel()
+        acc = torch.zeros((C, G, pooled, pooled), dtype=torch.float32)
+        s_sh, s_sw, s_bh, s_bw = sh[sel, None], sw[sel, None], bh[sel, None], bw[sel, None]
         for iy in range(ghr):
-            y = sh[r] + p * bh[r] + (torch.tensor(float(iy)) + 0.5) * bh[r] / float(ghr)      # [P]
+            y = s_sh + p[None, :] * s_bh + (torch.tensor(float(iy)) + 0.5) * s_bh / float(ghr)      # [G,P]
             for ix in range(gwr):
-                x = sw[r] + p * bw[r] + (torch.tensor(float(ix)) + 0.5) * bw[r] / float(gwr)  # [P]
-                Y = y[:, None].expand(pooled, pooled)
-                X = x[None, :].expand(pooled, pooled)
+                x = s_sw + p[None, :] * s_bw + (torch.tensor(float(ix)) + 0.5) * s_bw / float(gwr)  # [G,P]
+                Y = y[:, :, None].expand(G, pooled, pooled)
+                X = x[:, None, :].expand(G, pooled, pooled)
                 oob = (Y < -1.0) | (Y > H) | (X < -1.0) | (X > W)
                 yy = torch.clamp(Y, min=0.0)
                 xx = torch.clamp(X, min=0.0)
@@ -259,14 +264,19 @@ def roi_align_fast(feat, rois, spatial_scale: float, pooled: int):
                 hy = 1.0 - ly
                 hx = 1.0 - lx
                 w1, w2, w3, w4 = hy * hx, hy * lx, ly * hx, ly * lx
-                v1 = flat[:, (yl * W + xl).reshape(-1)].reshape(C, pooled, pooled)
-                v2 = flat[:, (yl * W + xh).reshape(-1)].reshape(C, pooled, pooled)
-                v3 = flat[:, (yh * W + xl).reshape(-1)].reshape(C, pooled, pooled)
-                v4 = flat[:, (yh * W + xh).reshape(-1)].reshape(C, pooled, pooled)
+                yl = torch.where(oob, torch.zeros_like(yl), yl)
+                yh = torch.where(oob, torch.zeros_like(yh), yh)
+                xl = torch.where(oob, torch.zeros_like(xl), xl)
+                xh = torch.where(oob, torch.zeros_like(xh), xh)
+                shp = (C, G, pooled, pooled)
+                v1 = flat[:, (yl * W + xl).reshape(-1)].reshape(shp)
+                v2 = flat[:, (yl * W + xh).reshape(-1)].reshape(shp)
+                v3 = flat[:, (yh * W + xl).reshape(-1)].reshape(shp)
+                v4 = flat[:, (yh * W + xh).reshape(-1)].reshape(shp)
                 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4
                 val = torch.where(oob[None], torch.zeros_like(val), val)
                 acc = acc + val
-        out[r] = acc / count
+        out[sel] = (acc / count).permute(1, 0, 2, 3)
     return out.numpy()
 
 

@@ -48,6 +48,9 @@ SIGNATURES = {
     "td_engine_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int)]),
     "td_engine_read_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "td_engine_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "td_engine_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_double), C.c_int]),
     "td_last_error": (C.c_char_p, []),
     "td_engine_destroy": (None, [C.c_void_p]),
     "td_resize_tile_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -47,13 +47,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs a) {
         const int md = *a.m_dyn * a.m_mul;
         M = md < M ? md : M;
     }
+    // the grid is sized for a.M; with a device-side row count only the first `nblk` blocks have work, and the
+    // XCD remap runs over THAT count so the live tiles still spread over all 8 XCDs
     const int tiles_n = (a.Cout + BN - 1) / BN;
-    const int tiles_m_all = (a.M + BM - 1) / BM;
-    const int nblk = tiles_m_all * tiles_n;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int nblk = tiles_m * tiles_n;
+    if ((int)blockIdx.x >= nblk) return;
     const int pid = xcd_remap(blockIdx.x, nblk);
     const int tm = pid / tiles_n, tn = pid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    if (m0 >= M) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;

@@ -95,6 +95,16 @@ struct td_engine {
     int *o_classes = nullptr, *o_count = nullptr;
 
     std::map<std::string, NamedTensor> named;
+
+    // optional per-category device timing (td_engine_profile_*)
+    bool prof = false;
+    struct ProfRec { hipEvent_t a, b; int cat; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_free;
+    double prof_ms[TD_PROF_CATEGORIES] = {};
+    int64_t prof_launches[TD_PROF_CATEGORIES] = {};
+    double prof_flops[TD_PROF_CATEGORIES] = {};
+    double prof_bytes[TD_PROF_CATEGORIES] = {};
 };
 
 namespace {
@@ -201,9 +211,9 @@ td_status load_conv_bias(td_engine* e, const TensorMap& tm, const std::string& p
     return upload(e, std::vector<float>(b->data, b->data + L.cout), &L.bias);
 }
 
-td_status run_conv(const ConvLayer& L, const float* x, int B, int H, int W, int stride, int pad, bool relu, float* y,
-                   const float* res, int res_shift, hipStream_t s, int precision, const int* m_dyn = nullptr,
-                   int m_mul = 1, int out_mode = 0) {
+td_status run_conv_raw(const ConvLayer& L, const float* x, int B, int H, int W, int stride, int pad, bool relu, float* y,
+                       const float* res, int res_shift, hipStream_t s, int precision, const int* m_dyn, int m_mul,
+                       int out_mode) {
     ConvArgs a{};
     a.x = x; a.w = L.w; a.scale = L.scale; a.bias = L.bias; a.res = res; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = L.cin; a.Cout = L.cout; a.KH = L.kh; a.KW = L.kw;
@@ -223,6 +233,39 @@ void set_named(td_engine* e, const char* name, void* p, int64_t d0, int64_t d1 =
     t.elem = elem;
     e->named[name] = t;
 }
+
+hipEvent_t prof_event(td_engine* e) {
+    hipEvent_t ev = nullptr;
+    if (!e->prof_free.empty()) {
+        ev = e->prof_free.back();
+        e->prof_free.pop_back();
+    } else {
+        (void)hipEventCreate(&ev);
+    }
+    return ev;
+}
+
+// RAII bracket: records start on construction and stop on destruction (only when profiling is on)
+struct ProfScope {
+    td_engine* e;
+    hipStream_t s;
+    hipEvent_t a = nullptr;
+    int cat;
+    ProfScope(td_engine* e_, hipStream_t s_, int cat_, double flops = 0.0, double bytes = 0.0) : e(e_), s(s_), cat(cat_) {
+        if (!e->prof) return;
+        a = prof_event(e);
+        (void)hipEventRecord(a, s);
+        e->prof_flops[cat] += flops;
+        e->prof_bytes[cat] += bytes;
+        e->prof_launches[cat] += 1;
+    }
+    ~ProfScope() {
+        if (!a) return;
+        hipEvent_t b = prof_event(e);
+        (void)hipEventRecord(b, s);
+        e->prof_recs.push_back({a, b, cat});
+    }
+};
 
 void free_pool(std::vector<void*>& pool) {
     for (void* p : pool) (void)hipFree(p);
@@ -258,6 +301,8 @@ void td_engine_destroy(td_engine* e) {
     (void)hipSetDevice(e->device);
     free_pool(e->weight_allocs);
     free_pool(e->ws_allocs);
+    for (auto& r : e->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto ev : e->prof_free) (void)hipEventDestroy(ev);
     delete e;
 }
 
@@ -540,11 +585,23 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
     }
     e->named.clear();
     td_status st;
+    auto run_conv = [&](const ConvLayer& L, const float* x_, int B_, int H_, int W_, int stride, int pad, bool relu,
+                        float* y_, const float* res_, int res_shift, hipStream_t s_, int prec_,
+                        const int* m_dyn = nullptr, int m_mul = 1, int out_mode = 0) -> td_status {
+        const int Ho = (H_ + 2 * pad - L.kh) / stride + 1, Wo = (W_ + 2 * pad - L.kw) / stride + 1;
+        const double M = (double)B_ * Ho * Wo, K = (double)L.kh * L.kw * L.cin;
+        const double flops = 2.0 * M * L.cout * K;
+        const double bytes = 4.0 * ((double)B_ * H_ * W_ * L.cin / (stride * stride) + M * L.cout * (res_ ? 2.0 : 1.0) + L.cout * K);
+        ProfScope ps(e, s_, m_dyn ? 7 : 0, m_dyn ? 0.0 : flops, m_dyn ? 0.0 : bytes);
+        return run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode);
+    };
     // ---- backbone ------------------------------------------------------------------------------------------
+    { ProfScope ps(e, s, 1);
     if ((st = stem_launch(images, input_format, valid, B, Hp, Wp, e->stem_w, e->stem_scale, e->stem_bias, e->stem_out,
-                          e->stem_c, prec, s)) < 0) return st;
+                          e->stem_c, prec, s)) < 0) return st; }
     set_named(e, "stem", e->stem_out, B, Hp / 2, Wp / 2, e->stem_c);
-    if ((st = maxpool3x3s2_launch(e->stem_out, e->pool_out, B, Hp / 2, Wp / 2, e->stem_c, prec, s)) < 0) return st;
+    { ProfScope ps(e, s, 2);
+    if ((st = maxpool3x3s2_launch(e->stem_out, e->pool_out, B, Hp / 2, Wp / 2, e->stem_c, prec, s)) < 0) return st; }
     set_named(e, "pool", e->pool_out, B, Hp / 4, Wp / 4, e->stem_c);
     int hs[5], wsz[5];
     for (int l = 0; l < 4; ++l) {
@@ -583,7 +640,8 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
         if ((st = run_conv(e->lateral[l], e->res[l], B, hs[l], wsz[l], 1, 0, false, e->inner[l], td_res, td_res ? 1 : 0, s, prec)) < 0) return st;
         if ((st = run_conv(e->fpn_out[l], e->inner[l], B, hs[l], wsz[l], 1, 1, false, e->pfeat[l], nullptr, 0, s, prec)) < 0) return st;
     }
-    if ((st = subsample2_launch(e->pfeat[3], e->pfeat[4], B, hs[3], wsz[3], e->fpn_c, prec, s)) < 0) return st;
+    { ProfScope ps(e, s, 2);
+    if ((st = subsample2_launch(e->pfeat[3], e->pfeat[4], B, hs[3], wsz[3], e->fpn_c, prec, s)) < 0) return st; }
     for (int l = 0; l < 5; ++l) {
         const std::string nm = "p" + std::to_string(l + 2);
         set_named(e, nm.c_str(), e->pfeat[l], B, hs[l], wsz[l], e->fpn_c);
@@ -617,19 +675,22 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
         }
         lv.total_anchors = off;
     }
+    { ProfScope ps(e, s, 3);
     if ((st = rpn_topk_decode_launch(lv, valid, B, e->desc.pre_nms_topk, e->key_ws, e->cand_boxes, e->cand_scores,
-                                     e->cand_valid, e->cand_idx, s)) < 0) return st;
+                                     e->cand_valid, e->cand_idx, s)) < 0) return st; }
     set_named(e, "rpn_cand_boxes", e->cand_boxes, B, RPN_LEVELS, RPN_CAND, 4);
     set_named(e, "rpn_cand_scores", e->cand_scores, B, RPN_LEVELS, RPN_CAND);
     set_named(e, "rpn_cand_valid", e->cand_valid, B, RPN_LEVELS, RPN_CAND);
     set_named(e, "rpn_cand_idx", e->cand_idx, B, RPN_LEVELS, RPN_CAND);
+    { ProfScope ps(e, s, 3);
     if ((st = nms_launch(e->cand_boxes, nullptr, e->cand_valid, B * RPN_LEVELS, RPN_CAND, e->desc.rpn_nms_thresh,
-                         e->nms_mask, e->rpn_keep, e->rpn_keep_count, RPN_CAND, s)) < 0) return st;
+                         e->nms_mask, e->rpn_keep, e->rpn_keep_count, RPN_CAND, s)) < 0) return st; }
     set_named(e, "rpn_keep", e->rpn_keep, B, RPN_LEVELS, RPN_CAND);
     set_named(e, "rpn_keep_count", e->rpn_keep_count, B, RPN_LEVELS);
     const int P = e->desc.post_nms_topk, D = e->desc.detections_per_image;
+    { ProfScope ps(e, s, 3);
     if ((st = rpn_merge_launch(e->cand_boxes, e->cand_scores, e->rpn_keep, e->rpn_keep_count, B, P, e->props,
-                               e->prop_scores, e->prop_count, P, s)) < 0) return st;
+                               e->prop_scores, e->prop_count, P, s)) < 0) return st; }
     set_named(e, "proposals", e->props, B, P, 4);
     set_named(e, "proposal_scores", e->prop_scores, B, P);
     set_named(e, "proposal_count", e->prop_count, B);
@@ -642,31 +703,37 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
         fl.scale[l] = 1.0f / (float)(4 << l);
     }
     fl.C = e->fpn_c;
-    if ((st = roi_align_launch(fl, e->props, e->prop_count, B, P, 7, 0, e->pooled7, nullptr, prec, s)) < 0) return st;
+    { ProfScope ps(e, s, 4);
+    if ((st = roi_align_launch(fl, e->props, e->prop_count, B, P, 7, 0, e->pooled7, nullptr, prec, s)) < 0) return st; }
     set_named(e, "pooled7", e->pooled7, (int64_t)B * P, 7, 7, e->fpn_c);
     if ((st = run_conv(e->fc1, e->pooled7, B * P, 1, 1, 1, 0, true, e->fc1_out, nullptr, 0, s, prec)) < 0) return st;
     if ((st = run_conv(e->fc2, e->fc1_out, B * P, 1, 1, 1, 0, true, e->fc2_out, nullptr, 0, s, prec)) < 0) return st;
     if ((st = run_conv(e->pred, e->fc2_out, B * P, 1, 1, 1, 0, false, e->pred_out, nullptr, 0, s, prec)) < 0) return st;
     set_named(e, "box_pred", e->pred_out, (int64_t)B * P, 6);
+    { ProfScope ps(e, s, 5);
     if ((st = det_decode_launch(e->pred_out, 6, e->props, e->prop_count, valid, B, P, e->desc.score_thresh, e->dboxes,
-                                e->dscores, e->dflags, s)) < 0) return st;
+                                e->dscores, e->dflags, s)) < 0) return st; }
     set_named(e, "det_all_boxes", e->dboxes, B, P, 4);
     set_named(e, "det_all_scores", e->dscores, B, P);
     set_named(e, "det_flags", e->dflags, B, P);
+    { ProfScope ps(e, s, 5);
     if ((st = sort_boxes_launch(e->dboxes, e->dscores, e->dflags, e->prop_count, B, P, e->sboxes, e->sscores, e->sidx,
-                                e->scount, s)) < 0) return st;
+                                e->scount, s)) < 0) return st; }
+    { ProfScope ps(e, s, 5);
     if ((st = nms_launch(e->sboxes, e->scount, nullptr, B, P, e->desc.nms_thresh, e->nms_mask, e->det_keep,
-                         e->det_keep_count, D, s)) < 0) return st;
+                         e->det_keep_count, D, s)) < 0) return st; }
     float* o_boxes = out->boxes ? out->boxes : e->o_boxes;
     float* o_scores = out->scores ? out->scores : e->o_scores;
     int* o_classes = out->classes ? out->classes : e->o_classes;
     int* o_count = out->count ? out->count : e->o_count;
+    { ProfScope ps(e, s, 5);
     if ((st = det_finalize_launch(e->sboxes, e->sscores, e->det_keep, e->det_keep_count, valid, outsz, B, P, D,
-                                  e->det_boxes_net, o_boxes, o_scores, o_classes, o_count, s)) < 0) return st;
+                                  e->det_boxes_net, o_boxes, o_scores, o_classes, o_count, s)) < 0) return st; }
     set_named(e, "det_boxes_net", e->det_boxes_net, B, D, 4);
     // ---- mask head (compact rows: only live detections are computed) ------------------------------------------
     const int mrows = B * D;
-    if ((st = roi_align_launch(fl, e->det_boxes_net, o_count, B, D, 14, 1, e->pooled14, e->total_rows, prec, s)) < 0) return st;
+    { ProfScope ps(e, s, 4);
+    if ((st = roi_align_launch(fl, e->det_boxes_net, o_count, B, D, 14, 1, e->pooled14, e->total_rows, prec, s)) < 0) return st; }
     set_named(e, "pooled14", e->pooled14, mrows, 14, 14, e->fpn_c);
     const float* mx = e->pooled14;
     float* mbuf[2] = {e->mbuf0, e->mbuf1};
@@ -675,16 +742,19 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
         mx = mbuf[i & 1];
     }
     if ((st = run_conv(e->deconv, mx, mrows, 14, 14, 1, 0, true, e->deconv_out, nullptr, 0, s, prec, e->total_rows, 196, 1)) < 0) return st;
+    { ProfScope ps(e, s, 6);
     if ((st = mask_predict_launch(e->deconv_out, e->mask_pred_w, e->mask_pred_b, e->deconv.cout / 4, mrows * 784,
-                                  e->total_rows, 784, e->mask_logits, e->mask_probs_compact, prec, s)) < 0) return st;
+                                  e->total_rows, 784, e->mask_logits, e->mask_probs_compact, prec, s)) < 0) return st; }
     set_named(e, "mask_logits", e->mask_logits, mrows, 28, 28);
     float* o_probs = out->mask_probs ? out->mask_probs : e->o_mask_probs;
-    if ((st = mask_scatter_launch(e->mask_probs_compact, o_count, B, D, o_probs, s)) < 0) return st;
+    { ProfScope ps(e, s, 6);
+    if ((st = mask_scatter_launch(e->mask_probs_compact, o_count, B, D, o_probs, s)) < 0) return st; }
     if (out->mask_bits) {
         TD_REQUIRE(out->mask_region && out->mask_offset && out->mask_words_per_image > 0, "td_engine_forward: mask_bits needs mask_region, mask_offset and mask_words_per_image");
+        { ProfScope ps(e, s, 6);
         if ((st = paste_masks_launch(o_probs, o_boxes, o_count, outsz, B, D, e->desc.mask_thresh, out->mask_region,
                                      reinterpret_cast<long long*>(out->mask_offset), out->mask_bits,
-                                     out->mask_words_per_image, s)) < 0) return st;
+                                     out->mask_words_per_image, s)) < 0) return st; }
     }
     return TD_OK;
 }
@@ -699,6 +769,38 @@ td_status td_engine_tensor(td_engine* e, const char* name, void** dev_ptr, int64
     *dev_ptr = it->second.p;
     for (int i = 0; i < 4; ++i) dims[i] = it->second.dims[i];
     if (elem_size) *elem_size = it->second.elem;
+    return TD_OK;
+}
+
+td_status td_engine_profile_enable(td_engine* e, int enable) {
+    TD_REQUIRE(e, "td_engine_profile_enable: null engine");
+    e->prof = enable != 0;
+    return TD_OK;
+}
+
+td_status td_engine_profile_read(td_engine* e, double* ms, int64_t* launches, double* flops, double* bytes, int reset) {
+    TD_REQUIRE(e, "td_engine_profile_read: null engine");
+    for (auto& r : e->prof_recs) {
+        TD_HIP_CHECK(hipEventSynchronize(r.b));
+        float t = 0.f;
+        TD_HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
+        e->prof_ms[r.cat] += t;
+        e->prof_free.push_back(r.a);
+        e->prof_free.push_back(r.b);
+    }
+    e->prof_recs.clear();
+    for (int c = 0; c < TD_PROF_CATEGORIES; ++c) {
+        if (ms) ms[c] = e->prof_ms[c];
+        if (launches) launches[c] = e->prof_launches[c];
+        if (flops) flops[c] = e->prof_flops[c];
+        if (bytes) bytes[c] = e->prof_bytes[c];
+        if (reset) {
+            e->prof_ms[c] = 0.0;
+            e->prof_launches[c] = 0;
+            e->prof_flops[c] = 0.0;
+            e->prof_bytes[c] = 0.0;
+        }
+    }
     return TD_OK;
 }
 

@@ -151,6 +151,50 @@ class Engine:
         torch.cuda.synchronize()
         return t
 
+    # -- tile preprocessing (reference Predictor._process_tile, prediction.py:159-176) -----------------------
+    def resize_shape(self, h: int, w: int) -> tuple:
+        a, b = C.c_int(), C.c_int()
+        self.lib.td_resize_shape(int(h), int(w), 800, 1333, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def preprocess_tiles_u8(self, tiles: Sequence[torch.Tensor]):
+        """uint8 CUDA tiles [h,w,C>=3] (band order as in the file: R,G,B[,I]) → (uint8 [B,Hp,Wp,3] BGR batch resized with
+        Pillow-exact bilinear, hw_valid, hw_out). Everything stays in HBM."""
+        shapes = [self.resize_shape(t.shape[0], t.shape[1]) for t in tiles]
+        Hp = _round_up(max(s[0] for s in shapes), 32)
+        Wp = _round_up(max(s[1] for s in shapes), 32)
+        dev = torch.device("cuda", self.device)
+        key = (len(tiles), Hp, Wp)
+        if getattr(self, "_pp_key", None) != key:
+            self._pp_batch = torch.zeros((len(tiles), Hp, Wp, 3), dtype=torch.uint8, device=dev)
+            self._pp_key = key
+        batch = self._pp_batch
+        need_tmp = max(t.shape[0] * s[1] * 3 for t, s in zip(tiles, shapes))
+        if getattr(self, "_pp_tmp", None) is None or self._pp_tmp.numel() < need_tmp:
+            self._pp_tmp = torch.empty((need_tmp,), dtype=torch.uint8, device=dev)
+        st = _lib.stream_ptr()
+        for i, (t, (oh, ow)) in enumerate(zip(tiles, shapes)):
+            assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous() and t.shape[2] >= 3
+            if oh < Hp or ow < Wp:
+                batch[i].zero_()
+            _lib.check(self.lib.td_resize_tile_u8(t.data_ptr(), t.shape[0], t.shape[1], t.shape[2], batch[i].data_ptr(),
+                                                  oh, ow, Wp, self._pp_tmp.data_ptr(), st), "td_resize_tile_u8")
+        hw_out = [(int(t.shape[0]), int(t.shape[1])) for t in tiles]
+        return batch, shapes, hw_out
+
+    # -- device timing ------------------------------------------------------------------------------------
+    PROF_NAMES = ("conv_igemm", "stem", "pool", "rpn_select", "roi_align", "detect", "mask_tail", "mask_convs")
+
+    def profile_enable(self, on: bool = True) -> None:
+        _lib.check(self.lib.td_engine_profile_enable(self._h, int(on)), "td_engine_profile_enable")
+
+    def profile_read(self, reset: bool = True) -> Dict[str, dict]:
+        n = len(self.PROF_NAMES)
+        ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+        la = (C.c_int64 * n)()
+        _lib.check(self.lib.td_engine_profile_read(self._h, ms, la, fl, by, int(reset)), "td_engine_profile_read")
+        return {k: {"ms": ms[i], "launches": int(la[i]), "flops": fl[i], "bytes": by[i]} for i, k in enumerate(self.PROF_NAMES)}
+
     # -- the reference's model seam ---------------------------------------------------------------------
     def __call__(self, batched_inputs: List[dict], paste: bool = True) -> List[dict]:
         """Same contract as ``self.model(batch_tensors)`` (prediction.py:182-183).

@@ -143,9 +143,9 @@ def make_synthetic_state_dict(depth: int = 50, seed: int = 0, num_classes: int =
             if name.endswith("objectness_logits"):
                 w *= np.float32(1.5)
             if name.endswith("cls_score"):
-                w *= np.float32(1.0)
+                w *= np.float32(3.0)
                 b[:] = 0.0
-                b[-1] = 2.6       # background logit bias: most proposals stay below 0.3
+                b[-1] = 4.6       # background logit bias: a few % of the proposals pass 0.3
             if name.endswith("bbox_pred"):
                 w *= np.float32(0.6)
             if name.endswith("mask_head.predictor"):
