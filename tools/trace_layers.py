@@ -1,0 +1,59 @@
+"""Per-layer view of a rocprofv3 --kernel-trace CSV of bench.py: pairs the conv_igemm launches of the LAST forward
+with the engine's layer schedule (R50/R101, B x Hp x Wp) and prints GFLOP, µs and TFLOP/s per launch."""
+import csv
+import sys
+
+
+def schedule(depth=50, B=8, Hp=800, Wp=800, P=1000):
+    blocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}[depth]
+    mids, outs = (64, 128, 256, 512), (256, 512, 1024, 2048)
+    L = []
+    cin, h, w = 64, Hp // 4, Wp // 4
+    for si, nb in enumerate(blocks):
+        for bi in range(nb):
+            s = 2 if (bi == 0 and si > 0) else 1
+            ho, wo = h // s, w // s
+            if bi == 0:
+                L.append((f"res{si+2}.{bi}.shortcut", B * ho * wo, outs[si], cin))
+            L.append((f"res{si+2}.{bi}.conv1", B * ho * wo, mids[si], cin))
+            L.append((f"res{si+2}.{bi}.conv2", B * ho * wo, mids[si], mids[si] * 9))
+            L.append((f"res{si+2}.{bi}.conv3", B * ho * wo, outs[si], mids[si]))
+            cin, h, w = outs[si], ho, wo
+    hs = [Hp >> (l + 2) for l in range(4)]
+    ws = [Wp >> (l + 2) for l in range(4)]
+    for l in (3, 2, 1, 0):
+        L.append((f"fpn_lateral{l+2}", B * hs[l] * ws[l], 256, outs[l]))
+        L.append((f"fpn_output{l+2}", B * hs[l] * ws[l], 256, 2304))
+    hs.append((hs[3] - 1) // 2 + 1)
+    ws.append((ws[3] - 1) // 2 + 1)
+    for l in range(5):
+        L.append((f"rpn_conv p{l+2}", B * hs[l] * ws[l], 256, 2304))
+        L.append((f"rpn_head p{l+2}", B * hs[l] * ws[l], 15, 256))
+    L.append(("fc1", B * P, 1024, 12544))
+    L.append(("fc2", B * P, 1024, 1024))
+    L.append(("box_pred", B * P, 6, 1024))
+    for i in range(4):
+        L.append((f"mask_fcn{i+1} (dyn)", 0, 256, 2304))
+    L.append(("mask_deconv (dyn)", 0, 1024, 256))
+    return L
+
+
+def main(path, depth=50):
+    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"]]
+    L = schedule(depth)
+    n = len(L)
+    last = rows[-n:]
+    tot_f = tot_t = 0.0
+    for (name, M, N, K), r in zip(L, last):
+        us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        gf = 2.0 * M * N * K / 1e9
+        kern = r["Kernel_Name"].split("conv_igemm_")[1].split("(")[0]
+        print(f"{name:24s} M={M:7d} N={N:5d} K={K:6d} {kern:14s} grid={int(r['Grid_Size_X'])//256:5d} {us:9.1f} us {gf:8.2f} GF {gf/us*1e-3 if us else 0:7.1f} TF/s")
+        if M:
+            tot_f += gf
+            tot_t += us
+    print(f"static convs: {tot_f:.1f} GF in {tot_t/1e3:.2f} ms = {tot_f/tot_t*1e-3:.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 50)
