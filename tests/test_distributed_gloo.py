@@ -1,0 +1,79 @@
+"""N > 1 path on CPU: 2 processes over gloo — tile sharding covers the list exactly once and the fixed-shape gather
+delivers every rank's detections to rank 0 (the exchange step the bench and the Predictor run over RCCL)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from treedetection_amd import distributed as D
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_tiles, B, Dn = 11, 4, 5
+        mine = D.shard_indices(n_tiles)
+        rounds = D.padded_rounds(n_tiles, B)
+        seen = []
+        for r in range(rounds):
+            idx = mine[r * B:(r + 1) * B]
+            out = {"count": torch.zeros(B, dtype=torch.int32), "boxes": torch.zeros(B, Dn, 4),
+                   "scores": torch.zeros(B, Dn), "mask_probs": torch.zeros(B, Dn, 28, 28)}
+            for j, t in enumerate(idx):     # tile t yields (t % 3) detections, all stamped with t
+                out["count"][j] = t % 3
+                out["boxes"][j, : t % 3] = float(t)
+                out["scores"][j, : t % 3] = float(t) / 100
+                out["mask_probs"][j, : t % 3] = float(t)
+            g = D.gather_detections(out, dst=0)
+            metas = D.gather_objects([{"tile": t} for t in idx], dst=0)
+            if rank == 0:
+                assert len(g) == world and len(metas) == world
+                for rk, (gd, ms) in enumerate(zip(g, metas)):
+                    for j, m in enumerate(ms):
+                        t = m["tile"]
+                        assert int(gd["count"][j]) == t % 3
+                        assert (gd["boxes"][j, : t % 3] == float(t)).all() and (gd["mask_probs"][j, : t % 3] == float(t)).all()
+                        seen.append(t)
+            else:
+                assert g is None and metas is None
+        if rank == 0:
+            q.put(sorted(seen))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_and_gather_two_ranks():
+    assert D.shard_indices(7, 0, 2) == [0, 2, 4, 6] and D.shard_indices(7, 1, 2) == [1, 3, 5]
+    assert D.padded_rounds(11, 4, 2) == 2 and D.padded_rounds(8, 4, 2) == 1 and D.padded_rounds(0, 4, 2) == 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    seen = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert seen == list(range(11))      # every tile exactly once, all delivered to rank 0
+
+
+def test_single_process_paths():
+    out = {"count": torch.zeros(2, dtype=torch.int32), "boxes": torch.zeros(2, 3, 4), "scores": torch.zeros(2, 3),
+           "mask_probs": torch.zeros(2, 3, 28, 28)}
+    assert D.world() == 1 and D.rank() == 0
+    assert D.gather_detections(out)[0]["boxes"] is out["boxes"]
+    assert D.gather_objects([1]) == [[1]]

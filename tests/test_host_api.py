@@ -1,0 +1,163 @@
+"""Host-side mirror of the reference's API (config / tiling / recovery / exclusion / polygon epilogue) — CPU only."""
+import json
+import logging
+import os
+import re
+
+import numpy as np
+import pytest
+import yaml
+
+from treedetection_amd import recoveries
+from treedetection_amd.config import get_config, setup_model_cfg
+from treedetection_amd.geotiff import GeoTiff, write_geotiff
+from treedetection_amd.prediction import Predictor, polygons_from_masks
+from treedetection_amd.preprocessing import tile_single_file
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_geotiff_roundtrip_and_windows(tmp_path):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (4, 300, 500), dtype=np.uint8)
+    p = str(tmp_path / "a.tif")
+    write_geotiff(p, img, (0.2, 0, 412000.0, 0, -0.2, 5318100.0), 25832)
+    g = GeoTiff(p)
+    assert (g.width, g.height, g.count, g.epsg) == (500, 300, 4, 25832)
+    assert g.bounds == (412000.0, 5318040.0, 412100.0, 5318100.0)
+    assert np.array_equal(g.read(), img)
+    # bbox on pixel boundaries: rasterio.mask(crop=True) returns exactly the covered window
+    w = g.read_bounds([412010, 5318060, 412030, 5318090])
+    assert w.shape == (4, 150, 100)
+    assert np.array_equal(w, img[:, 50:200, 50:150])
+    # bbox hanging over the raster edge is clipped (reference: 350 px edge tiles)
+    w = g.read_bounds([411990, 5318080, 412010, 5318120])
+    assert w.shape == (4, 100, 50) and np.array_equal(w, img[:, :100, :50])
+    with pytest.raises(ValueError):
+        g.read_bounds([0, 0, 10, 10])
+    f = rng.standard_normal((1, 20, 30)).astype(np.float32)
+    write_geotiff(str(tmp_path / "f.tif"), f, (1, 0, 0, 0, -1, 20), 25832)
+    assert np.array_equal(GeoTiff(str(tmp_path / "f.tif")).read(), f)
+
+
+def test_tile_metadata_matches_reference_format(tmp_path):
+    img = np.zeros((4, 500, 500), dtype=np.uint8)     # 100 m x 100 m at 0.2 m
+    p = str(tmp_path / "324125317.tif")
+    write_geotiff(p, img, (0.2, 0, 412000.0, 0, -0.2, 5318100.0), 25832)
+    tile_single_file(p, str(tmp_path / "tiles"), buffer=20, tile_width=50, tile_height=50)
+    meta = json.load(open(tmp_path / "tiles" / "324125317.json"))
+    assert len(meta) == 4
+    # id scheme preprocessing.py:59; grid origin = raster bounds (left, bottom)
+    assert list(meta)[0] == "324125317_412000_5318000_50_20_25832"
+    t = meta["324125317_412050_5318050_50_20_25832"]
+    assert t["bounds"] == [412030.0, 5318030.0, 412120.0, 5318120.0]
+    assert t["crs"] == 25832 and t["only_forest"] is False and t["only_urban"] is False
+    # window transform of the clipped window (col 150, row 0): 9-number affine like json.dumps(Affine)
+    assert len(t["transform"]) == 9
+    assert t["transform"][:6] == pytest.approx([0.2, 0.0, 412030.0, 0.0, -0.2, 5318100.0])
+    t0 = meta["324125317_412000_5318000_50_20_25832"]
+    assert t0["transform"][:6] == pytest.approx([0.2, 0.0, 412000.0, 0.0, -0.2, 5318070.0])
+
+
+def test_forest_flags(tmp_path):
+    img = np.zeros((3, 500, 500), dtype=np.uint8)
+    p = str(tmp_path / "x.tif")
+    write_geotiff(p, img, (0.2, 0, 0.0, 0, -0.2, 100.0), 25832)
+    outline = {"type": "FeatureCollection", "features": [{"type": "Feature", "properties": {}, "geometry": {
+        "type": "Polygon", "coordinates": [[[-100, -100], [49, -100], [49, 300], [-100, 300], [-100, -100]]]}}]}
+    op = str(tmp_path / "forest.geojson")
+    json.dump(outline, open(op, "w"))
+    from treedetection_amd.preprocessing import _load_outline
+    tile_single_file(p, str(tmp_path / "t"), buffer=5, tile_width=25, tile_height=25, forest_polys=_load_outline(op))
+    meta = json.load(open(tmp_path / "t" / "x.json"))
+    assert meta["x_0_0_25_5_25832"]["only_forest"] and not meta["x_0_0_25_5_25832"]["only_urban"]
+    assert meta["x_75_75_25_5_25832"]["only_urban"] and not meta["x_75_75_25_5_25832"]["only_forest"]
+    assert not meta["x_25_0_25_5_25832"]["only_forest"] and not meta["x_25_0_25_5_25832"]["only_urban"]   # straddles
+
+
+def test_recovery_files_match_reference_fixture(tmp_path):
+    """tests/golden/recovery_fixture.json was produced by the reference's own recoveries.py (generator committed)."""
+    fx = json.load(open(os.path.join(HERE, "golden", "recovery_fixture.json")))
+    os.chdir(tmp_path)
+    os.makedirs("tiles")
+    os.makedirs("out/a")
+    os.makedirs("out/b")
+    for stem, m in fx["metas"].items():
+        json.dump(m, open(f"tiles/{stem}.json", "w"))
+    for k in fx["metas"]["a"]:
+        open(f"out/a/Prediction_{k}.json", "w").write("[]")
+    open("out/b/Prediction_b_0_0_50_20_25832.json", "w").write("[]")
+    recoveries.save_prediction_recovery_data("out", "tiles", "model.pth", {"img/b.tif"}, ["img/a.tif"])
+    assert yaml.safe_load(open("out/prediction_recovery.yaml")) == yaml.safe_load(fx["yaml"])
+    assert open("out/prediction_recovery.yaml").read() == fx["yaml"]          # byte-compatible
+    log = logging.getLogger("t")
+    for case in fx["cases"]:
+        if "removed" in case:
+            os.remove(f"out/a/Prediction_{case['removed']}.json")
+        fl, done = recoveries.load_prediction_recovery_data("out", "tiles", case["model"], log, case["exclude"])
+        assert fl == case["file_list"] and sorted(done) == case["processed"], case
+
+
+def test_get_config_defaults_and_asserts(tmp_path):
+    (tmp_path / "rgb").mkdir()
+    (tmp_path / "ndsm").mkdir()
+    (tmp_path / "m.npz").write_bytes(b"x")
+    cfg_path = tmp_path / "config.yml"
+    cfg_path.write_text(yaml.safe_dump({"image_directory": str(tmp_path / "rgb"), "height_data_path": str(tmp_path / "ndsm"),
+                                        "combined_model": str(tmp_path / "m.npz"),
+                                        "output_directory": str(tmp_path / "out"), "tile_width": 40}))
+    config, obj = get_config(str(cfg_path))
+    assert config["tile_width"] == 40 and config["tile_height"] == 50 and config["buffer"] == 20 and config["batch_size"] == 10
+    assert config["merged_path"] == "merged" and config["simplify_tolerance"] == 0.2 and config["iou_threshold"] == 0.5
+    assert config["continue"] == os.path.join(str(tmp_path / "out"), "continue.yml")
+    assert config["device"] in ("cpu", "0") and obj.tile_width == 40
+    bad = tmp_path / "bad.yml"
+    bad.write_text(yaml.safe_dump({"image_directory": str(tmp_path / "rgb"), "height_data_path": str(tmp_path / "ndsm")}))
+    with pytest.raises(AssertionError):
+        get_config(str(bad))
+
+
+def test_setup_model_cfg_mirrors_reference_values():
+    cfg = setup_model_cfg(update_model="x.pth", device="cpu")
+    assert cfg.MODEL.WEIGHTS == "x.pth" and cfg.MODEL.RESNETS.DEPTH == 101 and cfg.MODEL.DEVICE == "cpu"
+    assert cfg.MODEL.ROI_HEADS.NUM_CLASSES == 1 and cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST == 0.3
+    assert cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST == 0.5 and cfg.TEST.DETECTIONS_PER_IMAGE == 100
+    assert setup_model_cfg("COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x.yaml").MODEL.RESNETS.DEPTH == 50
+
+
+def test_exclusion_and_tile_order(tmp_path):
+    meta = {f"t{i}": {"bounds": [0, 0, 1, 1], "transform": [1, 0, 0, 0, -1, 0, 0, 0, 1], "crs": 1,
+                      "only_forest": i % 2 == 0, "only_urban": i == 3} for i in range(5)}
+    p = tmp_path / "img.json"
+    p.write_text(json.dumps(meta))
+    pr = Predictor.__new__(Predictor)        # host logic only: no engine, no GPU
+    pr.exclude_vars = ["only_forest"]
+    tiles = pr._load_tiles(str(p))
+    assert [t["tile_id"] for t in tiles] == ["t1", "t3"]          # JSON key order, flagged tiles dropped
+    assert "only_forest" not in tiles[0]
+    pr.exclude_vars = []
+    assert [t["tile_id"] for t in pr._load_tiles(str(p))] == [f"t{i}" for i in range(5)]
+
+
+def test_predictor_refuses_cpu():
+    with pytest.raises(RuntimeError):
+        Predictor(setup_model_cfg(update_model="x.npz", device="cpu"), device_type="cpu")
+
+
+def test_polygons_from_masks_schema_and_affine():
+    masks = np.zeros((2, 40, 50), bool)
+    masks[0, 10:20, 5:15] = True
+    masks[1, 0:2, 0:1] = True         # 2 points only: dropped (contour.size < 8)
+    regions = np.array([[4, 9, 16, 21], [0, 0, 3, 4]], np.int32)
+    t = [0.2, 0.0, 412000.0, 0.0, -0.2, 5318100.0, 0, 0, 1]
+    ev = polygons_from_masks(masks, regions, np.array([0.9, 0.8], np.float32), np.array([0, 0]), t, "a.tif")
+    assert len(ev) == 1
+    e = ev[0]
+    assert set(e) == {"image_id", "category_id", "score", "polygon_coords"} and e["image_id"] == "a.tif"
+    assert e["category_id"] == 0 and abs(e["score"] - 0.9) < 1e-6
+    ring = e["polygon_coords"][0]
+    assert ring[0] == ring[-1] and len(ring) == 5
+    # pixel-corner affine (no +0.5): pixel (5,10) → x = 412000 + 0.2*5, y = 5318100 - 0.2*10
+    assert ring[0] == pytest.approx([412001.0, 5318098.0])
+    assert ring[2] == pytest.approx([412000 + 0.2 * 14, 5318100 - 0.2 * 19])
+    json.dumps(ev)

@@ -1,0 +1,36 @@
+"""Mask → polygon epilogue of the reference's ``_process_and_save_single`` (prediction.py:229-249), host side.
+
+``find_contours`` = cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE) computed by td_find_contours in
+libtreedet_hip.so (pure host code in that library); ``xy`` = TreeDetection/utilities.py:182-207 (``xy_gpu``: affine
+on pixel-corner integer coordinates, float64) without the cupy round trip.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+def find_contours(mask: np.ndarray) -> List[np.ndarray]:
+    """uint8/bool [h,w] → list of int32 [n,2] (x,y) contours in cv2 RETR_TREE order."""
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    h, w = m.shape
+    lib = _lib.load()
+    max_pts = max(64, 2 * h * w + 16)
+    max_ct = max(16, (h * w) // 2 + 8)
+    pts = np.empty((max_pts, 2), dtype=np.int32)
+    starts = np.empty((max_ct + 1,), dtype=np.int32)
+    n = lib.td_find_contours(m.ctypes.data, h, w, pts.ctypes.data, max_pts, starts.ctypes.data, max_ct)
+    _lib.check(n, "td_find_contours")
+    return [pts[starts[i]:starts[i + 1]].copy() for i in range(n)]
+
+
+def xy(transform: Sequence[float], rows: Sequence[float], cols: Sequence[float]) -> Tuple[np.ndarray, np.ndarray]:
+    """x' = a*col + b*row + c ; y' = d*col + e*row + f   (utilities.py:203-204; no +0.5 pixel-centre offset)."""
+    a, b, c, d, e, f = (float(v) for v in transform[:6])
+    r = np.asarray(rows, dtype=np.float64)
+    k = np.asarray(cols, dtype=np.float64)
+    return a * k + b * r + c, d * k + e * r + f

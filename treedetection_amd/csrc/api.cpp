@@ -135,9 +135,4 @@ td_status td_paste_masks(const float* mask_probs, const float* boxes, int n, int
     return TD_OK;
 }
 
-int td_find_contours(const uint8_t*, int, int, int32_t*, int, int32_t*, int) {
-    td_set_error("td_find_contours: not built yet");
-    return TD_ERR_STATE;
-}
-
 }  // extern "C"

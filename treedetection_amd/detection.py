@@ -1,0 +1,184 @@
+"""Public API of the reference, kept: ``process_files`` / ``preprocess_files`` / ``predict_tiles`` /
+``postprocess_files`` / ``predict_on_model`` (TreeDetection/detection.py:342,256,134,23,62).
+
+``predict_tiles`` / ``predict_on_model`` are the hot path this package accelerates (model forward on the MI355X);
+``preprocess_files`` produces the tile metadata; stitching writes GeoJSON (treedetection_amd/stitching.py);
+``postprocess_files`` (crown filtering with nDSM / NDVI statistics, TreeDetection/postprocessing.py) is outside this
+round's scope and only hands the stitched files through.
+"""
+from __future__ import annotations
+
+import os
+import re
+import shutil
+import time
+from pathlib import Path
+
+from . import distributed as D
+from .config import Config, get_config, setup_model_cfg  # noqa: F401  (re-exported like the reference)
+from .prediction import Predictor
+from .preprocessing import tile_data
+from .recoveries import load_prediction_recovery_data, save_prediction_recovery_data
+from .stitching import process_and_stitch_predictions
+
+
+def predict_on_model(config, model_path, tiles_path, output_path, batch_size=10, exclude_vars=None):
+    """Reference detection.py:62-132: build the predictor once, walk the images (+ ``merged/``) sequentially, swallow
+    and log per-image errors, write the resume file."""
+    logger = config.get("logger", None)
+    for path, name in [(model_path, "Model file"), (tiles_path, "Tiles directory")]:
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{name} not found: {path}")
+        if name == "Tiles directory" and not os.path.isdir(path):
+            raise NotADirectoryError(f"{name} is not a directory: {path}")
+    os.makedirs(output_path, exist_ok=True)
+    cfg = setup_model_cfg(update_model=model_path, device=config["device"])
+    predictor = Predictor(cfg, device_type=config["device"], max_batch_size=batch_size, output_dir=output_path,
+                          exclude_vars=exclude_vars, precision=config.get("precision", "fp32"))
+    images_directory = Path(config["image_directory"])
+    images_paths = sorted(str(f) for f in images_directory.glob("*.tif"))
+    merged_directory = Path(f"{images_directory}/{config['merged_path']}")
+    images_paths.extend(sorted(str(f) for f in merged_directory.glob("*.tif")))
+    if not images_paths:
+        logger.warning("No TIF files found for prediction.")
+        return
+    file_list, processed_files = load_prediction_recovery_data(output_path, tiles_path, model_path, logger, exclude_vars)
+    if not file_list:
+        images_paths = [f for f in images_paths if f not in processed_files]
+    if not images_paths:
+        logger.info("All files have already been predicted. Exiting Prediction.")
+        return
+    total = len(images_paths)
+    for i, fp in enumerate(images_paths):
+        cur, prev = int(100 * (i + 1) / total), int(100 * i / total)
+        if logger and ((cur // 5) != (prev // 5) or cur == 100 or i == 0):
+            logger.info(f"Predicting file {i + 1}/{total} ({cur}%)")
+        tile_json = os.path.join(tiles_path, os.path.basename(fp).replace(".tif", ".json"))
+        try:
+            predictor(fp, tile_json)
+        except Exception as e:
+            logger.error(f"Error processing {fp}: {e}")
+    logger.info(f"Completed prediction for {len(images_paths)} images.")
+    if D.rank() == 0:
+        save_prediction_recovery_data(output_path, tiles_path, model_path, processed_files, images_paths)
+
+
+def _stitch(config, pred_dir, out_dir):
+    if D.rank() != 0:
+        return
+    process_and_stitch_predictions(tiles_path=config["tiles_path"], pred_fold=pred_dir, output_path=out_dir,
+                                   max_workers=config["num_workers"], shift=1,
+                                   simplify_tolerance=config["simplify_tolerance"], logger=config["logger"])
+
+
+def predict_tiles(config):
+    """Reference detection.py:134-253: two-model flow (urban + forest, exclude flags) when all three of urban_model,
+    forrest_model, forrest_outline exist, else the combined model, else FileNotFoundError."""
+    Config()._load_into_config(config)
+    logger = config["logger"]
+    out = config["output_directory"]
+    two = all(config.get(k) and os.path.exists(config[k]) for k in ("urban_model", "forrest_model", "forrest_outline"))
+    if two:
+        logger.info("Urban, forrest models and forrest outline are available. Starting prediction...")
+        t0 = time.time()
+        predict_on_model(config, config["urban_model"], config["tiles_path"], os.path.join(out, "urban_predictions"),
+                         batch_size=config["batch_size"], exclude_vars=["only_forest"])
+        t1 = time.time()
+        predict_on_model(config, config["forrest_model"], config["tiles_path"], os.path.join(out, "forrest_predictions"),
+                         batch_size=config["batch_size"], exclude_vars=["only_urban"])
+        t2 = time.time()
+        _stitch(config, os.path.join(out, "urban_predictions"), os.path.join(out, "urban_geojson"))
+        _stitch(config, os.path.join(out, "forrest_predictions"), os.path.join(out, "forrest_geojson"))
+        # fusion by forest outline (helpers.fuse_predictions) needs a geometry engine: both sets are kept side by side
+        logger.info("Predictions have been processed and stitched (fusion by outline is not part of this package yet).")
+        logger.debug(f"predict on model for urban took {t1 - t0} seconds")
+        logger.debug(f"predict on model for forrest took {t2 - t1} seconds")
+    elif config.get("combined_model") and os.path.exists(config["combined_model"]):
+        logger.info("Only Combined Model is given. Starting prediction...")
+        t0 = time.time()
+        predict_on_model(config, config["combined_model"], config["tiles_path"], os.path.join(out, "predictions"),
+                         batch_size=config["batch_size"])
+        t1 = time.time()
+        _stitch(config, os.path.join(out, "predictions"), os.path.join(out, "geojson_predictions"))
+        logger.debug(f"Prediction took {t1 - t0} seconds")
+    else:
+        raise FileNotFoundError("No model available for prediction. Either urban model or forrest model + outline or "
+                                "combined model must be available.")
+
+
+def preprocess_files(config):
+    """Reference detection.py:256-339 without the neighbour-mosaic step (merging.py is raster I/O outside the scope)."""
+    Config()._load_into_config(config)
+    logger = config["logger"]
+    for key, what in (("image_directory", "Image"), ("height_data_path", "Height")):
+        p = config[key]
+        if not os.path.exists(p):
+            raise FileNotFoundError(f"{what} directory not found: {p}")
+        if not os.path.isdir(p):
+            raise NotADirectoryError(f"{what} directory is not a directory: {p}")
+    images = sorted(os.path.join(config["image_directory"], f) for f in os.listdir(config["image_directory"]) if f.endswith(".tif"))
+    heights = sorted(os.path.join(config["height_data_path"], f) for f in os.listdir(config["height_data_path"]) if f.endswith(".tif"))
+    if os.path.exists(config["continue"]):
+        with open(config["continue"]) as f:
+            done = f.read().splitlines()
+        images = [f for f in images if f not in done]
+    irx = re.compile(config.get("image_regex", "(\\d+)\\.tif"))
+    hrx = re.compile(config.get("height_data_regex", "(\\d+)\\.tif"))
+    images = [f for f in images if irx.search(os.path.basename(f))]
+    ids = {"".join(irx.search(os.path.basename(f)).groups()): f for f in images}
+    hids = {"".join(hrx.search(os.path.basename(f)).groups()) for f in heights if hrx.search(os.path.basename(f))}
+    if config["use_overlap"]:
+        logger.warning("use_overlap: neighbour mosaics (merging.merge_and_crop_images) are not built in this package; "
+                       "continuing without seam strips.")
+    for ident, path in ids.items():
+        if ident not in hids:
+            logger.warning(f"No corresponding height data found for image file {path}")
+    if not images:
+        raise FileNotFoundError(f"No image TIF-files matching the pattern found in the directory: "
+                                f"{config['image_directory']} or all files have already been processed.")
+    logger.info(f"Found {len(images)} images for processing. Starting tiling...")
+    tile_data(images, config["tiles_path"], config["buffer"], config["tile_width"], config["tile_height"],
+              parallel=config["parallel"], max_workers=config["num_workers"], logger=logger,
+              forest_shapefile=config.get("forrest_outline", None))
+    return images
+
+
+def postprocess_files(config):
+    """Hand-through of the stitched predictions into ``output_directory`` (the reference's crown filtering —
+    postprocessing.py — is a later stage outside this round's scope)."""
+    Config()._load_into_config(config)
+    logger = config["logger"]
+    src = os.path.join(config["output_directory"], "geojson_predictions")
+    if not os.path.isdir(src):
+        logger.warning("No stitched predictions to post-process.")
+        return
+    for name in sorted(os.listdir(src)):
+        if name.endswith(".geojson"):
+            shutil.copy(os.path.join(src, name), os.path.join(config["output_directory"], name))
+    logger.info("Postprocessing: stitched predictions copied (height / NDVI crown filtering is not built yet).")
+
+
+def cleanup_files(config):
+    if not config.get("keep_intermediate", False):
+        shutil.rmtree(config["tiles_path"], ignore_errors=True)
+        for folder in os.listdir(config["output_directory"]):
+            p = os.path.join(config["output_directory"], folder)
+            if os.path.isdir(p) and folder != "logs":
+                shutil.rmtree(p, ignore_errors=True)
+
+
+def process_files(config):
+    """Reference detection.py:342-373."""
+    logger = config["logger"]
+    Config()._load_into_config(config)
+    t0 = time.time()
+    preprocess_files(config)
+    t1 = time.time()
+    predict_tiles(config)
+    t2 = time.time()
+    postprocess_files(config)
+    t3 = time.time()
+    cleanup_files(config)
+    logger.debug(f"preprocess step took {t1 - t0} seconds. ")
+    logger.debug(f"predict step took {t2 - t1} seconds. ")
+    logger.debug(f"postprocess step took {t3 - t2} seconds. ")
