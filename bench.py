@@ -210,8 +210,19 @@ def main():
             conv = prof["conv_igemm"]
             peak = PEAK_F32_MATRIX_TFLOPS if args.precision == "fp32" else PEAK_F16_MATRIX_TFLOPS
             ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+            traffic, traffic_src = None, None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_igemm.json")
+            if args.precision == "fp32" and args.depth == 50 and B == 8 and os.path.exists(pmc):
+                # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE x2
+                # gfx950 correction + WRITE_SIZE; tools/pmc_summary.py) — counters cannot be read from inside bench.py
+                with open(pmc) as f:
+                    pj = json.load(f)
+                traffic = pj["hbm_traffic_gb_per_step"] * 1e9 / pj["launches"]
+                traffic_src = "profiles/r01_pmc_conv_igemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
             line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                                "traffic": None,
+                                "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
+                                "algorithmic_bytes_per_launch": conv["bytes"] / max(conv["launches"], 1),
+                                "algorithmic_flops_per_launch": conv["flops"] / max(conv["launches"], 1),
                                 "kernel": "conv_igemm_f32 (all trunk/FPN/RPN/box-head contractions)",
                                 "launches_per_step": conv["launches"] / args.steps,
                                 "avg_launch_us": 1e3 * conv["ms"] / max(conv["launches"], 1),

@@ -48,11 +48,11 @@ def main(path, depth=50):
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         gf = 2.0 * M * N * K / 1e9
         kern = r["Kernel_Name"].split("conv_igemm_")[1].split("(")[0]
-        print(f"{name:24s} M={M:7d} N={N:5d} K={K:6d} {kern:14s} grid={int(r['Grid_Size_X'])//256:5d} {us:9.1f} us {gf:8.2f} GF {gf/us*1e-3 if us else 0:7.1f} TF/s")
+        print(f"{name:24s} M={M:7d} N={N:5d} K={K:6d} {kern:14s} grid={int(r['Grid_Size_X'])//256:5d} {us:9.1f} us {gf:8.2f} GF {gf/us*1e3 if us else 0:7.1f} TF/s")
         if M:
             tot_f += gf
             tot_t += us
-    print(f"static convs: {tot_f:.1f} GF in {tot_t/1e3:.2f} ms = {tot_f/tot_t*1e-3:.1f} TF/s")
+    print(f"static convs: {tot_f:.1f} GF in {tot_t/1e3:.2f} ms = {tot_f/tot_t*1e3:.1f} TF/s")
 
 
 if __name__ == "__main__":

@@ -44,7 +44,9 @@ struct ConvArgs {
     int M;                // B*Ho*Wo
     const int* m_dyn;     // optional device scalar: effective rows = min(M, *m_dyn * m_mul)
     int m_mul;
+    int tile_cfg;         // -1 = heuristic; 0..3 = block tile 128x128, 128x64, 64x128, 64x64 (engine autotunes)
 };
+#define TD_CONV_TILE_CFGS 4
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
 
 // ---- stem / pooling / resize (stem.hip) ---------------------------------------------------------

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs a) {
     const float* __restrict__ Wt = static_cast<const float*>(a.w);
     const int K = a.KH * a.KW * a.Cin;
     const int cchunks = a.Cin / BK;
-    const int nit = a.KH * a.KW * cchunks;
+    const int ntaps = a.KH * a.KW;
+    const int nit = ntaps * cchunks;
 
     // per-thread A rows: pixel index of tap (0,0) and its (iy, ix)
     int a_pix[AROWS], a_iy[AROWS], a_ix[AROWS];
@@ -100,10 +101,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs a) {
 
     f32x4 ra[AROWS], rb[BROWS];
     auto load_global = [&](int it) {
-        const int tap = it / cchunks;
-        const int cc = it - tap * cchunks;
+        // k order: channel chunk OUTER, filter tap INNER — the 9 taps of a 3x3 re-read the same few input rows of one
+        // 128-B channel slice back to back, so the halo re-reads hit L1/L2 instead of going back to HBM
+        const int cc = it / ntaps;
+        const int tap = it - cc * ntaps;
         const int ky = tap / a.KW, kx = tap - ky * a.KW;
         const int coff = cc * BK + ld_c * 4;
+        const size_t woff = (size_t)tap * a.Cin + cc * BK;
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
             const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
-            if (b_ok[i]) rb[i] = *reinterpret_cast<const f32x4*>(Wt + b_off[i] + (size_t)it * BK);
+            if (b_ok[i]) rb[i] = *reinterpret_cast<const f32x4*>(Wt + b_off[i] + woff);
             else rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -169,53 +173,85 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs a) {
         cur ^= 1;
     }
 
-    // ---- epilogue: scale/bias (+residual) (+ReLU), one IEEE op per step (no fma contraction) ----
-    float* __restrict__ Y = static_cast<float*>(a.y);
-    const float* __restrict__ Rs = static_cast<const float*>(a.res);
-    const int Cq = a.out_mode == 1 ? a.Cout >> 2 : a.Cout;
+    // ---- epilogue: accumulators → LDS tile → 16-B-per-lane rows: scale/bias (+residual) (+ReLU), one IEEE op per
+    // step (no fma contraction). Staging through LDS turns the MFMA layout (32 lanes x 4 B per row) into whole
+    // 512-B / 256-B row segments, so residual loads and stores are dwordx4 and fully coalesced (HBM-bound 1x1 layers).
+    constexpr int CS = BN + 4;                         // padded row stride of the staged tile (floats)
+    static_assert(BM * CS <= 2 * (BM + BN) * LDS_STRIDE, "epilogue tile must fit in the k-loop LDS");
+    float* Cs = lds;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = n0 + wn * 32 * NT + j * 32 + (lane & 31);
-        if (n >= a.Cout) continue;
-        const int co = a.out_mode == 1 ? n % Cq : n;
-        const float sc = a.scale ? a.scale[co] : 1.f;
-        const float bi = a.bias ? a.bias[co] : 0.f;
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 * MT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int m = m0 + row;
-                if (m >= M) continue;
-                float v = acc[i][j][r];
-                if (a.scale) v = __fmul_rn(v, sc);
-                if (a.bias) v = __fadd_rn(v, bi);
-                size_t yoff;
-                if (a.out_mode == 0) {
-                    yoff = (size_t)m * a.Cout + n;
-                    if (Rs) {
-                        size_t roff = yoff;
-                        if (a.res_shift) {
-                            const int hw = a.Ho * a.Wo;
-                            const int b = m / hw;
-                            const int rem = m - b * hw;
-                            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-                            roff = ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout + n;
-                        }
-                        v = __fadd_rn(v, Rs[roff]);
-                    }
-                } else {
-                    const int q = n / Cq;   // dy*2+dx
-                    const int hw = a.Ho * a.Wo;
-                    const int b = m / hw;
-                    const int rem = m - b * hw;
-                    const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-                    yoff = ((size_t)(b * 2 * a.Ho + 2 * oy + (q >> 1)) * (2 * a.Wo) + 2 * ox + (q & 1)) * Cq + co;
-                }
-                if (a.relu) v = v > 0.f ? v : 0.f;
-                Y[yoff] = v;
+                const int col = wn * 32 * NT + j * 32 + (lane & 31);
+                Cs[row * CS + col] = acc[i][j][r];
             }
+    __syncthreads();
+
+    float* __restrict__ Y = static_cast<float*>(a.y);
+    const float* __restrict__ Rs = static_cast<const float*>(a.res);
+    const int Cq = a.out_mode == 1 ? a.Cout >> 2 : a.Cout;
+    constexpr int CHUNKS = BN / 4;                     // float4 chunks per tile row
+    constexpr int ROWS_PER_PASS = 256 / CHUNKS;
+    const int c4 = tid % CHUNKS;
+    const int n = n0 + c4 * 4;
+    const bool vec = (a.Cout & 3) == 0 && n + 3 < a.Cout;   // aligned, whole chunk in range
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (n + e < a.Cout) {
+            const int co = a.out_mode == 1 ? (n + e) % Cq : n + e;
+            if (a.scale) sc[e] = a.scale[co];
+            if (a.bias) bi[e] = a.bias[co];
         }
+    }
+    const int hw = a.Ho * a.Wo;
+    for (int row = tid / CHUNKS; row < BM; row += ROWS_PER_PASS) {
+        const int m = m0 + row;
+        if (m >= M || n >= a.Cout) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CS + c4 * 4]);
+        size_t yoff, roff = 0;
+        if (a.out_mode == 0) {
+            yoff = (size_t)m * a.Cout + n;
+            roff = yoff;
+            if (Rs && a.res_shift) {
+                const int b = m / hw;
+                const int rem = m - b * hw;
+                const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+                roff = ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout + n;
+            }
+        } else {
+            const int q = n / Cq, co = n - q * Cq;   // q = dy*2+dx; a chunk never straddles q (Cq % 4 == 0)
+            const int b = m / hw;
+            const int rem = m - b * hw;
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            yoff = ((size_t)(b * 2 * a.Ho + 2 * oy + (q >> 1)) * (2 * a.Wo) + 2 * ox + (q & 1)) * Cq + co;
+        }
+        f32x4 rs = {0.f, 0.f, 0.f, 0.f};
+        if (Rs) {
+            if (vec) rs = *reinterpret_cast<const f32x4*>(Rs + roff);
+            else
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < a.Cout) rs[e] = Rs[roff + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = v[e];
+            if (a.scale) t = __fmul_rn(t, sc[e]);
+            if (a.bias) t = __fadd_rn(t, bi[e]);
+            if (Rs) t = __fadd_rn(t, rs[e]);
+            if (a.relu) t = t > 0.f ? t : 0.f;
+            v[e] = t;
+        }
+        if (vec) *reinterpret_cast<f32x4*>(Y + yoff) = v;
+        else
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < a.Cout) Y[yoff + e] = v[e];
     }
 }
 
@@ -239,8 +275,18 @@ td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream) {
         td_set_error("conv2d: precision %d not built", precision);
         return TD_ERR_INVALID;
     }
-    // tile choice: wide N for wide layers, tall M otherwise; small problems take the 64-row tile
-    const bool small_m = a.M <= 64 * 256;   // fewer than one 128-row tile per CU
-    if (a.Cout <= 64) return small_m ? launch_f32<1, 1>(a, stream) : launch_f32<2, 1>(a, stream);
-    return small_m ? launch_f32<1, 2>(a, stream) : launch_f32<2, 2>(a, stream);
+    int cfg = a.tile_cfg;
+    if (cfg < 0) {
+        // heuristic (the engine replaces it by a measured choice per layer shape): wide N for wide layers, 64-row
+        // tiles when there is less than one 128-row tile per CU
+        const bool small_m = a.M <= 64 * 256;
+        cfg = a.Cout <= 64 ? (small_m ? 3 : 1) : (small_m ? 2 : 0);
+    }
+    switch (cfg) {
+        case 0: return launch_f32<2, 2>(a, stream);
+        case 1: return launch_f32<2, 1>(a, stream);
+        case 2: return launch_f32<1, 2>(a, stream);
+        case 3: return launch_f32<1, 1>(a, stream);
+        default: td_set_error("conv2d: bad tile_cfg %d", cfg); return TD_ERR_INVALID;
+    }
 }

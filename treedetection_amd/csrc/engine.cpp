@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 namespace {
@@ -95,6 +96,10 @@ struct td_engine {
     int *o_classes = nullptr, *o_count = nullptr;
 
     std::map<std::string, NamedTensor> named;
+
+    // measured block-tile choice per (layer weights, rows, stride): filled lazily by the first forward of a shape
+    bool autotune = true;
+    std::map<std::tuple<const void*, int, int>, int> tuned;
 
     // optional per-category device timing (td_engine_profile_*)
     bool prof = false;
@@ -213,7 +218,7 @@ td_status load_conv_bias(td_engine* e, const TensorMap& tm, const std::string& p
 
 td_status run_conv_raw(const ConvLayer& L, const float* x, int B, int H, int W, int stride, int pad, bool relu, float* y,
                        const float* res, int res_shift, hipStream_t s, int precision, const int* m_dyn, int m_mul,
-                       int out_mode) {
+                       int out_mode, int tile_cfg = -1) {
     ConvArgs a{};
     a.x = x; a.w = L.w; a.scale = L.scale; a.bias = L.bias; a.res = res; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = L.cin; a.Cout = L.cout; a.KH = L.kh; a.KW = L.kw;
@@ -221,7 +226,7 @@ td_status run_conv_raw(const ConvLayer& L, const float* x, int B, int H, int W, 
     a.Ho = (H + 2 * pad - L.kh) / stride + 1;
     a.Wo = (W + 2 * pad - L.kw) / stride + 1;
     a.res_shift = res_shift; a.relu = relu ? 1 : 0; a.out_mode = out_mode;
-    a.M = B * a.Ho * a.Wo; a.m_dyn = m_dyn; a.m_mul = m_mul;
+    a.M = B * a.Ho * a.Wo; a.m_dyn = m_dyn; a.m_mul = m_mul; a.tile_cfg = tile_cfg;
     return conv2d_launch(a, precision, s);
 }
 
@@ -592,8 +597,37 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
         const double M = (double)B_ * Ho * Wo, K = (double)L.kh * L.kw * L.cin;
         const double flops = 2.0 * M * L.cout * K;
         const double bytes = 4.0 * ((double)B_ * H_ * W_ * L.cin / (stride * stride) + M * L.cout * (res_ ? 2.0 : 1.0) + L.cout * K);
+        int cfg = -1;
+        if (e->autotune) {
+            const auto key = std::make_tuple((const void*)L.w, B_ * Ho * Wo, stride);
+            auto it = e->tuned.find(key);
+            if (it == e->tuned.end()) {
+                // time every block-tile shape on this very launch (idempotent: same inputs, same output buffer)
+                float best = 1e30f;
+                int best_cfg = -1;
+                hipEvent_t ea, eb;
+                TD_HIP_CHECK(hipEventCreate(&ea));
+                TD_HIP_CHECK(hipEventCreate(&eb));
+                for (int c = 0; c < TD_CONV_TILE_CFGS; ++c) {
+                    td_status st2 = run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, c);
+                    if (st2 < 0) return st2;
+                    TD_HIP_CHECK(hipEventRecord(ea, s_));
+                    for (int rep = 0; rep < 2; ++rep)
+                        if ((st2 = run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, c)) < 0) return st2;
+                    TD_HIP_CHECK(hipEventRecord(eb, s_));
+                    TD_HIP_CHECK(hipEventSynchronize(eb));
+                    float ms = 0.f;
+                    TD_HIP_CHECK(hipEventElapsedTime(&ms, ea, eb));
+                    if (ms < best) { best = ms; best_cfg = c; }
+                }
+                (void)hipEventDestroy(ea);
+                (void)hipEventDestroy(eb);
+                it = e->tuned.emplace(key, best_cfg).first;
+            }
+            cfg = it->second;
+        }
         ProfScope ps(e, s_, m_dyn ? 7 : 0, m_dyn ? 0.0 : flops, m_dyn ? 0.0 : bytes);
-        return run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode);
+        return run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, cfg);
     };
     // ---- backbone ------------------------------------------------------------------------------------------
     { ProfScope ps(e, s, 1);
