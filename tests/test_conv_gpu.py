@@ -54,3 +54,46 @@ def test_conv_matches_torch(case):
     assert got.shape == ref.shape
     err = np.abs(got - ref).max()
     assert err <= 5e-5 * max(1.0, np.abs(ref).max()), f"max abs err {err}"
+
+
+FP16_CASES = [
+    (1, 64, 16, 16, 64, 1, 1, 0, True, True, 0, True),
+    (2, 64, 20, 24, 128, 3, 1, 1, True, True, 0, True),
+    (2, 128, 33, 17, 256, 1, 1, 0, True, True, 1, True),
+    (1, 256, 40, 40, 128, 1, 2, 0, True, True, 0, True),
+    (1, 512, 16, 16, 256, 1, 1, 0, False, True, 2, False),
+    (1, 256, 60, 60, 15, 1, 1, 0, False, True, 0, False),
+    (2, 1024, 13, 13, 512, 1, 1, 0, True, True, 1, True),
+    (1, 256, 50, 50, 256, 3, 1, 1, False, True, 0, True),
+]
+
+
+@pytest.mark.parametrize("case", FP16_CASES)
+def test_conv_fp16_matches_torch(case):
+    """fp16 storage + v_mfma_f32_32x32x16_f16 (fp32 accumulate): compare with an fp32 conv of the SAME fp16-rounded
+    inputs; tolerance = one fp16 rounding of the output (2^-10 relative) plus accumulation-order noise."""
+    B, Cin, H, W, Cout, k, stride, pad, use_scale, use_bias, res, relu = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, Cin, H, W), dtype=np.float32).astype(np.float16).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k), dtype=np.float32) / np.float32(np.sqrt(Cin * k * k))).astype(np.float16).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32) if use_scale else None
+    bias = rng.standard_normal(Cout).astype(np.float32) if use_bias else None
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), None, stride=stride, padding=pad)
+    if use_scale:
+        ref = ref * torch.from_numpy(scale).reshape(1, -1, 1, 1)
+    if use_bias:
+        ref = ref + torch.from_numpy(bias).reshape(1, -1, 1, 1)
+    r = None
+    if res == 1:
+        r = rng.standard_normal(tuple(ref.shape), dtype=np.float32).astype(np.float16).astype(np.float32)
+        ref = ref + torch.from_numpy(r)
+    elif res == 2:
+        Ho, Wo = ref.shape[-2:]
+        r = rng.standard_normal((B, Cout, Ho // 2, Wo // 2), dtype=np.float32).astype(np.float16).astype(np.float32)
+        ref = ref + F.interpolate(torch.from_numpy(r), scale_factor=2.0, mode="nearest")
+    if relu:
+        ref = F.relu(ref)
+    got = conv2d_hip(x, w, scale, bias, r, res_shift=1 if res == 2 else 0, stride=stride, pad=pad, relu=relu, precision=1)
+    ref = ref.numpy()
+    err = np.abs(got - ref)
+    assert (err <= 2e-3 * np.maximum(np.abs(ref), 1.0)).all(), f"max err {err.max()}"

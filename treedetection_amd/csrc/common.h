@@ -44,6 +44,7 @@ struct ConvArgs {
     int M;                // B*Ho*Wo
     const int* m_dyn;     // optional device scalar: effective rows = min(M, *m_dyn * m_mul)
     int m_mul;
+    int out_f32;          // fp16 path only: write y as float32 (RPN / box-predictor heads feed the fp32 selection kernels)
     int tile_cfg;         // -1 = heuristic; 0..3 = block tile 128x128, 128x64, 64x128, 64x64 (engine autotunes)
 };
 #define TD_CONV_TILE_CFGS 4

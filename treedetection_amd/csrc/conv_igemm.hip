@@ -1,32 +1,38 @@
 // Implicit-GEMM NHWC convolution on the gfx950 matrix cores.
 //
 //   y[m][n] = act( (sum_k A[m][k] * Wt[n][k]) * scale[n] + bias[n] (+ residual[m][n]) )
-//   m = (b, oy, ox)   n = output channel   k = (ky, kx, c)  — c fastest, so one k-chunk of 32 is a
-//   contiguous 128-B run of one input pixel (coalesced HBM reads, no im2col buffer).
+//   m = (b, oy, ox)   n = output channel   k = (c-chunk, ky, kx, c-in-chunk)
+//   One k-chunk is a contiguous 128-B run of one input pixel (32 floats / 64 halves): coalesced HBM reads, no
+//   im2col buffer; the chunk loop is OUTER and the filter-tap loop INNER, so the 9 taps of a 3x3 re-read the same
+//   few rows of one channel slice back to back (halo re-reads hit L1/L2; measured HBM traffic 1.27x algorithmic).
 //
 // This one kernel family carries every contraction of the reference's forward
-// (TreeDetection/prediction.py:183 → detectron2 GeneralizedRCNN):
-// bottleneck 1x1 / 3x3 (stride lives in the 1x1, STRIDE_IN_1X1), FPN lateral (+ nearest-2x
-// upsampled top-down add in the epilogue) and output convs, RPN conv + heads, the box-head FCs
-// (1x1 "conv" over R rows), the mask-head 3x3s and the 2x2/s2 deconv (out_mode 1: four 1x1
-// GEMMs with a pixel-shuffle store).
+// (TreeDetection/prediction.py:183 → detectron2 GeneralizedRCNN): bottleneck 1x1 / 3x3
+// (stride lives in the 1x1, STRIDE_IN_1X1), FPN lateral (+ nearest-2x upsampled top-down add in the epilogue) and
+// output convs, RPN conv + heads, the box-head FCs (1x1 "conv" over R rows), the mask-head 3x3s and the 2x2/s2
+// deconv (out_mode 1: four 1x1 GEMMs with a pixel-shuffle store).
 //
-// fp32 path: v_mfma_f32_32x32x2_f32 — exact f32 fmaf chains (MI355X_MICROARCH.md §Matrix cores),
-// 128x128x32 block tile, 4 waves (2x2), 64x64 per wave, LDS rows padded to 36 floats so every
-// ds_read_b128 lane group hits 16 distinct 16-B slots. Global→register→LDS double buffering with
-// one barrier per k-step.
+// Two element types share the structure (everything is addressed in bytes; a k-chunk is 128 B either way):
+//   float    — v_mfma_f32_32x32x2_f32: exact f32 fmaf chains; one 16-B fragment read feeds 4 MFMAs (k-pairs {e,e+4})
+//   _Float16 — v_mfma_f32_32x32x16_f16: f32 accumulate; one 16-B fragment read (8 halves) feeds 1 MFMA
+// Block tile 128x128 (also 128x64, 64x128, 64x64; the engine measures which is fastest per layer), 4 waves as 2x2,
+// LDS rows padded to 144 B so every ds_read_b128 lane group hits 16 distinct 16-B slots, global→register→LDS double
+// buffering with one barrier per k-step, bijective XCD-aware block remap over the live tile count, and an epilogue
+// staged through LDS so residual loads / stores are whole coalesced row segments.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BK = 32;        // k-chunk (floats)
-constexpr int LDS_STRIDE = 36;  // padded row stride in floats (144 B = 9 x 16 B)
+constexpr int CHUNK_BYTES = 128;     // one k-chunk of one row
+constexpr int ROW_BYTES = 144;       // padded LDS row stride (9 x 16 B)
 
-// XCD-aware bijective remap of a 1-D block id: blocks that share an XCD (id % 8) get a
-// contiguous run of tiles, so the A rows / weight panels they share stay in that XCD's L2.
+// XCD-aware bijective remap of a 1-D block id: blocks that share an XCD (id % 8) get a contiguous run of tiles,
+// so the A rows / weight panels they share stay in that XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, local = bid >> 3;
@@ -34,13 +40,36 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return start + local;
 }
 
-template <int MT, int NT>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs a) {
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+    static constexpr int PER_CHUNK = 32;
+    static __device__ __forceinline__ void mma(const f32x4& fa, const f32x4& fb, f32x16& acc) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f32(float v) { return v; }
+};
+template <>
+struct Elem<_Float16> {
+    static constexpr int PER_CHUNK = 64;
+    static __device__ __forceinline__ void mma(const f32x4& fa, const f32x4& fb, f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa), __builtin_bit_cast(f16x8, fb), acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f32(_Float16 v) { return (float)v; }
+};
+
+// T = element type of x / w / residual; TO = element type of y (float outputs are kept for the RPN / box heads)
+template <typename T, typename TO, int MT, int NT>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int BM = 64 * MT, BN = 64 * NT;
-    constexpr int AROWS = BM / 32, BROWS = BN / 32;  // rows staged per thread
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_STRIDE];
-    float* As = lds;                          // [2][BM][36]
-    float* Bs = lds + 2 * BM * LDS_STRIDE;    // [2][BN][36]
+    constexpr int AROWS = BM / 32, BROWS = BN / 32;   // rows staged per thread
+    constexpr int ES = sizeof(T);
+    constexpr int KE = Elem<T>::PER_CHUNK;            // elements per k-chunk
+    __shared__ __attribute__((aligned(16))) char lds[2 * (BM + BN) * ROW_BYTES];
+    char* As = lds;                                   // [2][BM][144 B]
+    char* Bs = lds + 2 * BM * ROW_BYTES;              // [2][BN][144 B]
 
     int M = a.M;
     if (a.m_dyn) {
@@ -60,15 +89,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int ld_c = tid & 7;    // 16-B chunk inside the 128-B k-run
+    const int ld_c = tid & 7;    // 16-B piece inside the 128-B k-chunk
     const int ld_r = tid >> 3;   // 0..31
 
-    const float* __restrict__ X = static_cast<const float*>(a.x);
-    const float* __restrict__ Wt = static_cast<const float*>(a.w);
+    const char* __restrict__ X = static_cast<const char*>(a.x);
+    const char* __restrict__ Wt = static_cast<const char*>(a.w);
     const int K = a.KH * a.KW * a.Cin;
-    const int cchunks = a.Cin / BK;
+    const int cchunks = a.Cin / KE;
     const int ntaps = a.KH * a.KW;
     const int nit = ntaps * cchunks;
+    const size_t pix_bytes = (size_t)a.Cin * ES;
 
     // per-thread A rows: pixel index of tap (0,0) and its (iy, ix)
     int a_pix[AROWS], a_iy[AROWS], a_ix[AROWS];
@@ -96,24 +126,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs a) {
     for (int i = 0; i < BROWS; ++i) {
         const int n = n0 + ld_r + 32 * i;
         b_ok[i] = n < a.Cout;
-        b_off[i] = (size_t)(b_ok[i] ? n : 0) * K + ld_c * 4;
+        b_off[i] = ((size_t)(b_ok[i] ? n : 0) * K) * ES + ld_c * 16;
     }
 
-    f32x4 ra[AROWS], rb[BROWS];
+    f32x4 ra[AROWS], rb[BROWS];   // raw 16-B pieces
     auto load_global = [&](int it) {
-        // k order: channel chunk OUTER, filter tap INNER — the 9 taps of a 3x3 re-read the same few input rows of one
-        // 128-B channel slice back to back, so the halo re-reads hit L1/L2 instead of going back to HBM
         const int cc = it / ntaps;
         const int tap = it - cc * ntaps;
         const int ky = tap / a.KW, kx = tap - ky * a.KW;
-        const int coff = cc * BK + ld_c * 4;
-        const size_t woff = (size_t)tap * a.Cin + cc * BK;
+        const int coff = cc * CHUNK_BYTES + ld_c * 16;
+        const size_t woff = ((size_t)tap * a.Cin) * ES + (size_t)cc * CHUNK_BYTES;
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
             const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
             const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             if (ok) {
-                const size_t off = (size_t)(a_pix[i] + ky * a.W + kx) * a.Cin + coff;
+                const size_t off = (size_t)(a_pix[i] + ky * a.W + kx) * pix_bytes + coff;
                 ra[i] = *reinterpret_cast<const f32x4*>(X + off);
             } else {
                 ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -128,10 +156,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs a) {
     auto store_lds = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < AROWS; ++i)
-            *reinterpret_cast<f32x4*>(&As[(buf * BM + ld_r + 32 * i) * LDS_STRIDE + ld_c * 4]) = ra[i];
+            *reinterpret_cast<f32x4*>(&As[(buf * BM + ld_r + 32 * i) * ROW_BYTES + ld_c * 16]) = ra[i];
 #pragma unroll
         for (int i = 0; i < BROWS; ++i)
-            *reinterpret_cast<f32x4*>(&Bs[(buf * BN + ld_r + 32 * i) * LDS_STRIDE + ld_c * 4]) = rb[i];
+            *reinterpret_cast<f32x4*>(&Bs[(buf * BN + ld_r + 32 * i) * ROW_BYTES + ld_c * 16]) = rb[i];
     };
 
     f32x16 acc[MT][NT];
@@ -147,38 +175,35 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs a) {
     __syncthreads();
 
     const int frag_row = lane & 31;
-    const int frag_k = (lane >> 5) * 4;
+    const int frag_b = (lane >> 5) * 16;     // lanes 0-31 take the first 16 B of each 32-B k-step, lanes 32-63 the second
     int cur = 0;
     for (int it = 0; it < nit; ++it) {
         if (it + 1 < nit) load_global(it + 1);
-        const float* Ab = &As[(cur * BM + wm * 32 * MT + frag_row) * LDS_STRIDE + frag_k];
-        const float* Bb = &Bs[(cur * BN + wn * 32 * NT + frag_row) * LDS_STRIDE + frag_k];
+        const char* Ab = &As[(cur * BM + wm * 32 * MT + frag_row) * ROW_BYTES + frag_b];
+        const char* Bb = &Bs[(cur * BN + wn * 32 * NT + frag_row) * ROW_BYTES + frag_b];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             f32x4 fa[MT], fb[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_STRIDE + kk * 8);
+            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * ROW_BYTES + kk * 32);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_STRIDE + kk * 8);
+            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * ROW_BYTES + kk * 32);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) Elem<T>::mma(fa[i], fb[j], acc[i][j]);
         }
         if (it + 1 < nit) store_lds(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
 
-    // ---- epilogue: accumulators → LDS tile → 16-B-per-lane rows: scale/bias (+residual) (+ReLU), one IEEE op per
-    // step (no fma contraction). Staging through LDS turns the MFMA layout (32 lanes x 4 B per row) into whole
-    // 512-B / 256-B row segments, so residual loads and stores are dwordx4 and fully coalesced (HBM-bound 1x1 layers).
+    // ---- epilogue: accumulators → LDS tile → 4 channels per lane: scale/bias (+residual) (+ReLU), one IEEE op per
+    // step (no fma contraction). Staging through LDS turns the MFMA layout (32 lanes x 4 B per row) into whole row
+    // segments, so residual loads and stores are vector accesses and fully coalesced (HBM-bound 1x1 layers).
     constexpr int CS = BN + 4;                         // padded row stride of the staged tile (floats)
-    static_assert(BM * CS <= 2 * (BM + BN) * LDS_STRIDE, "epilogue tile must fit in the k-loop LDS");
-    float* Cs = lds;
+    static_assert(BM * CS * 4 <= 2 * (BM + BN) * ROW_BYTES, "epilogue tile must fit in the k-loop LDS");
+    float* Cs = reinterpret_cast<float*>(lds);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -191,14 +216,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs a) {
             }
     __syncthreads();
 
-    float* __restrict__ Y = static_cast<float*>(a.y);
-    const float* __restrict__ Rs = static_cast<const float*>(a.res);
+    TO* __restrict__ Y = static_cast<TO*>(a.y);
+    const T* __restrict__ Rs = static_cast<const T*>(a.res);
     const int Cq = a.out_mode == 1 ? a.Cout >> 2 : a.Cout;
-    constexpr int CHUNKS = BN / 4;                     // float4 chunks per tile row
+    constexpr int CHUNKS = BN / 4;                     // 4-channel pieces per tile row
     constexpr int ROWS_PER_PASS = 256 / CHUNKS;
     const int c4 = tid % CHUNKS;
     const int n = n0 + c4 * 4;
-    const bool vec = (a.Cout & 3) == 0 && n + 3 < a.Cout;   // aligned, whole chunk in range
+    const bool vec = (a.Cout & 3) == 0 && n + 3 < a.Cout;   // aligned, whole piece in range
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -224,19 +249,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs a) {
                 roff = ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout + n;
             }
         } else {
-            const int q = n / Cq, co = n - q * Cq;   // q = dy*2+dx; a chunk never straddles q (Cq % 4 == 0)
+            const int q = n / Cq, co = n - q * Cq;   // q = dy*2+dx; a piece never straddles q (Cq % 4 == 0)
             const int b = m / hw;
             const int rem = m - b * hw;
             const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
             yoff = ((size_t)(b * 2 * a.Ho + 2 * oy + (q >> 1)) * (2 * a.Wo) + 2 * ox + (q & 1)) * Cq + co;
         }
-        f32x4 rs = {0.f, 0.f, 0.f, 0.f};
+        float rs[4] = {0.f, 0.f, 0.f, 0.f};
         if (Rs) {
-            if (vec) rs = *reinterpret_cast<const f32x4*>(Rs + roff);
-            else
+            if (vec) {
+                if constexpr (sizeof(T) == 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(Rs + roff);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rs[e] = t[e];
+                } else {
+                    const f16x4 t = *reinterpret_cast<const f16x4*>(Rs + roff);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rs[e] = (float)t[e];
+                }
+            } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (n + e < a.Cout) rs[e] = Rs[roff + e];
+                    if (n + e < a.Cout) rs[e] = Elem<T>::to_f32(Rs[roff + e]);
+            }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -247,34 +282,52 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs a) {
             if (a.relu) t = t > 0.f ? t : 0.f;
             v[e] = t;
         }
-        if (vec) *reinterpret_cast<f32x4*>(Y + yoff) = v;
-        else
+        if (vec) {
+            if constexpr (sizeof(TO) == 4) {
+                *reinterpret_cast<f32x4*>(Y + yoff) = v;
+            } else {
+                f16x4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
+                *reinterpret_cast<f16x4*>(Y + yoff) = h;
+            }
+        } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (n + e < a.Cout) Y[yoff + e] = v[e];
+                if (n + e < a.Cout) Y[yoff + e] = (TO)v[e];
+        }
     }
 }
 
-template <int MT, int NT>
-td_status launch_f32(const ConvArgs& a, hipStream_t stream) {
+template <typename T, typename TO, int MT, int NT>
+td_status launch(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = 64 * MT, BN = 64 * NT;
     const int tiles = td_cdiv(a.M, BM) * td_cdiv(a.Cout, BN);
-    hipLaunchKernelGGL((conv_igemm_f32<MT, NT>), dim3(tiles), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, TO, MT, NT>), dim3(tiles), dim3(256), 0, stream, a);
     TD_KERNEL_CHECK();
     return TD_OK;
+}
+
+template <typename T, typename TO>
+td_status dispatch(const ConvArgs& a, int cfg, hipStream_t stream) {
+    switch (cfg) {
+        case 0: return launch<T, TO, 2, 2>(a, stream);
+        case 1: return launch<T, TO, 2, 1>(a, stream);
+        case 2: return launch<T, TO, 1, 2>(a, stream);
+        case 3: return launch<T, TO, 1, 1>(a, stream);
+        default: td_set_error("conv2d: bad tile_cfg %d", cfg); return TD_ERR_INVALID;
+    }
 }
 
 }  // namespace
 
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream) {
-    TD_REQUIRE(a.Cin % BK == 0, "conv2d: Cin=%d must be a multiple of %d", a.Cin, BK);
+    const int ke = precision == TD_PRECISION_FP16 ? 64 : 32;
+    TD_REQUIRE(precision == TD_PRECISION_FP32 || precision == TD_PRECISION_FP16, "conv2d: bad precision %d", precision);
+    TD_REQUIRE(a.Cin % ke == 0, "conv2d: Cin=%d must be a multiple of %d", a.Cin, ke);
     TD_REQUIRE(a.M > 0 && a.Cout > 0, "conv2d: empty problem (M=%d, Cout=%d)", a.M, a.Cout);
     TD_REQUIRE((size_t)a.B * a.H * a.W * (size_t)a.Cin < (1ull << 31), "conv2d: input too large for 32-bit pixel math");
-    TD_REQUIRE(a.out_mode == 0 || (a.Cout % 4 == 0 && !a.res), "conv2d: bad deconv configuration");
-    if (precision != TD_PRECISION_FP32) {
-        td_set_error("conv2d: precision %d not built", precision);
-        return TD_ERR_INVALID;
-    }
+    TD_REQUIRE(a.out_mode == 0 || (a.Cout % 16 == 0 && !a.res), "conv2d: bad deconv configuration");
     int cfg = a.tile_cfg;
     if (cfg < 0) {
         // heuristic (the engine replaces it by a measured choice per layer shape): wide N for wide layers, 64-row
@@ -282,11 +335,7 @@ td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream) {
         const bool small_m = a.M <= 64 * 256;
         cfg = a.Cout <= 64 ? (small_m ? 3 : 1) : (small_m ? 2 : 0);
     }
-    switch (cfg) {
-        case 0: return launch_f32<2, 2>(a, stream);
-        case 1: return launch_f32<2, 1>(a, stream);
-        case 2: return launch_f32<1, 2>(a, stream);
-        case 3: return launch_f32<1, 1>(a, stream);
-        default: td_set_error("conv2d: bad tile_cfg %d", cfg); return TD_ERR_INVALID;
-    }
+    if (precision == TD_PRECISION_FP32) return dispatch<float, float>(a, cfg, stream);
+    if (a.out_f32) return dispatch<_Float16, float>(a, cfg, stream);
+    return dispatch<_Float16, _Float16>(a, cfg, stream);
 }

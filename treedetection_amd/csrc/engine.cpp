@@ -29,9 +29,10 @@ struct HostTensor {
 
 struct ConvLayer {
     int cout = 0, cin = 0, kh = 1, kw = 1;
-    float* w = nullptr;       // [cout][kh][kw][cin]
+    void* w = nullptr;        // [cout][kh][kw][cin], float32 or float16 (engine precision)
     float* scale = nullptr;   // [cout] or null
     float* bias = nullptr;    // [cout] or null
+    bool out_f32 = false;     // fp16 engine: this layer still writes float32 (feeds the fp32 selection kernels)
 };
 
 struct Block {
@@ -71,10 +72,12 @@ struct td_engine {
 
     // workspace (sized by reserve)
     int rB = 0, rHp = 0, rWp = 0;
-    float *stem_out = nullptr, *pool_out = nullptr;
-    float *t1[4] = {}, *t2[4] = {}, *scb[4] = {}, *res[4] = {}, *xtmp[4] = {};
-    float *inner[4] = {}, *pfeat[5] = {};
-    float *rpn_t = nullptr, *rpn_headbuf[5] = {};
+    // activations (element type = engine precision)
+    void *stem_out = nullptr, *pool_out = nullptr;
+    void *t1[4] = {}, *t2[4] = {}, *scb[4] = {}, *res[4] = {}, *xtmp[4] = {};
+    void *inner[4] = {}, *pfeat[5] = {};
+    void* rpn_t = nullptr;
+    float* rpn_headbuf[5] = {};
     uint32_t* key_ws = nullptr;
     float *cand_boxes = nullptr, *cand_scores = nullptr;
     int *cand_valid = nullptr, *cand_idx = nullptr;
@@ -82,13 +85,14 @@ struct td_engine {
     int *rpn_keep = nullptr, *rpn_keep_count = nullptr;
     float *props = nullptr, *prop_scores = nullptr;
     int* prop_count = nullptr;
-    float *pooled7 = nullptr, *fc1_out = nullptr, *fc2_out = nullptr, *pred_out = nullptr;
+    void *pooled7 = nullptr, *fc1_out = nullptr, *fc2_out = nullptr;
+    float* pred_out = nullptr;
     float *dboxes = nullptr, *dscores = nullptr;
     int* dflags = nullptr;
     float *sboxes = nullptr, *sscores = nullptr;
     int *sidx = nullptr, *scount = nullptr, *det_keep = nullptr, *det_keep_count = nullptr;
     float* det_boxes_net = nullptr;
-    float *pooled14 = nullptr, *mbuf0 = nullptr, *mbuf1 = nullptr, *deconv_out = nullptr;
+    void *pooled14 = nullptr, *mbuf0 = nullptr, *mbuf1 = nullptr, *deconv_out = nullptr;
     float *mask_logits = nullptr, *mask_probs_compact = nullptr;
     int* total_rows = nullptr;
     // fallback outputs when the caller passes NULL fields
@@ -129,6 +133,22 @@ td_status upload(td_engine* e, const std::vector<T>& h, T** d) {
     TD_HIP_CHECK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     *d = static_cast<T*>(p);
     return TD_OK;
+}
+
+// conv / fc weight matrix in the engine's precision (float16: round-to-nearest-even on the host)
+td_status upload_w(td_engine* e, const std::vector<float>& h, void** d) {
+    if (e->desc.precision == TD_PRECISION_FP16) {
+        std::vector<_Float16> hh(h.size());
+        for (size_t i = 0; i < h.size(); ++i) hh[i] = (_Float16)h[i];
+        _Float16* p = nullptr;
+        td_status st = upload(e, hh, &p);
+        *d = p;
+        return st;
+    }
+    float* p = nullptr;
+    td_status st = upload(e, h, &p);
+    *d = p;
+    return st;
 }
 
 using TensorMap = std::map<std::string, HostTensor>;
@@ -191,7 +211,7 @@ td_status load_conv_bn(td_engine* e, const TensorMap& tm, const std::string& p, 
     L.cin = (int)w->shape[1];
     L.kh = (int)w->shape[2];
     L.kw = (int)w->shape[3];
-    if ((st = upload(e, pack_ohwi(*w), &L.w)) < 0) return st;
+    if ((st = upload_w(e, pack_ohwi(*w), &L.w)) < 0) return st;
     std::vector<float> s, b;
     if ((st = bn_fold(tm, p, L.cout, s, b)) < 0) return st;
     if ((st = upload(e, s, &L.scale)) < 0) return st;
@@ -211,13 +231,13 @@ td_status load_conv_bias(td_engine* e, const TensorMap& tm, const std::string& p
         td_set_error("load_weights: bias of '%s' has wrong length", p.c_str());
         return TD_ERR_WEIGHTS;
     }
-    if ((st = upload(e, pack_ohwi(*w), &L.w)) < 0) return st;
+    if ((st = upload_w(e, pack_ohwi(*w), &L.w)) < 0) return st;
     L.scale = nullptr;
     return upload(e, std::vector<float>(b->data, b->data + L.cout), &L.bias);
 }
 
-td_status run_conv_raw(const ConvLayer& L, const float* x, int B, int H, int W, int stride, int pad, bool relu, float* y,
-                       const float* res, int res_shift, hipStream_t s, int precision, const int* m_dyn, int m_mul,
+td_status run_conv_raw(const ConvLayer& L, const void* x, int B, int H, int W, int stride, int pad, bool relu, void* y,
+                       const void* res, int res_shift, hipStream_t s, int precision, const int* m_dyn, int m_mul,
                        int out_mode, int tile_cfg = -1) {
     ConvArgs a{};
     a.x = x; a.w = L.w; a.scale = L.scale; a.bias = L.bias; a.res = res; a.y = y;
@@ -226,7 +246,7 @@ td_status run_conv_raw(const ConvLayer& L, const float* x, int B, int H, int W, 
     a.Ho = (H + 2 * pad - L.kh) / stride + 1;
     a.Wo = (W + 2 * pad - L.kw) / stride + 1;
     a.res_shift = res_shift; a.relu = relu ? 1 : 0; a.out_mode = out_mode;
-    a.M = B * a.Ho * a.Wo; a.m_dyn = m_dyn; a.m_mul = m_mul; a.tile_cfg = tile_cfg;
+    a.M = B * a.Ho * a.Wo; a.m_dyn = m_dyn; a.m_mul = m_mul; a.tile_cfg = tile_cfg; a.out_f32 = L.out_f32 ? 1 : 0;
     return conv2d_launch(a, precision, s);
 }
 
@@ -286,7 +306,7 @@ td_status td_engine_create(const td_model_desc* desc, int device, td_engine** ou
     td_model_desc d;
     if (desc) d = *desc; else td_model_desc_default(&d);
     TD_REQUIRE(d.num_classes == 1, "td_engine_create: num_classes=%d (the reference configures exactly 1, config.py:35)", d.num_classes);
-    TD_REQUIRE(d.precision == TD_PRECISION_FP32, "td_engine_create: precision %d not built in this round (fp32 only)", d.precision);
+    TD_REQUIRE(d.precision == TD_PRECISION_FP32 || d.precision == TD_PRECISION_FP16, "td_engine_create: bad precision %d", d.precision);
     TD_REQUIRE(d.pre_nms_topk >= 1 && d.pre_nms_topk <= RPN_CAND, "td_engine_create: pre_nms_topk must be in [1,%d]", RPN_CAND);
     TD_REQUIRE(d.post_nms_topk >= 1 && d.post_nms_topk <= 1024, "td_engine_create: post_nms_topk must be in [1,1024]");
     TD_REQUIRE(d.detections_per_image >= 1 && d.detections_per_image <= 1024, "td_engine_create: detections_per_image must be in [1,1024]");
@@ -389,7 +409,8 @@ td_status td_engine_load_weights(td_engine* e, const td_tensor_desc* tensors, si
         std::memcpy(b.data(), bo->data, sizeof(float) * RPN_A);
         std::memcpy(b.data() + RPN_A, bd->data, sizeof(float) * 4 * RPN_A);
         e->rpn_head.cout = RPN_HEAD_C; e->rpn_head.cin = c; e->rpn_head.kh = e->rpn_head.kw = 1;
-        if ((st = upload(e, w, &e->rpn_head.w)) < 0) return st;
+        e->rpn_head.out_f32 = true;
+        if ((st = upload_w(e, w, &e->rpn_head.w)) < 0) return st;
         if ((st = upload(e, b, &e->rpn_head.bias)) < 0) return st;
     }
     {   // fc1: input index c*49 + y*7 + x → (y*7 + x)*C + c (RoIAlign writes NHWC rows)
@@ -407,7 +428,7 @@ td_status td_engine_load_weights(td_engine* e, const td_tensor_desc* tensors, si
                 for (int q = 0; q < 49; ++q) p[(size_t)r * c * 49 + (size_t)q * c + ch] = w->data[(size_t)r * c * 49 + (size_t)ch * 49 + q];
         e->fc1.cout = o; e->fc1.cin = c * 49; e->fc1.kh = e->fc1.kw = 1;
         e->fc_dim = o;
-        if ((st = upload(e, p, &e->fc1.w)) < 0) return st;
+        if ((st = upload_w(e, p, &e->fc1.w)) < 0) return st;
         if ((st = upload(e, std::vector<float>(b->data, b->data + o), &e->fc1.bias)) < 0) return st;
     }
     {
@@ -415,7 +436,7 @@ td_status td_engine_load_weights(td_engine* e, const td_tensor_desc* tensors, si
         if ((st = need(tm, "roi_heads.box_head.fc2.weight", 2, &w)) < 0) return st;
         if ((st = need(tm, "roi_heads.box_head.fc2.bias", 1, &b)) < 0) return st;
         e->fc2.cout = (int)w->shape[0]; e->fc2.cin = (int)w->shape[1]; e->fc2.kh = e->fc2.kw = 1;
-        if ((st = upload(e, std::vector<float>(w->data, w->data + w->numel()), &e->fc2.w)) < 0) return st;
+        if ((st = upload_w(e, std::vector<float>(w->data, w->data + w->numel()), &e->fc2.w)) < 0) return st;
         if ((st = upload(e, std::vector<float>(b->data, b->data + e->fc2.cout), &e->fc2.bias)) < 0) return st;
     }
     {
@@ -436,7 +457,8 @@ td_status td_engine_load_weights(td_engine* e, const td_tensor_desc* tensors, si
         std::memcpy(b.data(), bc->data, sizeof(float) * 2);
         std::memcpy(b.data() + 2, br->data, sizeof(float) * 4);
         e->pred.cout = 6; e->pred.cin = k; e->pred.kh = e->pred.kw = 1;
-        if ((st = upload(e, w, &e->pred.w)) < 0) return st;
+        e->pred.out_f32 = true;
+        if ((st = upload_w(e, w, &e->pred.w)) < 0) return st;
         if ((st = upload(e, b, &e->pred.bias)) < 0) return st;
     }
     for (int i = 0; i < 4; ++i)
@@ -455,7 +477,7 @@ td_status td_engine_load_weights(td_engine* e, const td_tensor_desc* tensors, si
             for (int o = 0; o < co; ++o)
                 for (int q = 0; q < 4; ++q) p[((size_t)q * co + o) * ci + i] = w->data[((size_t)i * co + o) * 4 + q];
         e->deconv.cout = 4 * co; e->deconv.cin = ci; e->deconv.kh = e->deconv.kw = 1;
-        if ((st = upload(e, p, &e->deconv.w)) < 0) return st;
+        if ((st = upload_w(e, p, &e->deconv.w)) < 0) return st;
         if ((st = upload(e, std::vector<float>(b->data, b->data + co), &e->deconv.bias)) < 0) return st;
     }
     {
@@ -491,11 +513,13 @@ td_status td_engine_reserve(td_engine* e, int B, int Hp, int Wp) {
         *p = static_cast<std::remove_reference_t<decltype(*p)>>(q);
         return st;
     };
+    const size_t es = e->desc.precision == TD_PRECISION_FP16 ? 2 : 4;
+    auto AA = [&](void** p, size_t elems) -> td_status { return dev_alloc(e->ws_allocs, p, elems * es); };
     td_status st;
     const size_t b = B;
     const int H2 = Hp / 4, W2 = Wp / 4;
-    if ((st = A(&e->stem_out, b * (Hp / 2) * (Wp / 2) * e->stem_c)) < 0) return st;
-    if ((st = A(&e->pool_out, b * H2 * W2 * e->stem_c)) < 0) return st;
+    if ((st = AA(&e->stem_out, b * (Hp / 2) * (Wp / 2) * e->stem_c)) < 0) return st;
+    if ((st = AA(&e->pool_out, b * H2 * W2 * e->stem_c)) < 0) return st;
     int hs[5], wsz[5];
     for (int l = 0; l < 4; ++l) {
         hs[l] = Hp >> (l + 2);
@@ -506,21 +530,21 @@ td_status td_engine_reserve(td_engine* e, int B, int Hp, int Wp) {
     for (int s = 0; s < 4; ++s) {
         const size_t px = b * hs[s] * wsz[s];
         const int mid = e->stages[s][0].c1.cout, co = e->stages[s][0].c3.cout;
-        if ((st = A(&e->t1[s], px * mid)) < 0) return st;
-        if ((st = A(&e->t2[s], px * mid)) < 0) return st;
-        if ((st = A(&e->scb[s], px * co)) < 0) return st;
-        if ((st = A(&e->res[s], px * co)) < 0) return st;
-        if ((st = A(&e->xtmp[s], px * co)) < 0) return st;
-        if ((st = A(&e->inner[s], px * e->fpn_c)) < 0) return st;
+        if ((st = AA(&e->t1[s], px * mid)) < 0) return st;
+        if ((st = AA(&e->t2[s], px * mid)) < 0) return st;
+        if ((st = AA(&e->scb[s], px * co)) < 0) return st;
+        if ((st = AA(&e->res[s], px * co)) < 0) return st;
+        if ((st = AA(&e->xtmp[s], px * co)) < 0) return st;
+        if ((st = AA(&e->inner[s], px * e->fpn_c)) < 0) return st;
     }
     size_t total_anchors = 0;
     for (int l = 0; l < 5; ++l) {
         const size_t px = b * hs[l] * wsz[l];
-        if ((st = A(&e->pfeat[l], px * e->fpn_c)) < 0) return st;
+        if ((st = AA(&e->pfeat[l], px * e->fpn_c)) < 0) return st;
         if ((st = A(&e->rpn_headbuf[l], px * RPN_HEAD_C)) < 0) return st;
         total_anchors += (size_t)hs[l] * wsz[l] * RPN_A;
     }
-    if ((st = A(&e->rpn_t, b * hs[0] * wsz[0] * e->fpn_c)) < 0) return st;
+    if ((st = AA(&e->rpn_t, b * hs[0] * wsz[0] * e->fpn_c)) < 0) return st;
     if ((st = A(&e->key_ws, b * total_anchors)) < 0) return st;
     const size_t nc = b * RPN_LEVELS * RPN_CAND;
     if ((st = A(&e->cand_boxes, nc * 4)) < 0) return st;
@@ -534,9 +558,9 @@ td_status td_engine_reserve(td_engine* e, int B, int Hp, int Wp) {
     if ((st = A(&e->props, b * P * 4)) < 0) return st;
     if ((st = A(&e->prop_scores, b * P)) < 0) return st;
     if ((st = A(&e->prop_count, b)) < 0) return st;
-    if ((st = A(&e->pooled7, b * P * 49 * e->fpn_c)) < 0) return st;
-    if ((st = A(&e->fc1_out, b * P * e->fc_dim)) < 0) return st;
-    if ((st = A(&e->fc2_out, b * P * e->fc_dim)) < 0) return st;
+    if ((st = AA(&e->pooled7, b * P * 49 * e->fpn_c)) < 0) return st;
+    if ((st = AA(&e->fc1_out, b * P * e->fc_dim)) < 0) return st;
+    if ((st = AA(&e->fc2_out, b * P * e->fc_dim)) < 0) return st;
     if ((st = A(&e->pred_out, b * P * 6)) < 0) return st;
     if ((st = A(&e->dboxes, b * P * 4)) < 0) return st;
     if ((st = A(&e->dscores, b * P)) < 0) return st;
@@ -549,10 +573,10 @@ td_status td_engine_reserve(td_engine* e, int B, int Hp, int Wp) {
     if ((st = A(&e->det_keep_count, b)) < 0) return st;
     if ((st = A(&e->det_boxes_net, b * D * 4)) < 0) return st;
     const size_t mrows = b * D;
-    if ((st = A(&e->pooled14, mrows * 196 * e->fpn_c)) < 0) return st;
-    if ((st = A(&e->mbuf0, mrows * 196 * e->fpn_c)) < 0) return st;
-    if ((st = A(&e->mbuf1, mrows * 196 * e->fpn_c)) < 0) return st;
-    if ((st = A(&e->deconv_out, mrows * 784 * (e->deconv.cout / 4))) < 0) return st;
+    if ((st = AA(&e->pooled14, mrows * 196 * e->fpn_c)) < 0) return st;
+    if ((st = AA(&e->mbuf0, mrows * 196 * e->fpn_c)) < 0) return st;
+    if ((st = AA(&e->mbuf1, mrows * 196 * e->fpn_c)) < 0) return st;
+    if ((st = AA(&e->deconv_out, mrows * 784 * (e->deconv.cout / 4))) < 0) return st;
     if ((st = A(&e->mask_logits, mrows * 784)) < 0) return st;
     if ((st = A(&e->mask_probs_compact, mrows * 784)) < 0) return st;
     if ((st = A(&e->total_rows, 4)) < 0) return st;
@@ -590,13 +614,14 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
     }
     e->named.clear();
     td_status st;
-    auto run_conv = [&](const ConvLayer& L, const float* x_, int B_, int H_, int W_, int stride, int pad, bool relu,
-                        float* y_, const float* res_, int res_shift, hipStream_t s_, int prec_,
+    auto run_conv = [&](const ConvLayer& L, const void* x_, int B_, int H_, int W_, int stride, int pad, bool relu,
+                        void* y_, const void* res_, int res_shift, hipStream_t s_, int prec_,
                         const int* m_dyn = nullptr, int m_mul = 1, int out_mode = 0) -> td_status {
         const int Ho = (H_ + 2 * pad - L.kh) / stride + 1, Wo = (W_ + 2 * pad - L.kw) / stride + 1;
         const double M = (double)B_ * Ho * Wo, K = (double)L.kh * L.kw * L.cin;
         const double flops = 2.0 * M * L.cout * K;
-        const double bytes = 4.0 * ((double)B_ * H_ * W_ * L.cin / (stride * stride) + M * L.cout * (res_ ? 2.0 : 1.0) + L.cout * K);
+        const double es = prec_ == TD_PRECISION_FP16 ? 2.0 : 4.0;
+        const double bytes = es * ((double)B_ * H_ * W_ * L.cin / (stride * stride) + M * L.cout * (res_ ? 2.0 : 1.0) + L.cout * K);
         int cfg = -1;
         if (e->autotune) {
             const auto key = std::make_tuple((const void*)L.w, B_ * Ho * Wo, stride);
@@ -633,10 +658,10 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
     { ProfScope ps(e, s, 1);
     if ((st = stem_launch(images, input_format, valid, B, Hp, Wp, e->stem_w, e->stem_scale, e->stem_bias, e->stem_out,
                           e->stem_c, prec, s)) < 0) return st; }
-    set_named(e, "stem", e->stem_out, B, Hp / 2, Wp / 2, e->stem_c);
+    set_named(e, "stem", e->stem_out, B, Hp / 2, Wp / 2, e->stem_c, (e->desc.precision == TD_PRECISION_FP16 ? 2 : 4));
     { ProfScope ps(e, s, 2);
     if ((st = maxpool3x3s2_launch(e->stem_out, e->pool_out, B, Hp / 2, Wp / 2, e->stem_c, prec, s)) < 0) return st; }
-    set_named(e, "pool", e->pool_out, B, Hp / 4, Wp / 4, e->stem_c);
+    set_named(e, "pool", e->pool_out, B, Hp / 4, Wp / 4, e->stem_c, (e->desc.precision == TD_PRECISION_FP16 ? 2 : 4));
     int hs[5], wsz[5];
     for (int l = 0; l < 4; ++l) {
         hs[l] = Hp >> (l + 2);
@@ -644,7 +669,7 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
     }
     hs[4] = (hs[3] - 1) / 2 + 1;
     wsz[4] = (wsz[3] - 1) / 2 + 1;
-    const float* x = e->pool_out;
+    const void* x = e->pool_out;
     int xh = hs[0], xw = wsz[0];
     for (int si = 0; si < 4; ++si) {
         const int nb = (int)e->stages[si].size();
@@ -652,8 +677,8 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
         for (int bi = 0; bi < nb; ++bi) {
             const Block& blk = e->stages[si][bi];
             // the last block must land in res[si]: alternate so that block nb-1 writes res
-            float* y = ((nb - 1 - bi) % 2 == 0) ? e->res[si] : e->xtmp[si];
-            const float* shortcut = x;
+            void* y = ((nb - 1 - bi) % 2 == 0) ? e->res[si] : e->xtmp[si];
+            const void* shortcut = x;
             if (blk.has_sc) {
                 if ((st = run_conv(blk.sc, x, B, xh, xw, blk.stride, 0, false, e->scb[si], nullptr, 0, s, prec)) < 0) return st;
                 shortcut = e->scb[si];
@@ -666,11 +691,11 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
             xw = ow;
         }
         const std::string nm = "res" + std::to_string(si + 2);
-        set_named(e, nm.c_str(), e->res[si], B, oh, ow, e->stages[si][0].c3.cout);
+        set_named(e, nm.c_str(), e->res[si], B, oh, ow, e->stages[si][0].c3.cout, (e->desc.precision == TD_PRECISION_FP16 ? 2 : 4));
     }
     // ---- FPN (top-down; the nearest-2x upsampled add rides in the lateral conv's epilogue) ---------------------
     for (int l = 3; l >= 0; --l) {
-        const float* td_res = l == 3 ? nullptr : e->inner[l + 1];
+        const void* td_res = l == 3 ? nullptr : e->inner[l + 1];
         if ((st = run_conv(e->lateral[l], e->res[l], B, hs[l], wsz[l], 1, 0, false, e->inner[l], td_res, td_res ? 1 : 0, s, prec)) < 0) return st;
         if ((st = run_conv(e->fpn_out[l], e->inner[l], B, hs[l], wsz[l], 1, 1, false, e->pfeat[l], nullptr, 0, s, prec)) < 0) return st;
     }
@@ -678,7 +703,7 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
     if ((st = subsample2_launch(e->pfeat[3], e->pfeat[4], B, hs[3], wsz[3], e->fpn_c, prec, s)) < 0) return st; }
     for (int l = 0; l < 5; ++l) {
         const std::string nm = "p" + std::to_string(l + 2);
-        set_named(e, nm.c_str(), e->pfeat[l], B, hs[l], wsz[l], e->fpn_c);
+        set_named(e, nm.c_str(), e->pfeat[l], B, hs[l], wsz[l], e->fpn_c, (e->desc.precision == TD_PRECISION_FP16 ? 2 : 4));
     }
     // ---- RPN -----------------------------------------------------------------------------------------------------
     RpnLevels lv{};
@@ -739,7 +764,7 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
     fl.C = e->fpn_c;
     { ProfScope ps(e, s, 4);
     if ((st = roi_align_launch(fl, e->props, e->prop_count, B, P, 7, 0, e->pooled7, nullptr, prec, s)) < 0) return st; }
-    set_named(e, "pooled7", e->pooled7, (int64_t)B * P, 7, 7, e->fpn_c);
+    set_named(e, "pooled7", e->pooled7, (int64_t)B * P, 7, 7, e->fpn_c, (e->desc.precision == TD_PRECISION_FP16 ? 2 : 4));
     if ((st = run_conv(e->fc1, e->pooled7, B * P, 1, 1, 1, 0, true, e->fc1_out, nullptr, 0, s, prec)) < 0) return st;
     if ((st = run_conv(e->fc2, e->fc1_out, B * P, 1, 1, 1, 0, true, e->fc2_out, nullptr, 0, s, prec)) < 0) return st;
     if ((st = run_conv(e->pred, e->fc2_out, B * P, 1, 1, 1, 0, false, e->pred_out, nullptr, 0, s, prec)) < 0) return st;
@@ -768,9 +793,9 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
     const int mrows = B * D;
     { ProfScope ps(e, s, 4);
     if ((st = roi_align_launch(fl, e->det_boxes_net, o_count, B, D, 14, 1, e->pooled14, e->total_rows, prec, s)) < 0) return st; }
-    set_named(e, "pooled14", e->pooled14, mrows, 14, 14, e->fpn_c);
-    const float* mx = e->pooled14;
-    float* mbuf[2] = {e->mbuf0, e->mbuf1};
+    set_named(e, "pooled14", e->pooled14, mrows, 14, 14, e->fpn_c, (e->desc.precision == TD_PRECISION_FP16 ? 2 : 4));
+    const void* mx = e->pooled14;
+    void* mbuf[2] = {e->mbuf0, e->mbuf1};
     for (int i = 0; i < 4; ++i) {
         if ((st = run_conv(e->mask_fcn[i], mx, mrows, 14, 14, 1, 1, true, mbuf[i & 1], nullptr, 0, s, prec, e->total_rows, 196)) < 0) return st;
         mx = mbuf[i & 1];

@@ -8,6 +8,19 @@
 
 namespace {
 
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const _Float16* p) {
+    const h4 v = *reinterpret_cast<const h4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void store4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void store4(_Float16* p, const float4& v) {
+    h4 h;
+    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+    *reinterpret_cast<h4*>(p) = h;
+}
+
 __device__ __forceinline__ int fpn_level(float x1, float y1, float x2, float y2) {
     const float area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
     const float s = sqrtf(area);
@@ -40,7 +53,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(FeatLevels fl, const flo
     const int lvl = single_level ? 0 : fpn_level(bx.x, bx.y, bx.z, bx.w);
     const int H = fl.h[lvl], W = fl.w[lvl], C = fl.C;
     const float sc = fl.scale[lvl];
-    const float* __restrict__ feat = static_cast<const float*>(fl.feat[lvl]) + (single_level ? 0 : (size_t)item * H * W * C);
+    const T* __restrict__ feat = static_cast<const T*>(fl.feat[lvl]) + (single_level ? 0 : (size_t)item * H * W * C);
 
     const float sw = __fsub_rn(__fmul_rn(bx.x, sc), 0.5f), sh = __fsub_rn(__fmul_rn(bx.y, sc), 0.5f);
     const float ew = __fsub_rn(__fmul_rn(bx.z, sc), 0.5f), eh = __fsub_rn(__fmul_rn(bx.w, sc), 0.5f);
@@ -72,10 +85,10 @@ __global__ __launch_bounds__(256) void roi_align_kernel(FeatLevels fl, const flo
                     const float ly = __fsub_rn(yy, (float)yl), lx = __fsub_rn(xx, (float)xl);
                     const float hy = __fsub_rn(1.f, ly), hx = __fsub_rn(1.f, lx);
                     const float w1 = __fmul_rn(hy, hx), w2 = __fmul_rn(hy, lx), w3 = __fmul_rn(ly, hx), w4 = __fmul_rn(ly, lx);
-                    const float4 v1 = *reinterpret_cast<const float4*>(feat + ((size_t)yl * W + xl) * C + c0);
-                    const float4 v2 = *reinterpret_cast<const float4*>(feat + ((size_t)yl * W + xh) * C + c0);
-                    const float4 v3 = *reinterpret_cast<const float4*>(feat + ((size_t)yh * W + xl) * C + c0);
-                    const float4 v4 = *reinterpret_cast<const float4*>(feat + ((size_t)yh * W + xh) * C + c0);
+                    const float4 v1 = load4(feat + ((size_t)yl * W + xl) * C + c0);
+                    const float4 v2 = load4(feat + ((size_t)yl * W + xh) * C + c0);
+                    const float4 v3 = load4(feat + ((size_t)yh * W + xl) * C + c0);
+                    const float4 v4 = load4(feat + ((size_t)yh * W + xh) * C + c0);
 #define TD_RA(f) acc.f = __fadd_rn(acc.f, __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w1, v1.f), __fmul_rn(w2, v2.f)), __fmul_rn(w3, v3.f)), __fmul_rn(w4, v4.f)))
                     TD_RA(x); TD_RA(y); TD_RA(z); TD_RA(w);
 #undef TD_RA
@@ -85,7 +98,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(FeatLevels fl, const flo
             acc.y = __fdiv_rn(acc.y, count);
             acc.z = __fdiv_rn(acc.z, count);
             acc.w = __fdiv_rn(acc.w, count);
-            *reinterpret_cast<float4*>(out + (row * nbins + bin) * C + c0) = acc;
+            store4(out + (row * nbins + bin) * C + c0, acc);
         }
     }
 }
@@ -162,7 +175,8 @@ __global__ void det_finalize_kernel(const float* __restrict__ sboxes, const floa
 }
 
 // mask predictor: one wave per pixel, dot over C channels, + bias, sigmoid
-__global__ __launch_bounds__(256) void mask_predict_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <typename T>
+__global__ __launch_bounds__(256) void mask_predict_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                            float bias, int C, int rows_max, const int* __restrict__ rows_dyn,
                                                            int rows_mul, float* __restrict__ logits,
                                                            float* __restrict__ probs) {
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(256) void mask_predict_kernel(const float* __restri
     if (row >= rows) return;
     float acc = 0.f;
     for (int c = lane * 4; c < C; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * C + c);
+        const float4 v = load4(x + (size_t)row * C + c);
         const float4 k = *reinterpret_cast<const float4*>(w + c);
         acc = __fmaf_rn(v.x, k.x, acc);
         acc = __fmaf_rn(v.y, k.y, acc);
@@ -291,22 +305,28 @@ __global__ __launch_bounds__(256) void paste_fill_kernel(const float* __restrict
 
 td_status roi_align_launch(const FeatLevels& fl, const float* rois, const int* counts, int items, int roi_stride,
                            int pooled, int compact, void* out, int* total_rows, int precision, hipStream_t stream) {
-    TD_REQUIRE(precision == TD_PRECISION_FP32, "roi_align: precision %d not built", precision);
     TD_REQUIRE(fl.C % 4 == 0, "roi_align: C must be a multiple of 4");
-    hipLaunchKernelGGL((roi_align_kernel<float>), dim3(roi_stride, items), dim3(256), 0, stream, fl, rois, counts, items,
-                       roi_stride, pooled, compact, static_cast<float*>(out), total_rows, 0);
+    if (precision == TD_PRECISION_FP16)
+        hipLaunchKernelGGL((roi_align_kernel<_Float16>), dim3(roi_stride, items), dim3(256), 0, stream, fl, rois, counts,
+                           items, roi_stride, pooled, compact, static_cast<_Float16*>(out), total_rows, 0);
+    else
+        hipLaunchKernelGGL((roi_align_kernel<float>), dim3(roi_stride, items), dim3(256), 0, stream, fl, rois, counts,
+                           items, roi_stride, pooled, compact, static_cast<float*>(out), total_rows, 0);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
 
 td_status roi_align_single_launch(const void* feat, int H, int W, int C, const float* rois, int R, float scale,
                                   int pooled, void* out, int precision, hipStream_t stream) {
-    TD_REQUIRE(precision == TD_PRECISION_FP32, "roi_align: precision %d not built", precision);
     TD_REQUIRE(C % 4 == 0 && R >= 1, "roi_align: bad shape");
     FeatLevels fl{};
     fl.feat[0] = feat; fl.h[0] = H; fl.w[0] = W; fl.scale[0] = scale; fl.C = C;
-    hipLaunchKernelGGL((roi_align_kernel<float>), dim3(R, 1), dim3(256), 0, stream, fl, rois, (const int*)nullptr, 1, R,
-                       pooled, 0, static_cast<float*>(out), (int*)nullptr, 1);
+    if (precision == TD_PRECISION_FP16)
+        hipLaunchKernelGGL((roi_align_kernel<_Float16>), dim3(R, 1), dim3(256), 0, stream, fl, rois, (const int*)nullptr,
+                           1, R, pooled, 0, static_cast<_Float16*>(out), (int*)nullptr, 1);
+    else
+        hipLaunchKernelGGL((roi_align_kernel<float>), dim3(R, 1), dim3(256), 0, stream, fl, rois, (const int*)nullptr, 1,
+                           R, pooled, 0, static_cast<float*>(out), (int*)nullptr, 1);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
@@ -332,10 +352,14 @@ td_status det_finalize_launch(const float* sboxes, const float* sscores, const i
 
 td_status mask_predict_launch(const void* x, const float* w, float bias, int C, int rows_max, const int* rows_dyn,
                               int rows_mul, float* logits_out, float* probs_out, int precision, hipStream_t stream) {
-    TD_REQUIRE(precision == TD_PRECISION_FP32 && C % 4 == 0, "mask_predict: unsupported configuration");
+    TD_REQUIRE(C % 4 == 0, "mask_predict: C must be a multiple of 4");
     if (rows_max <= 0) return TD_OK;
-    hipLaunchKernelGGL(mask_predict_kernel, dim3(td_cdiv(rows_max, 4)), dim3(256), 0, stream,
-                       static_cast<const float*>(x), w, bias, C, rows_max, rows_dyn, rows_mul, logits_out, probs_out);
+    if (precision == TD_PRECISION_FP16)
+        hipLaunchKernelGGL((mask_predict_kernel<_Float16>), dim3(td_cdiv(rows_max, 4)), dim3(256), 0, stream,
+                           static_cast<const _Float16*>(x), w, bias, C, rows_max, rows_dyn, rows_mul, logits_out, probs_out);
+    else
+        hipLaunchKernelGGL((mask_predict_kernel<float>), dim3(td_cdiv(rows_max, 4)), dim3(256), 0, stream,
+                           static_cast<const float*>(x), w, bias, C, rows_max, rows_dyn, rows_mul, logits_out, probs_out);
     TD_KERNEL_CHECK();
     return TD_OK;
 }

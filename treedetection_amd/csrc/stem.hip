@@ -135,10 +135,10 @@ constexpr int ST = 16;                 // output tile side
 constexpr int SP = 2 * ST + 5;         // input patch side (37)
 constexpr int SPW = SP * 3 + 1;        // patch row stride in floats (padded)
 
-template <int FORMAT, int COUT>
+template <int FORMAT, int COUT, typename TO>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const void* __restrict__ images, ImgSizes valid, int Hp, int Wp,
                                                         const float* __restrict__ w_kc, const float* __restrict__ scale,
-                                                        const float* __restrict__ bias, float* __restrict__ y) {
+                                                        const float* __restrict__ bias, TO* __restrict__ y) {
     __shared__ float patch[SP * SPW];
     const int b = blockIdx.z;
     const int oy0 = blockIdx.y * ST, ox0 = blockIdx.x * ST;
@@ -179,66 +179,93 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const void* __restrict__
     }
     const int oy = oy0 + ty, ox = ox0 + tx;
     if (oy < Ho && ox < Wo) {
-        float* o = y + ((size_t)(b * Ho + oy) * Wo + ox) * COUT;
+        TO* o = y + ((size_t)(b * Ho + oy) * Wo + ox) * COUT;
 #pragma unroll
-        for (int co = 0; co < COUT; co += 4) {
-            float4 v;
-            float* pv = reinterpret_cast<float*>(&v);
+        for (int co = 0; co < COUT; co += 8) {
+            float t[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float t = __fadd_rn(__fmul_rn(acc[co + q], scale[co + q]), bias[co + q]);
-                pv[q] = t > 0.f ? t : 0.f;
+            for (int q = 0; q < 8; ++q) {
+                const float u = __fadd_rn(__fmul_rn(acc[co + q], scale[co + q]), bias[co + q]);
+                t[q] = u > 0.f ? u : 0.f;
             }
-            *reinterpret_cast<float4*>(o + co) = v;
+            if constexpr (sizeof(TO) == 4) {
+                *reinterpret_cast<float4*>(o + co) = make_float4(t[0], t[1], t[2], t[3]);
+                *reinterpret_cast<float4*>(o + co + 4) = make_float4(t[4], t[5], t[6], t[7]);
+            } else {
+                typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                h8 h;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) h[q] = (_Float16)t[q];
+                *reinterpret_cast<h8*>(o + co) = h;
+            }
         }
     }
 }
 
-// ---- max-pool 3x3 / s2 / p1 over NHWC (float4 of channels per thread) ------------------------------
-__global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C,
-                                    int Ho, int Wo) {
-    const int c4 = C >> 2;
+// ---- max-pool 3x3 / s2 / p1 over NHWC (16 bytes of channels per thread: 4 floats or 8 halves) -------------------------
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<float> {
+    typedef float type __attribute__((ext_vector_type(4)));
+    static constexpr int N = 4;
+};
+template <>
+struct Vec16<_Float16> {
+    typedef _Float16 type __attribute__((ext_vector_type(8)));
+    static constexpr int N = 8;
+};
+
+template <typename T>
+__global__ void maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho,
+                                    int Wo) {
+    typedef typename Vec16<T>::type V;
+    constexpr int N = Vec16<T>::N;
+    const int cv = C / N;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)B * Ho * Wo * c4;
+    const size_t total = (size_t)B * Ho * Wo * cv;
     if (idx >= total) return;
-    const int c = (int)(idx % c4);
-    size_t p = idx / c4;
+    const int c = (int)(idx % cv);
+    size_t p = idx / cv;
     const int ox = (int)(p % Wo);
     p /= Wo;
     const int oy = (int)(p % Ho);
     const int b = (int)(p / Ho);
-    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    V m;
+#pragma unroll
+    for (int q = 0; q < N; ++q) m[q] = (T)(-65504.f);     // every window holds at least one real pixel
     for (int dy = -1; dy <= 1; ++dy) {
         const int iy = 2 * oy + dy;
         if (iy < 0 || iy >= H) continue;
         for (int dx = -1; dx <= 1; ++dx) {
             const int ix = 2 * ox + dx;
             if (ix < 0 || ix >= W) continue;
-            const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)(b * H + iy) * W + ix) * C + c * 4);
-            m.x = fmaxf(m.x, v.x);
-            m.y = fmaxf(m.y, v.y);
-            m.z = fmaxf(m.z, v.z);
-            m.w = fmaxf(m.w, v.w);
+            const V v = *reinterpret_cast<const V*>(x + ((size_t)(b * H + iy) * W + ix) * C + c * N);
+#pragma unroll
+            for (int q = 0; q < N; ++q) m[q] = v[q] > m[q] ? v[q] : m[q];
         }
     }
-    *reinterpret_cast<float4*>(y + ((size_t)(b * Ho + oy) * Wo + ox) * C + c * 4) = m;
+    *reinterpret_cast<V*>(y + ((size_t)(b * Ho + oy) * Wo + ox) * C + c * N) = m;
 }
 
 // ---- p6 = max_pool2d(p5, kernel 1, stride 2) = p5[::2, ::2] ------------------------------------------
-__global__ void subsample2_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C,
-                                  int Ho, int Wo) {
-    const int c4 = C >> 2;
+template <typename T>
+__global__ void subsample2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho,
+                                  int Wo) {
+    typedef typename Vec16<T>::type V;
+    constexpr int N = Vec16<T>::N;
+    const int cv = C / N;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)B * Ho * Wo * c4;
+    const size_t total = (size_t)B * Ho * Wo * cv;
     if (idx >= total) return;
-    const int c = (int)(idx % c4);
-    size_t p = idx / c4;
+    const int c = (int)(idx % cv);
+    size_t p = idx / cv;
     const int ox = (int)(p % Wo);
     p /= Wo;
     const int oy = (int)(p % Ho);
     const int b = (int)(p / Ho);
-    *reinterpret_cast<float4*>(y + ((size_t)(b * Ho + oy) * Wo + ox) * C + c * 4) =
-        *reinterpret_cast<const float4*>(x + ((size_t)(b * H + 2 * oy) * W + 2 * ox) * C + c * 4);
+    *reinterpret_cast<V*>(y + ((size_t)(b * Ho + oy) * Wo + ox) * C + c * N) =
+        *reinterpret_cast<const V*>(x + ((size_t)(b * H + 2 * oy) * W + 2 * ox) * C + c * N);
 }
 
 }  // namespace
@@ -265,43 +292,59 @@ td_status resize_tile_u8_launch(const uint8_t* src, int h, int w, int c, uint8_t
 td_status stem_launch(const void* images, int input_format, const ImgSizes& valid, int B, int Hp, int Wp,
                       const float* w_kc, const float* scale, const float* bias, void* y, int cout, int precision,
                       hipStream_t stream) {
-    TD_REQUIRE(precision == TD_PRECISION_FP32, "stem: precision %d not built", precision);
     TD_REQUIRE(Hp % 2 == 0 && Wp % 2 == 0 && B <= TD_MAX_BATCH, "stem: bad geometry");
     const dim3 grid(td_cdiv(Wp / 2, ST), td_cdiv(Hp / 2, ST), B);
-#define TD_STEM_CASE(F, C)                                                                                          \
-    hipLaunchKernelGGL((stem_conv_kernel<F, C>), grid, dim3(256), 0, stream, images, valid, Hp, Wp, w_kc, scale, \
-                       bias, static_cast<float*>(y))
-    if (cout == 64) {
-        if (input_format == TD_INPUT_U8_HWC) TD_STEM_CASE(TD_INPUT_U8_HWC, 64);
-        else TD_STEM_CASE(TD_INPUT_F32_CHW, 64);
-    } else if (cout == 32) {
-        if (input_format == TD_INPUT_U8_HWC) TD_STEM_CASE(TD_INPUT_U8_HWC, 32);
-        else TD_STEM_CASE(TD_INPUT_F32_CHW, 32);
-    } else {
+    const bool u8 = input_format == TD_INPUT_U8_HWC, h = precision == TD_PRECISION_FP16;
+#define TD_STEM_CASE(F, C, TO)                                                                                       \
+    hipLaunchKernelGGL((stem_conv_kernel<F, C, TO>), grid, dim3(256), 0, stream, images, valid, Hp, Wp, w_kc, scale, \
+                       bias, static_cast<TO*>(y))
+#define TD_STEM_FMT(C)                                                             \
+    do {                                                                           \
+        if (u8 && h) TD_STEM_CASE(TD_INPUT_U8_HWC, C, _Float16);                   \
+        else if (u8) TD_STEM_CASE(TD_INPUT_U8_HWC, C, float);                      \
+        else if (h) TD_STEM_CASE(TD_INPUT_F32_CHW, C, _Float16);                   \
+        else TD_STEM_CASE(TD_INPUT_F32_CHW, C, float);                             \
+    } while (0)
+    if (cout == 64) TD_STEM_FMT(64);
+    else if (cout == 32) TD_STEM_FMT(32);
+    else {
         td_set_error("stem: %d output channels not built (32 or 64)", cout);
         return TD_ERR_INVALID;
     }
+#undef TD_STEM_FMT
 #undef TD_STEM_CASE
     TD_KERNEL_CHECK();
     return TD_OK;
 }
 
 td_status maxpool3x3s2_launch(const void* x, void* y, int B, int H, int W, int C, int precision, hipStream_t stream) {
-    TD_REQUIRE(precision == TD_PRECISION_FP32 && C % 4 == 0, "maxpool: unsupported configuration");
+    TD_REQUIRE(C % 8 == 0, "maxpool: C must be a multiple of 8");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    const size_t total = (size_t)B * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                       static_cast<const float*>(x), static_cast<float*>(y), B, H, W, C, Ho, Wo);
+    if (precision == TD_PRECISION_FP16) {
+        const size_t total = (size_t)B * Ho * Wo * (C / 8);
+        hipLaunchKernelGGL((maxpool3x3s2_kernel<_Float16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                           static_cast<const _Float16*>(x), static_cast<_Float16*>(y), B, H, W, C, Ho, Wo);
+    } else {
+        const size_t total = (size_t)B * Ho * Wo * (C / 4);
+        hipLaunchKernelGGL((maxpool3x3s2_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                           static_cast<const float*>(x), static_cast<float*>(y), B, H, W, C, Ho, Wo);
+    }
     TD_KERNEL_CHECK();
     return TD_OK;
 }
 
 td_status subsample2_launch(const void* x, void* y, int B, int H, int W, int C, int precision, hipStream_t stream) {
-    TD_REQUIRE(precision == TD_PRECISION_FP32 && C % 4 == 0, "subsample: unsupported configuration");
+    TD_REQUIRE(C % 8 == 0, "subsample: C must be a multiple of 8");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const size_t total = (size_t)B * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(subsample2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                       static_cast<const float*>(x), static_cast<float*>(y), B, H, W, C, Ho, Wo);
+    if (precision == TD_PRECISION_FP16) {
+        const size_t total = (size_t)B * Ho * Wo * (C / 8);
+        hipLaunchKernelGGL((subsample2_kernel<_Float16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                           static_cast<const _Float16*>(x), static_cast<_Float16*>(y), B, H, W, C, Ho, Wo);
+    } else {
+        const size_t total = (size_t)B * Ho * Wo * (C / 4);
+        hipLaunchKernelGGL((subsample2_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                           static_cast<const float*>(x), static_cast<float*>(y), B, H, W, C, Ho, Wo);
+    }
     TD_KERNEL_CHECK();
     return TD_OK;
 }
