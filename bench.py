@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=6)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-fp16", action="store_true", help="skip the second timed region with the fp16 engine")
     return ap.parse_args()
 
 
@@ -128,8 +129,6 @@ def main():
     torch.set_num_threads(host_cores())
     log("generating weights")
     sd = make_synthetic_state_dict(args.depth, seed=0)
-    log("creating engine")
-    eng = Engine(sd, device=local_rank, precision=args.precision)
     log("generating tile stream")
     B, S = args.batch, args.tile
     # every rank gets its own shard of the stream: tile t of the global stream goes to rank t % world
@@ -141,48 +140,58 @@ def main():
     dev = torch.device("cuda", local_rank)
     rgb = torch.from_numpy(rgb_np).to(dev)            # [n,S,S,3] uint8, resident in HBM before the timed region
     ndsm = torch.from_numpy(ndsm_np).to(dev)          # side band: travels with the tile, not a network input
-    out = eng.alloc_outputs(B, S, S, paste=True)
     gather_keys = ("boxes", "scores", "count", "mask_probs")
-    gl = None
-    if world > 1 and rank == 0:
-        gl = {k: [torch.empty_like(out[k]) for _ in range(world)] for k in gather_keys}
 
-    def step(i):
-        tiles = [rgb[(i * B + j) % n_local] for j in range(B)]
-        batch, hw_valid, hw_out = eng.preprocess_tiles_u8(tiles)
-        eng.forward_raw(batch, INPUT_U8_HWC, hw_valid, hw_out, out)
+    def run(precision):
+        """Warm-up + timed region for one engine precision → (seconds max over ranks, profile dict, detections)."""
+        log(f"creating engine ({precision})")
+        eng = Engine(sd, device=local_rank, precision=precision)
+        out = eng.alloc_outputs(B, S, S, paste=True)
+        gl = None
+        if world > 1 and rank == 0:
+            gl = {k: [torch.empty_like(out[k]) for _ in range(world)] for k in gather_keys}
+
+        def step(i):
+            tiles = [rgb[(i * B + j) % n_local] for j in range(B)]
+            batch, hw_valid, hw_out = eng.preprocess_tiles_u8(tiles)
+            eng.forward_raw(batch, INPUT_U8_HWC, hw_valid, hw_out, out)
+            if world > 1:
+                for k in gather_keys:   # RCCL gather of the per-tile detections to rank 0 (hand-off to stitching)
+                    dist.gather(out[k], gl[k] if rank == 0 else None, dst=0)
+
+        log("warm-up (the first forward also measures the block-tile choice per layer)")
+        for i in range(args.warmup):
+            step(i)
+            torch.cuda.synchronize()
+            log(f"warm-up step {i + 1}/{args.warmup} done")
+        if not args.no_profile:
+            eng.profile_enable(True)
+            eng.profile_read(reset=True)
         if world > 1:
-            for k in gather_keys:   # RCCL gather of the per-tile detections to rank 0 (hand-off to stitching)
-                dist.gather(out[k], gl[k] if rank == 0 else None, dst=0)
-
-    log("warm-up")
-    for i in range(args.warmup):
-        step(i)
+            dist.barrier()
         torch.cuda.synchronize()
-        log(f"warm-up step {i + 1}/{args.warmup} done")
-    if not args.no_profile:
-        eng.profile_enable(True)
-        eng.profile_read(reset=True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ndet = 0
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    log(f"timed region done: {dt:.3f} s")
-    prof = eng.profile_read(reset=True) if not args.no_profile else None
-    eng.profile_enable(False)
-    ndet = int(out["count"].sum().item())     # detections of the last batch (for the mask-head FLOP estimate)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        log(f"timed region done ({precision}): {dt:.3f} s")
+        prof = eng.profile_read(reset=True) if not args.no_profile else None
+        eng.profile_enable(False)
+        ndet = int(out["count"].sum().item())     # detections of the last batch (for the mask-head FLOP estimate)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        eng.close()
+        return float(tmax.item()), prof, ndet
+
+    dt, prof, ndet = run(args.precision)
+    extra = None
+    if args.precision == "fp32" and not args.no_fp16:
+        extra = run("fp16")
 
     if rank == 0:
         tiles_total = args.steps * B * world
@@ -223,12 +232,25 @@ def main():
                                 "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
                                 "algorithmic_bytes_per_launch": conv["bytes"] / max(conv["launches"], 1),
                                 "algorithmic_flops_per_launch": conv["flops"] / max(conv["launches"], 1),
-                                "kernel": "conv_igemm_f32 (all trunk/FPN/RPN/box-head contractions)",
+                                "kernel": "conv_igemm_kernel (all trunk/FPN/RPN/box-head contractions)",
                                 "launches_per_step": conv["launches"] / args.steps,
                                 "avg_launch_us": 1e3 * conv["ms"] / max(conv["launches"], 1),
                                 "gflop_per_step": conv["flops"] / args.steps / 1e9,
                                 "algorithmic_gbytes_per_step": conv["bytes"] / args.steps / 1e9}
             line["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items()}
+        if extra is not None:
+            dt16, prof16, ndet16 = extra
+            o = {"value": tiles_total / dt16, "unit": "tiles/s", "ms_per_step": 1000.0 * dt16 / args.steps, "dtype": "f16",
+                 "note": "same workload through the fp16 engine (fp16 storage, v_mfma_f32_32x32x16_f16, fp32 accumulate "
+                         "and selection); parity tolerances in tests/test_engine_fp16_gpu.py",
+                 "detections_last_batch": ndet16}
+            if prof16 is not None:
+                c16 = prof16["conv_igemm"]
+                a16 = c16["flops"] / (c16["ms"] * 1e-3) / 1e12 if c16["ms"] > 0 else 0.0
+                o["roofline"] = {"bound": "mfma", "achieved": a16, "peak": PEAK_F16_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": a16 / PEAK_F16_MATRIX_TFLOPS, "traffic": None}
+                o["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof16.items()}
+            line["fp16"] = o
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, rgb_np, args.cpu_tiles)
         print(json.dumps(line), flush=True)

@@ -1,0 +1,46 @@
+"""Diagnostic: where does a big 3x3 conv lose time? Times td_conv2d_nhwc for the fpn_output2 shape with three builds
+of conv_igemm.hip — product, no global loads in the k-loop, no loads + no barrier — built into /tmp (never shipped)."""
+import ctypes as C, os, subprocess, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CS = os.path.join(ROOT, "treedetection_amd", "csrc")
+
+def build(tag, defs):
+    out = f"/tmp/libdiag_{tag}.so"
+    srcs = [os.path.join(CS, f) for f in ("conv_igemm.hip", "api.cpp", "stem.hip", "rpn.hip", "roi.hip", "engine.cpp", "contours.cpp")]
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", "-x", "hip"] + defs + srcs + ["-o", out]
+    subprocess.run(cmd, check=True)
+    return out
+
+def bench(lib, prec, B, H, W, Cin, Cout, k, cfg_name):
+    es = 4 if prec == 0 else 2
+    dt = torch.float32 if prec == 0 else torch.float16
+    x = torch.randn(B, H, W, Cin, device="cuda").to(dt)
+    w = (torch.randn(Cout, k, k, Cin, device="cuda") / (Cin * k * k) ** 0.5).to(dt)
+    y = torch.empty(B, H, W, Cout, device="cuda", dtype=dt)
+    bias = torch.zeros(Cout, device="cuda")
+    f = lib.td_conv2d_nhwc
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p] + [C.c_int] * 11 + [C.c_void_p]
+    args = (x.data_ptr(), w.data_ptr(), None, bias.data_ptr(), None, 0, y.data_ptr(), B, H, W, Cin, Cout, k, k, 1, k // 2, 1, prec, None)
+    for _ in range(3):
+        assert f(*args) == 0
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    n = 10
+    for _ in range(n):
+        f(*args)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / n
+    fl = 2.0 * B * H * W * Cout * Cin * k * k
+    print(f"{cfg_name:28s} prec={prec} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s", flush=True)
+
+if __name__ == "__main__":
+    libs = {"product": [], "no_loads": ["-DTD_DIAG_NO_LOADS"], "no_loads_no_barrier": ["-DTD_DIAG_NO_LOADS", "-DTD_DIAG_NO_BARRIER"]}
+    for tag, defs in libs.items():
+        lib = C.CDLL(build(tag, defs))
+        for prec in (0, 1):
+            bench(lib, prec, 8, 200, 200, 256, 256, 3, tag + " 3x3 256->256 M=320k")
+            bench(lib, prec, 8, 100, 100, 128, 128, 3, tag + " 3x3 128->128 M=80k")

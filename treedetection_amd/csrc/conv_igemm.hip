@@ -28,8 +28,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int CHUNK_BYTES = 128;     // one k-chunk of one row
-constexpr int ROW_BYTES = 144;       // padded LDS row stride (9 x 16 B)
+constexpr int CHUNK_BYTES = 128;     // one k-chunk of one row = one LDS row (8 pieces of 16 B, XOR-swizzled)
 
 // XCD-aware bijective remap of a 1-D block id: blocks that share an XCD (id % 8) get a contiguous run of tiles,
 // so the A rows / weight panels they share stay in that XCD's L2.
@@ -67,9 +66,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int AROWS = BM / 32, BROWS = BN / 32;   // rows staged per thread
     constexpr int ES = sizeof(T);
     constexpr int KE = Elem<T>::PER_CHUNK;            // elements per k-chunk
-    __shared__ __attribute__((aligned(16))) char lds[2 * (BM + BN) * ROW_BYTES];
-    char* As = lds;                                   // [2][BM][144 B]
-    char* Bs = lds + 2 * BM * ROW_BYTES;              // [2][BN][144 B]
+    constexpr int CS = BN + 4;                        // padded row stride (floats) of the epilogue's staged tile
+    constexpr int STAGE_BYTES = 2 * (BM + BN) * CHUNK_BYTES, EPI_BYTES = BM * CS * 4;
+    __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES];
+    char* As = lds;                                   // [2][BM][128 B]   piece c of row r sits at slot c ^ ((r>>1)&7)
+    char* Bs = lds + 2 * BM * CHUNK_BYTES;            // [2][BN][128 B]
 
     int M = a.M;
     if (a.m_dyn) {
@@ -92,74 +93,80 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     const int ld_c = tid & 7;    // 16-B piece inside the 128-B k-chunk
     const int ld_r = tid >> 3;   // 0..31
 
-    const char* __restrict__ X = static_cast<const char*>(a.x);
-    const char* __restrict__ Wt = static_cast<const char*>(a.w);
+    // ---- global → LDS staging by LDS-DMA (buffer_load ... lds) ---------------------------------------------------
+    // One wave instruction moves 64 x 16 B = 8 rows x 128 B straight into LDS (no VGPR round trip, no ds_write:
+    // the write path of ds_write_b128, ~80 B/clk/CU, was the fp16 bottleneck). The LDS image is lane-linear, so the
+    // bank-conflict fix is an XOR swizzle applied on the SOURCE piece (lane (r, c) fetches piece c ^ ((r>>1)&7)) and
+    // again on the fragment reads. Every lane keeps ONE 32-bit byte offset per staged row (tap (0,0)); the per-step
+    // part of the address (filter tap, channel chunk) is wave-uniform. Rows / taps in the zero padding (or past M /
+    // Cout) get an offset beyond num_records: the range check makes the DMA write zeros (tools/lds_dma_probe.hip).
     const int K = a.KH * a.KW * a.Cin;
     const int cchunks = a.Cin / KE;
     const int ntaps = a.KH * a.KW;
     const int nit = ntaps * cchunks;
-    const size_t pix_bytes = (size_t)a.Cin * ES;
+    const unsigned pix_bytes = (unsigned)a.Cin * ES;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.x), 0, (int)((size_t)a.B * a.H * a.W * pix_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.w), 0, (int)((size_t)a.Cout * K * ES), 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+    const unsigned src_piece = (unsigned)(ld_c ^ ((ld_r >> 1) & 7)) * 16;
 
-    // per-thread A rows: pixel index of tap (0,0) and its (iy, ix)
-    int a_pix[AROWS], a_iy[AROWS], a_ix[AROWS];
+    unsigned a_off[AROWS], a_ok[AROWS];      // byte offset of tap (0,0); bit t set = tap t reads a real pixel
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
         const int m = m0 + ld_r + 32 * i;
+        a_off[i] = 0;
+        a_ok[i] = 0;
         if (m < M) {
             const int hw = a.Ho * a.Wo;
             const int b = m / hw;
             const int rem = m - b * hw;
             const int oy = rem / a.Wo;
             const int ox = rem - oy * a.Wo;
-            a_iy[i] = oy * a.stride - a.pad;
-            a_ix[i] = ox * a.stride - a.pad;
-            a_pix[i] = (b * a.H + a_iy[i]) * a.W + a_ix[i];
-        } else {
-            a_iy[i] = -(1 << 28);   // fails every bounds test
-            a_ix[i] = -(1 << 28);
-            a_pix[i] = 0;
+            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+            a_off[i] = (unsigned)((b * a.H + iy0) * a.W + ix0) * pix_bytes + src_piece;
+            for (int ky = 0; ky < a.KH; ++ky)
+                for (int kx = 0; kx < a.KW; ++kx)
+                    if ((unsigned)(iy0 + ky) < (unsigned)a.H && (unsigned)(ix0 + kx) < (unsigned)a.W)
+                        a_ok[i] |= 1u << (ky * a.KW + kx);
         }
     }
-    size_t b_off[BROWS];
-    bool b_ok[BROWS];
+    unsigned b_off[BROWS];
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
         const int n = n0 + ld_r + 32 * i;
-        b_ok[i] = n < a.Cout;
-        b_off[i] = ((size_t)(b_ok[i] ? n : 0) * K) * ES + ld_c * 16;
+        b_off[i] = n < a.Cout ? (unsigned)n * (unsigned)K * ES + src_piece : OOB;
     }
 
-    f32x4 ra[AROWS], rb[BROWS];   // raw 16-B pieces
-    auto load_global = [&](int it) {
-        const int cc = it / ntaps;
-        const int tap = it - cc * ntaps;
-        const int ky = tap / a.KW, kx = tap - ky * a.KW;
-        const int coff = cc * CHUNK_BYTES + ld_c * 16;
-        const size_t woff = ((size_t)tap * a.Cin) * ES + (size_t)cc * CHUNK_BYTES;
+    typedef __attribute__((address_space(3))) void lds_void;
+    const unsigned wave_rows = (unsigned)__builtin_amdgcn_readfirstlane(wave) * 8u;   // this wave stages rows 8w..8w+7 of each 32
+    int ld_tap = 0, ld_ky = 0, ld_kx = 0, ld_cc = 0;     // scalar walk over (chunk outer, tap inner)
+    auto stage = [&](int buf) {
+        const unsigned xs = (unsigned)(ld_ky * a.W + ld_kx) * pix_bytes + (unsigned)ld_cc * CHUNK_BYTES;
+        const unsigned ws = (unsigned)ld_tap * pix_bytes + (unsigned)ld_cc * CHUNK_BYTES;
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
-            const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
-            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            if (ok) {
-                const size_t off = (size_t)(a_pix[i] + ky * a.W + kx) * pix_bytes + coff;
-                ra[i] = *reinterpret_cast<const f32x4*>(X + off);
-            } else {
-                ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            const unsigned off = ((a_ok[i] >> ld_tap) & 1u) ? a_off[i] + xs : OOB;
+            char* dst = As + ((unsigned)buf * BM + 32u * i + wave_rows) * CHUNK_BYTES;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)dst, 16, off, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
-            if (b_ok[i]) rb[i] = *reinterpret_cast<const f32x4*>(Wt + b_off[i] + woff);
-            else rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const unsigned off = b_off[i] == OOB ? OOB : b_off[i] + ws;
+            char* dst = Bs + ((unsigned)buf * BN + 32u * i + wave_rows) * CHUNK_BYTES;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)dst, 16, off, 0, 0, 0);
         }
-    };
-    auto store_lds = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < AROWS; ++i)
-            *reinterpret_cast<f32x4*>(&As[(buf * BM + ld_r + 32 * i) * ROW_BYTES + ld_c * 16]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BROWS; ++i)
-            *reinterpret_cast<f32x4*>(&Bs[(buf * BN + ld_r + 32 * i) * ROW_BYTES + ld_c * 16]) = rb[i];
+        if (++ld_kx == a.KW) {
+            ld_kx = 0;
+            ++ld_ky;
+        }
+        if (++ld_tap == ntaps) {
+            ld_tap = 0;
+            ld_ky = 0;
+            ld_kx = 0;
+            ++ld_cc;
+        }
     };
 
     f32x16 acc[MT][NT];
@@ -170,39 +177,45 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_global(0);
-    store_lds(0);
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int frag_row = lane & 31;
-    const int frag_b = (lane >> 5) * 16;     // lanes 0-31 take the first 16 B of each 32-B k-step, lanes 32-63 the second
+    // fragment reads: row = lane & 31, piece = 2*kk + (lane >> 5), swizzled with the row's key (lane >> 1) & 7
+    const unsigned frag_row = lane & 31;
+    const unsigned swz = (lane >> 1) & 7, hi = lane >> 5;
+    unsigned frag_off[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) frag_off[kk] = frag_row * CHUNK_BYTES + (((unsigned)(2 * kk) + hi) ^ swz) * 16;
     int cur = 0;
     for (int it = 0; it < nit; ++it) {
-        if (it + 1 < nit) load_global(it + 1);
-        const char* Ab = &As[(cur * BM + wm * 32 * MT + frag_row) * ROW_BYTES + frag_b];
-        const char* Bb = &Bs[(cur * BN + wn * 32 * NT + frag_row) * ROW_BYTES + frag_b];
+#if !defined(TD_DIAG_NO_LOADS)     // diagnostic builds only (tools/conv_diag.py): never defined in the product
+        if (it + 1 < nit) stage(cur ^ 1);
+#endif
+        const char* Ab = &As[(cur * BM + wm * 32 * MT) * CHUNK_BYTES];
+        const char* Bb = &Bs[(cur * BN + wn * 32 * NT) * CHUNK_BYTES];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             f32x4 fa[MT], fb[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * ROW_BYTES + kk * 32);
+            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * CHUNK_BYTES + frag_off[kk]);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * ROW_BYTES + kk * 32);
+            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * CHUNK_BYTES + frag_off[kk]);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) Elem<T>::mma(fa[i], fb[j], acc[i][j]);
         }
-        if (it + 1 < nit) store_lds(cur ^ 1);
-        __syncthreads();
+#if !defined(TD_DIAG_NO_BARRIER)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed ...
+        __syncthreads();                                    // ... and so have everyone else's; buf[cur] is free again
+#endif
         cur ^= 1;
     }
 
     // ---- epilogue: accumulators → LDS tile → 4 channels per lane: scale/bias (+residual) (+ReLU), one IEEE op per
     // step (no fma contraction). Staging through LDS turns the MFMA layout (32 lanes x 4 B per row) into whole row
     // segments, so residual loads and stores are vector accesses and fully coalesced (HBM-bound 1x1 layers).
-    constexpr int CS = BN + 4;                         // padded row stride of the staged tile (floats)
-    static_assert(BM * CS * 4 <= 2 * (BM + BN) * ROW_BYTES, "epilogue tile must fit in the k-loop LDS");
     float* Cs = reinterpret_cast<float*>(lds);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -326,7 +339,10 @@ td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream) {
     TD_REQUIRE(precision == TD_PRECISION_FP32 || precision == TD_PRECISION_FP16, "conv2d: bad precision %d", precision);
     TD_REQUIRE(a.Cin % ke == 0, "conv2d: Cin=%d must be a multiple of %d", a.Cin, ke);
     TD_REQUIRE(a.M > 0 && a.Cout > 0, "conv2d: empty problem (M=%d, Cout=%d)", a.M, a.Cout);
-    TD_REQUIRE((size_t)a.B * a.H * a.W * (size_t)a.Cin < (1ull << 31), "conv2d: input too large for 32-bit pixel math");
+    const size_t es = precision == TD_PRECISION_FP16 ? 2 : 4;
+    TD_REQUIRE((size_t)a.B * a.H * a.W * (size_t)a.Cin * es < 0xfffffff0ull - (1u << 20), "conv2d: input tensor must stay below 4 GB (32-bit buffer offsets)");
+    TD_REQUIRE((size_t)a.Cout * a.KH * a.KW * a.Cin * es < 0xfffffff0ull - (1u << 20), "conv2d: weight tensor must stay below 4 GB");
+    TD_REQUIRE(a.KH * a.KW <= 32, "conv2d: at most 32 filter taps (got %dx%d)", a.KH, a.KW);
     TD_REQUIRE(a.out_mode == 0 || (a.Cout % 16 == 0 && !a.res), "conv2d: bad deconv configuration");
     int cfg = a.tile_cfg;
     if (cfg < 0) {

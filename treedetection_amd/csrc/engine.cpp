@@ -9,6 +9,7 @@
 #include "detect.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -103,6 +104,7 @@ struct td_engine {
 
     // measured block-tile choice per (layer weights, rows, stride): filled lazily by the first forward of a shape
     bool autotune = true;
+    int backbone_subbatch = 0;    // 0 = whole batch; else images per backbone pass (TD_BACKBONE_SUBBATCH)
     std::map<std::tuple<const void*, int, int>, int> tuned;
 
     // optional per-category device timing (td_engine_profile_*)
@@ -315,6 +317,7 @@ td_status td_engine_create(const td_model_desc* desc, int device, td_engine** ou
     TD_REQUIRE(device >= 0 && device < ndev, "td_engine_create: device %d of %d", device, ndev);
     TD_HIP_CHECK(hipSetDevice(device));
     td_engine* e = new td_engine();
+    if (const char* sbenv = getenv("TD_BACKBONE_SUBBATCH")) e->backbone_subbatch = atoi(sbenv);
     e->desc = d;
     e->device = device;
     *out = e;
@@ -655,13 +658,9 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
         return run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, cfg);
     };
     // ---- backbone ------------------------------------------------------------------------------------------
-    { ProfScope ps(e, s, 1);
-    if ((st = stem_launch(images, input_format, valid, B, Hp, Wp, e->stem_w, e->stem_scale, e->stem_bias, e->stem_out,
-                          e->stem_c, prec, s)) < 0) return st; }
-    set_named(e, "stem", e->stem_out, B, Hp / 2, Wp / 2, e->stem_c, (e->desc.precision == TD_PRECISION_FP16 ? 2 : 4));
-    { ProfScope ps(e, s, 2);
-    if ((st = maxpool3x3s2_launch(e->stem_out, e->pool_out, B, Hp / 2, Wp / 2, e->stem_c, prec, s)) < 0) return st; }
-    set_named(e, "pool", e->pool_out, B, Hp / 4, Wp / 4, e->stem_c, (e->desc.precision == TD_PRECISION_FP16 ? 2 : 4));
+    // Runs in sub-batches of `sb` images (stem → res5 per sub-batch): the stage-2/3 activations of a sub-batch
+    // (≈ 80 MB per 256-channel tensor and image at fp32) then hand over from layer to layer through the 256 MiB
+    // Infinity Cache instead of HBM. sb comes from TD_BACKBONE_SUBBATCH (default: the whole batch at once).
     int hs[5], wsz[5];
     for (int l = 0; l < 4; ++l) {
         hs[l] = Hp >> (l + 2);
@@ -669,29 +668,61 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
     }
     hs[4] = (hs[3] - 1) / 2 + 1;
     wsz[4] = (wsz[3] - 1) / 2 + 1;
-    const void* x = e->pool_out;
-    int xh = hs[0], xw = wsz[0];
-    for (int si = 0; si < 4; ++si) {
-        const int nb = (int)e->stages[si].size();
-        const int oh = hs[si], ow = wsz[si];
-        for (int bi = 0; bi < nb; ++bi) {
-            const Block& blk = e->stages[si][bi];
-            // the last block must land in res[si]: alternate so that block nb-1 writes res
-            void* y = ((nb - 1 - bi) % 2 == 0) ? e->res[si] : e->xtmp[si];
-            const void* shortcut = x;
-            if (blk.has_sc) {
-                if ((st = run_conv(blk.sc, x, B, xh, xw, blk.stride, 0, false, e->scb[si], nullptr, 0, s, prec)) < 0) return st;
-                shortcut = e->scb[si];
-            }
-            if ((st = run_conv(blk.c1, x, B, xh, xw, blk.stride, 0, true, e->t1[si], nullptr, 0, s, prec)) < 0) return st;
-            if ((st = run_conv(blk.c2, e->t1[si], B, oh, ow, 1, 1, true, e->t2[si], nullptr, 0, s, prec)) < 0) return st;
-            if ((st = run_conv(blk.c3, e->t2[si], B, oh, ow, 1, 0, true, y, shortcut, 0, s, prec)) < 0) return st;
-            x = y;
-            xh = oh;
-            xw = ow;
+    const size_t esz = prec == TD_PRECISION_FP16 ? 2 : 4;
+    auto off = [&](void* p, size_t elems) -> void* { return static_cast<char*>(p) + elems * esz; };
+    int sb = e->backbone_subbatch > 0 ? e->backbone_subbatch : B;
+    if (sb > B) sb = B;
+    for (int b0 = 0; b0 < B; b0 += sb) {
+        const int nb_img = (B - b0) < sb ? (B - b0) : sb;
+        ImgSizes vsub{};
+        for (int i = 0; i < nb_img; ++i) {
+            vsub.h[i] = valid.h[b0 + i];
+            vsub.w[i] = valid.w[b0 + i];
         }
+        const size_t in_img = input_format == TD_INPUT_U8_HWC ? (size_t)Hp * Wp * 3 : (size_t)Hp * Wp * 3 * 4;
+        const void* img_sub = static_cast<const char*>(images) + (size_t)b0 * in_img;
+        void* stem_sub = off(e->stem_out, (size_t)b0 * (Hp / 2) * (Wp / 2) * e->stem_c);
+        void* pool_sub = off(e->pool_out, (size_t)b0 * hs[0] * wsz[0] * e->stem_c);
+        { ProfScope ps(e, s, 1);
+        if ((st = stem_launch(img_sub, input_format, vsub, nb_img, Hp, Wp, e->stem_w, e->stem_scale, e->stem_bias, stem_sub,
+                              e->stem_c, prec, s)) < 0) return st; }
+        { ProfScope ps(e, s, 2);
+        if ((st = maxpool3x3s2_launch(stem_sub, pool_sub, nb_img, Hp / 2, Wp / 2, e->stem_c, prec, s)) < 0) return st; }
+        const void* x = pool_sub;
+        int xh = hs[0], xw = wsz[0];
+        for (int si = 0; si < 4; ++si) {
+            const int nb = (int)e->stages[si].size();
+            const int oh = hs[si], ow = wsz[si];
+            const size_t px = (size_t)b0 * oh * ow;
+            const int mid = e->stages[si][0].c1.cout, co = e->stages[si][0].c3.cout;
+            void* t1 = off(e->t1[si], px * mid);
+            void* t2 = off(e->t2[si], px * mid);
+            void* scb = off(e->scb[si], px * co);
+            void* resb = off(e->res[si], px * co);
+            void* xtmp = off(e->xtmp[si], px * co);
+            for (int bi = 0; bi < nb; ++bi) {
+                const Block& blk = e->stages[si][bi];
+                // the last block must land in res[si]: alternate so that block nb-1 writes res
+                void* y = ((nb - 1 - bi) % 2 == 0) ? resb : xtmp;
+                const void* shortcut = x;
+                if (blk.has_sc) {
+                    if ((st = run_conv(blk.sc, x, nb_img, xh, xw, blk.stride, 0, false, scb, nullptr, 0, s, prec)) < 0) return st;
+                    shortcut = scb;
+                }
+                if ((st = run_conv(blk.c1, x, nb_img, xh, xw, blk.stride, 0, true, t1, nullptr, 0, s, prec)) < 0) return st;
+                if ((st = run_conv(blk.c2, t1, nb_img, oh, ow, 1, 1, true, t2, nullptr, 0, s, prec)) < 0) return st;
+                if ((st = run_conv(blk.c3, t2, nb_img, oh, ow, 1, 0, true, y, shortcut, 0, s, prec)) < 0) return st;
+                x = y;
+                xh = oh;
+                xw = ow;
+            }
+        }
+    }
+    set_named(e, "stem", e->stem_out, B, Hp / 2, Wp / 2, e->stem_c, (int)esz);
+    set_named(e, "pool", e->pool_out, B, Hp / 4, Wp / 4, e->stem_c, (int)esz);
+    for (int si = 0; si < 4; ++si) {
         const std::string nm = "res" + std::to_string(si + 2);
-        set_named(e, nm.c_str(), e->res[si], B, oh, ow, e->stages[si][0].c3.cout, (e->desc.precision == TD_PRECISION_FP16 ? 2 : 4));
+        set_named(e, nm.c_str(), e->res[si], B, hs[si], wsz[si], e->stages[si][0].c3.cout, (int)esz);
     }
     // ---- FPN (top-down; the nearest-2x upsampled add rides in the lateral conv's epilogue) ---------------------
     for (int l = 3; l >= 0; --l) {
