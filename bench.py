@@ -117,10 +117,16 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     import torch.distributed as dist
 
+    # one process per GPU; TD_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 code path
+    backend = os.environ.get("TD_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from treedetection_amd.engine import Engine, INPUT_U8_HWC
     from treedetection_amd.synth import make_stream
@@ -157,7 +163,11 @@ def main():
             eng.forward_raw(batch, INPUT_U8_HWC, hw_valid, hw_out, out)
             if world > 1:
                 for k in gather_keys:   # RCCL gather of the per-tile detections to rank 0 (hand-off to stitching)
-                    dist.gather(out[k], gl[k] if rank == 0 else None, dst=0)
+                    if backend == "nccl":
+                        dist.gather(out[k], gl[k] if rank == 0 else None, dst=0)
+                    else:   # rehearsal backend: gloo moves host tensors
+                        h = out[k].cpu()
+                        dist.gather(h, [torch.empty_like(h) for _ in range(world)] if rank == 0 else None, dst=0)
 
         log("warm-up (the first forward also measures the block-tile choice per layer)")
         for i in range(args.warmup):
@@ -182,7 +192,7 @@ def main():
         prof = eng.profile_read(reset=True) if not args.no_profile else None
         eng.profile_enable(False)
         ndet = int(out["count"].sum().item())     # detections of the last batch (for the mask-head FLOP estimate)
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         eng.close()

@@ -204,3 +204,37 @@ def test_mask_head_on_identical_inputs(setup):
         ref_masks = R.paste_masks(got[n]["mask_probs"], got[n]["pred_boxes"], setup["inputs"][n]["height"],
                                   setup["inputs"][n]["width"], 0.5)
         assert np.array_equal(ref_masks, got[n]["pred_masks"])     # paste is bit-exact on identical inputs
+
+
+def test_rpn_topk_with_massive_ties(setup):
+    """All objectness logits equal (weights and bias zeroed): every level's top-k is decided purely by the tie rule
+    (lower index first) — the ordered-compaction path of the top-k kernel. Compared with the oracle on the engine's
+    own head outputs: indices must agree exactly."""
+    from treedetection_amd.engine import Engine
+    sd = dict(setup["sd"])
+    k = "proposal_generator.rpn_head.objectness_logits"
+    sd[k + ".weight"] = np.zeros_like(sd[k + ".weight"])
+    sd[k + ".bias"] = np.zeros_like(sd[k + ".bias"])
+    eng = Engine(sd)
+    eng(setup["inputs"])
+    oracle = MaskRCNNOracle(sd)
+    logits, deltas, feat_hw = [], [], []
+    for li in range(5):
+        head = eng.tensor(f"rpn_head{li + 2}").cpu()
+        B, h, w, _ = head.shape
+        assert float(head[..., :3].abs().max()) == 0.0
+        logits.append(head[..., :3].reshape(B, -1).contiguous())
+        deltas.append(head[..., 3:].reshape(B, -1, 4).contiguous())
+        feat_hw.append((h, w))
+    props, rtaps = oracle.rpn_proposals(logits, deltas, feat_hw, setup["taps"]["sizes"])
+    cand_idx = eng.tensor("rpn_cand_idx").cpu().numpy()
+    gs = eng.tensor("proposal_scores").cpu().numpy()
+    gc = eng.tensor("proposal_count").cpu().numpy()
+    gp = eng.tensor("proposals").cpu().numpy()
+    for n in range(len(props)):
+        for li in range(5):
+            ref_idx = rtaps[n]["per_level"][li]["topk_idx"]
+            assert np.array_equal(cand_idx[n, li, : len(ref_idx)], ref_idx), (n, li)
+            assert np.array_equal(ref_idx, np.arange(len(ref_idx)))      # lowest indices win the tie
+        assert gc[n] == len(props[n][1])
+        assert np.abs(gp[n, : gc[n]] - props[n][0]).max() < 1e-3

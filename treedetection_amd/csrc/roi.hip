@@ -65,6 +65,41 @@ __global__ __launch_bounds__(256) void roi_align_kernel(FeatLevels fl, const flo
     const int ghw = gh * gw;
     const float count = (float)(ghw > 1 ? ghw : 1);
 
+    // Sample coordinates are the same for every channel lane: tabulate the (lo, hi, weights, in-range) tuple of every
+    // y-sample and x-sample of this RoI ONCE in LDS (same float32 operation order as the oracle), so the bin loop
+    // below is loads + multiply-adds only (the per-sample divisions made this kernel VALU-bound).
+    constexpr int TAB = 14 * 24;     // pooled * grid entries per axis held in LDS; larger grids take the direct path
+    __shared__ int t_lo[2][TAB], t_hi[2][TAB];
+    __shared__ float t_l[2][TAB], t_h[2][TAB];
+    const bool tab = pooled * gh <= TAB && pooled * gw <= TAB;
+    auto sample = [&](float start, float bin, int p, int i, int g, int size, int& lo, int& hi, float& l, float& h) -> bool {
+        const float c = __fadd_rn(__fadd_rn(start, __fmul_rn((float)p, bin)),
+                                  __fdiv_rn(__fmul_rn(__fadd_rn((float)i, 0.5f), bin), (float)g));
+        if (c < -1.f || c > (float)size) return false;
+        float cc = c <= 0.f ? 0.f : c;
+        lo = (int)cc;
+        if (lo >= size - 1) { hi = lo = size - 1; cc = (float)lo; } else hi = lo + 1;
+        l = __fsub_rn(cc, (float)lo);
+        h = __fsub_rn(1.f, l);
+        return true;
+    };
+    if (tab) {
+        for (int t = threadIdx.x; t < pooled * gh + pooled * gw; t += blockDim.x) {
+            const int ax = t < pooled * gh ? 0 : 1;
+            const int u = ax ? t - pooled * gh : t;
+            const int g = ax ? gw : gh;
+            const int p = u / g, i = u - p * g;
+            int lo = 0, hi = 0;
+            float l = 0.f, h = 0.f;
+            const bool ok = ax ? sample(sw, bw, p, i, g, W, lo, hi, l, h) : sample(sh, bh, p, i, g, H, lo, hi, l, h);
+            t_lo[ax][u] = ok ? lo : -1;
+            t_hi[ax][u] = hi;
+            t_l[ax][u] = l;
+            t_h[ax][u] = h;
+        }
+        __syncthreads();
+    }
+
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nbins = pooled * pooled;
     for (int bin = wave; bin < nbins; bin += 4) {
@@ -72,18 +107,25 @@ __global__ __launch_bounds__(256) void roi_align_kernel(FeatLevels fl, const flo
         for (int c0 = lane * 4; c0 < C; c0 += 256) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int iy = 0; iy < gh; ++iy) {
-                const float y = __fadd_rn(__fadd_rn(sh, __fmul_rn((float)ph, bh)),
-                                          __fdiv_rn(__fmul_rn(__fadd_rn((float)iy, 0.5f), bh), (float)gh));
+                int yl, yh;
+                float ly, hy;
+                if (tab) {
+                    yl = t_lo[0][ph * gh + iy];
+                    if (yl < 0) continue;
+                    yh = t_hi[0][ph * gh + iy];
+                    ly = t_l[0][ph * gh + iy];
+                    hy = t_h[0][ph * gh + iy];
+                } else if (!sample(sh, bh, ph, iy, gh, H, yl, yh, ly, hy)) continue;
                 for (int ix = 0; ix < gw; ++ix) {
-                    const float x = __fadd_rn(__fadd_rn(sw, __fmul_rn((float)pw, bw)),
-                                              __fdiv_rn(__fmul_rn(__fadd_rn((float)ix, 0.5f), bw), (float)gw));
-                    if (y < -1.f || y > (float)H || x < -1.f || x > (float)W) continue;
-                    float yy = y <= 0.f ? 0.f : y, xx = x <= 0.f ? 0.f : x;
-                    int yl = (int)yy, xl = (int)xx, yh, xh;
-                    if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
-                    if (xl >= W - 1) { xh = xl = W - 1; xx = (float)xl; } else xh = xl + 1;
-                    const float ly = __fsub_rn(yy, (float)yl), lx = __fsub_rn(xx, (float)xl);
-                    const float hy = __fsub_rn(1.f, ly), hx = __fsub_rn(1.f, lx);
+                    int xl, xh;
+                    float lx, hx;
+                    if (tab) {
+                        xl = t_lo[1][pw * gw + ix];
+                        if (xl < 0) continue;
+                        xh = t_hi[1][pw * gw + ix];
+                        lx = t_l[1][pw * gw + ix];
+                        hx = t_h[1][pw * gw + ix];
+                    } else if (!sample(sw, bw, pw, ix, gw, W, xl, xh, lx, hx)) continue;
                     const float w1 = __fmul_rn(hy, hx), w2 = __fmul_rn(hy, lx), w3 = __fmul_rn(ly, hx), w4 = __fmul_rn(ly, lx);
                     const float4 v1 = load4(feat + ((size_t)yl * W + xl) * C + c0);
                     const float4 v2 = load4(feat + ((size_t)yl * W + xh) * C + c0);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void rpn_topk_decode_kernel(RpnLevels
 
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long sel[1024];
-    __shared__ unsigned int s_prefix, s_need, s_cnt_gt, s_cnt_eq;
+    __shared__ unsigned int s_prefix, s_need, s_cnt_gt, s_cnt_eq, s_eq_total;
     __shared__ unsigned int wave_cnt[2][TOPK_THREADS / 64];
 
     const int tid = threadIdx.x;
@@ -97,55 +97,70 @@ __global__ __launch_bounds__(TOPK_THREADS) void rpn_topk_decode_kernel(RpnLevels
             }
             s_prefix = prefix | (bin << shift);
             s_need = need;
+            s_eq_total = hist[bin];      // after the last pass: how many keys equal the threshold exactly
         }
         __syncthreads();
     }
     const uint32_t thr = s_prefix;
     const unsigned int need_eq = s_need;
-    // ordered compaction: every key > thr, plus the first need_eq keys == thr (index order)
+    // compaction: every key > thr, plus need_eq keys == thr. When ALL keys equal to the threshold belong to the
+    // top-k (the normal case: float logits rarely tie exactly at the cut) the slot order is irrelevant — the bitonic
+    // sort below orders by (key, index) — so one barrier-free pass with an LDS counter does it. Only a tie that
+    // straddles the cut needs the ordered pass (lowest indices first).
     if (tid == 0) {
         s_cnt_gt = 0;
         s_cnt_eq = 0;
     }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
-    for (int base = 0; base < n; base += TOPK_THREADS) {
-        const int i = base + tid;
-        uint32_t key = 0;
-        bool gt = false, eq = false;
-        if (i < n) {
-            key = keys[i];
-            gt = key > thr;
-            eq = key == thr;
-        }
-        const unsigned long long mg = __ballot(gt), me = __ballot(eq);
-        if (lane == 0) {
-            wave_cnt[0][wave] = __popcll(mg);
-            wave_cnt[1][wave] = __popcll(me);
-        }
-        __syncthreads();
-        unsigned int off_g = s_cnt_gt, off_e = s_cnt_eq;
-        for (int w = 0; w < wave; ++w) {
-            off_g += wave_cnt[0][w];
-            off_e += wave_cnt[1][w];
-        }
-        const unsigned long long below = (1ull << lane) - 1ull;
-        off_g += __popcll(mg & below);
-        off_e += __popcll(me & below);
-        // slots: [0, k - need_eq) hold the > thr keys, [k - need_eq, k) the == thr keys
-        if (gt) sel[off_g] = ((unsigned long long)key << 32) | (0xffffffffu - (uint32_t)i);
-        if (eq && off_e < need_eq) sel[k - need_eq + off_e] = ((unsigned long long)key << 32) | (0xffffffffu - (uint32_t)i);
-        __syncthreads();
-        if (tid == 0) {
-            unsigned int tg = 0, te = 0;
-            for (int w = 0; w < TOPK_THREADS / 64; ++w) {
-                tg += wave_cnt[0][w];
-                te += wave_cnt[1][w];
+    if (s_eq_total == need_eq) {
+        for (int i = tid; i < n; i += TOPK_THREADS) {
+            const uint32_t key = keys[i];
+            if (key >= thr) {
+                const unsigned int pos = atomicAdd(&s_cnt_gt, 1u);
+                sel[pos] = ((unsigned long long)key << 32) | (0xffffffffu - (uint32_t)i);
             }
-            s_cnt_gt += tg;
-            s_cnt_eq += te;
         }
         __syncthreads();
+    } else {
+        for (int base = 0; base < n; base += TOPK_THREADS) {
+            const int i = base + tid;
+            uint32_t key = 0;
+            bool gt = false, eq = false;
+            if (i < n) {
+                key = keys[i];
+                gt = key > thr;
+                eq = key == thr;
+            }
+            const unsigned long long mg = __ballot(gt), me = __ballot(eq);
+            if (lane == 0) {
+                wave_cnt[0][wave] = __popcll(mg);
+                wave_cnt[1][wave] = __popcll(me);
+            }
+            __syncthreads();
+            unsigned int off_g = s_cnt_gt, off_e = s_cnt_eq;
+            for (int w = 0; w < wave; ++w) {
+                off_g += wave_cnt[0][w];
+                off_e += wave_cnt[1][w];
+            }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            off_g += __popcll(mg & below);
+            off_e += __popcll(me & below);
+            // slots: [0, k - need_eq) hold the > thr keys, [k - need_eq, k) the == thr keys
+            if (gt) sel[off_g] = ((unsigned long long)key << 32) | (0xffffffffu - (uint32_t)i);
+            if (eq && off_e < need_eq) sel[k - need_eq + off_e] = ((unsigned long long)key << 32) | (0xffffffffu - (uint32_t)i);
+            __syncthreads();
+            if (tid == 0) {
+                unsigned int tg = 0, te = 0;
+                for (int w = 0; w < TOPK_THREADS / 64; ++w) {
+                    tg += wave_cnt[0][w];
+                    te += wave_cnt[1][w];
+                }
+                s_cnt_gt += tg;
+                s_cnt_eq += te;
+            }
+            __syncthreads();
+        }
     }
     for (int i = k + tid; i < 1024; i += TOPK_THREADS) sel[i] = 0ull;   // padding sorts last
     __syncthreads();
