@@ -1,0 +1,122 @@
+"""Parity and size-independent properties at the BASELINE workload size: full-width R50-FPN, 1000x1000 uint8 tiles
+from the synthetic stream, device resize → forward → paste (the exact path bench.py times)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops_ref as R
+from oracle.maskrcnn_ref import MaskRCNNOracle
+from treedetection_amd import _lib
+from treedetection_amd.synth import make_tile
+from treedetection_amd.weights import make_synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full():
+    from treedetection_amd.engine import Engine, INPUT_U8_HWC, unpack_outputs
+    torch.set_num_threads(8)
+    sd = make_synthetic_state_dict(50, seed=0)
+    tiles_np = [make_tile(i, 1000)[0] for i in range(3)]
+    eng = Engine(sd)
+    tiles = [torch.from_numpy(t).cuda() for t in tiles_np]
+    batch, hw_valid, hw_out = eng.preprocess_tiles_u8(tiles)
+    out = eng.alloc_outputs(len(tiles), 1000, 1000, paste=True)
+    eng.forward_raw(batch, INPUT_U8_HWC, hw_valid, hw_out, out)
+    torch.cuda.synchronize()
+    got = unpack_outputs(out, hw_out, True)
+    snap = {k: v.clone() for k, v in out.items()}
+    return dict(sd=sd, eng=eng, tiles_np=tiles_np, tiles=tiles, batch=batch.clone(), hw_valid=hw_valid, hw_out=hw_out,
+                got=got, snap=snap)
+
+
+def test_device_resize_is_pillow_exact_at_full_size(full):
+    ref = R.pil_resize_bilinear_u8(full["tiles_np"][0][:, :, ::-1], 800, 800)      # BGR pick then resize
+    assert np.array_equal(full["batch"][0].cpu().numpy(), ref)
+
+
+def test_full_size_tile_matches_oracle(full):
+    oracle = MaskRCNNOracle(full["sd"])
+    for i in (0, 2):
+        x, h, w = R.preprocess_tile_u8(full["tiles_np"][i].transpose(2, 0, 1))
+        ref = oracle.forward([{"image": x, "height": h, "width": w}])[0]
+        g = full["got"][i]
+        assert len(ref["scores"]) >= 5
+        assert abs(len(g["scores"]) - len(ref["scores"])) <= 1
+        matched = 0
+        for j in range(len(ref["scores"])):
+            d = np.abs(g["pred_boxes"] - ref["pred_boxes"][j]).max(axis=1)
+            k = int(np.argmin(d))
+            if d[k] <= 1e-2 and abs(g["scores"][k] - ref["scores"][j]) <= 1e-4:
+                a, b = g["pred_masks"][k], ref["pred_masks"][j]
+                u = (a | b).sum()
+                assert u == 0 or (a & b).sum() / u >= 0.995
+                assert np.abs(g["mask_probs"][k] - ref["mask_probs"][j]).max() <= 1e-3
+                matched += 1
+        assert matched >= len(ref["scores"]) - 1, (matched, len(ref["scores"]))
+
+
+def test_output_invariants(full):
+    for g, (h, w) in zip(full["got"], full["hw_out"]):
+        n = len(g["scores"])
+        assert 0 < n <= 100
+        assert (np.diff(g["scores"]) <= 0).all() and (g["scores"] > 0.3).all()
+        b = g["pred_boxes"]
+        assert (b[:, 0] >= 0).all() and (b[:, 1] >= 0).all() and (b[:, 2] <= w).all() and (b[:, 3] <= h).all()
+        assert ((b[:, 2] - b[:, 0]) > 0).all() and ((b[:, 3] - b[:, 1]) > 0).all()
+        # NMS idempotence: the kept detections survive another pass of the same NMS untouched (in network units the
+        # threshold is exact; in output units boxes are uniformly scaled by 1.25, which preserves IoU up to rounding)
+        keep = R.nms(b, g["scores"], 0.5 + 1e-4)
+        assert np.array_equal(keep, np.arange(n))
+        # masks live inside the paste region, which hugs the box by at most 2 px
+        for d in range(n):
+            ys, xs = np.nonzero(g["pred_masks"][d])
+            if ys.size:
+                assert xs.min() >= np.floor(b[d, 0]) - 1 and xs.max() <= np.ceil(b[d, 2]) + 1
+                assert ys.min() >= np.floor(b[d, 1]) - 1 and ys.max() <= np.ceil(b[d, 3]) + 1
+
+
+def test_forward_is_deterministic_and_format_independent(full):
+    from treedetection_amd.engine import INPUT_F32_CHW, INPUT_U8_HWC
+    eng = full["eng"]
+    out2 = eng.alloc_outputs(3, 1000, 1000, paste=True)
+    eng.forward_raw(full["batch"], INPUT_U8_HWC, full["hw_valid"], full["hw_out"], out2)
+    torch.cuda.synchronize()
+    for k in ("count", "boxes", "scores", "mask_probs", "mask_region"):
+        assert torch.equal(out2[k], full["snap"][k]), k
+    # the same pixels handed over as float32 CHW (what prediction.py:170 builds) give bit-identical results
+    chw = full["batch"].permute(0, 3, 1, 2).float().contiguous()
+    out3 = eng.alloc_outputs(3, 1000, 1000, paste=True)
+    eng.forward_raw(chw, INPUT_F32_CHW, full["hw_valid"], full["hw_out"], out3)
+    torch.cuda.synchronize()
+    for k in ("count", "boxes", "scores", "mask_probs"):
+        assert torch.equal(out3[k], full["snap"][k]), k
+
+
+def test_no_detections_and_error_paths(full):
+    import ctypes as C
+    from treedetection_amd.engine import Engine, INPUT_U8_HWC
+    eng = Engine(full["sd"], score_thresh=0.9999)
+    tiles = full["tiles"][:1]
+    batch, hv, ho = eng.preprocess_tiles_u8(tiles)
+    out = eng.alloc_outputs(1, 1000, 1000, paste=True)
+    eng.forward_raw(batch, INPUT_U8_HWC, hv, ho, out)
+    torch.cuda.synchronize()
+    assert int(out["count"][0]) == 0
+    assert float(out["scores"].abs().max()) == 0.0
+    lib = _lib.load()
+    # capacity: a forward larger than what reserve() sized is refused with a message, not a fault
+    big = torch.zeros((1, 3, 64, 64), dtype=torch.float32, device="cuda")
+    h = C.c_void_p()
+    d = _lib.ModelDesc()
+    lib.td_model_desc_default(C.byref(d))
+    _lib.check(lib.td_engine_create(C.byref(d), 0, C.byref(h)), "create")
+    hv1 = (C.c_int32 * 2)(64, 64)
+    det = _lib.Detections()
+    st = lib.td_engine_forward(h, big.data_ptr(), 0, hv1, hv1, 1, 64, 64, None, C.byref(det))
+    assert st < 0 and b"load weights" in lib.td_last_error()
+    assert lib.td_engine_reserve(h, 1, 64, 64) < 0
+    lib.td_engine_destroy(h)
+    with pytest.raises(_lib.TdError):
+        Engine({"backbone.bottom_up.stem.conv1.weight": np.zeros((64, 3, 7, 7), np.float32)})
