@@ -183,12 +183,13 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(args.warmup + i)
+        t_enq = time.perf_counter() - t0          # host time to enqueue everything (launch-bound if close to dt)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        log(f"timed region done ({precision}): {dt:.3f} s")
+        log(f"timed region done ({precision}): {dt:.3f} s (host enqueue {t_enq:.3f} s)")
         prof = eng.profile_read(reset=True) if not args.no_profile else None
         eng.profile_enable(False)
         ndet = int(out["count"].sum().item())     # detections of the last batch (for the mask-head FLOP estimate)
