@@ -9,6 +9,7 @@
 #include "detect.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -105,7 +106,9 @@ struct td_engine {
     // measured block-tile choice per (layer weights, rows, stride): filled lazily by the first forward of a shape
     bool autotune = true;
     int backbone_subbatch = 0;    // 0 = whole batch; else images per backbone pass (TD_BACKBONE_SUBBATCH)
-    std::map<std::tuple<const void*, int, int>, int> tuned;
+    // key: (cout, cin, kh*16+kw, rows, stride*4 + out_mode*2 + has_residual) — layers of identical shape share it
+    std::map<std::tuple<int, int, int, int, int>, int> tuned;
+    std::string tune_cache;       // TD_TUNE_CACHE: load / append measured choices (keeps profiled runs free of tuning launches)
 
     // optional per-category device timing (td_engine_profile_*)
     bool prof = false;
@@ -328,6 +331,15 @@ td_status td_engine_create(const td_model_desc* desc, int device, td_engine** ou
     TD_HIP_CHECK(hipSetDevice(device));
     td_engine* e = new td_engine();
     if (const char* sbenv = getenv("TD_BACKBONE_SUBBATCH")) e->backbone_subbatch = atoi(sbenv);
+    if (const char* tc = getenv("TD_TUNE_CACHE")) {
+        e->tune_cache = tc;
+        if (FILE* f = fopen(tc, "r")) {
+            int pr, a0, a1, a2, a3, a4, cfg;
+            while (fscanf(f, "%d %d %d %d %d %d %d", &pr, &a0, &a1, &a2, &a3, &a4, &cfg) == 7)
+                if (pr == d.precision && cfg >= 0 && cfg < TD_CONV_TILE_CFGS) e->tuned[std::make_tuple(a0, a1, a2, a3, a4)] = cfg;
+            fclose(f);
+        }
+    }
     e->desc = d;
     e->device = device;
     *out = e;
@@ -637,7 +649,7 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
         const double bytes = es * ((double)B_ * H_ * W_ * L.cin / (stride * stride) + M * L.cout * (res_ ? 2.0 : 1.0) + L.cout * K);
         int cfg = -1;
         if (e->autotune) {
-            const auto key = std::make_tuple((const void*)L.w, B_ * Ho * Wo, stride);
+            const auto key = std::make_tuple(L.cout, L.cin, L.kh * 16 + L.kw, B_ * Ho * Wo, stride * 4 + out_mode * 2 + (res_ ? 1 : 0));
             auto it = e->tuned.find(key);
             if (it == e->tuned.end()) {
                 // time every block-tile shape on this very launch (idempotent: same inputs, same output buffer)
@@ -661,6 +673,12 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
                 (void)hipEventDestroy(ea);
                 (void)hipEventDestroy(eb);
                 it = e->tuned.emplace(key, best_cfg).first;
+                if (!e->tune_cache.empty()) {
+                    if (FILE* f = fopen(e->tune_cache.c_str(), "a")) {
+                        fprintf(f, "%d %d %d %d %d %d %d\n", prec_, std::get<0>(key), std::get<1>(key), std::get<2>(key), std::get<3>(key), std::get<4>(key), best_cfg);
+                        fclose(f);
+                    }
+                }
             }
             cfg = it->second;
         }
