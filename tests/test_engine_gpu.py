@@ -238,3 +238,20 @@ def test_rpn_topk_with_massive_ties(setup):
             assert np.array_equal(ref_idx, np.arange(len(ref_idx)))      # lowest indices win the tie
         assert gc[n] == len(props[n][1])
         assert np.abs(gp[n, : gc[n]] - props[n][0]).max() < 1e-3
+
+
+def test_resnet101_layout(setup):
+    """The reference hard-codes R101 (config.py:25): blocks [3,4,23,3] are read from the checkpoint keys."""
+    from treedetection_amd.engine import Engine
+    from treedetection_amd.weights import infer_depth
+    sd = make_synthetic_state_dict(101, seed=9, width_div=2)
+    assert infer_depth(sd) == 101
+    inputs = setup["inputs"][:1]
+    ref, taps = MaskRCNNOracle(sd).forward(inputs, return_taps=True)
+    eng = Engine(sd)
+    got = eng(inputs)
+    r4 = taps["res"]["res4"].numpy()
+    assert np.abs(nchw(eng.tensor("res4")) - r4).max() <= TOL_ACT * np.abs(r4).max()
+    assert abs(len(got[0]["scores"]) - len(ref[0]["scores"])) <= 1
+    m = min(len(got[0]["scores"]), len(ref[0]["scores"]))
+    assert m > 0 and np.abs(np.sort(got[0]["scores"])[-m:] - np.sort(ref[0]["scores"])[-m:]).max() <= 1e-3

@@ -97,3 +97,74 @@ def test_prediction_json_matches_oracle_pipeline(workspace):
         assert same >= 0.9 * len(exp), (tile_id, same, len(exp))
         checked += len(exp)
     assert checked > 5
+
+
+def test_two_model_flow_with_exclude_flags(tmp_path):
+    """BASELINE config #3 shape: urban + forest models, forest outline → only_forest / only_urban flags; each model
+    skips the tiles flagged for the other (reference detection.py:154-164, prediction.py:79-93)."""
+    import treedetection_amd as T
+    root = tmp_path
+    (root / "rgb").mkdir()
+    (root / "ndsm").mkdir()
+    for seed, name in ((3, "urban"), (4, "forest")):
+        np.savez(root / f"model_{name}.npz", **make_synthetic_state_dict(50, seed=seed, width_div=2))
+    rgb, ndsm = make_tile(7, 500)
+    t = (0.2, 0.0, 0.0, 0.0, -0.2, 100.0)       # 100 m x 100 m
+    write_geotiff(str(root / "rgb" / "1.tif"), np.ascontiguousarray(rgb.transpose(2, 0, 1)), t, 25832)
+    write_geotiff(str(root / "ndsm" / "1.tif"), ndsm[::5, ::5].copy(), (1.0, 0, 0, 0, -1.0, 100.0), 25832)
+    outline = {"type": "FeatureCollection", "features": [{"type": "Feature", "properties": {}, "geometry": {
+        "type": "Polygon", "coordinates": [[[-50, -50], [49, -50], [49, 150], [-50, 150], [-50, -50]]]}}]}
+    (root / "forest.geojson").write_text(json.dumps(outline))
+    cfg = {"image_directory": str(root / "rgb"), "height_data_path": str(root / "ndsm"),
+           "urban_model": str(root / "model_urban.npz"), "forrest_model": str(root / "model_forest.npz"),
+           "forrest_outline": str(root / "forest.geojson"), "output_directory": str(root / "output"),
+           "tiles_path": str(root / "tiles"), "use_overlap": False, "tile_width": 25, "tile_height": 25, "buffer": 5,
+           "batch_size": 3, "parallel": False, "num_workers": 2, "keep_intermediate": True, "device": "0"}
+    (root / "config.yml").write_text(yaml.safe_dump(cfg))
+    config, _ = T.get_config(str(root / "config.yml"))
+    T.preprocess_files(config)
+    meta = json.load(open(root / "tiles" / "1.json"))
+    assert len(meta) == 16
+    only_forest = {k for k, v in meta.items() if v["only_forest"]}
+    only_urban = {k for k, v in meta.items() if v["only_urban"]}
+    assert only_forest and only_urban and not (only_forest & only_urban)
+    T.predict_tiles(config)
+    urban = {f[len("Prediction_"):-5] for f in os.listdir(root / "output" / "urban_predictions" / "1")}
+    forest = {f[len("Prediction_"):-5] for f in os.listdir(root / "output" / "forrest_predictions" / "1")}
+    assert urban == set(meta) - only_forest          # urban model skips forest-only tiles
+    assert forest == set(meta) - only_urban          # forest model skips urban-only tiles
+    assert os.path.exists(root / "output" / "urban_geojson" / "1.geojson")
+    assert os.path.exists(root / "output" / "forrest_geojson" / "1.geojson")
+
+
+def test_sixteen_bit_tiles_take_the_float_path(tmp_path):
+    """uint16 imagery (max(band 1) > 255): 255*x/65535, then detectron2's float resize (F.interpolate bilinear) —
+    reference prediction.py:167-169 — and the engine's float32 CHW input. Compared with the oracle fed the same way."""
+    import torch
+    import torch.nn.functional as F
+    import treedetection_amd as T
+    from treedetection_amd.config import setup_model_cfg
+    sd = make_synthetic_state_dict(50, seed=3, width_div=2)
+    rgb, _ = make_tile(11, 300)
+    img16 = (rgb.astype(np.uint16) * 257).transpose(2, 0, 1)
+    p = str(tmp_path / "a.tif")
+    write_geotiff(p, np.ascontiguousarray(img16), (0.2, 0, 0, 0, -0.2, 60.0), 25832)
+    meta = {"a_0_0_60_0_25832": {"crs": 25832, "transform": [0.2, 0, 0, 0, -0.2, 60.0, 0, 0, 1], "bounds": [0, 0, 60, 60],
+                                 "only_forest": False, "only_urban": False}}
+    (tmp_path / "a.json").write_text(json.dumps(meta))
+    cfg = setup_model_cfg(update_model="unused", device="0")
+    cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST = 0.05      # the half-width fixture model scores low on this tile
+    pred = T.Predictor(cfg, device_type="0", max_batch_size=2, output_dir=str(tmp_path / "out"), state_dict=sd)
+    got = pred(p, str(tmp_path / "a.json"))
+    bgr = np.stack((img16[2], img16[1], img16[0])).astype(np.float64) * 255.0 / 65535.0
+    x = F.interpolate(torch.from_numpy(bgr)[None], size=(800, 800), mode="bilinear", align_corners=False)[0].float().numpy()
+    from oracle.maskrcnn_ref import Cfg
+    ocfg = Cfg()
+    ocfg.score_thresh = 0.05
+    ref = MaskRCNNOracle(sd, ocfg).forward([{"image": x, "height": 300, "width": 300}])[0]
+    n_ref = sum(1 for d in range(len(ref["scores"])) for c in ref_contours(ref["pred_masks"][d]) if c.size >= 8)
+    assert len(ref["scores"]) > 3
+    assert abs(len(got) - n_ref) <= 1
+    ref_scores = sorted({round(float(s), 4) for s in ref["scores"]})
+    got_scores = sorted({round(e["score"], 4) for e in got})
+    assert len(set(ref_scores) & set(got_scores)) >= len(ref_scores) - 1
