@@ -161,3 +161,35 @@ def test_polygons_from_masks_schema_and_affine():
     assert ring[0] == pytest.approx([412001.0, 5318098.0])
     assert ring[2] == pytest.approx([412000 + 0.2 * 14, 5318100 - 0.2 * 19])
     json.dumps(ev)
+
+
+def test_polygons_from_packed_equals_polygons_from_masks():
+    """The production epilogue reads the engine's packed bit rows per paste region; it must produce exactly what the
+    full-frame path (reference prediction.py:229-261) produces."""
+    from treedetection_amd.prediction import polygons_from_packed
+    rng = np.random.default_rng(2)
+    h, w, n = 60, 90, 5
+    masks = np.zeros((n, h, w), bool)
+    regions = np.zeros((n, 4), np.int32)
+    offsets = np.zeros(n, np.int64)
+    words = []
+    off = 0
+    for d in range(n):
+        x0, y0 = int(rng.integers(0, 40)), int(rng.integers(0, 30))
+        x1, y1 = x0 + int(rng.integers(5, 45)), y0 + int(rng.integers(5, 28))
+        sub = rng.uniform(0, 1, (y1 - y0, x1 - x0)) < 0.6
+        masks[d, y0:y1, x0:x1] = sub
+        regions[d] = (x0, y0, x1, y1)
+        wpr = (x1 - x0 + 31) // 32
+        padded = np.zeros((y1 - y0, wpr * 32), np.uint8)
+        padded[:, : x1 - x0] = sub
+        rows = np.packbits(padded, axis=1, bitorder="little").view(np.uint32)
+        offsets[d] = off
+        off += rows.size
+        words.append(rows.ravel())
+    bits = np.concatenate(words).view(np.int32)
+    t = [0.2, 0.0, 10.0, 0.0, -0.2, 99.0, 0, 0, 1]
+    scores = rng.uniform(0.3, 1, n).astype(np.float32)
+    a = polygons_from_masks(masks, regions, scores, np.zeros(n, np.int64), t, "x.tif")
+    b = polygons_from_packed(regions, offsets, bits, scores, np.zeros(n, np.int64), t, "x.tif")
+    assert a == b and len(a) > n

@@ -45,9 +45,10 @@ struct ConvArgs {
     const int* m_dyn;     // optional device scalar: effective rows = min(M, *m_dyn * m_mul)
     int m_mul;
     int out_f32;          // fp16 path only: write y as float32 (RPN / box-predictor heads feed the fp32 selection kernels)
-    int tile_cfg;         // -1 = heuristic; 0..3 = block tile 128x128, 128x64, 64x128, 64x64 (engine autotunes)
+    int tile_cfg;         // -1 = heuristic; 0..3 = block tile 128x128, 128x64, 64x128, 64x64 with 2 LDS stages,
+                          // 4..7 = the same tiles with 3 stages (engine autotunes)
 };
-#define TD_CONV_TILE_CFGS 4
+#define TD_CONV_TILE_CFGS 4   // the engine tunes over the 2-stage tiles; 3-stage variants (4..7) measured no better
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
 
 // ---- stem / pooling / resize (stem.hip) ---------------------------------------------------------

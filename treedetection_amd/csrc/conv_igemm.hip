@@ -60,17 +60,17 @@ struct Elem<_Float16> {
 };
 
 // T = element type of x / w / residual; TO = element type of y (float outputs are kept for the RPN / box heads)
-template <typename T, typename TO, int MT, int NT>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
+template <typename T, typename TO, int MT, int NT, int NSTAGE>
+__global__ __launch_bounds__(256, (NSTAGE == 3 && MT * NT == 4) ? 1 : 2) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int BM = 64 * MT, BN = 64 * NT;
     constexpr int AROWS = BM / 32, BROWS = BN / 32;   // rows staged per thread
     constexpr int ES = sizeof(T);
     constexpr int KE = Elem<T>::PER_CHUNK;            // elements per k-chunk
     constexpr int CS = BN + 4;                        // padded row stride (floats) of the epilogue's staged tile
-    constexpr int STAGE_BYTES = 2 * (BM + BN) * CHUNK_BYTES, EPI_BYTES = BM * CS * 4;
+    constexpr int STAGE_BYTES = NSTAGE * (BM + BN) * CHUNK_BYTES, EPI_BYTES = BM * CS * 4;
     __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES];
-    char* As = lds;                                   // [2][BM][128 B]   piece c of row r sits at slot c ^ ((r>>1)&7)
-    char* Bs = lds + 2 * BM * CHUNK_BYTES;            // [2][BN][128 B]
+    char* As = lds;                                   // [NSTAGE][BM][128 B]   piece c of row r sits at slot c ^ ((r>>1)&7)
+    char* Bs = lds + NSTAGE * BM * CHUNK_BYTES;       // [NSTAGE][BN][128 B]
 
     int M = a.M;
     if (a.m_dyn) {
@@ -177,9 +177,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // ---- software pipeline: NSTAGE LDS buffers, NSTAGE-1 k-steps of DMA in flight --------------------------------
+    // Each wave issues LOADS = AROWS + BROWS DMA instructions per k-step. Before the barrier that closes k-step `it`,
+    // `s_waitcnt vmcnt((NSTAGE-2)*LOADS)` retires this wave's pieces of step it+1 and leaves the younger steps in
+    // flight; the barrier then (a) publishes step it+1's buffer to every wave and (b) frees buffer it % NSTAGE, which
+    // the DMA of step it+NSTAGE overwrites right after it. A RAW s_barrier is used on purpose: __syncthreads() would
+    // drain vmcnt to 0 and serialise the pipeline (cdna_hip_programming.md §5 "Pipelining across barriers").
+    constexpr int LOADS = AROWS + BROWS;
+    constexpr int INFLIGHT = (NSTAGE - 2) * LOADS;
+    auto wait_stage = [&]() {
+        if constexpr (INFLIGHT == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (INFLIGHT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if constexpr (INFLIGHT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (INFLIGHT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (INFLIGHT == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if constexpr (INFLIGHT == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else static_assert(INFLIGHT < 0, "add the vmcnt immediate for this configuration");
+    };
+#pragma unroll
+    for (int p = 0; p < NSTAGE - 1; ++p)
+        if (p < nit) stage(p);
+    // prologue: step 0 must have landed; with fewer than NSTAGE-1 steps issued simply drain
+    if (nit >= NSTAGE - 1) wait_stage();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
     // fragment reads: row = lane & 31, piece = 2*kk + (lane >> 5), swizzled with the row's key (lane >> 1) & 7
     const unsigned frag_row = lane & 31;
@@ -187,10 +208,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     unsigned frag_off[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) frag_off[kk] = frag_row * CHUNK_BYTES + (((unsigned)(2 * kk) + hi) ^ swz) * 16;
-    int cur = 0;
+    int cur = 0, nxt = NSTAGE - 1;       // buffer of step it / buffer the DMA of step it+NSTAGE-1 goes to
     for (int it = 0; it < nit; ++it) {
 #if !defined(TD_DIAG_NO_LOADS)     // diagnostic builds only (tools/conv_diag.py): never defined in the product
-        if (it + 1 < nit) stage(cur ^ 1);
+        if (it + NSTAGE - 1 < nit) stage(nxt);
 #endif
         const char* Ab = &As[(cur * BM + wm * 32 * MT) * CHUNK_BYTES];
         const char* Bb = &Bs[(cur * BN + wn * 32 * NT) * CHUNK_BYTES];
@@ -207,10 +228,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
                 for (int j = 0; j < NT; ++j) Elem<T>::mma(fa[i], fb[j], acc[i][j]);
         }
 #if !defined(TD_DIAG_NO_BARRIER)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed ...
-        __syncthreads();                                    // ... and so have everyone else's; buf[cur] is free again
+        // retire step it+1 (younger DMA stays in flight while steps remain to be issued; the tail drains fully)
+        if (it + NSTAGE - 1 < nit) wait_stage();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of buf[cur] are done
+        __builtin_amdgcn_s_barrier();
 #endif
-        cur ^= 1;
+        cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+        nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
     }
 
     // ---- epilogue: accumulators → LDS tile → 4 channels per lane: scale/bias (+residual) (+ReLU), one IEEE op per
@@ -312,22 +337,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     }
 }
 
-template <typename T, typename TO, int MT, int NT>
+template <typename T, typename TO, int MT, int NT, int NSTAGE>
 td_status launch(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = 64 * MT, BN = 64 * NT;
     const int tiles = td_cdiv(a.M, BM) * td_cdiv(a.Cout, BN);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, TO, MT, NT>), dim3(tiles), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, TO, MT, NT, NSTAGE>), dim3(tiles), dim3(256), 0, stream, a);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
 
 template <typename T, typename TO>
 td_status dispatch(const ConvArgs& a, int cfg, hipStream_t stream) {
-    switch (cfg) {
-        case 0: return launch<T, TO, 2, 2>(a, stream);
-        case 1: return launch<T, TO, 2, 1>(a, stream);
-        case 2: return launch<T, TO, 1, 2>(a, stream);
-        case 3: return launch<T, TO, 1, 1>(a, stream);
+    switch (cfg) {      // 0-3: two LDS stages (one k-step of DMA in flight); 4-7: three stages (two in flight)
+        case 0: return launch<T, TO, 2, 2, 2>(a, stream);
+        case 1: return launch<T, TO, 2, 1, 2>(a, stream);
+        case 2: return launch<T, TO, 1, 2, 2>(a, stream);
+        case 3: return launch<T, TO, 1, 1, 2>(a, stream);
+        case 4: return launch<T, TO, 2, 2, 3>(a, stream);
+        case 5: return launch<T, TO, 2, 1, 3>(a, stream);
+        case 6: return launch<T, TO, 1, 2, 3>(a, stream);
+        case 7: return launch<T, TO, 1, 1, 3>(a, stream);
         default: td_set_error("conv2d: bad tile_cfg %d", cfg); return TD_ERR_INVALID;
     }
 }

@@ -165,10 +165,12 @@ class Engine:
         Wp = _round_up(max(s[1] for s in shapes), 32)
         dev = torch.device("cuda", self.device)
         key = (len(tiles), Hp, Wp)
-        if getattr(self, "_pp_key", None) != key:
-            self._pp_batch = torch.zeros((len(tiles), Hp, Wp, 3), dtype=torch.uint8, device=dev)
-            self._pp_key = key
-        batch = self._pp_batch
+        cache = self.__dict__.setdefault("_pp_cache", {})
+        if key not in cache:
+            if len(cache) >= 8:
+                cache.clear()
+            cache[key] = torch.zeros((len(tiles), Hp, Wp, 3), dtype=torch.uint8, device=dev)
+        batch = cache[key]
         need_tmp = max(t.shape[0] * s[1] * 3 for t, s in zip(tiles, shapes))
         if getattr(self, "_pp_tmp", None) is None or self._pp_tmp.numel() < need_tmp:
             self._pp_tmp = torch.empty((need_tmp,), dtype=torch.uint8, device=dev)

@@ -197,6 +197,30 @@ class GeoTiff:
         a, b, c, d, e, f = self.transform
         return (a, b, c + a * col_off + b * row_off, d, e, f + d * col_off + e * row_off)
 
+    def read_bounds_hwc(self, bounds: Sequence[float]) -> np.ndarray:
+        """Same pixels as :meth:`read_bounds` but pixel-interleaved [rows, cols, bands] and contiguous — the layout
+        the device resize consumes; for chunky files this is a plain row-slab copy of the memory map."""
+        c0, r0, w, h = self.window_of_bounds(bounds)
+        if w <= 0 or h <= 0:
+            raise ValueError("Input shapes do not overlap raster.")
+        data = self._load()
+        base = getattr(data, "base", None)
+        if isinstance(data, np.ndarray) and data.ndim == 3 and data.strides[0] == data.dtype.itemsize:
+            hwc = np.ascontiguousarray(data.transpose(1, 2, 0)[r0:r0 + h, c0:c0 + w, :])    # already HWC in memory
+        else:
+            hwc = np.ascontiguousarray(np.asarray(data[:, r0:r0 + h, c0:c0 + w]).transpose(1, 2, 0))
+        a, _, c, _, e, f = self.transform
+        minx, miny, maxx, maxy = (float(v) for v in bounds[:4])
+        xs = c + a * (np.arange(c0, c0 + w) + 0.5)
+        ys = f + e * (np.arange(r0, r0 + h) + 0.5)
+        okx = (xs >= minx) & (xs <= maxx)
+        oky = (ys >= miny) & (ys <= maxy)
+        if not okx.all():
+            hwc[:, ~okx, :] = 0
+        if not oky.all():
+            hwc[~oky, :, :] = 0
+        return hwc
+
     def read_bounds(self, bounds: Sequence[float]) -> np.ndarray:
         """``rasterio.mask.mask(img, [bbox], crop=True)[0]``: the window covering the bbox, all bands, pixels whose
         centre lies outside the bbox set to 0. Raises ValueError when the bbox does not overlap the raster."""

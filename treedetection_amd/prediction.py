@@ -72,19 +72,20 @@ class Predictor:
     # -- one tile: crop → BGR → (16-bit rescale) → device -------------------------------------------------------
     def _process_tile(self, tile, img: GeoTiff):
         try:
-            out_img = img.read_bounds(tile["bounds"])
-            if out_img.shape[0] < 3:
-                raise ValueError(f"tile has {out_img.shape[0]} bands, need >= 3")
-            _, orig_h, orig_w = out_img.shape
+            hwc = img.read_bounds_hwc(tile["bounds"])                  # [h, w, bands], band order of the file
+            if hwc.shape[2] < 3:
+                raise ValueError(f"tile has {hwc.shape[2]} bands, need >= 3")
+            orig_h, orig_w = hwc.shape[:2]
             info = {"orig_height": orig_h, "orig_width": orig_w, "height": orig_h, "width": orig_w,
                     "json_name": tile["json_name"], "tile_id": tile["tile_id"], "meta": tile["meta"]}
-            if out_img.dtype == np.uint8 or np.max(out_img[1]) <= 255:
-                if out_img.dtype != np.uint8:
-                    raise ValueError("non-uint8 raster with 8-bit values: convert the raster to uint8")
-                hwc = np.ascontiguousarray(out_img.transpose(1, 2, 0))    # band order of the file; BGR pick on device
-                return {"u8": torch.from_numpy(hwc)}, info
-            # 16-bit imagery: 255 * x / 65535 in float, then detectron2's float resize path (F.interpolate bilinear)
-            bgr = np.stack((out_img[2], out_img[1], out_img[0])).astype(np.float64) * 255.0 / 65535.0
+            if hwc.dtype == np.uint8:                                   # max(band 1) <= 255 by construction
+                return {"u8": torch.from_numpy(hwc)}, info                 # BGR pick happens on the device
+            out_img = hwc.transpose(2, 0, 1)
+            # non-uint8 rasters take detectron2's float resize path (F.interpolate bilinear); 16-bit imagery
+            # (max(band 1) > 255) is first rescaled 255 * x / 65535 — reference prediction.py:167
+            bgr = np.stack((out_img[2], out_img[1], out_img[0])).astype(np.float64)
+            if np.max(out_img[1]) > 255:
+                bgr = 255.0 * bgr / 65535.0
             return {"f": torch.from_numpy(bgr)}, info
         except Exception as e:
             print(f"Error processing tile {tile['json_name']}: {e}")
@@ -126,12 +127,10 @@ class Predictor:
             torch.cuda.synchronize()
         if D.world() == 1:
             host = {k: v.cpu().numpy() for k, v in out.items()}
-            futures = [self._pool.submit(self._process_and_save_single, b, i, host, pred_subdir, tifpath)
-                       for i, b in enumerate(batch)]
-            preds = []
-            for f in futures:
-                preds.extend(f.result())
-            return preds
+            # host epilogue (unpack → contours → JSON) runs on the thread pool while the NEXT batch is read and
+            # launched; __call__ collects the futures (at most two batches are kept pending)
+            return [self._pool.submit(self._process_and_save_single, b, i, host, pred_subdir, tifpath)
+                    for i, b in enumerate(batch)]
         # ---- multi-GPU: fixed-shape gather (every rank pads its batch to max_batch_size) → rank 0 writes ----
         B, Dn = self.max_batch_size, self.engine.D
         dev = torch.device(self.device)
@@ -161,10 +160,8 @@ class Predictor:
     def _process_and_save_single(self, b, i, host, pred_subdir, tifpath):
         output_file = os.path.join(pred_subdir, f"Prediction_{os.path.basename(b['tile_id'])}.json")
         n = int(host["count"][i])
-        h, w = b["orig_height"], b["orig_width"]
-        masks = unpack_masks(host["mask_region"][i], host["mask_offset"][i], host["mask_bits"][i], n, h, w)
-        evaluations = polygons_from_masks(masks, host["mask_region"][i][:n], host["scores"][i][:n], host["classes"][i][:n],
-                                          b["meta"]["transform"], tifpath)
+        evaluations = polygons_from_packed(host["mask_region"][i][:n], host["mask_offset"][i][:n], host["mask_bits"][i],
+                                           host["scores"][i][:n], host["classes"][i][:n], b["meta"]["transform"], tifpath)
         with open(output_file, "w") as f:
             f.write(json.dumps(evaluations))
         return evaluations
@@ -175,8 +172,14 @@ class Predictor:
         tiles = self._load_tiles(tilepath)
         mine = D.shard_indices(len(tiles))
         rounds = D.padded_rounds(len(tiles), self.max_batch_size)   # identical on every rank: collectives line up
-        predictions = []
+        predictions, pending = [], []
         img = GeoTiff(tifpath)
+
+        def collect(keep):
+            while len(pending) > keep:
+                for f in pending.pop(0):
+                    predictions.extend(f.result() if hasattr(f, "result") else f)
+
         for r in range(rounds):
             batch = []
             for idx in mine[r * self.max_batch_size:(r + 1) * self.max_batch_size]:
@@ -184,8 +187,42 @@ class Predictor:
                 if data is not None:
                     batch.append({"data": data, **info})
             if batch or D.world() > 1:
-                predictions.extend(self._process_and_save_batch(batch, pred_subdir, tifpath))
+                res = self._process_and_save_batch(batch, pred_subdir, tifpath)
+                pending.append(res if D.world() == 1 else [res])
+                collect(1)
+        collect(0)
         return predictions
+
+
+def _ring_entries(sub: np.ndarray, x0: int, y0: int, score: float, cls: int, transform, tifpath, out: List[dict]) -> None:
+    for contour in find_contours(sub):
+        if contour.size < 8:
+            continue
+        cx = (contour[:, 0] + x0).tolist()
+        cy = (contour[:, 1] + y0).tolist()
+        if (cx[0], cy[0]) != (cx[-1], cy[-1]):
+            cx.append(cx[0])
+            cy.append(cy[0])
+        gx, gy = xy(transform, rows=cy, cols=cx)
+        out.append({"image_id": tifpath, "category_id": cls, "score": score,
+                    "polygon_coords": [[[float(a), float(b)] for a, b in zip(gx, gy)]]})
+
+
+def polygons_from_packed(regions, offsets, bits, scores, classes, transform, tifpath) -> List[dict]:
+    """Same result as :func:`polygons_from_masks`, straight from the engine's packed bit rows: each detection's
+    paste region is unpacked on its own (no full-frame [n,h,w] array; the mask is zero outside its region)."""
+    words = np.asarray(bits).view(np.uint32)
+    out: List[dict] = []
+    for d in range(len(scores)):
+        x0, y0, x1, y1 = (int(v) for v in regions[d])
+        if x1 <= x0 or y1 <= y0:
+            continue
+        wpr = (x1 - x0 + 31) // 32
+        o = int(offsets[d])
+        rows = words[o:o + wpr * (y1 - y0)].reshape(y1 - y0, wpr)
+        sub = np.unpackbits(rows.view(np.uint8).reshape(y1 - y0, wpr * 4), axis=1, bitorder="little")[:, : x1 - x0]
+        _ring_entries(sub, x0, y0, float(scores[d]), int(classes[d]), transform, tifpath, out)
+    return out
 
 
 def polygons_from_masks(masks: np.ndarray, regions: np.ndarray, scores, classes, transform, tifpath) -> List[dict]:
