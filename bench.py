@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--stream-tiles", type=int, default=256)
     ap.add_argument("--distinct", type=int, default=16, help="distinct seeds generated (cycled over the stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tiles", type=int, default=6)
+    ap.add_argument("--cpu-tiles", type=int, default=16)   # ≈ 13 s of CPU work on 16 threads
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-fp16", action="store_true", help="skip the second timed region with the fp16 engine")
     return ap.parse_args()

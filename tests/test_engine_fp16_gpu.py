@@ -50,7 +50,7 @@ def test_fp16_trunk_close_to_fp32(setup16):
 
 
 def test_fp16_detections_within_tolerance(setup16):
-    """Measured on this fixture (tools/fp16_stats.py): same detection sets (59/59, 78/79), boxes <= 0.25 px, scores
+    """Measured on this fixture (tests/fp16_stats.py): same detection sets (59/59, 78/79), boxes <= 0.25 px, scores
     <= 0.0098, mask probabilities <= 0.0233, pasted-mask IoU 0.86 .. 1.0. The synthetic heads amplify rounding
     (classifier gain x3, mask predictor gain x2, many mask pixels within 1e-2 of the 0.5 cut), so the bounds below
     are this fixture's, looser than the fp16 row BASELINE.md proposes for trained weights."""

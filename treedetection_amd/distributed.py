@@ -50,8 +50,11 @@ def gather_detections(out: Dict[str, torch.Tensor], dst: int = 0) -> Optional[Li
     res = None
     if me == dst:
         res = [dict() for _ in range(world())]
+    host_backend = dist.get_backend() != "nccl"      # gloo (CPU tests, single-GPU rehearsal) moves host tensors
     for k in GATHER_KEYS:
         t = out[k].contiguous()
+        if host_backend and t.is_cuda:
+            t = t.cpu()
         lst = [torch.empty_like(t) for _ in range(world())] if me == dst else None
         dist.gather(t, lst, dst=dst)
         if me == dst:
