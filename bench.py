@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--cpu-tiles", type=int, default=16)   # ≈ 13 s of CPU work on 16 threads
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-fp16", action="store_true", help="skip the second timed region with the fp16 engine")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-stream timed region")
+    ap.add_argument("--streams", type=int, default=1, help="engines / HIP streams the batches alternate over (the "
+                    "low-occupancy selection tail of one batch overlaps the next batch's convolutions)")
     return ap.parse_args()
 
 
@@ -148,35 +151,41 @@ def main():
     ndsm = torch.from_numpy(ndsm_np).to(dev)          # side band: travels with the tile, not a network input
     gather_keys = ("boxes", "scores", "count", "mask_probs")
 
-    def run(precision):
-        """Warm-up + timed region for one engine precision → (seconds max over ranks, profile dict, detections)."""
-        log(f"creating engine ({precision})")
-        eng = Engine(sd, device=local_rank, precision=precision)
-        out = eng.alloc_outputs(B, S, S, paste=True)
+    def run(precision, ns, profile):
+        """Warm-up + timed region for one engine precision over `ns` engines / HIP streams → (seconds max over
+        ranks, profile dict or None, detections)."""
+        log(f"creating engine ({precision}, {ns} stream(s))")
+        engs = [Engine(sd, device=local_rank, precision=precision) for _ in range(ns)]
+        outs = [e.alloc_outputs(B, S, S, paste=True) for e in engs]
+        streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(ns - 1)]
+        eng, out = engs[0], outs[0]
         gl = None
         if world > 1 and rank == 0:
             gl = {k: [torch.empty_like(out[k]) for _ in range(world)] for k in gather_keys}
 
         def step(i):
-            tiles = [rgb[(i * B + j) % n_local] for j in range(B)]
-            batch, hw_valid, hw_out = eng.preprocess_tiles_u8(tiles)
-            eng.forward_raw(batch, INPUT_U8_HWC, hw_valid, hw_out, out)
-            if world > 1:
-                for k in gather_keys:   # RCCL gather of the per-tile detections to rank 0 (hand-off to stitching)
-                    if backend == "nccl":
-                        dist.gather(out[k], gl[k] if rank == 0 else None, dst=0)
-                    else:   # rehearsal backend: gloo moves host tensors
-                        h = out[k].cpu()
-                        dist.gather(h, [torch.empty_like(h) for _ in range(world)] if rank == 0 else None, dst=0)
+            e, o = engs[i % ns], outs[i % ns]
+            with torch.cuda.stream(streams[i % ns]):
+                tiles = [rgb[(i * B + j) % n_local] for j in range(B)]
+                batch, hw_valid, hw_out = e.preprocess_tiles_u8(tiles)
+                e.forward_raw(batch, INPUT_U8_HWC, hw_valid, hw_out, o)
+                if world > 1:
+                    for k in gather_keys:   # RCCL gather of the per-tile detections to rank 0 (hand-off to stitching)
+                        if backend == "nccl":
+                            dist.gather(o[k], gl[k] if rank == 0 else None, dst=0)
+                        else:   # rehearsal backend: gloo moves host tensors
+                            h = o[k].cpu()
+                            dist.gather(h, [torch.empty_like(h) for _ in range(world)] if rank == 0 else None, dst=0)
 
         log("warm-up (the first forward also measures the block-tile choice per layer)")
-        for i in range(args.warmup):
+        for i in range(max(args.warmup, ns)):
             step(i)
             torch.cuda.synchronize()
-            log(f"warm-up step {i + 1}/{args.warmup} done")
-        if not args.no_profile:
-            eng.profile_enable(True)
-            eng.profile_read(reset=True)
+            log(f"warm-up step {i + 1} done")
+        if profile:
+            for e in engs:
+                e.profile_enable(True)
+                e.profile_read(reset=True)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -190,19 +199,33 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         log(f"timed region done ({precision}): {dt:.3f} s (host enqueue {t_enq:.3f} s)")
-        prof = eng.profile_read(reset=True) if not args.no_profile else None
-        eng.profile_enable(False)
-        ndet = int(out["count"].sum().item())     # detections of the last batch (for the mask-head FLOP estimate)
+        prof = None
+        if profile:
+            for e in engs:      # sum the per-engine accumulators
+                p1 = e.profile_read(reset=True)
+                e.profile_enable(False)
+                if prof is None:
+                    prof = p1
+                else:
+                    for k in prof:
+                        for f in prof[k]:
+                            prof[k][f] += p1[k][f]
+        ndet = int(out["count"].sum().item())     # detections of one batch (for the mask-head FLOP estimate)
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        eng.close()
+        for e in engs:
+            e.close()
         return float(tmax.item()), prof, ndet
 
-    dt, prof, ndet = run(args.precision)
-    extra = None
+    dt, prof, ndet = run(args.precision, max(1, args.streams), not args.no_profile)
+    extra = piped = None
     if args.precision == "fp32" and not args.no_fp16:
-        extra = run("fp16")
+        extra = run("fp16", 1, not args.no_profile)
+    if args.streams == 1 and not args.no_pipelined:
+        # informational: the same steps with batches alternating over two engines / streams (no event brackets: with
+        # two streams in flight the per-kernel spans overlap, so the roofline above stays the single-stream one)
+        piped = run(args.precision, 2, False)
 
     if rank == 0:
         tiles_total = args.steps * B * world
@@ -262,6 +285,13 @@ def main():
                                  "frac": a16 / PEAK_F16_MATRIX_TFLOPS, "traffic": None}
                 o["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof16.items()}
             line["fp16"] = o
+        if piped is not None:
+            line["pipelined_2_streams"] = {"value": tiles_total / piped[0], "unit": "tiles/s",
+                                           "ms_per_step": 1000.0 * piped[0] / args.steps,
+                                           "note": "same K steps, batches alternate over two engines on two HIP streams: "
+                                                   "the low-occupancy selection tail (top-k, NMS, RoIAlign, mask head) of "
+                                                   "one batch overlaps the next batch's convolutions; informational — "
+                                                   "`value` and `roofline` are the single-stream region"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, rgb_np, args.cpu_tiles)
         print(json.dumps(line), flush=True)
