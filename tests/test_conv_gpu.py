@@ -97,3 +97,18 @@ def test_conv_fp16_matches_torch(case):
     ref = ref.numpy()
     err = np.abs(got - ref)
     assert (err <= 2e-3 * np.maximum(np.abs(ref), 1.0)).all(), f"max err {err.max()}"
+
+
+@pytest.mark.parametrize("cfg", [4, 7, 8, 9, 10])
+def test_conv_every_block_tile_variant(cfg):
+    """The engine picks a block tile per layer by measurement; every variant must compute the same convolution.
+    TD_CONV_CFG forces one variant for a whole process (diagnostic hook), so the cases above re-run in a child."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TD_CONV_CFG=str(cfg))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_conv_gpu.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "matches_torch"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "18 passed" in r.stdout

@@ -38,6 +38,16 @@ def bench(lib, prec, B, H, W, Cin, Cout, k, cfg_name):
     print(f"{cfg_name:28s} prec={prec} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s", flush=True)
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "tiles":
+        # product build only, one forced block tile per process (TD_CONV_CFG is read once per process)
+        lib = C.CDLL(os.path.join(ROOT, "treedetection_amd", "libtreedet_hip.so"))
+        tag = "cfg" + os.environ.get("TD_CONV_CFG", "-1")
+        for prec in (0, 1):
+            bench(lib, prec, 8, 200, 200, 256, 256, 3, tag + " 3x3 256->256 M=320k")
+            bench(lib, prec, 8, 100, 100, 128, 128, 3, tag + " 3x3 128->128 M=80k")
+            bench(lib, prec, 8, 50, 50, 1024, 256, 1, tag + " 1x1 1024->256 M=20k")
+            bench(lib, prec, 8000, 1, 1, 12544, 1024, 1, tag + " fc1 M=8000")
+        sys.exit(0)
     libs = {"product": [], "no_loads": ["-DTD_DIAG_NO_LOADS"], "no_loads_no_barrier": ["-DTD_DIAG_NO_LOADS", "-DTD_DIAG_NO_BARRIER"]}
     for tag, defs in libs.items():
         lib = C.CDLL(build(tag, defs))

@@ -48,7 +48,10 @@ struct ConvArgs {
     int tile_cfg;         // -1 = heuristic; 0..3 = block tile 128x128, 128x64, 64x128, 64x64 with 2 LDS stages,
                           // 4..7 = the same tiles with 3 stages (engine autotunes)
 };
-#define TD_CONV_TILE_CFGS 4   // the engine tunes over the 2-stage tiles; 3-stage variants (4..7) measured no better
+// tile_cfg ids: 0..3 4-wave tiles (2 LDS stages), 4..7 the same with 3 stages (measured no better: not tuned over),
+// 8 = 256x128 / 9 = 128x256 (8 waves), 10 = 256x256 (16 waves)
+#define TD_CONV_TILE_CFG_MAX 10
+static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10};   // 8 / 9 never won a layer (tools/conv_diag.py tiles)
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
 
 // ---- stem / pooling / resize (stem.hip) ---------------------------------------------------------

@@ -20,6 +20,7 @@
 // buffering with one barrier per k-step, bijective XCD-aware block remap over the live tile count, and an epilogue
 // staged through LDS so residual loads / stores are whole coalesced row segments.
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -60,14 +61,25 @@ struct Elem<_Float16> {
 };
 
 // T = element type of x / w / residual; TO = element type of y (float outputs are kept for the RPN / box heads)
-template <typename T, typename TO, int MT, int NT, int NSTAGE>
-__global__ __launch_bounds__(256, (NSTAGE == 3 && MT * NT == 4) ? 1 : 2) void conv_igemm_kernel(const ConvArgs a) {
-    constexpr int BM = 64 * MT, BN = 64 * NT;
-    constexpr int AROWS = BM / 32, BROWS = BN / 32;   // rows staged per thread
+// WM x WN waves per block (each wave owns a (32*MT) x (32*NT) output sub-tile): 2x2 = the 4-wave tiles above;
+// 4x2 / 2x4 / 4x4 = 256x128 / 128x256 / 256x256 block tiles whose larger operand reuse cuts the DMA instructions and
+// the L2 traffic per flop (what bounds the fp16 path).
+template <typename T, typename TO, int MT, int NT, int NSTAGE, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int THREADS = 64 * WM * WN;
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+    constexpr int LDROWS = THREADS / 8;               // rows staged per pass (8 lanes x 16 B per row)
+    constexpr int AROWS = BM / LDROWS, BROWS = BN / LDROWS;   // rows staged per thread
+    static_assert(BM % LDROWS == 0 && BN % LDROWS == 0 && LDROWS % 16 == 0, "tile / thread-count mismatch");
     constexpr int ES = sizeof(T);
     constexpr int KE = Elem<T>::PER_CHUNK;            // elements per k-chunk
     constexpr int CS = BN + 4;                        // padded row stride (floats) of the epilogue's staged tile
-    constexpr int STAGE_BYTES = NSTAGE * (BM + BN) * CHUNK_BYTES, EPI_BYTES = BM * CS * 4;
+    constexpr int WROW = 32 * MT;                     // rows of one wave-row
+    constexpr int STAGE_BYTES = NSTAGE * (BM + BN) * CHUNK_BYTES;
+    // the epilogue stages RWM wave-rows at a time through LDS (all of them when the k-loop's LDS is large enough)
+    constexpr int FIT = STAGE_BYTES / (WROW * CS * 4);
+    constexpr int RWM = FIT >= WM ? WM : (FIT >= 2 && WM % 2 == 0 ? 2 : 1);
+    constexpr int EPI_BYTES = RWM * WROW * CS * 4;
     __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES];
     char* As = lds;                                   // [NSTAGE][BM][128 B]   piece c of row r sits at slot c ^ ((r>>1)&7)
     char* Bs = lds + NSTAGE * BM * CHUNK_BYTES;       // [NSTAGE][BN][128 B]
@@ -89,7 +101,7 @@ __global__ __launch_bounds__(256, (NSTAGE == 3 && MT * NT == 4) ? 1 : 2) void co
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int ld_c = tid & 7;    // 16-B piece inside the 128-B k-chunk
     const int ld_r = tid >> 3;   // 0..31
 
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(256, (NSTAGE == 3 && MT * NT == 4) ? 1 : 2) void co
     unsigned a_off[AROWS], a_ok[AROWS];      // byte offset of tap (0,0); bit t set = tap t reads a real pixel
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-        const int m = m0 + ld_r + 32 * i;
+        const int m = m0 + ld_r + LDROWS * i;
         a_off[i] = 0;
         a_ok[i] = 0;
         if (m < M) {
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(256, (NSTAGE == 3 && MT * NT == 4) ? 1 : 2) void co
     unsigned b_off[BROWS];
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
-        const int n = n0 + ld_r + 32 * i;
+        const int n = n0 + ld_r + LDROWS * i;
         b_off[i] = n < a.Cout ? (unsigned)n * (unsigned)K * ES + src_piece : OOB;
     }
 
@@ -148,13 +160,13 @@ __global__ __launch_bounds__(256, (NSTAGE == 3 && MT * NT == 4) ? 1 : 2) void co
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
             const unsigned off = ((a_ok[i] >> ld_tap) & 1u) ? a_off[i] + xs : OOB;
-            char* dst = As + ((unsigned)buf * BM + 32u * i + wave_rows) * CHUNK_BYTES;
+            char* dst = As + ((unsigned)buf * BM + (unsigned)LDROWS * i + wave_rows) * CHUNK_BYTES;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)dst, 16, off, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
             const unsigned off = b_off[i] == OOB ? OOB : b_off[i] + ws;
-            char* dst = Bs + ((unsigned)buf * BN + 32u * i + wave_rows) * CHUNK_BYTES;
+            char* dst = Bs + ((unsigned)buf * BN + (unsigned)LDROWS * i + wave_rows) * CHUNK_BYTES;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)dst, 16, off, 0, 0, 0);
         }
         if (++ld_kx == a.KW) {
@@ -242,23 +254,11 @@ __global__ __launch_bounds__(256, (NSTAGE == 3 && MT * NT == 4) ? 1 : 2) void co
     // step (no fma contraction). Staging through LDS turns the MFMA layout (32 lanes x 4 B per row) into whole row
     // segments, so residual loads and stores are vector accesses and fully coalesced (HBM-bound 1x1 layers).
     float* Cs = reinterpret_cast<float*>(lds);
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 32 * MT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int col = wn * 32 * NT + j * 32 + (lane & 31);
-                Cs[row * CS + col] = acc[i][j][r];
-            }
-    __syncthreads();
-
     TO* __restrict__ Y = static_cast<TO*>(a.y);
     const T* __restrict__ Rs = static_cast<const T*>(a.res);
     const int Cq = a.out_mode == 1 ? a.Cout >> 2 : a.Cout;
     constexpr int CHUNKS = BN / 4;                     // 4-channel pieces per tile row
-    constexpr int ROWS_PER_PASS = 256 / CHUNKS;
+    constexpr int ROWS_PER_PASS = THREADS / CHUNKS;
     const int c4 = tid % CHUNKS;
     const int n = n0 + c4 * 4;
     const bool vec = (a.Cout & 3) == 0 && n + 3 < a.Cout;   // aligned, whole piece in range
@@ -272,76 +272,92 @@ __global__ __launch_bounds__(256, (NSTAGE == 3 && MT * NT == 4) ? 1 : 2) void co
         }
     }
     const int hw = a.Ho * a.Wo;
-    for (int row = tid / CHUNKS; row < BM; row += ROWS_PER_PASS) {
-        const int m = m0 + row;
-        if (m >= M || n >= a.Cout) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CS + c4 * 4]);
-        size_t yoff, roff = 0;
-        if (a.out_mode == 0) {
-            yoff = (size_t)m * a.Cout + n;
-            roff = yoff;
-            if (Rs && a.res_shift) {
+    for (int q = 0; q < WM; q += RWM) {
+        if (q > 0) __syncthreads();                    // the previous round's readers are done with Cs
+        if (wm >= q && wm < q + RWM) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (wm - q) * WROW + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const int col = wn * 32 * NT + j * 32 + (lane & 31);
+                        Cs[row * CS + col] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        for (int row = tid / CHUNKS; row < RWM * WROW; row += ROWS_PER_PASS) {
+            const int m = m0 + q * WROW + row;
+            if (m >= M || n >= a.Cout) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CS + c4 * 4]);
+            size_t yoff, roff = 0;
+            if (a.out_mode == 0) {
+                yoff = (size_t)m * a.Cout + n;
+                roff = yoff;
+                if (Rs && a.res_shift) {
+                    const int b = m / hw;
+                    const int rem = m - b * hw;
+                    const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+                    roff = ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout + n;
+                }
+            } else {
+                const int qq = n / Cq, co = n - qq * Cq;   // qq = dy*2+dx; a piece never straddles it (Cq % 4 == 0)
                 const int b = m / hw;
                 const int rem = m - b * hw;
                 const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-                roff = ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout + n;
+                yoff = ((size_t)(b * 2 * a.Ho + 2 * oy + (qq >> 1)) * (2 * a.Wo) + 2 * ox + (qq & 1)) * Cq + co;
             }
-        } else {
-            const int q = n / Cq, co = n - q * Cq;   // q = dy*2+dx; a piece never straddles q (Cq % 4 == 0)
-            const int b = m / hw;
-            const int rem = m - b * hw;
-            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-            yoff = ((size_t)(b * 2 * a.Ho + 2 * oy + (q >> 1)) * (2 * a.Wo) + 2 * ox + (q & 1)) * Cq + co;
-        }
-        float rs[4] = {0.f, 0.f, 0.f, 0.f};
-        if (Rs) {
-            if (vec) {
-                if constexpr (sizeof(T) == 4) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(Rs + roff);
+            float rs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (Rs) {
+                if (vec) {
+                    if constexpr (sizeof(T) == 4) {
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(Rs + roff);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) rs[e] = t[e];
+                        for (int e = 0; e < 4; ++e) rs[e] = t[e];
+                    } else {
+                        const f16x4 t = *reinterpret_cast<const f16x4*>(Rs + roff);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rs[e] = (float)t[e];
+                    }
                 } else {
-                    const f16x4 t = *reinterpret_cast<const f16x4*>(Rs + roff);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) rs[e] = (float)t[e];
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < a.Cout) rs[e] = Elem<T>::to_f32(Rs[roff + e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[e];
+                if (a.scale) t = __fmul_rn(t, sc[e]);
+                if (a.bias) t = __fadd_rn(t, bi[e]);
+                if (Rs) t = __fadd_rn(t, rs[e]);
+                if (a.relu) t = t > 0.f ? t : 0.f;
+                v[e] = t;
+            }
+            if (vec) {
+                if constexpr (sizeof(TO) == 4) {
+                    *reinterpret_cast<f32x4*>(Y + yoff) = v;
+                } else {
+                    f16x4 h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
+                    *reinterpret_cast<f16x4*>(Y + yoff) = h;
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (n + e < a.Cout) rs[e] = Elem<T>::to_f32(Rs[roff + e]);
+                    if (n + e < a.Cout) Y[yoff + e] = (TO)v[e];
             }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float t = v[e];
-            if (a.scale) t = __fmul_rn(t, sc[e]);
-            if (a.bias) t = __fadd_rn(t, bi[e]);
-            if (Rs) t = __fadd_rn(t, rs[e]);
-            if (a.relu) t = t > 0.f ? t : 0.f;
-            v[e] = t;
-        }
-        if (vec) {
-            if constexpr (sizeof(TO) == 4) {
-                *reinterpret_cast<f32x4*>(Y + yoff) = v;
-            } else {
-                f16x4 h;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
-                *reinterpret_cast<f16x4*>(Y + yoff) = h;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (n + e < a.Cout) Y[yoff + e] = (TO)v[e];
         }
     }
 }
 
-template <typename T, typename TO, int MT, int NT, int NSTAGE>
+template <typename T, typename TO, int MT, int NT, int NSTAGE, int WM = 2, int WN = 2>
 td_status launch(const ConvArgs& a, hipStream_t stream) {
-    constexpr int BM = 64 * MT, BN = 64 * NT;
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     const int tiles = td_cdiv(a.M, BM) * td_cdiv(a.Cout, BN);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, TO, MT, NT, NSTAGE>), dim3(tiles), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, TO, MT, NT, NSTAGE, WM, WN>), dim3(tiles), dim3(64 * WM * WN), 0, stream, a);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
@@ -357,6 +373,9 @@ td_status dispatch(const ConvArgs& a, int cfg, hipStream_t stream) {
         case 5: return launch<T, TO, 2, 1, 3>(a, stream);
         case 6: return launch<T, TO, 1, 2, 3>(a, stream);
         case 7: return launch<T, TO, 1, 1, 3>(a, stream);
+        case 8: return launch<T, TO, 2, 2, 2, 4, 2>(a, stream);     // 256 x 128, 8 waves
+        case 9: return launch<T, TO, 2, 2, 2, 2, 4>(a, stream);     // 128 x 256, 8 waves
+        case 10: return launch<T, TO, 2, 2, 2, 4, 4>(a, stream);    // 256 x 256, 16 waves
         default: td_set_error("conv2d: bad tile_cfg %d", cfg); return TD_ERR_INVALID;
     }
 }
@@ -374,6 +393,10 @@ td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream) {
     TD_REQUIRE(a.KH * a.KW <= 32, "conv2d: at most 32 filter taps (got %dx%d)", a.KH, a.KW);
     TD_REQUIRE(a.out_mode == 0 || (a.Cout % 16 == 0 && !a.res), "conv2d: bad deconv configuration");
     int cfg = a.tile_cfg;
+    if (cfg < 0) {
+        static const char* forced = getenv("TD_CONV_CFG");     // diagnostics only (tools/conv_diag.py)
+        if (forced) cfg = atoi(forced);
+    }
     if (cfg < 0) {
         // heuristic (the engine replaces it by a measured choice per layer shape): wide N for wide layers, 64-row
         // tiles when there is less than one 128-row tile per CU

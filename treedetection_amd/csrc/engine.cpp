@@ -336,7 +336,7 @@ td_status td_engine_create(const td_model_desc* desc, int device, td_engine** ou
         if (FILE* f = fopen(tc, "r")) {
             int pr, a0, a1, a2, a3, a4, cfg;
             while (fscanf(f, "%d %d %d %d %d %d %d", &pr, &a0, &a1, &a2, &a3, &a4, &cfg) == 7)
-                if (pr == d.precision && cfg >= 0 && cfg < TD_CONV_TILE_CFGS) e->tuned[std::make_tuple(a0, a1, a2, a3, a4)] = cfg;
+                if (pr == d.precision && cfg >= 0 && cfg <= TD_CONV_TILE_CFG_MAX) e->tuned[std::make_tuple(a0, a1, a2, a3, a4)] = cfg;
             fclose(f);
         }
     }
@@ -658,7 +658,7 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
                 hipEvent_t ea, eb;
                 TD_HIP_CHECK(hipEventCreate(&ea));
                 TD_HIP_CHECK(hipEventCreate(&eb));
-                for (int c = 0; c < TD_CONV_TILE_CFGS; ++c) {
+                for (int c : TD_CONV_TUNE_CANDIDATES) {
                     td_status st2 = run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, c);
                     if (st2 < 0) return st2;
                     TD_HIP_CHECK(hipEventRecord(ea, s_));
