@@ -119,6 +119,10 @@ void td_engine_destroy(td_engine* e);
  * dst dev uint8 [dst_pitch_rows.., 3] written at dst[(y*dst_pitch_px + x)*3 + c] for y<out_h, x<out_w. */
 td_status td_resize_tile_u8(const uint8_t* src, int h, int w, int c, uint8_t* dst, int out_h, int out_w,
                             int dst_pitch_px, void* tmp_dev /* >= h*out_w*3 bytes */, void* stream);
+/* The same for n tiles of one common size in two launches: src_tiles = HOST array of n device pointers; tile i is
+ * written to dst + i*dst_image_stride_bytes; tmp_dev >= n*h*out_w*3 bytes. */
+td_status td_resize_batch_u8(const uint8_t* const* src_tiles, int n, int h, int w, int c, uint8_t* dst, int out_h,
+                             int out_w, int dst_pitch_px, int64_t dst_image_stride_bytes, void* tmp_dev, void* stream);
 /* ResizeShortestEdge(800, 1333) output shape for an h x w tile (Appendix A item 2). */
 void td_resize_shape(int h, int w, int short_edge, int max_size, int* out_h, int* out_w);
 

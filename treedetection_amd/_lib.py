@@ -55,6 +55,8 @@ SIGNATURES = {
     "td_engine_destroy": (None, [C.c_void_p]),
     "td_resize_tile_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p]),
+    "td_resize_batch_u8": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "td_resize_shape": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "td_conv2d_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
                        + [C.c_int] * 11 + [C.c_void_p]),

@@ -61,6 +61,12 @@ td_status td_resize_tile_u8(const uint8_t* src, int h, int w, int c, uint8_t* ds
     return resize_tile_u8_launch(src, h, w, c, dst, out_h, out_w, dst_pitch_px, tmp_dev, static_cast<hipStream_t>(stream));
 }
 
+td_status td_resize_batch_u8(const uint8_t* const* src_tiles, int n, int h, int w, int c, uint8_t* dst, int out_h,
+                             int out_w, int dst_pitch_px, int64_t dst_image_stride_bytes, void* tmp_dev, void* stream) {
+    return resize_batch_u8_launch(src_tiles, n, h, w, c, dst, out_h, out_w, dst_pitch_px, (size_t)dst_image_stride_bytes,
+                                  tmp_dev, static_cast<hipStream_t>(stream));
+}
+
 void td_resize_shape(int h, int w, int short_edge, int max_size, int* out_h, int* out_w) {
     // detectron2 ResizeShortestEdge.get_output_shape (python doubles; int(x + 0.5)) — Appendix A item 2
     const double scale = (double)short_edge / (double)(h < w ? h : w);

@@ -296,41 +296,57 @@ __global__ __launch_bounds__(1024) void rpn_merge_kernel(const float* __restrict
                                                          const int* __restrict__ keep_count, int post_topk,
                                                          float* __restrict__ props, float* __restrict__ prop_scores,
                                                          int* __restrict__ prop_count, int prop_stride) {
+    // Every level's keep list is already ordered (score desc, candidate index asc), and the composite
+    // (score key, concat index) is unique, so the merged position of an element is its own rank plus, for each other
+    // level, the number of that level's elements that sort before it — four binary searches in LDS, no sort.
     const int b = blockIdx.x;
-    constexpr int N = RPN_LEVELS * RPN_CAND_POW2;   // 5 * 1024 → sort size 8192
-    __shared__ unsigned long long s[8192];
-    for (int i = threadIdx.x; i < 8192; i += blockDim.x) {
+    __shared__ unsigned long long s[RPN_LEVELS][RPN_CAND_POW2];
+    __shared__ int s_cnt[RPN_LEVELS];
+    if (threadIdx.x < RPN_LEVELS) s_cnt[threadIdx.x] = keep_count[b * RPN_LEVELS + threadIdx.x];
+    __syncthreads();
+    for (int i = threadIdx.x; i < RPN_LEVELS * RPN_CAND_POW2; i += blockDim.x) {
+        const int level = i >> 10, r = i & 1023;
         unsigned long long e = 0ull;
-        if (i < N) {
-            const int level = i >> 10, r = i & 1023;
+        if (r < s_cnt[level]) {
             const int item = b * RPN_LEVELS + level;
-            if (r < keep_count[item]) {
-                const int ci = keep_idx[(size_t)item * RPN_CAND + r];
-                const float sc = cand_scores[(size_t)item * RPN_CAND + ci];
-                // concat index: level-major, then rank inside the level's (filtered, score-sorted) list
-                e = ((unsigned long long)float_to_key(sc) << 32) | (0xffffffffu - (uint32_t)(level * RPN_CAND_POW2 + ci));
-            }
+            const int ci = keep_idx[(size_t)item * RPN_CAND + r];
+            const float sc = cand_scores[(size_t)item * RPN_CAND + ci];
+            // concat index: level-major, then rank inside the level's (filtered, score-sorted) list
+            e = ((unsigned long long)float_to_key(sc) << 32) | (0xffffffffu - (uint32_t)(level * RPN_CAND_POW2 + ci));
         }
-        s[i] = e;
+        s[level][r] = e;
     }
     __syncthreads();
-    bitonic_sort_desc(s, 8192);
     int total = 0;
-    for (int l = 0; l < RPN_LEVELS; ++l) total += keep_count[b * RPN_LEVELS + l];
+    for (int l = 0; l < RPN_LEVELS; ++l) total += s_cnt[l];
     const int cnt = total < post_topk ? total : post_topk;
-    for (int i = threadIdx.x; i < prop_stride; i += blockDim.x) {
-        float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
-        float sc = 0.f;
-        if (i < cnt) {
-            const unsigned long long e = s[i];
-            const uint32_t ci_all = 0xffffffffu - (uint32_t)(e & 0xffffffffull);
-            const int level = ci_all >> 10, ci = ci_all & 1023;
-            const size_t src = ((size_t)(b * RPN_LEVELS + level)) * RPN_CAND + ci;
-            bx = *reinterpret_cast<const float4*>(cand_boxes + src * 4);
-            sc = cand_scores[src];
+    for (int i = threadIdx.x; i < RPN_LEVELS * RPN_CAND_POW2; i += blockDim.x) {
+        const int level = i >> 10, r = i & 1023;
+        if (r >= s_cnt[level]) continue;
+        const unsigned long long e = s[level][r];
+        int rank = r;
+        for (int l = 0; l < RPN_LEVELS; ++l) {
+            if (l == level) continue;
+            int lo = 0, hi = s_cnt[l];          // first position whose composite is < e (list is descending)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s[l][mid] > e) lo = mid + 1;
+                else hi = mid;
+            }
+            rank += lo;
         }
-        *reinterpret_cast<float4*>(props + ((size_t)b * prop_stride + i) * 4) = bx;
-        prop_scores[(size_t)b * prop_stride + i] = sc;
+        if (rank < cnt) {
+            const uint32_t ci_all = 0xffffffffu - (uint32_t)(e & 0xffffffffull);
+            const int ci = ci_all & 1023;
+            const size_t src = ((size_t)(b * RPN_LEVELS + level)) * RPN_CAND + ci;
+            *reinterpret_cast<float4*>(props + ((size_t)b * prop_stride + rank) * 4) =
+                *reinterpret_cast<const float4*>(cand_boxes + src * 4);
+            prop_scores[(size_t)b * prop_stride + rank] = cand_scores[src];
+        }
+    }
+    for (int i = cnt + threadIdx.x; i < prop_stride; i += blockDim.x) {
+        *reinterpret_cast<float4*>(props + ((size_t)b * prop_stride + i) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        prop_scores[(size_t)b * prop_stride + i] = 0.f;
     }
     if (threadIdx.x == 0) prop_count[b] = cnt;
 }

@@ -87,12 +87,18 @@ __device__ __forceinline__ uint8_t clip8(int v) {
     return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
-// horizontal pass + band pick: tmp[y][x][j] = sum_t src[y][xmin+t][2-j] * kk[x][t]
-__global__ void resize_h_u8(const uint8_t* __restrict__ src, int h, int w, int c, uint8_t* __restrict__ tmp,
+struct TilePtrs {             // device pointers of the tiles of one batch, passed by value
+    const uint8_t* p[TD_MAX_BATCH];
+};
+
+// horizontal pass + band pick: tmp[y][x][j] = sum_t src[y][xmin+t][2-j] * kk[x][t]      (blockIdx.z = tile)
+__global__ void resize_h_u8(TilePtrs srcs, int h, int w, int c, uint8_t* __restrict__ tmp_all,
                             int out_w, const int* __restrict__ bounds, const int* __restrict__ kk, int ksize) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= out_w) return;
+    const uint8_t* __restrict__ src = srcs.p[blockIdx.z];
+    uint8_t* __restrict__ tmp = tmp_all + (size_t)blockIdx.z * h * out_w * 3;
     const int xmin = bounds[x];
     int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0;
     const uint8_t* row = src + (size_t)y * w * c;
@@ -111,13 +117,15 @@ __global__ void resize_h_u8(const uint8_t* __restrict__ src, int h, int w, int c
     o[2] = clip8(s2);
 }
 
-// vertical pass over the 3-channel intermediate
-__global__ void resize_v_u8(const uint8_t* __restrict__ tmp, int h, int row_bytes, uint8_t* __restrict__ dst,
-                            int out_h, int dst_pitch_bytes, const int* __restrict__ bounds,
+// vertical pass over the 3-channel intermediate      (blockIdx.z = tile; images dst_img_bytes apart)
+__global__ void resize_v_u8(const uint8_t* __restrict__ tmp_all, int h, int row_bytes, uint8_t* __restrict__ dst_all,
+                            int out_h, int dst_pitch_bytes, size_t dst_img_bytes, const int* __restrict__ bounds,
                             const int* __restrict__ kk, int ksize) {
     const int xb = blockIdx.x * blockDim.x + threadIdx.x;   // byte column (x*3 + j)
     const int y = blockIdx.y;
     if (xb >= row_bytes) return;
+    const uint8_t* __restrict__ tmp = tmp_all + (size_t)blockIdx.z * h * row_bytes;
+    uint8_t* __restrict__ dst = dst_all + (size_t)blockIdx.z * dst_img_bytes;
     const int ymin = bounds[y];
     int s = 1 << (PIL_PRECISION_BITS - 1);
     for (int t = 0; t < ksize; ++t) {
@@ -270,23 +278,33 @@ __global__ void subsample2_kernel(const T* __restrict__ x, T* __restrict__ y, in
 
 }  // namespace
 
-td_status resize_tile_u8_launch(const uint8_t* src, int h, int w, int c, uint8_t* dst, int out_h, int out_w,
-                                int dst_pitch_px, void* tmp, hipStream_t stream) {
-    TD_REQUIRE(src && dst && tmp, "resize: null pointer");
+td_status resize_batch_u8_launch(const uint8_t* const* srcs, int n, int h, int w, int c, uint8_t* dst, int out_h,
+                                 int out_w, int dst_pitch_px, size_t dst_img_bytes, void* tmp, hipStream_t stream) {
+    TD_REQUIRE(srcs && dst && tmp && n >= 1 && n <= TD_MAX_BATCH, "resize: bad batch");
     TD_REQUIRE(h > 0 && w > 0 && c >= 3 && out_h > 0 && out_w > 0 && dst_pitch_px >= out_w, "resize: bad geometry");
     CoeffTable th, tv;
     td_status st = get_coeffs(w, out_w, th);
     if (st < 0) return st;
     st = get_coeffs(h, out_h, tv);
     if (st < 0) return st;
-    hipLaunchKernelGGL(resize_h_u8, dim3(td_cdiv(out_w, 256), h), dim3(256), 0, stream, src, h, w, c,
+    TilePtrs tp{};
+    for (int i = 0; i < n; ++i) {
+        TD_REQUIRE(srcs[i], "resize: null tile pointer");
+        tp.p[i] = srcs[i];
+    }
+    hipLaunchKernelGGL(resize_h_u8, dim3(td_cdiv(out_w, 256), h, n), dim3(256), 0, stream, tp, h, w, c,
                        static_cast<uint8_t*>(tmp), out_w, th.d_bounds, th.d_kk, th.ksize);
     TD_KERNEL_CHECK();
-    hipLaunchKernelGGL(resize_v_u8, dim3(td_cdiv(out_w * 3, 256), out_h), dim3(256), 0, stream,
-                       static_cast<const uint8_t*>(tmp), h, out_w * 3, dst, out_h, dst_pitch_px * 3, tv.d_bounds,
-                       tv.d_kk, tv.ksize);
+    hipLaunchKernelGGL(resize_v_u8, dim3(td_cdiv(out_w * 3, 256), out_h, n), dim3(256), 0, stream,
+                       static_cast<const uint8_t*>(tmp), h, out_w * 3, dst, out_h, dst_pitch_px * 3, dst_img_bytes,
+                       tv.d_bounds, tv.d_kk, tv.ksize);
     TD_KERNEL_CHECK();
     return TD_OK;
+}
+
+td_status resize_tile_u8_launch(const uint8_t* src, int h, int w, int c, uint8_t* dst, int out_h, int out_w,
+                                int dst_pitch_px, void* tmp, hipStream_t stream) {
+    return resize_batch_u8_launch(&src, 1, h, w, c, dst, out_h, out_w, dst_pitch_px, 0, tmp, stream);
 }
 
 td_status stem_launch(const void* images, int input_format, const ImgSizes& valid, int B, int Hp, int Wp,

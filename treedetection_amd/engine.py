@@ -171,16 +171,26 @@ class Engine:
                 cache.clear()
             cache[key] = torch.zeros((len(tiles), Hp, Wp, 3), dtype=torch.uint8, device=dev)
         batch = cache[key]
-        need_tmp = max(t.shape[0] * s[1] * 3 for t, s in zip(tiles, shapes))
+        need_tmp = sum(t.shape[0] * s[1] * 3 for t, s in zip(tiles, shapes))
         if getattr(self, "_pp_tmp", None) is None or self._pp_tmp.numel() < need_tmp:
             self._pp_tmp = torch.empty((need_tmp,), dtype=torch.uint8, device=dev)
         st = _lib.stream_ptr()
-        for i, (t, (oh, ow)) in enumerate(zip(tiles, shapes)):
+        for t in tiles:
             assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous() and t.shape[2] >= 3
+        if len({tuple(t.shape) for t in tiles}) == 1:       # the common case: one launch pair for the whole batch
+            oh, ow = shapes[0]
             if oh < Hp or ow < Wp:
-                batch[i].zero_()
-            _lib.check(self.lib.td_resize_tile_u8(t.data_ptr(), t.shape[0], t.shape[1], t.shape[2], batch[i].data_ptr(),
-                                                  oh, ow, Wp, self._pp_tmp.data_ptr(), st), "td_resize_tile_u8")
+                batch.zero_()
+            ptrs = (C.c_void_p * len(tiles))(*[t.data_ptr() for t in tiles])
+            t0 = tiles[0]
+            _lib.check(self.lib.td_resize_batch_u8(ptrs, len(tiles), t0.shape[0], t0.shape[1], t0.shape[2], batch.data_ptr(),
+                                                   oh, ow, Wp, Hp * Wp * 3, self._pp_tmp.data_ptr(), st), "td_resize_batch_u8")
+        else:
+            for i, (t, (oh, ow)) in enumerate(zip(tiles, shapes)):
+                if oh < Hp or ow < Wp:
+                    batch[i].zero_()
+                _lib.check(self.lib.td_resize_tile_u8(t.data_ptr(), t.shape[0], t.shape[1], t.shape[2], batch[i].data_ptr(),
+                                                      oh, ow, Wp, self._pp_tmp.data_ptr(), st), "td_resize_tile_u8")
         hw_out = [(int(t.shape[0]), int(t.shape[1])) for t in tiles]
         return batch, shapes, hw_out
 
