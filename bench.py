@@ -50,7 +50,8 @@ def parse():
     ap.add_argument("--cpu-tiles", type=int, default=16)   # ≈ 13 s of CPU work on 16 threads
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-fp16", action="store_true", help="skip the second timed region with the fp16 engine")
-    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-stream timed region")
+    ap.add_argument("--no-pipeline", action="store_true", help="plain loop: one batch at a time on one stream")
+    ap.add_argument("--no-serial", action="store_true", help="skip the extra informational single-stream region")
     ap.add_argument("--streams", type=int, default=1, help="engines / HIP streams the batches alternate over (the "
                     "low-occupancy selection tail of one batch overlaps the next batch's convolutions)")
     return ap.parse_args()
@@ -218,14 +219,98 @@ def main():
             e.close()
         return float(tmax.item()), prof, ndet
 
-    dt, prof, ndet = run(args.precision, max(1, args.streams), not args.no_profile)
+    def run_pipelined(precision, profile):
+        """Three engines, two HIP streams: every tick enqueues, on the main stream, the mask-head convs of batch t-2,
+        the box-head FCs of batch t-1 and the trunk of batch t (contractions back to back, never overlapping each
+        other), and on the side stream the selection phase that follows each of them (top-k / NMS / RoIAlign /
+        detections / paste) — those low-occupancy kernels then run underneath the next contractions. K batches take
+        K + 2 ticks; the timed region covers all of them (fill and drain included)."""
+        log(f"creating 3 engines ({precision}, software pipeline over a main and a side stream)")
+        engs = [Engine(sd, device=local_rank, precision=precision) for _ in range(3)]
+        outs = [e.alloc_outputs(B, S, S, paste=True) for e in engs]
+        main, side = torch.cuda.Stream(), torch.cuda.Stream()
+        gl = None
+        if world > 1 and rank == 0:
+            gl = {k: [torch.empty_like(outs[0][k]) for _ in range(world)] for k in gather_keys}
+
+        def tick(t, first, last):
+            for age, (pm, ps) in ((2, (4, 5)), (1, (2, 3)), (0, (0, 1))):
+                i = t - age
+                if not first <= i < last:
+                    continue
+                e, o = engs[i % 3], outs[i % 3]
+                if pm == 0:
+                    with torch.cuda.stream(main):
+                        tiles = [rgb[(i * B + j) % n_local] for j in range(B)]
+                        batch, hw_valid, hw_out = e.preprocess_tiles_u8(tiles)
+                    e.forward_phase(0, main, batch, INPUT_U8_HWC, hw_valid, hw_out, o)
+                else:
+                    e.forward_phase(pm, main)
+                e.forward_phase(ps, side)
+                if ps == 5 and world > 1:
+                    with torch.cuda.stream(side):
+                        for k in gather_keys:   # RCCL gather of the finished batch's detections to rank 0
+                            if backend == "nccl":
+                                dist.gather(o[k], gl[k] if rank == 0 else None, dst=0)
+                            else:
+                                h = o[k].cpu()
+                                dist.gather(h, [torch.empty_like(h) for _ in range(world)] if rank == 0 else None, dst=0)
+
+        def run_batches(first, last):
+            for t in range(first, last + 2):
+                tick(t, first, last)
+
+        log("warm-up (each engine measures its block-tile choices on its first batch)")
+        nw = max(args.warmup, 3)
+        run_batches(0, nw)
+        torch.cuda.synchronize()
+        if profile:
+            for e in engs:
+                e.profile_enable(True)
+                e.profile_read(reset=True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_batches(nw, nw + args.steps)
+        t_enq = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        log(f"timed region done ({precision}, pipelined): {dt:.3f} s (host enqueue {t_enq:.3f} s)")
+        prof = None
+        if profile:
+            for e in engs:
+                p1 = e.profile_read(reset=True)
+                e.profile_enable(False)
+                if prof is None:
+                    prof = p1
+                else:
+                    for k in prof:
+                        for f in prof[k]:
+                            prof[k][f] += p1[k][f]
+        ndet = int(outs[0]["count"].sum().item())
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        for e in engs:
+            e.close()
+        return float(tmax.item()), prof, ndet
+
+    if "TD_TUNE_CACHE" not in os.environ:     # engines of one run share their measured block-tile choices
+        import tempfile
+        os.environ["TD_TUNE_CACHE"] = os.path.join(tempfile.mkdtemp(prefix="td_tune_"), f"tiles_rank{rank}.txt")
+    if args.no_pipeline:
+        dt, prof, ndet = run(args.precision, max(1, args.streams), not args.no_profile)
+    else:
+        dt, prof, ndet = run_pipelined(args.precision, not args.no_profile)
     extra = piped = None
     if args.precision == "fp32" and not args.no_fp16:
-        extra = run("fp16", 1, not args.no_profile)
-    if args.streams == 1 and not args.no_pipelined:
-        # informational: the same steps with batches alternating over two engines / streams (no event brackets: with
-        # two streams in flight the per-kernel spans overlap, so the roofline above stays the single-stream one)
-        piped = run(args.precision, 2, False)
+        extra = run("fp16", 1, not args.no_profile) if args.no_pipeline else run_pipelined("fp16", not args.no_profile)
+    if not args.no_pipeline and not args.no_serial:
+        piped = run(args.precision, 1, False)      # informational: the plain one-batch-at-a-time loop
 
     if rank == 0:
         tiles_total = args.steps * B * world
@@ -247,6 +332,8 @@ def main():
                                    f"resize 800x800 + forward + paste on device, inputs resident in HBM",
                        "depth": args.depth, "batch_per_gpu": B, "tile": S, "net_input": "3x800x800",
                        "parallelism": f"tile-shard x{world} (replicated weights, RCCL gather of detections to rank 0)",
+                       "schedule": "plain loop" if args.no_pipeline else "3 batches in flight per GPU: contraction phases on a main "
+                                   "HIP stream, selection phases (top-k/NMS/RoIAlign/paste) on a side stream",
                        "detections_last_batch": ndet},
         }
         if prof is not None:
@@ -286,12 +373,8 @@ def main():
                 o["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof16.items()}
             line["fp16"] = o
         if piped is not None:
-            line["pipelined_2_streams"] = {"value": tiles_total / piped[0], "unit": "tiles/s",
-                                           "ms_per_step": 1000.0 * piped[0] / args.steps,
-                                           "note": "same K steps, batches alternate over two engines on two HIP streams: "
-                                                   "the low-occupancy selection tail (top-k, NMS, RoIAlign, mask head) of "
-                                                   "one batch overlaps the next batch's convolutions; informational — "
-                                                   "`value` and `roofline` are the single-stream region"}
+            line["single_stream"] = {"value": tiles_total / piped[0], "unit": "tiles/s", "ms_per_step": 1000.0 * piped[0] / args.steps,
+                                     "note": "same K steps as a plain loop, one batch at a time on one stream (informational)"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, rgb_np, args.cpu_tiles)
         print(json.dumps(line), flush=True)

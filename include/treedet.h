@@ -94,6 +94,16 @@ td_status td_engine_reserve(td_engine* e, int max_batch, int max_hp, int max_wp)
  * Asynchronous on `stream`; results are complete once the stream has drained. */
 td_status td_engine_forward(td_engine* e, const void* images, int input_format, const int32_t* hw_valid,
                             const int32_t* hw_out, int B, int Hp, int Wp, void* stream, td_detections* out);
+/* The same forward cut into six phases for cross-batch software pipelining (three engines, two streams):
+ *   0 trunk (stem .. RPN heads)   1 RPN top-k / NMS / merge + RoIAlign 7x7   2 box-head FCs + predictors
+ *   3 detections + RoIAlign 14x14 4 mask-head convolutions                   5 mask predictor, scatter, paste
+ * Even phases are dense contractions, odd phases low-occupancy selection work: enqueue the even phases of successive
+ * batches back to back on a main stream and the odd phases on a side stream, and the selection work of one batch
+ * overlaps the contractions of the next. Phase 0 takes the arguments of td_engine_forward and stores them; phases 1-5
+ * ignore everything but `e`, `phase` and `stream`. Each phase waits (hipStreamWaitEvent) for the previous phase of the
+ * same batch and phase 0 for the engine's previous batch, so any stream assignment is correct. */
+td_status td_engine_forward_phase(td_engine* e, int phase, const void* images, int input_format, const int32_t* hw_valid,
+                                  const int32_t* hw_out, int B, int Hp, int Wp, void* stream, td_detections* out);
 /* Expose an internal activation of the last forward() for stage-wise parity tests: names
  * "stem","pool","res2".."res5","p2".."p6","rpn_logits","rpn_deltas","proposals","proposal_scores",
  * "proposal_count","pooled7","cls_logits","box_deltas","det_boxes_net","pooled14","mask_logits".

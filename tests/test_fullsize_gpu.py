@@ -120,3 +120,47 @@ def test_no_detections_and_error_paths(full):
     lib.td_engine_destroy(h)
     with pytest.raises(_lib.TdError):
         Engine({"backbone.bottom_up.stem.conv1.weight": np.zeros((64, 3, 7, 7), np.float32)})
+
+
+def test_phased_forward_on_two_streams_equals_plain_forward(full):
+    """td_engine_forward_phase: contraction phases on one stream, selection phases on another, three engines keeping
+    three batches in flight (the bench's software pipeline) — every batch must come out bit-identical to the
+    single-stream forward."""
+    from treedetection_amd.engine import Engine, INPUT_U8_HWC
+    sd = full["sd"]
+    engs = [Engine(sd) for _ in range(3)]
+    main, side = torch.cuda.Stream(), torch.cuda.Stream()
+    tiles = full["tiles"]
+    batches = [[tiles[(i + j) % 3] for j in range(2)] for i in range(5)]      # 5 different 2-tile batches
+    ref = []
+    for b in batches:
+        x, hv, ho = full["eng"].preprocess_tiles_u8(b)
+        o = full["eng"].alloc_outputs(2, 1000, 1000, paste=True)
+        full["eng"].forward_raw(x.clone(), INPUT_U8_HWC, hv, ho, o)
+        torch.cuda.synchronize()
+        ref.append({k: v.clone() for k, v in o.items()})
+    outs = [None] * len(batches)
+    ins = [None] * len(batches)
+    torch.cuda.synchronize()
+    n = len(batches)
+    for t in range(n + 2):          # tick t: P3/S3 of batch t-2, P2/S2 of batch t-1, P1/S1 of batch t
+        for age, (pm, ps) in ((2, (4, 5)), (1, (2, 3)), (0, (0, 1))):
+            i = t - age
+            if not 0 <= i < n:
+                continue
+            e = engs[i % 3]
+            if pm == 0:
+                with torch.cuda.stream(main):
+                    x, hv, ho = e.preprocess_tiles_u8(batches[i])
+                    ins[i] = x.clone()
+                outs[i] = e.alloc_outputs(2, 1000, 1000, paste=True)
+                e.forward_phase(0, main, ins[i], INPUT_U8_HWC, hv, ho, outs[i])
+            else:
+                e.forward_phase(pm, main)
+            e.forward_phase(ps, side)
+    torch.cuda.synchronize()
+    for i in range(n):
+        for k in ("count", "boxes", "scores", "mask_probs", "mask_region", "mask_offset"):
+            assert torch.equal(outs[i][k], ref[i][k]), (i, k)
+        used = int(ref[i]["mask_offset"].max().item()) + 1
+        assert torch.equal(outs[i]["mask_bits"][:, :used], ref[i]["mask_bits"][:, :used]), i

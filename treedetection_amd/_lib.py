@@ -45,6 +45,8 @@ SIGNATURES = {
     "td_engine_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "td_engine_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Detections)]),
+    "td_engine_forward_phase": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                          C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Detections)]),
     "td_engine_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int)]),
     "td_engine_read_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),

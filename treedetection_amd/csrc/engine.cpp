@@ -110,6 +110,17 @@ struct td_engine {
     std::map<std::tuple<int, int, int, int, int>, int> tuned;
     std::string tune_cache;       // TD_TUNE_CACHE: load / append measured choices (keeps profiled runs free of tuning launches)
 
+    // forward context (kept between the phases of td_engine_forward_phase) and the per-phase completion events
+    struct FwdCtx {
+        const void* images = nullptr;
+        int input_format = 0, B = 0, Hp = 0, Wp = 0;
+        ImgSizes valid{}, outsz{};
+        td_detections out{};
+        bool valid_ctx = false;
+    } ctx;
+    hipEvent_t phase_ev[6] = {};
+    bool phase_ev_recorded[6] = {};
+
     // optional per-category device timing (td_engine_profile_*)
     bool prof = false;
     bool prof_group_open = false;
@@ -353,6 +364,7 @@ void td_engine_destroy(td_engine* e) {
     free_pool(e->ws_allocs);
     for (auto& r : e->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto ev : e->prof_free) (void)hipEventDestroy(ev);
+    for (auto ev : e->phase_ev) if (ev) (void)hipEventDestroy(ev);
     delete e;
 }
 
@@ -616,28 +628,24 @@ td_status td_engine_reserve(td_engine* e, int B, int Hp, int Wp) {
     return TD_OK;
 }
 
-td_status td_engine_forward(td_engine* e, const void* images, int input_format, const int32_t* hw_valid,
-                            const int32_t* hw_out, int B, int Hp, int Wp, void* stream_v, td_detections* out) {
-    TD_REQUIRE(e && images && hw_valid && hw_out && out, "td_engine_forward: null argument");
-    TD_REQUIRE(e->loaded, "td_engine_forward: load weights first");
-    TD_REQUIRE(input_format == TD_INPUT_F32_CHW || input_format == TD_INPUT_U8_HWC, "td_engine_forward: bad input format %d", input_format);
-    TD_REQUIRE(B >= 1 && Hp % 32 == 0 && Wp % 32 == 0 && Hp >= 64 && Wp >= 64, "td_engine_forward: bad batch geometry B=%d %dx%d", B, Hp, Wp);
-    if (B > e->rB || Hp > e->rHp || Wp > e->rWp) {
-        td_set_error("td_engine_forward: B=%d %dx%d exceeds the reserved B=%d %dx%d", B, Hp, Wp, e->rB, e->rHp, e->rWp);
-        return TD_ERR_CAPACITY;
-    }
-    hipStream_t s = static_cast<hipStream_t>(stream_v);
+}  // extern "C"
+
+namespace {
+
+// The forward in six phases. Contractions (0 trunk: stem..RPN heads, 2 box-head FCs, 4 mask-head convs) and the
+// low-occupancy selection work (1 RPN top-k/NMS/merge + RoIAlign 7x7, 3 detections + RoIAlign 14x14, 5 mask
+// predictor/scatter/paste) alternate, so a caller can keep three batches in flight: contraction phases of successive
+// batches back to back on a main stream, selection phases on a side stream where they overlap the next contractions.
+td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
+    const td_engine::FwdCtx& c = e->ctx;
+    const void* images = c.images;
+    const int input_format = c.input_format, B = c.B, Hp = c.Hp, Wp = c.Wp;
+    const ImgSizes& valid = c.valid;
+    const ImgSizes& outsz = c.outsz;
+    const td_detections* out = &c.out;
     const int prec = e->desc.precision;
-    ImgSizes valid{}, outsz{};
-    for (int i = 0; i < B; ++i) {
-        valid.h[i] = hw_valid[2 * i];
-        valid.w[i] = hw_valid[2 * i + 1];
-        outsz.h[i] = hw_out[2 * i];
-        outsz.w[i] = hw_out[2 * i + 1];
-        TD_REQUIRE(valid.h[i] >= 1 && valid.h[i] <= Hp && valid.w[i] >= 1 && valid.w[i] <= Wp, "td_engine_forward: image %d valid size %dx%d outside %dx%d", i, valid.h[i], valid.w[i], Hp, Wp);
-        TD_REQUIRE(outsz.h[i] >= 1 && outsz.w[i] >= 1, "td_engine_forward: image %d has an empty output size", i);
-    }
-    e->named.clear();
+    auto PH = [&](int k) { return (phase_mask >> k) & 1u; };
+    if (PH(0)) e->named.clear();
     td_status st;
     auto run_conv = [&](const ConvLayer& L, const void* x_, int B_, int H_, int W_, int stride, int pad, bool relu,
                         void* y_, const void* res_, int res_shift, hipStream_t s_, int prec_,
@@ -700,7 +708,7 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
     auto off = [&](void* p, size_t elems) -> void* { return static_cast<char*>(p) + elems * esz; };
     int sb = e->backbone_subbatch > 0 ? e->backbone_subbatch : B;
     if (sb > B) sb = B;
-    for (int b0 = 0; b0 < B; b0 += sb) {
+    for (int b0 = 0; PH(0) && b0 < B; b0 += sb) {
         const int nb_img = (B - b0) < sb ? (B - b0) : sb;
         ImgSizes vsub{};
         for (int i = 0; i < nb_img; ++i) {
@@ -747,6 +755,7 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
             }
         }
     }
+    if (PH(0)) {
     set_named(e, "stem", e->stem_out, B, Hp / 2, Wp / 2, e->stem_c, (int)esz);
     set_named(e, "pool", e->pool_out, B, Hp / 4, Wp / 4, e->stem_c, (int)esz);
     for (int si = 0; si < 4; ++si) {
@@ -769,15 +778,22 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
         set_named(e, nm.c_str(), e->pfeat[l], B, hs[l], wsz[l], e->fpn_c, (e->desc.precision == TD_PRECISION_FP16 ? 2 : 4));
     }
     // ---- RPN -----------------------------------------------------------------------------------------------------
+    {
+        ProfScope rpn_group(e, s, 0, 0.0, 0.0, true);
+        for (int l = 0; l < 5; ++l) {
+            if ((st = run_conv(e->rpn_conv, e->pfeat[l], B, hs[l], wsz[l], 1, 1, true, e->rpn_t, nullptr, 0, s, prec)) < 0) return st;
+            if ((st = run_conv(e->rpn_head, e->rpn_t, B, hs[l], wsz[l], 1, 0, false, e->rpn_headbuf[l], nullptr, 0, s, prec)) < 0) return st;
+            const std::string nm = "rpn_head" + std::to_string(l + 2);
+            set_named(e, nm.c_str(), e->rpn_headbuf[l], B, hs[l], wsz[l], RPN_HEAD_C);
+        }
+    }
+    }   // phase 0
     RpnLevels lv{};
     {
         static const int sizes[5] = {32, 64, 128, 256, 512};
         static const double ratios[3] = {0.5, 1.0, 2.0};
         int off = 0;
-        ProfScope rpn_group(e, s, 0, 0.0, 0.0, true);
         for (int l = 0; l < 5; ++l) {
-            if ((st = run_conv(e->rpn_conv, e->pfeat[l], B, hs[l], wsz[l], 1, 1, true, e->rpn_t, nullptr, 0, s, prec)) < 0) return st;
-            if ((st = run_conv(e->rpn_head, e->rpn_t, B, hs[l], wsz[l], 1, 0, false, e->rpn_headbuf[l], nullptr, 0, s, prec)) < 0) return st;
             lv.head[l] = e->rpn_headbuf[l];
             lv.h[l] = hs[l];
             lv.w[l] = wsz[l];
@@ -793,11 +809,25 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
                 lv.base[l][a][2] = (float)(w / 2.0);
                 lv.base[l][a][3] = (float)(h / 2.0);
             }
-            const std::string nm = "rpn_head" + std::to_string(l + 2);
-            set_named(e, nm.c_str(), e->rpn_headbuf[l], B, hs[l], wsz[l], RPN_HEAD_C);
         }
         lv.total_anchors = off;
     }
+    const int P = e->desc.post_nms_topk, D = e->desc.detections_per_image;
+    FeatLevels fl{};
+    for (int l = 0; l < 4; ++l) {
+        fl.feat[l] = e->pfeat[l];
+        fl.h[l] = hs[l];
+        fl.w[l] = wsz[l];
+        fl.scale[l] = 1.0f / (float)(4 << l);
+    }
+    fl.C = e->fpn_c;
+    float* o_boxes = out->boxes ? out->boxes : e->o_boxes;
+    float* o_scores = out->scores ? out->scores : e->o_scores;
+    int* o_classes = out->classes ? out->classes : e->o_classes;
+    int* o_count = out->count ? out->count : e->o_count;
+    float* o_probs = out->mask_probs ? out->mask_probs : e->o_mask_probs;
+    const int mrows = B * D;
+    if (PH(1)) {
     { ProfScope ps(e, s, 3);
     if ((st = rpn_topk_decode_launch(lv, valid, B, e->desc.pre_nms_topk, e->key_ws, e->cand_boxes, e->cand_scores,
                                      e->cand_valid, e->cand_idx, s)) < 0) return st; }
@@ -810,7 +840,6 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
                          e->nms_mask, e->rpn_keep, e->rpn_keep_count, RPN_CAND, s)) < 0) return st; }
     set_named(e, "rpn_keep", e->rpn_keep, B, RPN_LEVELS, RPN_CAND);
     set_named(e, "rpn_keep_count", e->rpn_keep_count, B, RPN_LEVELS);
-    const int P = e->desc.post_nms_topk, D = e->desc.detections_per_image;
     { ProfScope ps(e, s, 3);
     if ((st = rpn_merge_launch(e->cand_boxes, e->cand_scores, e->rpn_keep, e->rpn_keep_count, B, P, e->props,
                                e->prop_scores, e->prop_count, P, s)) < 0) return st; }
@@ -818,17 +847,11 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
     set_named(e, "proposal_scores", e->prop_scores, B, P);
     set_named(e, "proposal_count", e->prop_count, B);
     // ---- box head -----------------------------------------------------------------------------------------------
-    FeatLevels fl{};
-    for (int l = 0; l < 4; ++l) {
-        fl.feat[l] = e->pfeat[l];
-        fl.h[l] = hs[l];
-        fl.w[l] = wsz[l];
-        fl.scale[l] = 1.0f / (float)(4 << l);
-    }
-    fl.C = e->fpn_c;
     { ProfScope ps(e, s, 4);
     if ((st = roi_align_launch(fl, e->props, e->prop_count, B, P, 7, 0, e->pooled7, nullptr, prec, s)) < 0) return st; }
     set_named(e, "pooled7", e->pooled7, (int64_t)B * P, 7, 7, e->fpn_c, (e->desc.precision == TD_PRECISION_FP16 ? 2 : 4));
+    }   // phase 1
+    if (PH(2)) {
     {
     ProfScope box_group(e, s, 0, 0.0, 0.0, true);
     if ((st = run_conv(e->fc1, e->pooled7, B * P, 1, 1, 1, 0, true, e->fc1_out, nullptr, 0, s, prec)) < 0) return st;
@@ -836,6 +859,8 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
     if ((st = run_conv(e->pred, e->fc2_out, B * P, 1, 1, 1, 0, false, e->pred_out, nullptr, 0, s, prec)) < 0) return st;
     }
     set_named(e, "box_pred", e->pred_out, (int64_t)B * P, 6);
+    }   // phase 2
+    if (PH(3)) {
     { ProfScope ps(e, s, 5);
     if ((st = det_decode_launch(e->pred_out, 6, e->props, e->prop_count, valid, B, P, e->desc.score_thresh, e->dboxes,
                                 e->dscores, e->dflags, s)) < 0) return st; }
@@ -848,19 +873,16 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
     { ProfScope ps(e, s, 5);
     if ((st = nms_launch(e->sboxes, e->scount, nullptr, B, P, e->desc.nms_thresh, e->nms_mask, e->det_keep,
                          e->det_keep_count, D, s)) < 0) return st; }
-    float* o_boxes = out->boxes ? out->boxes : e->o_boxes;
-    float* o_scores = out->scores ? out->scores : e->o_scores;
-    int* o_classes = out->classes ? out->classes : e->o_classes;
-    int* o_count = out->count ? out->count : e->o_count;
     { ProfScope ps(e, s, 5);
     if ((st = det_finalize_launch(e->sboxes, e->sscores, e->det_keep, e->det_keep_count, valid, outsz, B, P, D,
                                   e->det_boxes_net, o_boxes, o_scores, o_classes, o_count, s)) < 0) return st; }
     set_named(e, "det_boxes_net", e->det_boxes_net, B, D, 4);
     // ---- mask head (compact rows: only live detections are computed) ------------------------------------------
-    const int mrows = B * D;
     { ProfScope ps(e, s, 4);
     if ((st = roi_align_launch(fl, e->det_boxes_net, o_count, B, D, 14, 1, e->pooled14, e->total_rows, prec, s)) < 0) return st; }
     set_named(e, "pooled14", e->pooled14, mrows, 14, 14, e->fpn_c, (e->desc.precision == TD_PRECISION_FP16 ? 2 : 4));
+    }   // phase 3
+    if (PH(4)) {
     const void* mx = e->pooled14;
     void* mbuf[2] = {e->mbuf0, e->mbuf1};
     {
@@ -871,20 +893,87 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
     }
     if ((st = run_conv(e->deconv, mx, mrows, 14, 14, 1, 0, true, e->deconv_out, nullptr, 0, s, prec, e->total_rows, 196, 1)) < 0) return st;
     }
+    }   // phase 4
+    if (PH(5)) {
     { ProfScope ps(e, s, 6);
     if ((st = mask_predict_launch(e->deconv_out, e->mask_pred_w, e->mask_pred_b, e->deconv.cout / 4, mrows * 784,
                                   e->total_rows, 784, e->mask_logits, e->mask_probs_compact, prec, s)) < 0) return st; }
     set_named(e, "mask_logits", e->mask_logits, mrows, 28, 28);
-    float* o_probs = out->mask_probs ? out->mask_probs : e->o_mask_probs;
     { ProfScope ps(e, s, 6);
     if ((st = mask_scatter_launch(e->mask_probs_compact, o_count, B, D, o_probs, s)) < 0) return st; }
     if (out->mask_bits) {
-        TD_REQUIRE(out->mask_region && out->mask_offset && out->mask_words_per_image > 0, "td_engine_forward: mask_bits needs mask_region, mask_offset and mask_words_per_image");
         { ProfScope ps(e, s, 6);
         if ((st = paste_masks_launch(o_probs, o_boxes, o_count, outsz, B, D, e->desc.mask_thresh, out->mask_region,
                                      reinterpret_cast<long long*>(out->mask_offset), out->mask_bits,
                                      out->mask_words_per_image, s)) < 0) return st; }
     }
+    }   // phase 5
+    return TD_OK;
+}
+
+td_status set_forward_ctx(td_engine* e, const void* images, int input_format, const int32_t* hw_valid,
+                          const int32_t* hw_out, int B, int Hp, int Wp, const td_detections* out) {
+    TD_REQUIRE(e && images && hw_valid && hw_out && out, "td_engine_forward: null argument");
+    TD_REQUIRE(e->loaded, "td_engine_forward: load weights first");
+    TD_REQUIRE(input_format == TD_INPUT_F32_CHW || input_format == TD_INPUT_U8_HWC, "td_engine_forward: bad input format %d", input_format);
+    TD_REQUIRE(B >= 1 && Hp % 32 == 0 && Wp % 32 == 0 && Hp >= 64 && Wp >= 64, "td_engine_forward: bad batch geometry B=%d %dx%d", B, Hp, Wp);
+    if (B > e->rB || Hp > e->rHp || Wp > e->rWp) {
+        td_set_error("td_engine_forward: B=%d %dx%d exceeds the reserved B=%d %dx%d", B, Hp, Wp, e->rB, e->rHp, e->rWp);
+        return TD_ERR_CAPACITY;
+    }
+    td_engine::FwdCtx& c = e->ctx;
+    c.valid_ctx = false;
+    for (int i = 0; i < B; ++i) {
+        c.valid.h[i] = hw_valid[2 * i];
+        c.valid.w[i] = hw_valid[2 * i + 1];
+        c.outsz.h[i] = hw_out[2 * i];
+        c.outsz.w[i] = hw_out[2 * i + 1];
+        TD_REQUIRE(c.valid.h[i] >= 1 && c.valid.h[i] <= Hp && c.valid.w[i] >= 1 && c.valid.w[i] <= Wp, "td_engine_forward: image %d valid size %dx%d outside %dx%d", i, c.valid.h[i], c.valid.w[i], Hp, Wp);
+        TD_REQUIRE(c.outsz.h[i] >= 1 && c.outsz.w[i] >= 1, "td_engine_forward: image %d has an empty output size", i);
+    }
+    if (out->mask_bits)
+        TD_REQUIRE(out->mask_region && out->mask_offset && out->mask_words_per_image > 0, "td_engine_forward: mask_bits needs mask_region, mask_offset and mask_words_per_image");
+    c.images = images;
+    c.input_format = input_format;
+    c.B = B;
+    c.Hp = Hp;
+    c.Wp = Wp;
+    c.out = *out;
+    c.valid_ctx = true;
+    return TD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+td_status td_engine_forward(td_engine* e, const void* images, int input_format, const int32_t* hw_valid,
+                            const int32_t* hw_out, int B, int Hp, int Wp, void* stream_v, td_detections* out) {
+    td_status st = set_forward_ctx(e, images, input_format, hw_valid, hw_out, B, Hp, Wp, out);
+    if (st < 0) return st;
+    return forward_impl(e, 0x3fu, static_cast<hipStream_t>(stream_v));
+}
+
+td_status td_engine_forward_phase(td_engine* e, int phase, const void* images, int input_format, const int32_t* hw_valid,
+                                  const int32_t* hw_out, int B, int Hp, int Wp, void* stream_v, td_detections* out) {
+    TD_REQUIRE(e && phase >= 0 && phase < 6, "td_engine_forward_phase: bad phase %d", phase);
+    hipStream_t s = static_cast<hipStream_t>(stream_v);
+    td_status st;
+    if (phase == 0) {
+        if ((st = set_forward_ctx(e, images, input_format, hw_valid, hw_out, B, Hp, Wp, out)) < 0) return st;
+        // the engine's previous batch must have left its buffers (its last selection phase ran on another stream)
+        if (e->phase_ev_recorded[5]) TD_HIP_CHECK(hipStreamWaitEvent(s, e->phase_ev[5], 0));
+    } else {
+        TD_REQUIRE(e->ctx.valid_ctx, "td_engine_forward_phase: phase %d before phase 0", phase);
+        TD_REQUIRE(e->phase_ev_recorded[phase - 1], "td_engine_forward_phase: phase %d before phase %d", phase, phase - 1);
+        TD_HIP_CHECK(hipStreamWaitEvent(s, e->phase_ev[phase - 1], 0));
+    }
+    if ((st = forward_impl(e, 1u << phase, s)) < 0) return st;
+    if (!e->phase_ev[phase]) TD_HIP_CHECK(hipEventCreateWithFlags(&e->phase_ev[phase], hipEventDisableTiming));
+    TD_HIP_CHECK(hipEventRecord(e->phase_ev[phase], s));
+    e->phase_ev_recorded[phase] = true;
+    if (phase == 0)
+        for (int k = 1; k < 6; ++k) e->phase_ev_recorded[k] = false;
     return TD_OK;
 }
 

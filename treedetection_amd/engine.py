@@ -136,6 +136,29 @@ class Engine:
                                         _lib.stream_ptr(), C.byref(det))
         _lib.check(st, "td_engine_forward")
 
+    def forward_phase(self, phase: int, stream: torch.cuda.Stream, images: Optional[torch.Tensor] = None,
+                      input_format: int = INPUT_U8_HWC, hw_valid=None, hw_out=None, out: Optional[Dict[str, torch.Tensor]] = None) -> None:
+        """One of the six phases of the forward on `stream` (see td_engine_forward_phase). Phase 0 takes the batch."""
+        if phase == 0:
+            B, Hp, Wp = (images.shape[0], images.shape[2], images.shape[3]) if input_format == INPUT_F32_CHW else images.shape[:3]
+            self.reserve(B, Hp, Wp)
+            hv = (C.c_int32 * (2 * B))(*[int(v) for p in hw_valid for v in p])
+            ho = (C.c_int32 * (2 * B))(*[int(v) for p in hw_out for v in p])
+            det = Detections()
+            for k in ("boxes", "scores", "classes", "count", "mask_probs"):
+                setattr(det, k, out[k].data_ptr())
+            if "mask_bits" in out:
+                det.mask_region = out["mask_region"].data_ptr()
+                det.mask_offset = out["mask_offset"].data_ptr()
+                det.mask_bits = out["mask_bits"].data_ptr()
+                det.mask_words_per_image = out["mask_bits"].shape[1]
+            self._phase_keep = (images, out)      # keep the buffers alive until the batch has drained
+            st = self.lib.td_engine_forward_phase(self._h, 0, images.data_ptr(), input_format, hv, ho, B, Hp, Wp,
+                                                  int(stream.cuda_stream), C.byref(det))
+        else:
+            st = self.lib.td_engine_forward_phase(self._h, phase, None, 0, None, None, 0, 0, 0, int(stream.cuda_stream), None)
+        _lib.check(st, f"td_engine_forward_phase({phase})")
+
     def tensor(self, name: str) -> torch.Tensor:
         """Copy of an internal activation of the last forward (stage-wise parity tests)."""
         ptr = C.c_void_p()
