@@ -166,6 +166,36 @@ td_status td_paste_masks(const float* mask_probs, const float* boxes, int n, int
  * `starts` (capacity max_contours+1). Returns the number of contours, or < 0 on overflow/error. */
 int td_find_contours(const uint8_t* img, int h, int w, int32_t* points, int max_points, int32_t* starts,
                      int max_contours);
+/* Whole host epilogue of one tile (reference prediction.py:229-261, Predictor._process_and_save_single):
+ * the n detections' packed masks (mask_region / mask_offset / mask_bits of td_detections for ONE image, copied
+ * to host memory; mask_words = capacity of mask_bits in 32-bit words) → border following → contours with >= 4
+ * points, ring closed → pixel-corner coordinates through `transform` (rasterio order a,b,c,d,e,f; float64) →
+ * the JSON array the reference writes to Prediction_<tile>.json, one entry per contour:
+ *   {"image_id": <image_id>, "category_id": <class>, "score": <score>, "polygon_coords": [[[x, y], ...]]}
+ * byte-identical to Python's json.dumps of that list. Writes the text (no terminator) to buf if it fits in
+ * cap bytes; *needed always receives its length. Returns the number of entries, TD_ERR_CAPACITY when cap is
+ * too small (call again with *needed bytes), or another negative status. Thread-safe; host code only. */
+int td_tile_polygons_json(const int32_t* mask_region, const int64_t* mask_offset, const uint32_t* mask_bits,
+                          int64_t mask_words, const float* scores, const int32_t* classes, int n,
+                          const double* transform, const char* image_id, char* buf, int64_t cap, int64_t* needed);
+
+/* ---- stitching consumer of the prediction files (reference helpers.py:419-476) -------------- */
+/* `geometry.simplify(tolerance, preserve_topology=True)` (helpers.py:464-465) for one closed shell ring:
+ * topology-preserving Douglas-Peucker as GEOS' TopologyPreservingSimplifier performs it. xy = n (x,y) pairs,
+ * first == last for a ring; writes the kept vertices (a subsequence, closed again) to out_xy (capacity out_cap
+ * pairs) and returns their number (>= 4 for a ring of >= 4 points), or a negative status. Host code only. */
+int td_simplify_ring(const double* xy, int n, double tolerance, double* out_xy, int out_cap);
+/* One tile's prediction file → the features it contributes to the image's layer (helpers.py:436-470,
+ * process_prediction_file_sync): parse the JSON array the predictor wrote (`json` / `len`, UTF-8 text), take
+ * "score" and "polygon_coords" of every entry (coordinates flattened and paired like reshape(-1, 2); fewer than 4
+ * points or a missing key fail the whole file, as the reference's exception path does), simplify the ring
+ * (tolerance > 0), keep it when it lies `within` box = (minx, miny, maxx, maxy), and encode it as a GeoPackage
+ * geometry blob (header with envelope + `srs_id`, little-endian WKB polygon). Feature i = blobs[blob_offsets[i] ..
+ * blob_offsets[i+1]) with scores[i]. Returns the feature count; TD_ERR_CAPACITY (needed_bytes / needed_features
+ * say how much) when a buffer is too small; TD_ERR_INVALID for malformed input. Host code only, thread-safe. */
+int td_stitch_tile_json(const char* json, int64_t len, const double* box, double tolerance, int32_t srs_id,
+                        uint8_t* blobs, int64_t blob_cap, int64_t* blob_offsets, double* scores, int max_features,
+                        int64_t* needed_bytes, int* needed_features);
 
 #ifdef __cplusplus
 }

@@ -193,3 +193,72 @@ def test_polygons_from_packed_equals_polygons_from_masks():
     a = polygons_from_masks(masks, regions, scores, np.zeros(n, np.int64), t, "x.tif")
     b = polygons_from_packed(regions, offsets, bits, scores, np.zeros(n, np.int64), t, "x.tif")
     assert a == b and len(a) > n
+
+
+def _packed_fixture(rng, n, h, w, noise):
+    regions = np.zeros((n, 4), np.int32)
+    offsets = np.zeros(n, np.int64)
+    words, off = [], 0
+    for d in range(n):
+        x0, y0 = int(rng.integers(0, w - 40)), int(rng.integers(0, h - 40))
+        ww, hh = int(rng.integers(1, min(120, w - x0))), int(rng.integers(1, min(120, h - y0)))
+        yy, xx = np.mgrid[0:hh, 0:ww]
+        sub = ((xx - ww / 2) ** 2 / (ww / 2) ** 2 + (yy - hh / 2) ** 2 / (hh / 2) ** 2) < 1
+        sub ^= rng.random((hh, ww)) < noise
+        wpr = (ww + 31) // 32
+        padded = np.zeros((hh, wpr * 32), np.uint8)
+        padded[:, :ww] = sub
+        rows = np.packbits(padded, axis=1, bitorder="little").view(np.uint32)
+        regions[d] = (x0, y0, x0 + ww, y0 + hh)
+        offsets[d] = off
+        off += rows.size
+        words.append(rows.ravel())
+    return regions, offsets, np.concatenate(words).view(np.int32)
+
+
+@pytest.mark.parametrize("transform,image_id", [
+    ((0.2, 0.0, 412000.0, 0.0, -0.2, 5319000.0), '/data/rgb/ö "x"\\a\t\x7f.tif'),      # the usual UTM case + escapes
+    ((1e-7, 0.0, 1e-9, 0.0, -3e-8, 0.0), "a.tif"),                                       # small exponents, zeros
+    ((1e15, 3.3, 1e22, 0.1, -1e17, -5e16), "b.tif"),                                     # repr switches to e+XX at 1e16
+    ((0.30000000000000004, 0.1, -3.7, 0.01, -0.7, 1e16), "\U0001f600.tif"),              # 17-digit values, astral id
+])
+def test_tile_polygons_json_is_bytewise_json_dumps(transform, image_id):
+    """td_tile_polygons_json (the production epilogue: packed masks → contours → affine → text) must write exactly
+    the bytes ``json.dumps`` writes for the list the Python restatement of prediction.py:229-261 builds."""
+    from treedetection_amd.contours import tile_polygons_json
+    from treedetection_amd.prediction import polygons_from_packed
+    rng = np.random.default_rng(7)
+    n = 24
+    regions, offsets, bits = _packed_fixture(rng, n, 300, 300, 0.02)
+    regions[3] = (5, 5, 5, 9)                       # empty paste region: skipped
+    scores = rng.random(n).astype(np.float32)
+    classes = np.zeros(n, np.int32)
+    want = json.dumps(polygons_from_packed(regions, offsets, bits, scores, classes, transform, image_id)).encode()
+    got = tile_polygons_json(regions, offsets, bits, scores, classes, transform, image_id)
+    assert got == want and len(json.loads(got)) > n
+
+
+def test_tile_polygons_json_empty_and_errors():
+    from treedetection_amd import _lib
+    from treedetection_amd.contours import tile_polygons_json
+    z = np.zeros
+    assert tile_polygons_json(z((0, 4), np.int32), z(0, np.int64), z(1, np.int32), z(0, np.float32), z(0, np.int32),
+                              (1, 0, 0, 0, -1, 0), "x.tif") == b"[]"
+    with pytest.raises(_lib.TdError, match="outside"):       # rows beyond the buffer are refused, not read
+        tile_polygons_json(np.array([[0, 0, 64, 64]], np.int32), np.array([10], np.int64), z(16, np.int32),
+                           np.array([0.5], np.float32), z(1, np.int32), (1, 0, 0, 0, -1, 0), "x.tif")
+
+
+def test_geotiff_window_into_staging_buffer(tmp_path):
+    """The tile reader copies windows straight into (pinned) staging memory: same pixels as the allocating read."""
+    from treedetection_amd.geotiff import GeoTiff, write_geotiff
+    rng = np.random.default_rng(0)
+    data = rng.integers(0, 255, (4, 70, 90), dtype=np.uint8)
+    write_geotiff(str(tmp_path / "r.tif"), data, (0.5, 0, 100.0, 0, -0.5, 200.0), 25832)
+    g = GeoTiff(str(tmp_path / "r.tif"))
+    stage = np.full(5 + 40 * 30 * 4, 7, np.uint8)
+    for bounds in [(105.0, 180.0, 120.0, 200.0), (90.0, 150.0, 110.2, 170.1)]:
+        want = g.read_bounds_hwc(bounds)
+        got = g.read_bounds_hwc(bounds, out=stage, out_off=5)
+        assert got.base is not None and np.shares_memory(got, stage)
+        assert got.shape == want.shape and (got == want).all() and (stage[:5] == 7).all()

@@ -51,7 +51,7 @@ def test_outputs_exist_and_resume(workspace):
         assert files == sorted(f"Prediction_{k}.json" for k in meta)
     rec = yaml.safe_load(open(root / "output" / "predictions" / "prediction_recovery.yaml"))
     assert rec["model_path"] == config["combined_model"] and len(rec["files"]) == 2
-    assert os.path.exists(root / "output" / "geojson_predictions" / "324125317.geojson")
+    assert os.path.exists(root / "output" / "geojson_predictions" / "324125317.gpkg")
     # second call: everything is recovered, nothing re-predicted
     import treedetection_amd as T
     before = os.path.getmtime(root / "output" / "predictions" / "324125317" / sorted(os.listdir(root / "output" / "predictions" / "324125317"))[0])
@@ -133,8 +133,8 @@ def test_two_model_flow_with_exclude_flags(tmp_path):
     forest = {f[len("Prediction_"):-5] for f in os.listdir(root / "output" / "forrest_predictions" / "1")}
     assert urban == set(meta) - only_forest          # urban model skips forest-only tiles
     assert forest == set(meta) - only_urban          # forest model skips urban-only tiles
-    assert os.path.exists(root / "output" / "urban_geojson" / "1.geojson")
-    assert os.path.exists(root / "output" / "forrest_geojson" / "1.geojson")
+    assert os.path.exists(root / "output" / "urban_geojson" / "1.gpkg")
+    assert os.path.exists(root / "output" / "forrest_geojson" / "1.gpkg")
 
 
 def test_sixteen_bit_tiles_take_the_float_path(tmp_path):

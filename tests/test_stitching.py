@@ -1,0 +1,243 @@
+"""Stitching consumer (reference helpers.py:419-600): ring simplification vs. the oracle
+restatement of GEOS' TopologyPreservingSimplifier, the edge filter, the GeoPackage container and the resume file.
+GEOS/GDAL are absent here and the reference holds no fixture for this step: parity with them is unpinned; these tests
+pin the C++ product path to the independent exact-arithmetic oracle and to the properties the algorithm guarantees."""
+import json
+import os
+import sqlite3
+import sys
+
+import numpy as np
+import pytest
+import yaml
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle import simplify_ref as S  # noqa: E402
+from oracle.contours_ref import find_contours as ref_contours  # noqa: E402
+from treedetection_amd import gpkg  # noqa: E402
+from treedetection_amd.stitching import (box_filter, box_make, filename_geoinfo, process_and_stitch_predictions,  # noqa: E402
+                                         simplify_ring, within_box)
+
+
+def _blob_ring(rng, size=64, gsd=0.2, x0=412000.0, y0=5319000.0):
+    """Outer contour of a random blob, as the predictor emits it: integer pixel corners through the tile affine."""
+    yy, xx = np.mgrid[0:size, 0:size]
+    m = np.zeros((size, size), bool)
+    for _ in range(int(rng.integers(1, 4))):
+        cx, cy = rng.uniform(size * 0.3, size * 0.7, 2)
+        a, b = rng.uniform(size * 0.1, size * 0.3, 2)
+        m |= ((xx - cx) / a) ** 2 + ((yy - cy) / b) ** 2 < 1
+    c = max(ref_contours(m.astype(np.uint8)), key=len).astype(np.float64)
+    ring = np.concatenate([c, c[:1]])
+    return np.stack([gsd * ring[:, 0] + x0, -gsd * ring[:, 1] + y0], axis=1)
+
+
+def _is_subsequence(out, ring):
+    idx, k = [], 0
+    for q in out[:-1]:
+        while k < len(ring) and not (ring[k] == q).all():
+            k += 1
+        if k == len(ring):
+            return None
+        idx.append(k)
+    return idx
+
+
+@pytest.mark.parametrize("tol", [0.05, 0.2, 0.5, 2.0])
+def test_simplify_matches_oracle_on_contour_rings(tol):
+    rng = np.random.default_rng(int(tol * 100))
+    for _ in range(12):
+        ring = _blob_ring(rng)
+        got = simplify_ring(ring, tol)
+        want = np.array(S.simplify_ring([tuple(p) for p in ring], tol))
+        assert got.shape == want.shape and (got == want).all()
+        # what Douglas-Peucker guarantees: closed, >= 4 points, a subsequence (possibly rotated by the dropped ring
+        # endpoint), every dropped vertex within tol of the segment that replaced it — except on the one segment
+        # that merges the ring's first and last result segments, where only the old endpoint itself is re-checked
+        assert (got[0] == got[-1]).all() and 4 <= len(got) <= len(ring)
+        start = 0 if (got[0] == ring[0]).all() else int(np.where((ring[:-1] == got[0]).all(axis=1))[0][-1])
+        rolled = np.concatenate([ring[start:-1], ring[:start + 1]])
+        idx = _is_subsequence(got, rolled)
+        assert idx is not None
+        idx.append(len(rolled) - 1)
+        for n_seg, (a, b) in enumerate(zip(idx[:-1], idx[1:])):
+            slack = 2.0 if (start != 0 and n_seg == 0) else 1.0
+            for k in range(a + 1, b):
+                assert S.point_segment_distance(tuple(rolled[k]), tuple(rolled[a]), tuple(rolled[b])) <= slack * tol + 1e-12
+    assert len(got) < len(ring) or tol < 0.1
+
+
+def test_simplify_known_answers():
+    sq = np.array([[0, 0], [4, 0], [4, 4], [0, 4], [0, 0]], float)
+    assert (simplify_ring(sq, 1.0) == sq).all()                       # nothing within tolerance
+    # collinear mid-points and the collinear ring start vertex go; the square's corners stay
+    dense = np.array([[2, 0], [4, 0], [4, 2], [4, 4], [2, 4], [0, 4], [0, 2], [0, 0], [2, 0]], float)
+    out = simplify_ring(dense, 0.01)
+    assert {tuple(p) for p in out} == {(0, 0), (4, 0), (4, 4), (0, 4)} and len(out) == 5
+    # a staircase diagonal collapses to its end points
+    stair = [[0, 0]] + [[i + (j == 1), i + 1] for i in range(6) for j in (0, 1)] + [[0, 20], [0, 0]]
+    out = simplify_ring(np.array(stair, float), 1.0)
+    assert len(out) == 4 and (out[0] == out[-1]).all()
+    # minimum size: a sliver within tolerance of a line still keeps 4 points
+    sliver = np.array([[0, 0], [10, 0.01], [20, 0], [10, -0.01], [0, 0]], float)
+    assert len(simplify_ring(sliver, 1.0)) >= 4
+    # tolerance 0 removes only exactly collinear points; degenerate inputs pass through
+    assert len(simplify_ring(dense, 0.0)) == 5
+    assert simplify_ring(np.zeros((1, 2)), 1.0).shape == (1, 2)
+
+
+def test_simplify_refuses_to_create_crossings():
+    """A spike that reaches into a notch: flattening the notch would cut the spike — the topology check must refuse."""
+    ring = np.array([[0, 0], [10, 0], [10, 10], [6, 10], [6, 0.5], [4, 0.5], [4, 10], [0, 10], [0, 0]], float)
+    ring2 = np.array([[0, 0], [4.9, 0], [5, 0.6], [5.1, 0], [10, 0], [10, -5], [0, -5], [0, 0]], float)
+    for r in (ring, ring2):
+        for tol in (0.1, 0.7, 3.0, 20.0):
+            got = simplify_ring(r, tol)
+            want = np.array(S.simplify_ring([tuple(p) for p in r], tol))
+            assert got.shape == want.shape and (got == want).all()
+            segs = list(zip(got[:-1], got[1:]))
+            for i in range(len(segs)):
+                for j in range(i + 1, len(segs)):
+                    assert not S.interior_intersection(tuple(segs[i][0]), tuple(segs[i][1]), tuple(segs[j][0]), tuple(segs[j][1]))
+
+
+def test_box_filter_and_within():
+    name = "tiles/324125317_412000_5318000_90_30_25832"
+    assert filename_geoinfo(name + ".json") == (412000, 5318000, 90, 30, 25832)
+    assert box_make(412000, 5318000, 90, 30, 25832, 1) == (411971, 5317971, 412119, 5318119)
+    assert box_filter(name, 1) == (411971, 5317971, 412119, 5318119)
+    box = (0.0, 0.0, 10.0, 10.0)
+    inside = np.array([[1, 1], [2, 1], [2, 2], [1, 1]], float)
+    touching = np.array([[0, 0], [10, 0], [10, 10], [0, 0]], float)        # on the boundary but with area: within
+    outside = np.array([[1, 1], [11, 1], [2, 2], [1, 1]], float)
+    on_edge_line = np.array([[0, 1], [0, 2], [0, 3], [0, 1]], float)       # degenerate, entirely on the boundary
+    for ring, want in ((inside, True), (touching, True), (outside, False), (on_edge_line, False)):
+        assert within_box(ring, box) is want
+        assert S.polygon_within_box([tuple(p) for p in ring], box) is want
+
+
+def test_gpkg_container(tmp_path):
+    rings = [np.array([[412000.0, 5318000.0], [412010.2, 5318000.0], [412010.2, 5318007.4], [412000.0, 5318000.0]]),
+             np.array([[412100.0, 5318100.0], [412101.0, 5318100.0], [412101.0, 5318101.0], [412100.0, 5318101.0], [412100.0, 5318100.0]])]
+    path = str(tmp_path / "324125317.gpkg")
+    gpkg.write_polygons(path, rings, {"Confidence_score": [0.9, 0.5], "filter_index_right": [0, 0]}, 25832)
+    con = sqlite3.connect(path)
+    assert con.execute("PRAGMA application_id").fetchone()[0] == 0x47504B47
+    assert con.execute("PRAGMA user_version").fetchone()[0] == 10200
+    assert {r[0] for r in con.execute("SELECT srs_id FROM gpkg_spatial_ref_sys")} == {-1, 0, 4326, 25832}
+    name, wkt = con.execute("SELECT srs_name, definition FROM gpkg_spatial_ref_sys WHERE srs_id=25832").fetchone()
+    assert name == "ETRS89 / UTM zone 32N" and 'PARAMETER["central_meridian",9]' in wkt and wkt.endswith('AUTHORITY["EPSG","25832"]]')
+    row = con.execute("SELECT table_name, data_type, min_x, min_y, max_x, max_y, srs_id FROM gpkg_contents").fetchone()
+    assert row == ("324125317", "features", 412000.0, 5318000.0, 412101.0, 5318101.0, 25832)
+    assert con.execute("SELECT * FROM gpkg_geometry_columns").fetchone() == ("324125317", "geom", "POLYGON", 25832, 0, 0)
+    blob = con.execute('SELECT geom FROM "324125317" WHERE fid=1').fetchone()[0]
+    # GeoPackage binary header: magic, version 0, flags (LE + xy envelope), srs, envelope minx maxx miny maxy; then WKB polygon
+    assert blob[:4] == b"GP\x00\x03" and int.from_bytes(blob[4:8], "little") == 25832
+    assert np.frombuffer(blob, "<f8", 4, 8).tolist() == [412000.0, 412010.2, 5318000.0, 5318007.4]
+    assert blob[40:53] == b"\x01\x03\x00\x00\x00\x01\x00\x00\x00\x04\x00\x00\x00" and len(blob) == 53 + 4 * 16
+    con.close()
+    back, cols, srs = gpkg.read_polygons(path)
+    assert srs == 25832 and cols == {"Confidence_score": [0.9, 0.5], "filter_index_right": [0, 0]}
+    assert all((a == b).all() for a, b in zip(back, rings))
+    gpkg.write_polygons(path, [], {}, None)                       # empty layer, EPSG:4326 like the reference
+    back, cols, srs = gpkg.read_polygons(path)
+    assert back == [] and srs == 4326
+    assert gpkg.srs_definition(32733)[0] == "WGS 84 / UTM zone 33S" and gpkg.srs_definition(31467)[1] == "undefined"
+
+
+def _square(x, y, s):
+    return [[[x, y], [x + s, y], [x + s, y + s / 2], [x + s, y + s], [x, y + s], [x, y]]]
+
+
+def test_process_and_stitch_predictions(tmp_path):
+    tiles, preds, out = tmp_path / "tiles", tmp_path / "preds", tmp_path / "gpkg"
+    os.makedirs(tiles)
+    os.makedirs(preds / "img1")
+    ids = ["img1_1000_2000_50_10_25832", "img1_1050_2000_50_10_25832", "img1_1100_2000_50_10_25832"]
+    meta = {t: {"crs": 25832, "transform": [0.2, 0, 0, 0, -0.2, 0, 0, 0, 1], "bounds": [0, 0, 1, 1]} for t in ids}
+    (tiles / "img1.json").write_text(json.dumps(meta))
+    (tiles / "img2.json").write_text(json.dumps({}))             # an image without predictions → empty layer
+    (tiles / "recovery.yaml").write_text("x: 1")                  # non-JSON files in tiles_path are ignored
+    ev = lambda x, y, s, sc: {"image_id": "a.tif", "category_id": 0, "score": sc, "polygon_coords": _square(x, y, s)}  # noqa: E731
+    # tile 0 box with shift 1: [991, 1991, 1059, 2059]
+    (preds / "img1" / f"Prediction_{ids[0]}.json").write_text(json.dumps([
+        ev(1000, 2000, 5, 0.9),        # inside
+        ev(990.5, 2000, 5, 0.8),       # pokes into the 1 m edge band → dropped
+        ev(991, 1991, 5, 0.7)]))       # touches the shrunken box from inside → kept
+    (preds / "img1" / f"Prediction_{ids[1]}.json").write_text(json.dumps([]))
+    (preds / "img1" / f"Prediction_{ids[2]}.json").write_text("{ not json")          # unreadable file: skipped, logged
+    (preds / "img1" / "Prediction_img1_9_9_50_10_25832.json").write_text(json.dumps([ev(0, 0, 1, 0.5)]))  # unknown tile
+
+    class Log:
+        def __init__(self):
+            self.msgs = []
+
+        def __getattr__(self, name):
+            return lambda m: self.msgs.append((name, m))
+
+    log = Log()
+    assert process_and_stitch_predictions(str(tiles), str(preds), str(out), max_workers=4, shift=1, simplify_tolerance=0.2,
+                                          logger=log) == str(out)
+    rings, cols, srs = gpkg.read_polygons(str(out / "img1.gpkg"))
+    assert srs == 25832 and cols["Confidence_score"] == [0.9, 0.7] and cols["filter_index_right"] == [0, 0]
+    assert [len(r) for r in rings] == [5, 5]                      # the collinear mid-edge vertex was simplified away
+    assert rings[0].tolist() == [[1000, 2000], [1005, 2000], [1005, 2005], [1000, 2005], [1000, 2000]]
+    assert gpkg.read_polygons(str(out / "img2.gpkg"))[0] == []
+    assert sum(1 for lvl, m in log.msgs if lvl == "warning" and "Error processing file" in m) == 2
+    rec = yaml.safe_load(open(out / "stitching_recovery.yaml"))
+    assert rec == {"completed_files": ["img1", "img2"]}
+    # resume: listed images are not rebuilt
+    os.remove(out / "img1.gpkg")
+    process_and_stitch_predictions(str(tiles), str(preds), str(out), logger=log)
+    assert not os.path.exists(out / "img1.gpkg")
+    assert any("Skipping stiching 2 of 2" in m for _, m in log.msgs)
+    with pytest.raises(FileNotFoundError):
+        process_and_stitch_predictions(str(tiles), str(tmp_path / "nope"), str(out))
+
+
+def test_stitch_tile_json_equals_per_polygon_path(tmp_path):
+    """td_stitch_tile_json (parse + simplify + within + encode in one host call) against the same steps done one
+    polygon at a time through json.loads / td_simplify_ring / within_box / polygon_blob."""
+    from pathlib import Path
+    from treedetection_amd.stitching import process_prediction_file_sync
+    rng = np.random.default_rng(5)
+    tid = "img_412000_5319000_10_2_25832"          # box with shift 1: [411999, 5318999, 412011, 5319011]
+    entries = []
+    for k in range(40):
+        ring = _blob_ring(rng, size=48, gsd=0.2, x0=411995.0 + rng.uniform(0, 8), y0=5319014.0 - rng.uniform(0, 5))
+        entries.append({"image_id": 'a \\ " é.tif', "category_id": 0, "score": float(rng.random()),
+                        "extra": {"nested": [1, {"k": None}, 's"]\\'], "t": True}, "polygon_coords": [ring.tolist()]})
+    os.makedirs(tmp_path / "img")
+    f = tmp_path / "img" / f"Prediction_{tid}.json"
+    f.write_text(json.dumps(entries, indent=1))                    # whitespace-rich on purpose
+    meta = {tid: {"crs": "EPSG:25832"}}
+    got = process_prediction_file_sync(f, str(tmp_path), {tid: Path(tid)}, 1, 0.2, None, meta)
+    box = box_filter(tid, 1)
+    want_blobs, want_scores = [], []
+    for e in entries:
+        r = simplify_ring(np.array(e["polygon_coords"]).reshape(-1, 2), 0.2)
+        if within_box(r, box):
+            want_blobs.append(gpkg.polygon_blob(r, 25832))
+            want_scores.append(e["score"])
+    assert 0 < len(want_blobs) < len(entries)                      # the fixture exercises both sides of the filter
+    assert len(got) == len(want_blobs) and got.scores.tolist() == want_scores and got.epsg == "EPSG:25832"
+    assert [bytes(got.blobs[got.offsets[i]:got.offsets[i + 1]]) for i in range(len(got))] == want_blobs
+    assert (got.envelopes()[0] == np.frombuffer(want_blobs[0], "<f8", 4, 8)).all()
+    # tolerance 0 = no simplification at all (the reference skips the call, helpers.py:464)
+    raw = process_prediction_file_sync(f, str(tmp_path), {tid: Path(tid)}, -100, 0.0, None, meta)
+    assert all((a == np.array(e["polygon_coords"]).reshape(-1, 2)).all() for a, e in zip(raw.rings(), entries))
+
+    class Log:
+        msgs = []
+
+        def warning(self, m):
+            self.msgs.append(m)
+
+    for bad in ('[{"score": 1.0}]', '[{"score": 1, "polygon_coords": [[[0,0],[1,1],[0,1]]]}]', '[{"polygon_coords": [[[0,0],[1,0],[1,1],[0,0]]]}]',
+                '[{"score": 0.5, "polygon_coords": [[[0,0],[1,0],[1,1],[0]]]}]', '[{"score": 0.5, "polygon_coords": [[[0,0],[1,0],[1,1],[0,0]]]} x]', ''):
+        f.write_text(bad)
+        assert process_prediction_file_sync(f, str(tmp_path), {tid: Path(tid)}, 1, 0.2, Log(), meta) is None
+    assert len(Log.msgs) == 6 and "polygon_coords" in Log.msgs[0] and "at least 4" in Log.msgs[1]
+    f.write_text("[]")
+    assert len(process_prediction_file_sync(f, str(tmp_path), {tid: Path(tid)}, 1, 0.2, None, meta)) == 0

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtreedet_hip.so")
 
 _lib: Optional[C.CDLL] = None
+ERR_CAPACITY = -4   # TD_ERR_CAPACITY
 
 
 class TdError(RuntimeError):
@@ -68,6 +69,11 @@ SIGNATURES = {
     "td_paste_masks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "td_find_contours": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "td_simplify_ring": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int]),
+    "td_stitch_tile_json": (C.c_int, [C.c_char_p, C.c_int64, C.POINTER(C.c_double), C.c_double, C.c_int32, C.c_void_p,
+                                      C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "td_tile_polygons_json": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.POINTER(C.c_double), C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
 }
 
 

@@ -34,3 +34,29 @@ def xy(transform: Sequence[float], rows: Sequence[float], cols: Sequence[float])
     r = np.asarray(rows, dtype=np.float64)
     k = np.asarray(cols, dtype=np.float64)
     return a * k + b * r + c, d * k + e * r + f
+
+
+def tile_polygons_json(regions: np.ndarray, offsets: np.ndarray, bits: np.ndarray, scores: np.ndarray,
+                       classes: np.ndarray, transform: Sequence[float], image_id: str, _buf=None) -> bytes:
+    """The text of one tile's ``Prediction_*.json`` (reference prediction.py:229-261) straight from the engine's
+    packed masks — td_tile_polygons_json; the call releases the GIL, so tiles run in parallel on host threads."""
+    lib = _lib.load()
+    n = int(len(scores))
+    regions = np.ascontiguousarray(regions[:n], dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets[:n], dtype=np.int64)
+    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    classes = np.ascontiguousarray(classes[:n], dtype=np.int32)
+    words = np.ascontiguousarray(bits).view(np.uint32).reshape(-1)
+    tr = (C.c_double * 6)(*[float(v) for v in transform[:6]])
+    need = C.c_int64(0)
+    cap = 1 << 20
+    while True:
+        buf = C.create_string_buffer(cap)
+        st = lib.td_tile_polygons_json(regions.ctypes.data, offsets.ctypes.data, words.ctypes.data, words.size,
+                                       scores.ctypes.data, classes.ctypes.data, n, tr, image_id.encode("utf-8", "surrogateescape"),
+                                       buf, cap, C.byref(need))
+        if st == _lib.ERR_CAPACITY:
+            cap = int(need.value)
+            continue
+        _lib.check(st, "td_tile_polygons_json")
+        return buf.raw[: need.value]

@@ -11,6 +11,7 @@
 // label wrap. Pure host code: this runs on the CPU thread pool next to the GPU forward.
 #include "common.h"
 
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -22,18 +23,10 @@ struct Node {
     std::vector<int> children;
 };
 
-}  // namespace
-
-extern "C" int td_find_contours(const uint8_t* img, int h, int w, int32_t* points, int max_points, int32_t* starts,
-                                int max_contours) {
-    if (!img || !points || !starts || h < 1 || w < 1 || max_points < 1 || max_contours < 1) {
-        td_set_error("td_find_contours: bad argument");
-        return TD_ERR_INVALID;
-    }
+// Traces every border of the padded label image F ((h+2) x (w+2), 0/1 on entry) and appends the contours in
+// RETR_TREE order to `pts` (x,y pairs) / `starts` (point index of each contour + end sentinel).
+void trace_padded(std::vector<int32_t>& F, int h, int w, std::vector<int32_t>& pts, std::vector<int32_t>& starts) {
     const int step = w + 2;
-    std::vector<int32_t> F((size_t)(h + 2) * step, 0);
-    for (int y = 0; y < h; ++y)
-        for (int x = 0; x < w; ++x) F[(size_t)(y + 1) * step + x + 1] = img[(size_t)y * w + x] ? 1 : 0;
     // direction s: 0 E, 1 NE, 2 N, 3 NW, 4 W, 5 SW, 6 S, 7 SE (y grows downwards)
     const int dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
     const int dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
@@ -112,29 +105,61 @@ extern "C" int td_find_contours(const uint8_t* img, int h, int w, int32_t* point
         }
     }
     // ---- RETR_TREE order: pre-order DFS, children most-recently-found first ----
-    const int total = (int)nodes.size() - 2;
+    std::vector<int> stack;
+    for (int c : nodes[1].children) stack.push_back(c);   // popped from the back = most recent first
+    pts.clear();
+    starts.clear();
+    while (!stack.empty()) {
+        const int n = stack.back();
+        stack.pop_back();
+        starts.push_back((int32_t)(pts.size() / 2));
+        pts.insert(pts.end(), pool.begin() + 2 * (size_t)nodes[n].first,
+                   pool.begin() + 2 * (size_t)(nodes[n].first + nodes[n].count));
+        for (int c : nodes[n].children) stack.push_back(c);
+    }
+    starts.push_back((int32_t)(pts.size() / 2));
+}
+
+}  // namespace
+
+void td_trace_contours_u8(const uint8_t* img, int h, int w, std::vector<int32_t>& pts, std::vector<int32_t>& starts) {
+    const int step = w + 2;
+    std::vector<int32_t> F((size_t)(h + 2) * step, 0);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) F[(size_t)(y + 1) * step + x + 1] = img[(size_t)y * w + x] ? 1 : 0;
+    trace_padded(F, h, w, pts, starts);
+}
+
+void td_trace_contours_bits(const uint32_t* rows, int words_per_row, int h, int w, std::vector<int32_t>& pts,
+                            std::vector<int32_t>& starts) {
+    const int step = w + 2;
+    std::vector<int32_t> F((size_t)(h + 2) * step, 0);
+    for (int y = 0; y < h; ++y) {
+        const uint32_t* r = rows + (size_t)y * words_per_row;
+        int32_t* f = &F[(size_t)(y + 1) * step + 1];
+        for (int x = 0; x < w; ++x) f[x] = (r[x >> 5] >> (x & 31)) & 1u;
+    }
+    trace_padded(F, h, w, pts, starts);
+}
+
+extern "C" int td_find_contours(const uint8_t* img, int h, int w, int32_t* points, int max_points, int32_t* starts,
+                                int max_contours) {
+    if (!img || !points || !starts || h < 1 || w < 1 || max_points < 1 || max_contours < 1) {
+        td_set_error("td_find_contours: bad argument");
+        return TD_ERR_INVALID;
+    }
+    std::vector<int32_t> pts, st;
+    td_trace_contours_u8(img, h, w, pts, st);
+    const int total = (int)st.size() - 1;
     if (total > max_contours) {
         td_set_error("td_find_contours: %d contours exceed capacity %d", total, max_contours);
         return TD_ERR_CAPACITY;
     }
-    if ((int)(pool.size() / 2) > max_points) {
-        td_set_error("td_find_contours: %d points exceed capacity %d", (int)(pool.size() / 2), max_points);
+    if ((int)(pts.size() / 2) > max_points) {
+        td_set_error("td_find_contours: %d points exceed capacity %d", (int)(pts.size() / 2), max_points);
         return TD_ERR_CAPACITY;
     }
-    std::vector<int> stack;
-    for (int c : nodes[1].children) stack.push_back(c);   // popped from the back = most recent first
-    int nc = 0, np = 0;
-    while (!stack.empty()) {
-        const int n = stack.back();
-        stack.pop_back();
-        starts[nc++] = np;
-        for (int i = 0; i < nodes[n].count; ++i) {
-            points[2 * np] = pool[2 * (nodes[n].first + i)];
-            points[2 * np + 1] = pool[2 * (nodes[n].first + i) + 1];
-            ++np;
-        }
-        for (int c : nodes[n].children) stack.push_back(c);
-    }
-    starts[nc] = np;
-    return nc;
+    std::memcpy(points, pts.data(), pts.size() * sizeof(int32_t));
+    std::memcpy(starts, st.data(), st.size() * sizeof(int32_t));
+    return total;
 }

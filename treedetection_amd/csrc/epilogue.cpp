@@ -1,0 +1,189 @@
+// Host epilogue of one tile: packed instance masks → polygons → the text of the per-tile prediction file
+// (reference TreeDetection/prediction.py:229-261, `_process_and_save_single`; affine of utilities.py:182-207).
+//
+// Per detection: unpack the paste region from the engine's bit rows, follow every border (contours.cpp), keep
+// contours with >= 4 points (`contour.size >= 8`), close the ring, map the integer pixel-corner coordinates through
+// the tile's affine in float64 (x' = a*col + b*row + c, y' = d*col + e*row + f, evaluated left to right like the
+// numpy expression) and emit {"image_id", "category_id", "score", "polygon_coords": [[[x, y], ...]]}. The text is
+// byte-for-byte what `json.dumps(evaluations)` produces (default separators, ensure_ascii, float repr = shortest
+// round-trip digits laid out by CPython's rule), so a file written from it cannot be told from the reference's.
+// Pure host code; the Python host calls it from worker threads with the GIL released.
+#include "common.h"
+
+#include <charconv>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+void td_trace_contours_bits(const uint32_t* rows, int words_per_row, int h, int w, std::vector<int32_t>& pts,
+                            std::vector<int32_t>& starts);
+
+namespace {
+
+// repr(float) of CPython (float_repr_style 'short'): shortest digits that round-trip; fixed notation when
+// -4 < decpt <= 16, otherwise d[.ddd]e±XX with at least two exponent digits.
+void append_double(std::string& out, double v) {
+    if (std::isnan(v)) {
+        out += "NaN";
+        return;
+    }
+    if (std::isinf(v)) {
+        out += v < 0 ? "-Infinity" : "Infinity";
+        return;
+    }
+    if (v == 0.0) {
+        out += std::signbit(v) ? "-0.0" : "0.0";
+        return;
+    }
+    char sci[40];
+    auto r = std::to_chars(sci, sci + sizeof(sci) - 1, v, std::chars_format::scientific);
+    *r.ptr = 0;
+    const char* p = sci;
+    if (*p == '-') {
+        out += '-';
+        ++p;
+    }
+    char digits[24];
+    int nd = 0;
+    for (; p < r.ptr && *p != 'e'; ++p)
+        if (*p != '.') digits[nd++] = *p;
+    const int e10 = std::atoi(p + 1);          // "e+05" / "e-07"
+    while (nd > 1 && digits[nd - 1] == '0') --nd;
+    const int decpt = e10 + 1;
+    if (decpt > -4 && decpt <= 16) {
+        if (decpt <= 0) {
+            out += "0.";
+            out.append((size_t)-decpt, '0');
+            out.append(digits, nd);
+        } else if (decpt < nd) {
+            out.append(digits, decpt);
+            out += '.';
+            out.append(digits + decpt, nd - decpt);
+        } else {
+            out.append(digits, nd);
+            out.append((size_t)(decpt - nd), '0');
+            out += ".0";
+        }
+    } else {
+        out += digits[0];
+        if (nd > 1) {
+            out += '.';
+            out.append(digits + 1, nd - 1);
+        }
+        const int e = decpt - 1;
+        out += 'e';
+        out += e < 0 ? '-' : '+';
+        char eb[8];
+        std::snprintf(eb, sizeof(eb), "%02d", e < 0 ? -e : e);
+        out += eb;
+    }
+}
+
+// json.dumps(str) with ensure_ascii=True: UTF-8 in, \uXXXX (surrogate pairs above the BMP) out.
+void append_json_string(std::string& out, const char* s) {
+    out += '"';
+    const unsigned char* p = (const unsigned char*)s;
+    char buf[16];
+    while (*p) {
+        uint32_t cp;
+        int len;
+        if (*p < 0x80) { cp = *p; len = 1; }
+        else if ((*p >> 5) == 6 && (p[1] & 0xc0) == 0x80) { cp = ((*p & 0x1f) << 6) | (p[1] & 0x3f); len = 2; }
+        else if ((*p >> 4) == 14 && (p[1] & 0xc0) == 0x80 && (p[2] & 0xc0) == 0x80) {
+            cp = ((*p & 0x0f) << 12) | ((p[1] & 0x3f) << 6) | (p[2] & 0x3f); len = 3;
+        } else if ((*p >> 3) == 30 && (p[1] & 0xc0) == 0x80 && (p[2] & 0xc0) == 0x80 && (p[3] & 0xc0) == 0x80) {
+            cp = ((*p & 0x07) << 18) | ((p[1] & 0x3f) << 12) | ((p[2] & 0x3f) << 6) | (p[3] & 0x3f); len = 4;
+        } else { cp = 0xdc00 | *p; len = 1; }      // undecodable byte: what os.fsdecode's surrogateescape yields
+        p += len;
+        switch (cp) {
+            case '"': out += "\\\""; break;
+            case '\\': out += "\\\\"; break;
+            case '\n': out += "\\n"; break;
+            case '\r': out += "\\r"; break;
+            case '\t': out += "\\t"; break;
+            case '\b': out += "\\b"; break;
+            case '\f': out += "\\f"; break;
+            default:
+                if (cp >= 0x20 && cp < 0x7f) out += (char)cp;
+                else if (cp < 0x10000) {
+                    std::snprintf(buf, sizeof(buf), "\\u%04x", cp);
+                    out += buf;
+                } else {
+                    const uint32_t v = cp - 0x10000;
+                    std::snprintf(buf, sizeof(buf), "\\u%04x\\u%04x", 0xd800 | (v >> 10), 0xdc00 | (v & 0x3ff));
+                    out += buf;
+                }
+        }
+    }
+    out += '"';
+}
+
+}  // namespace
+
+extern "C" int td_tile_polygons_json(const int32_t* mask_region, const int64_t* mask_offset, const uint32_t* mask_bits,
+                                     int64_t mask_words, const float* scores, const int32_t* classes, int n,
+                                     const double* transform, const char* image_id, char* buf, int64_t cap,
+                                     int64_t* needed) {
+    if (n < 0 || !transform || !image_id || !needed || (n > 0 && (!mask_region || !mask_offset || !mask_bits || !scores)) ||
+        (cap > 0 && !buf)) {
+        td_set_error("td_tile_polygons_json: bad argument");
+        return TD_ERR_INVALID;
+    }
+    const double a = transform[0], b = transform[1], c = transform[2], d = transform[3], e = transform[4], f = transform[5];
+    std::string id;
+    append_json_string(id, image_id);
+    std::string out;
+    out.reserve(1 << 16);
+    out += '[';
+    int entries = 0;
+    std::vector<int32_t> pts, starts;
+    for (int k = 0; k < n; ++k) {
+        const int x0 = mask_region[4 * k], y0 = mask_region[4 * k + 1], x1 = mask_region[4 * k + 2], y1 = mask_region[4 * k + 3];
+        if (x1 <= x0 || y1 <= y0) continue;
+        const int w = x1 - x0, h = y1 - y0, wpr = (w + 31) / 32;
+        const int64_t o = mask_offset[k];
+        if (o < 0 || o + (int64_t)wpr * h > mask_words) {
+            td_set_error("td_tile_polygons_json: detection %d rows [%lld, +%lld) outside the %lld-word mask buffer", k,
+                         (long long)o, (long long)wpr * h, (long long)mask_words);
+            return TD_ERR_INVALID;
+        }
+        td_trace_contours_bits(mask_bits + o, wpr, h, w, pts, starts);
+        const int nc = (int)starts.size() - 1;
+        for (int ci = 0; ci < nc; ++ci) {
+            const int p0 = starts[ci], np = starts[ci + 1] - p0;
+            if (np < 4) continue;
+            if (entries++) out += ", ";
+            out += "{\"image_id\": ";
+            out += id;
+            out += ", \"category_id\": ";
+            out += std::to_string(classes ? classes[k] : 0);
+            out += ", \"score\": ";
+            append_double(out, (double)scores[k]);
+            out += ", \"polygon_coords\": [[";
+            const bool closed = pts[2 * p0] == pts[2 * (p0 + np - 1)] && pts[2 * p0 + 1] == pts[2 * (p0 + np - 1) + 1];
+            const int total = np + (closed ? 0 : 1);
+            for (int i = 0; i < total; ++i) {
+                const int j = p0 + (i < np ? i : 0);
+                const double col = (double)(pts[2 * j] + x0), row = (double)(pts[2 * j + 1] + y0);
+                const double gx = (a * col + b * row) + c;
+                const double gy = (d * col + e * row) + f;
+                if (i) out += ", ";
+                out += '[';
+                append_double(out, gx);
+                out += ", ";
+                append_double(out, gy);
+                out += ']';
+            }
+            out += "]]}";
+        }
+    }
+    out += ']';
+    *needed = (int64_t)out.size();
+    if ((int64_t)out.size() > cap) {
+        td_set_error("td_tile_polygons_json: %lld bytes needed, capacity %lld", (long long)out.size(), (long long)cap);
+        return TD_ERR_CAPACITY;
+    }
+    std::memcpy(buf, out.data(), out.size());
+    return entries;
+}

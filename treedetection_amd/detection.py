@@ -2,7 +2,8 @@
 ``postprocess_files`` / ``predict_on_model`` (TreeDetection/detection.py:342,256,134,23,62).
 
 ``predict_tiles`` / ``predict_on_model`` are the hot path this package accelerates (model forward on the MI355X);
-``preprocess_files`` produces the tile metadata; stitching writes GeoJSON (treedetection_amd/stitching.py);
+``preprocess_files`` produces the tile metadata; stitching writes one GeoPackage per image into the reference's
+``*_geojson`` / ``geojson_predictions`` folders (treedetection_amd/stitching.py);
 ``postprocess_files`` (crown filtering with nDSM / NDVI statistics, TreeDetection/postprocessing.py) is outside this
 round's scope and only hands the stitched files through.
 """
@@ -34,7 +35,8 @@ def predict_on_model(config, model_path, tiles_path, output_path, batch_size=10,
     os.makedirs(output_path, exist_ok=True)
     cfg = setup_model_cfg(update_model=model_path, device=config["device"])
     predictor = Predictor(cfg, device_type=config["device"], max_batch_size=batch_size, output_dir=output_path,
-                          exclude_vars=exclude_vars, precision=config.get("precision", "fp32"))
+                          exclude_vars=exclude_vars, precision=config.get("precision", "fp32"),
+                          return_predictions=False)       # the files are the product; the list is unused here
     images_directory = Path(config["image_directory"])
     images_paths = sorted(str(f) for f in images_directory.glob("*.tif"))
     merged_directory = Path(f"{images_directory}/{config['merged_path']}")
@@ -58,6 +60,7 @@ def predict_on_model(config, model_path, tiles_path, output_path, batch_size=10,
             predictor(fp, tile_json)
         except Exception as e:
             logger.error(f"Error processing {fp}: {e}")
+    predictor.close()
     logger.info(f"Completed prediction for {len(images_paths)} images.")
     if D.rank() == 0:
         save_prediction_recovery_data(output_path, tiles_path, model_path, processed_files, images_paths)
@@ -153,7 +156,7 @@ def postprocess_files(config):
         logger.warning("No stitched predictions to post-process.")
         return
     for name in sorted(os.listdir(src)):
-        if name.endswith(".geojson"):
+        if name.endswith(".gpkg"):
             shutil.copy(os.path.join(src, name), os.path.join(config["output_directory"], name))
     logger.info("Postprocessing: stitched predictions copied (height / NDVI crown filtering is not built yet).")
 

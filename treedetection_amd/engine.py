@@ -217,12 +217,12 @@ class Engine:
         hw_out = [(int(t.shape[0]), int(t.shape[1])) for t in tiles]
         return batch, shapes, hw_out
 
-    def paste_masks(self, probs: torch.Tensor, boxes: torch.Tensor, h: int, w: int, thresh: float = 0.5):
-        """td_paste_masks for n detections of one tile (CUDA tensors) → (region [n,4], bool masks [n,h,w]) on the host.
-        Used by rank 0 for detections gathered from other ranks."""
+    def paste_masks_packed(self, probs: torch.Tensor, boxes: torch.Tensor, h: int, w: int, thresh: float = 0.5):
+        """td_paste_masks for n detections of one tile (CUDA tensors) → (region [n,4] int32, offset [n] int64, packed
+        bit rows int32) on the host. Used by rank 0 for detections gathered from other ranks."""
         n = int(probs.shape[0])
         if n == 0:
-            return np.zeros((0, 4), np.int32), np.zeros((0, h, w), bool)
+            return np.zeros((0, 4), np.int32), np.zeros((0,), np.int64), np.zeros((1,), np.int32)
         dev = probs.device
         words = n * ((w + 2 + 31) // 32) * h
         region = torch.zeros((n, 4), dtype=torch.int32, device=dev)
@@ -233,8 +233,15 @@ class Engine:
         _lib.check(self.lib.td_paste_masks(probs.data_ptr(), boxes.data_ptr(), n, h, w, thresh, region.data_ptr(),
                                            offset.data_ptr(), bits.data_ptr(), words, _lib.stream_ptr()), "td_paste_masks")
         torch.cuda.synchronize()
-        rg = region.cpu().numpy()
-        return rg, unpack_masks(rg, offset.cpu().numpy(), bits.cpu().numpy(), n, h, w)
+        return region.cpu().numpy(), offset.cpu().numpy(), bits.cpu().numpy()
+
+    def paste_masks(self, probs: torch.Tensor, boxes: torch.Tensor, h: int, w: int, thresh: float = 0.5):
+        """:meth:`paste_masks_packed` unpacked to (region [n,4], bool masks [n,h,w])."""
+        n = int(probs.shape[0])
+        if n == 0:
+            return np.zeros((0, 4), np.int32), np.zeros((0, h, w), bool)
+        rg, off, bits = self.paste_masks_packed(probs, boxes, h, w, thresh)
+        return rg, unpack_masks(rg, off, bits, n, h, w)
 
     # -- device timing ------------------------------------------------------------------------------------
     PROF_NAMES = ("conv_igemm", "stem", "pool", "rpn_select", "roi_align", "detect", "mask_tail", "mask_convs")

@@ -197,18 +197,24 @@ class GeoTiff:
         a, b, c, d, e, f = self.transform
         return (a, b, c + a * col_off + b * row_off, d, e, f + d * col_off + e * row_off)
 
-    def read_bounds_hwc(self, bounds: Sequence[float]) -> np.ndarray:
+    def read_bounds_hwc(self, bounds: Sequence[float], out: Optional[np.ndarray] = None, out_off: int = 0) -> np.ndarray:
         """Same pixels as :meth:`read_bounds` but pixel-interleaved [rows, cols, bands] and contiguous — the layout
-        the device resize consumes; for chunky files this is a plain row-slab copy of the memory map."""
+        the device resize consumes; for chunky files this is a plain row-slab copy of the memory map. With ``out``
+        (a flat array of the raster's dtype, e.g. pinned staging memory) the window is written at ``out_off`` and the
+        returned array is a view of it."""
         c0, r0, w, h = self.window_of_bounds(bounds)
         if w <= 0 or h <= 0:
             raise ValueError("Input shapes do not overlap raster.")
         data = self._load()
-        base = getattr(data, "base", None)
         if isinstance(data, np.ndarray) and data.ndim == 3 and data.strides[0] == data.dtype.itemsize:
-            hwc = np.ascontiguousarray(data.transpose(1, 2, 0)[r0:r0 + h, c0:c0 + w, :])    # already HWC in memory
+            src = data.transpose(1, 2, 0)[r0:r0 + h, c0:c0 + w, :]    # already HWC in memory
         else:
-            hwc = np.ascontiguousarray(np.asarray(data[:, r0:r0 + h, c0:c0 + w]).transpose(1, 2, 0))
+            src = np.asarray(data[:, r0:r0 + h, c0:c0 + w]).transpose(1, 2, 0)
+        if out is not None:
+            hwc = out[out_off:out_off + h * w * self.count].reshape(h, w, self.count)
+            np.copyto(hwc, src)
+        else:
+            hwc = np.ascontiguousarray(src)
         a, _, c, _, e, f = self.transform
         minx, miny, maxx, maxy = (float(v) for v in bounds[:4])
         xs = c + a * (np.arange(c0, c0 + w) + 0.5)

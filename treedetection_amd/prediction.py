@@ -11,6 +11,8 @@ from __future__ import annotations
 
 import json
 import os
+import queue
+import threading
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List, Optional
 
@@ -18,17 +20,50 @@ import numpy as np
 import torch
 
 from . import distributed as D
-from .contours import find_contours, xy
+from .contours import find_contours, tile_polygons_json, xy
 from .engine import Engine, INPUT_F32_CHW, INPUT_U8_HWC, unpack_masks
 from .geotiff import GeoTiff
 from .weights import load_checkpoint
 
 
+class _Slot:
+    """Buffers of one in-flight batch: pinned tile staging + its device copy, the engine's device outputs and their
+    pinned host copies, and the event that marks the copies complete. A slot goes reader → launcher → epilogue
+    workers → back to the free list."""
+
+    def __init__(self):
+        self.pin_in = self.dev_in = None
+        self.dev_out = self.pin_out = self.host = None
+        self.out_key = None
+        self.event = torch.cuda.Event(blocking=True)
+        self.pending = 0
+        self.lock = threading.Lock()
+
+    def staging(self, nbytes: int, device) -> np.ndarray:
+        if self.pin_in is None or self.pin_in.numel() < nbytes:
+            self.pin_in = torch.empty((nbytes,), dtype=torch.uint8, pin_memory=True)
+            self.dev_in = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        return self.pin_in.numpy()
+
+    def outputs(self, engine: Engine, B: int, h: int, w: int) -> Dict[str, torch.Tensor]:
+        key = self.out_key
+        if key is None or B > key[0] or h > key[1] or w > key[2]:
+            key = (max(B, key[0]) if key else B, max(h, key[1]) if key else h, max(w, key[2]) if key else w)
+            self.dev_out = engine.alloc_outputs(*key, paste=True)
+            self.pin_out = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in self.dev_out.items()}
+            self.host = {k: v.numpy() for k, v in self.pin_out.items()}
+            self.out_key = key
+        return self.dev_out
+
+
 class Predictor:
     def __init__(self, cfg, device_type="cpu", max_batch_size=5, output_dir="./output", exclude_vars=None,
-                 precision: str = "fp32", state_dict: Optional[Dict[str, np.ndarray]] = None):
+                 precision: str = "fp32", state_dict: Optional[Dict[str, np.ndarray]] = None,
+                 return_predictions: bool = True, host_workers: Optional[int] = None):
         """cfg from ``setup_model_cfg``; ``device_type`` = GPU index ("0", 0) as config["device"] carries it.
-        ``state_dict`` lets tests and the bench inject weights instead of reading cfg.MODEL.WEIGHTS."""
+        ``state_dict`` lets tests and the bench inject weights instead of reading cfg.MODEL.WEIGHTS.
+        ``return_predictions=False`` skips rebuilding the Python list ``__call__`` returns (the reference's own caller
+        ignores it, detection.py:118); the per-tile files are written either way."""
         self.cfg = cfg
         if device_type == "cpu" or not torch.cuda.is_available():
             raise RuntimeError("treedetection_amd.Predictor runs on an MI355X only: the HIP path has no CPU fallback "
@@ -38,6 +73,7 @@ class Predictor:
         self.max_batch_size = max_batch_size
         self.output_dir = output_dir
         self.exclude_vars = exclude_vars or []
+        self.return_predictions = return_predictions
         os.makedirs(self.output_dir, exist_ok=True)
         sd = state_dict if state_dict is not None else load_checkpoint(cfg.MODEL.WEIGHTS)
         rh = cfg.MODEL.ROI_HEADS
@@ -45,7 +81,23 @@ class Predictor:
                              nms_thresh=rh.NMS_THRESH_TEST, rpn_nms_thresh=cfg.MODEL.RPN.NMS_THRESH,
                              pre_nms_topk=cfg.MODEL.RPN.PRE_NMS_TOPK_TEST, post_nms_topk=cfg.MODEL.RPN.POST_NMS_TOPK_TEST,
                              detections_per_image=cfg.TEST.DETECTIONS_PER_IMAGE)
-        self._pool = ThreadPoolExecutor(max_workers=8)
+        workers = host_workers or max(2, min(16, len(os.sched_getaffinity(0)) - 2))
+        self._pool = ThreadPoolExecutor(max_workers=workers)
+        self._slots = [_Slot() for _ in range(3)]
+
+    def close(self) -> None:
+        """Stops the host worker threads and releases the engine's device memory."""
+        if getattr(self, "_pool", None) is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+        if getattr(self, "engine", None) is not None:
+            self.engine.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     # -- tile metadata ---------------------------------------------------------------------------------------
     def _filter_excluded_vars(self, tiles):
@@ -70,15 +122,22 @@ class Predictor:
         return tiles
 
     # -- one tile: crop → BGR → (16-bit rescale) → device -------------------------------------------------------
-    def _process_tile(self, tile, img: GeoTiff):
+    def _process_tile(self, tile, img: GeoTiff, staging: Optional[np.ndarray] = None, staging_off: int = 0):
+        """Reference prediction.py:159-176. uint8 rasters: the window is copied (into the pinned ``staging`` buffer at
+        ``staging_off`` when given) as it lies in the file, the BGR pick and resize happen on the device."""
         try:
-            hwc = img.read_bounds_hwc(tile["bounds"])                  # [h, w, bands], band order of the file
+            if staging is not None and img.dtype == np.uint8:
+                hwc = img.read_bounds_hwc(tile["bounds"], out=staging, out_off=staging_off)
+            else:
+                hwc = img.read_bounds_hwc(tile["bounds"])              # [h, w, bands], band order of the file
             if hwc.shape[2] < 3:
                 raise ValueError(f"tile has {hwc.shape[2]} bands, need >= 3")
             orig_h, orig_w = hwc.shape[:2]
             info = {"orig_height": orig_h, "orig_width": orig_w, "height": orig_h, "width": orig_w,
                     "json_name": tile["json_name"], "tile_id": tile["tile_id"], "meta": tile["meta"]}
             if hwc.dtype == np.uint8:                                   # max(band 1) <= 255 by construction
+                if staging is not None:
+                    return {"staged": (staging_off, hwc.shape)}, info
                 return {"u8": torch.from_numpy(hwc)}, info                 # BGR pick happens on the device
             out_img = hwc.transpose(2, 0, 1)
             # non-uint8 rasters take detectron2's float resize path (F.interpolate bilinear); 16-bit imagery
@@ -91,9 +150,15 @@ class Predictor:
             print(f"Error processing tile {tile['json_name']}: {e}")
             return None, None
 
-    def _to_model_input(self, batch):
+    def _to_model_input(self, batch, slot: Optional[_Slot] = None):
         """→ (images tensor on device, format, hw_valid, hw_out)."""
         eng = self.engine
+        if slot is not None and batch and all("staged" in b["data"] for b in batch):
+            used = max(b["data"]["staged"][0] + int(np.prod(b["data"]["staged"][1])) for b in batch)
+            slot.dev_in[:used].copy_(slot.pin_in[:used], non_blocking=True)       # one H2D per batch, from pinned memory
+            tiles = [slot.dev_in[o:o + int(np.prod(shp))].view(*shp) for o, shp in (b["data"]["staged"] for b in batch)]
+            images, hw_valid, hw_out = eng.preprocess_tiles_u8(tiles)
+            return images, INPUT_U8_HWC, hw_valid, hw_out
         if all("u8" in b["data"] for b in batch):
             tiles = [b["data"]["u8"].to(self.device, non_blocking=True) for b in batch]
             images, hw_valid, hw_out = eng.preprocess_tiles_u8(tiles)
@@ -114,24 +179,103 @@ class Predictor:
             x[i, :, : p.shape[1], : p.shape[2]] = p
         return x, INPUT_F32_CHW, shapes, [(b["orig_height"], b["orig_width"]) for b in batch]
 
-    # -- batch: forward on the device, polygons + JSON on host threads -----------------------------------------------
+    # -- single process: reader thread → launcher (this thread) → epilogue workers --------------------------------
+    def _read_batch(self, tiles, indices, img: GeoTiff, slot: _Slot):
+        """Crops the tiles of one batch into the slot's pinned staging buffer (uint8 rasters) — reader thread."""
+        staging = None
+        if img.dtype == np.uint8:
+            need = 0
+            for idx in indices:
+                _, _, w, h = img.window_of_bounds(tiles[idx]["bounds"])
+                need += max(w, 0) * max(h, 0) * img.count
+            staging = slot.staging(max(need, 1), self.device)
+        batch, off = [], 0
+        for idx in indices:
+            data, info = self._process_tile(tiles[idx], img, staging, off)
+            if data is None:
+                continue
+            if "staged" in data:
+                off += int(np.prod(data["staged"][1]))
+            batch.append({"data": data, **info})
+        return batch
+
+    def _launch_batch(self, batch, slot: _Slot, pred_subdir, tifpath):
+        """Forward + asynchronous copy of the packed results to pinned memory; the per-tile host epilogue is queued on
+        the worker pool and waits on the slot's event, so this thread goes straight on to the next batch."""
+        images, fmt, hw_valid, hw_out = self._to_model_input(batch, slot)
+        dev_out = slot.outputs(self.engine, len(batch), max(h for h, _ in hw_out), max(w for _, w in hw_out))
+        view = {k: v[: len(batch)] for k, v in dev_out.items()}     # leading-dim slices stay contiguous
+        self.engine.forward_raw(images, fmt, hw_valid, hw_out, view)
+        for k, v in dev_out.items():
+            slot.pin_out[k][: len(batch)].copy_(v[: len(batch)], non_blocking=True)
+        slot.event.record()
+        slot.pending = len(batch)
+        return [self._pool.submit(self._process_and_save_single, b, i, slot, pred_subdir, tifpath)
+                for i, b in enumerate(batch)]
+
+    def _process_and_save_single(self, b, i, slot: _Slot, pred_subdir, tifpath):
+        """Reference prediction.py:198-266 for one tile: polygons of its instance masks → Prediction_<tile>.json."""
+        try:
+            slot.event.synchronize()
+            host = slot.host
+            output_file = os.path.join(pred_subdir, f"Prediction_{os.path.basename(b['tile_id'])}.json")
+            n = int(host["count"][i])
+            text = tile_polygons_json(host["mask_region"][i], host["mask_offset"][i], host["mask_bits"][i],
+                                      host["scores"][i][:n], host["classes"][i], b["meta"]["transform"], tifpath)
+            with open(output_file, "wb") as f:
+                f.write(text)
+            return json.loads(text) if self.return_predictions else []
+        finally:
+            with slot.lock:
+                slot.pending -= 1
+                if slot.pending == 0:
+                    self._free.put(slot)
+
+    def _run_single(self, tiles, img: GeoTiff, pred_subdir, tifpath):
+        B = self.max_batch_size
+        rounds = [list(range(r * B, min((r + 1) * B, len(tiles)))) for r in range((len(tiles) + B - 1) // B)]
+        self._free = queue.Queue()
+        for s in self._slots:
+            self._free.put(s)
+        ready: "queue.Queue" = queue.Queue(maxsize=2)
+
+        def reader():
+            try:
+                for indices in rounds:
+                    slot = self._free.get()
+                    ready.put((self._read_batch(tiles, indices, img, slot), slot))
+                ready.put((None, None))
+            except BaseException as e:      # surfaces in the launcher thread
+                ready.put((e, None))
+
+        t = threading.Thread(target=reader, name="td-tile-reader", daemon=True)
+        t.start()
+        futures, predictions = [], []
+        while True:
+            batch, slot = ready.get()
+            if isinstance(batch, BaseException):
+                raise batch
+            if batch is None:
+                break
+            if not batch:
+                self._free.put(slot)
+                continue
+            futures.extend(self._launch_batch(batch, slot, pred_subdir, tifpath))
+        t.join()
+        for f in futures:
+            predictions.extend(f.result())
+        return predictions
+
+    # -- multi-GPU: tiles shard over ranks, detections gather to rank 0 ------------------------------------------
     def _process_and_save_batch(self, batch, pred_subdir, tifpath):
-        """One (possibly empty, on a rank that ran out of tiles) batch: forward, then the host epilogue — locally with
-        one process, on rank 0 for every rank's detections when torch.distributed is initialised."""
+        """One (possibly empty, on a rank that ran out of tiles) batch: forward, fixed-shape gather (every rank pads
+        its batch to max_batch_size), and on rank 0 the host epilogue for every rank's detections."""
         out = None
         if batch:
             images, fmt, hw_valid, hw_out = self._to_model_input(batch)
-            out = self.engine.alloc_outputs(len(batch), max(h for h, _ in hw_out), max(w for _, w in hw_out),
-                                            paste=D.world() == 1)
+            out = self.engine.alloc_outputs(len(batch), max(h for h, _ in hw_out), max(w for _, w in hw_out), paste=False)
             self.engine.forward_raw(images, fmt, hw_valid, hw_out, out)
             torch.cuda.synchronize()
-        if D.world() == 1:
-            host = {k: v.cpu().numpy() for k, v in out.items()}
-            # host epilogue (unpack → contours → JSON) runs on the thread pool while the NEXT batch is read and
-            # launched; __call__ collects the futures (at most two batches are kept pending)
-            return [self._pool.submit(self._process_and_save_single, b, i, host, pred_subdir, tifpath)
-                    for i, b in enumerate(batch)]
-        # ---- multi-GPU: fixed-shape gather (every rank pads its batch to max_batch_size) → rank 0 writes ----
         B, Dn = self.max_batch_size, self.engine.D
         dev = torch.device(self.device)
         pad = {"count": torch.zeros((B,), dtype=torch.int32, device=dev),
@@ -149,48 +293,33 @@ class Predictor:
             for g, ms in zip(gathered, metas):
                 for i, m in enumerate(ms):
                     n = int(g["count"][i].item())
-                    region, masks = self.engine.paste_masks(g["mask_probs"][i, :n].to(dev), g["boxes"][i, :n].to(dev), m["h"], m["w"])
-                    ev = polygons_from_masks(masks, region, g["scores"][i, :n].cpu().numpy(), np.zeros(n, np.int64),
-                                             m["transform"], tifpath)
-                    with open(os.path.join(pred_subdir, f"Prediction_{os.path.basename(m['tile_id'])}.json"), "w") as f:
-                        f.write(json.dumps(ev))
-                    preds.extend(ev)
+                    region, offset, bits = self.engine.paste_masks_packed(g["mask_probs"][i, :n].to(dev), g["boxes"][i, :n].to(dev),
+                                                                          m["h"], m["w"])
+                    text = tile_polygons_json(region, offset, bits, g["scores"][i, :n].cpu().numpy(), np.zeros(n, np.int32),
+                                              m["transform"], tifpath)
+                    with open(os.path.join(pred_subdir, f"Prediction_{os.path.basename(m['tile_id'])}.json"), "wb") as f:
+                        f.write(text)
+                    if self.return_predictions:
+                        preds.extend(json.loads(text))
         return preds
-
-    def _process_and_save_single(self, b, i, host, pred_subdir, tifpath):
-        output_file = os.path.join(pred_subdir, f"Prediction_{os.path.basename(b['tile_id'])}.json")
-        n = int(host["count"][i])
-        evaluations = polygons_from_packed(host["mask_region"][i][:n], host["mask_offset"][i][:n], host["mask_bits"][i],
-                                           host["scores"][i][:n], host["classes"][i][:n], b["meta"]["transform"], tifpath)
-        with open(output_file, "w") as f:
-            f.write(json.dumps(evaluations))
-        return evaluations
 
     def __call__(self, tifpath, tilepath):
         pred_subdir = os.path.join(self.output_dir, os.path.basename(tifpath).replace(".tif", "").replace(".json", ""))
         os.makedirs(pred_subdir, exist_ok=True)
         tiles = self._load_tiles(tilepath)
+        img = GeoTiff(tifpath)
+        if D.world() == 1:
+            return self._run_single(tiles, img, pred_subdir, tifpath)
         mine = D.shard_indices(len(tiles))
         rounds = D.padded_rounds(len(tiles), self.max_batch_size)   # identical on every rank: collectives line up
-        predictions, pending = [], []
-        img = GeoTiff(tifpath)
-
-        def collect(keep):
-            while len(pending) > keep:
-                for f in pending.pop(0):
-                    predictions.extend(f.result() if hasattr(f, "result") else f)
-
+        predictions = []
         for r in range(rounds):
             batch = []
             for idx in mine[r * self.max_batch_size:(r + 1) * self.max_batch_size]:
                 data, info = self._process_tile(tiles[idx], img)
                 if data is not None:
                     batch.append({"data": data, **info})
-            if batch or D.world() > 1:
-                res = self._process_and_save_batch(batch, pred_subdir, tifpath)
-                pending.append(res if D.world() == 1 else [res])
-                collect(1)
-        collect(0)
+            predictions.extend(self._process_and_save_batch(batch, pred_subdir, tifpath))
         return predictions
 
 

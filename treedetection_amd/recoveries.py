@@ -65,3 +65,39 @@ def save_prediction_recovery_data(output_path, tiles_path, model_path, processed
             yaml.safe_dump(state, f, sort_keys=False)
     except Exception as e:   # the reference swallows and prints (recoveries.py:107-108)
         print(f"Failed to save prediction recovery file: {e}")
+
+
+# ---- stitching resume file (reference recoveries.py:111-144) -----------------------------------------------
+STITCHING_RECOVERY_NAME = "stitching_recovery.yaml"
+
+
+def load_stitching_recovery(output_path, logger=None):
+    """``stitching_recovery.yaml`` = ``{completed_files: [<image stem>, ...]}`` → set of stems (empty when the file is
+    missing or unreadable; a read error is logged, not raised)."""
+    recovery_file = os.path.join(output_path, STITCHING_RECOVERY_NAME)
+    completed = set()
+    if os.path.exists(recovery_file):
+        try:
+            with open(recovery_file) as f:
+                data = yaml.safe_load(f)
+            if data and "completed_files" in data:
+                completed = set(os.path.basename(p) for p in data["completed_files"])
+            if logger:
+                logger.info(f"Loaded {len(completed)} completed files from recovery.")
+        except Exception as e:
+            if logger:
+                logger.warning(f"Failed to load stitching recovery: {e}")
+    return completed
+
+
+def save_stitching_recovery(output_path, results, logger=None):
+    recovery_file = os.path.join(output_path, STITCHING_RECOVERY_NAME)
+    try:
+        stems = sorted({os.path.splitext(os.path.basename(r))[0] for r in results if r is not None})
+        with open(recovery_file, "w") as f:
+            yaml.safe_dump({"completed_files": stems}, f, sort_keys=False)
+        if logger:
+            logger.info(f"Saved recovery with {len(stems)} files.")
+    except Exception as e:
+        if logger:
+            logger.error(f"Failed to save stitching recovery: {e}")

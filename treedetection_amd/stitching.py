@@ -1,65 +1,196 @@
-"""Consumer of the per-tile prediction files: ``Prediction_*.json`` → one vector file per image.
+"""Consumer of the per-tile prediction files: ``Prediction_*.json`` → one GeoPackage per image
+(reference TreeDetection/helpers.py: ``process_and_stitch_predictions`` 556-600, ``process_folder_sync`` 524-554,
+``process_prediction_file_sync`` 419-476, ``box_filter`` 305-319 / ``box_make`` 281-303 / ``filename_geoinfo`` 265-279).
 
-The reference's ``process_and_stitch_predictions`` (TreeDetection/helpers.py:556-600) builds GeoPackages through
-geopandas/shapely (edge crop ``box_filter`` 305-319, simplify, CRS handling). Those libraries are not available here
-and the step is outside this round's hot-path scope, so this module provides the same entry
-point with the part that needs no geometry engine: it drops polygons whose centroid lies in the buffer band of their
-tile (the de-duplication role of ``box_filter`` with ``shift``), keeps score and class, and writes one GeoJSON
-FeatureCollection per image (CRS from the tile metadata) into ``output_path``.
+Same entry point, arguments, file layout and resume file as the reference; what it runs on is different. The reference
+goes through geopandas/shapely/GDAL (not installed here): a GeoDataFrame per tile, ``simplify(preserve_topology=True)``,
+``sjoin(..., "within")`` against the tile's shrunken box, ``to_file(driver="GPKG")``. Here each tile file is parsed
+once by ``td_stitch_tile_json`` (libtreedet_hip.so, host code, GIL released): rings are simplified by the GEOS
+algorithm restated in C++ (``td_simplify_ring``), the *within* test against an axis-parallel box is done on the
+vertices, geometries come back already encoded, and the layer is written by :mod:`treedetection_amd.gpkg`. Per feature the output carries what the reference's frame carries: geometry,
+``Confidence_score`` and ``filter_index_right`` (always 0 — the index of the single box row the join matched).
 """
 from __future__ import annotations
 
+import ctypes as C
 import json
 import os
-from concurrent.futures import ThreadPoolExecutor
-from typing import Optional
+from concurrent.futures import ThreadPoolExecutor, as_completed
+from pathlib import Path
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .gpkg import write_blobs
+from .recoveries import load_stitching_recovery, save_stitching_recovery
 
 
-def _stitch_folder(tiles_path: str, folder: str, output_path: str, shift: float, logger=None) -> Optional[str]:
-    stem = os.path.basename(folder)
-    meta_path = os.path.join(tiles_path, stem + ".json")
-    if not os.path.exists(meta_path):
+def filename_geoinfo(filename) -> Tuple[int, int, int, int, int]:
+    """``<stem>_<minx>_<miny>_<width>_<buffer>_<crs>`` → the five integers (helpers.py:265-279)."""
+    parts = os.path.basename(str(filename)).replace(".geojson", "").replace(".json", "").replace(".gpkg", "").split("_")
+    minx, miny, width, buffer, crs = (int(p) for p in parts[-5:])
+    return minx, miny, width, buffer, crs
+
+
+def box_make(minx: int, miny: int, width: int, buffer: int, crs=None, shift: int = 0) -> Tuple[float, float, float, float]:
+    """The tile's full extent (core + buffer) pulled in by ``shift`` on every side (helpers.py:281-303), as
+    (minx, miny, maxx, maxy)."""
+    return (minx - buffer + shift, miny - buffer + shift, minx + width + buffer - shift, miny + width + buffer - shift)
+
+
+def box_filter(filename, shift: int = 0) -> Tuple[float, float, float, float]:
+    minx, miny, width, buffer, crs = filename_geoinfo(filename)
+    return box_make(minx, miny, width, buffer, crs, shift)
+
+
+def simplify_ring(coords: np.ndarray, tolerance: float) -> np.ndarray:
+    """``Polygon(coords).simplify(tolerance, preserve_topology=True)`` for a single shell → [m,2] (td_simplify_ring)."""
+    xy = np.ascontiguousarray(coords, dtype=np.float64).reshape(-1, 2)
+    out = np.empty_like(xy)
+    m = _lib.load().td_simplify_ring(xy.ctypes.data, xy.shape[0], float(tolerance), out.ctypes.data, out.shape[0])
+    _lib.check(m, "td_simplify_ring")
+    return out[:m]
+
+
+def within_box(ring: np.ndarray, box: Tuple[float, float, float, float]) -> bool:
+    """``polygon.within(box)``: no vertex outside the closed box (the box is convex) and the interiors meet."""
+    minx, miny, maxx, maxy = box
+    x, y = ring[:, 0], ring[:, 1]
+    if x.min() < minx or x.max() > maxx or y.min() < miny or y.max() > maxy:
+        return False
+    if ((x > minx) & (x < maxx) & (y > miny) & (y < maxy)).any():
+        return True
+    return abs(float(np.dot(x[:-1], y[1:]) - np.dot(x[1:], y[:-1]))) > 0.0
+
+
+class TileFeatures:
+    """What one prediction file contributes to its image's layer: GeoPackage geometry blobs (one buffer + offsets),
+    their scores, and the tile's EPSG code."""
+
+    def __init__(self, blobs: bytes, offsets: np.ndarray, scores: np.ndarray, epsg):
+        self.blobs, self.offsets, self.scores, self.epsg = blobs, offsets, scores, epsg
+
+    def __len__(self) -> int:
+        return int(self.scores.shape[0])
+
+    def rings(self) -> List[np.ndarray]:
+        from .gpkg import parse_polygon_blob
+        return [parse_polygon_blob(self.blobs[self.offsets[i]:self.offsets[i + 1]])[1] for i in range(len(self))]
+
+    def envelopes(self) -> np.ndarray:
+        """[n, 4] (minx, maxx, miny, maxy) straight from the blob headers."""
+        if not len(self):
+            return np.zeros((0, 4))
+        raw = np.frombuffer(self.blobs, dtype=np.uint8)
+        idx = (self.offsets[:-1, None] + 8 + np.arange(32)[None, :]).reshape(-1)
+        return raw[idx].view("<f8").reshape(-1, 4)
+
+
+def _epsg_code(crs) -> int:
+    return int(str(crs).upper().replace("EPSG:", ""))
+
+
+def process_prediction_file_sync(file, tiles_path, tif_lookup, shift, simplify_tolerance, logger=None, metadata=None):
+    """One tile file → :class:`TileFeatures` of the crowns that survive the edge filter, or None on any error (logged,
+    like the reference's try/except around the whole file). ``metadata``: the image's tile JSON if already parsed.
+    Parsing, simplification, the *within* test and the geometry encoding run in td_stitch_tile_json (GIL released)."""
+    try:
+        file = Path(file)
+        tifpath = tif_lookup.get(file.stem.replace("Prediction_", ""))
+        folder = file.parent.name
+        if not tifpath:
+            raise FileNotFoundError(f"No matching TIFF file for {file}")
+        if metadata is None:
+            metadata_path = Path(tiles_path) / tifpath.with_name(f"{folder}.json")
+            if not os.path.exists(metadata_path):
+                raise FileNotFoundError(f"No matching metadata for {tifpath} (metadata_path: {metadata_path})")
+            with open(metadata_path) as f:
+                metadata = json.load(f)
+        if str(tifpath) not in metadata:
+            raise FileNotFoundError(f"No matching metadata for {tifpath}")
+        epsg = metadata[str(tifpath)]["crs"]
+        with open(file, "rb") as f:
+            text = f.read()
+        box = (C.c_double * 4)(*[float(v) for v in box_filter(str(tifpath), shift)])
+        lib = _lib.load()
+        need_b, need_f = C.c_int64(0), C.c_int(0)
+        cap_b, cap_f = max(len(text), 1024), max(len(text) // 64, 16)      # a blob is smaller than its JSON text
+        while True:
+            blobs = np.empty(cap_b, dtype=np.uint8)
+            offsets = np.empty(cap_f + 1, dtype=np.int64)
+            scores = np.empty(cap_f, dtype=np.float64)
+            n = lib.td_stitch_tile_json(text, len(text), box, float(simplify_tolerance), _epsg_code(epsg), blobs.ctypes.data,
+                                        cap_b, offsets.ctypes.data, scores.ctypes.data, cap_f, C.byref(need_b), C.byref(need_f))
+            if n == _lib.ERR_CAPACITY:
+                cap_b, cap_f = max(cap_b, int(need_b.value)), max(cap_f, int(need_f.value))
+                continue
+            _lib.check(n, "td_stitch_tile_json")
+            return TileFeatures(blobs[: int(need_b.value)].tobytes(), offsets[: n + 1].copy(), scores[:n].copy(), epsg)
+    except Exception as e:
         if logger:
-            logger.debug(f"Missing JSON metadata for {folder}. Skipping.")
+            logger.warning(f"Error processing file {file}: {e}")
         return None
-    with open(meta_path) as f:
-        meta = json.load(f)
-    feats, crs = [], None
-    for name in sorted(os.listdir(folder)):
-        if not (name.startswith("Prediction_") and name.endswith(".json")):
-            continue
-        tile_id = name[len("Prediction_"):-len(".json")]
-        td = meta.get(tile_id)
-        if td is None:
-            continue
-        crs = td.get("crs", crs)
-        parts = tile_id.rsplit("_", 5)   # <stem>_<minx>_<miny>_<tile_width>_<buffer>_<epsg>
-        buffer = float(parts[-2]) if len(parts) == 6 else 0.0
-        minx, miny, maxx, maxy = td["bounds"][:4]
-        inner = (minx + buffer - shift, miny + buffer - shift, maxx - buffer + shift, maxy - buffer + shift)
-        with open(os.path.join(folder, name)) as f:
-            for ev in json.load(f):
-                ring = ev["polygon_coords"][0]
-                cx = sum(p[0] for p in ring[:-1]) / max(len(ring) - 1, 1)
-                cy = sum(p[1] for p in ring[:-1]) / max(len(ring) - 1, 1)
-                if not (inner[0] <= cx <= inner[2] and inner[1] <= cy <= inner[3]):
-                    continue
-                feats.append({"type": "Feature",
-                              "properties": {"Confidence_score": ev["score"], "category_id": ev["category_id"], "tile": tile_id},
-                              "geometry": {"type": "Polygon", "coordinates": [ring]}})
-    fc = {"type": "FeatureCollection", "features": feats}
-    if crs:
-        fc["crs"] = {"type": "name", "properties": {"name": f"urn:ogc:def:crs:EPSG::{crs}"}}
-    out = os.path.join(output_path, stem + ".geojson")
-    with open(out, "w") as f:
-        json.dump(fc, f)
-    return out
 
 
-def process_and_stitch_predictions(tiles_path, pred_fold, output_path, max_workers=4, shift=1, simplify_tolerance=0.2,
-                                   logger=None, verbose=False):
-    """Same signature as the reference (helpers.py:556); see the module docstring for what is and is not done."""
+def process_folder_sync(folder, tiles_path, pred_fold, output_path, shift, simplify_tolerance, logger=None):
+    """All tile files of one image → ``<output_path>/<image>.gpkg`` (empty layer, EPSG:4326, when nothing survives)."""
+    try:
+        image_meta_path = os.path.join(tiles_path, f"{folder}")
+        folder = folder.replace(".json", "")
+        with open(image_meta_path) as f:
+            metadata = json.load(f)
+        tif_lookup = {Path(t).stem: Path(t) for t in metadata}
+        pred_files = sorted(Path(os.path.join(pred_fold, folder)).rglob("*.json"))
+        parts = [r for r in (process_prediction_file_sync(file, tiles_path, tif_lookup, shift, simplify_tolerance, logger, metadata)
+                             for file in pred_files) if r is not None and len(r)]
+        output_file = os.path.join(output_path, f"{folder}.gpkg")
+        if not parts:
+            if logger:
+                logger.debug(f"No valid results for folder {folder}. Creating empty output.")
+            write_blobs(output_file, [], {}, None, None)
+        else:
+            env = np.concatenate([t.envelopes() for t in parts])
+            extent = (float(env[:, 0].min()), float(env[:, 2].min()), float(env[:, 1].max()), float(env[:, 3].max()))
+            blobs = (memoryview(t.blobs)[t.offsets[i]:t.offsets[i + 1]] for t in parts for i in range(len(t)))
+            scores = np.concatenate([t.scores for t in parts]).tolist()
+            write_blobs(output_file, blobs, {"Confidence_score": scores, "filter_index_right": [0] * len(scores)},
+                        _epsg_code(parts[0].epsg), extent)
+        return output_file
+    except Exception as e:
+        if logger:
+            logger.error(f"Error processing folder {folder}: {e}")
+        return None
+
+
+def validate_paths(tiles_path, pred_fold, output_path) -> None:
+    if not os.path.exists(tiles_path):
+        raise FileNotFoundError(f"Tiles path not found: {tiles_path}")
+    if not os.path.exists(pred_fold):
+        raise FileNotFoundError(f"Predictions path not found: {pred_fold}")
     os.makedirs(output_path, exist_ok=True)
-    folders = [os.path.join(pred_fold, d) for d in sorted(os.listdir(pred_fold)) if os.path.isdir(os.path.join(pred_fold, d))]
-    with ThreadPoolExecutor(max_workers=max_workers or 4) as ex:
-        return [r for r in ex.map(lambda fo: _stitch_folder(tiles_path, fo, output_path, float(shift), logger), folders) if r]
+
+
+def process_and_stitch_predictions(tiles_path, pred_fold, output_path, max_workers=50, shift=1, simplify_tolerance=0.2,
+                                   logger=None):
+    """Reference helpers.py:556-600: every image JSON under ``tiles_path`` that the resume file does not list yet →
+    one GeoPackage; the resume file is rewritten with everything attempted. Returns ``output_path``."""
+    validate_paths(tiles_path, pred_fold, output_path)
+    completed = load_stitching_recovery(output_path, logger)
+    folders = [f for f in sorted(os.listdir(tiles_path)) if f.endswith(".json") and os.path.isfile(os.path.join(tiles_path, f))]
+    todo = [f for f in folders if os.path.splitext(f)[0] not in completed]
+    if logger and len(folders) - len(todo) > 0:
+        logger.info(f"Skipping stiching {len(folders) - len(todo)} of {len(folders)} folders that have already been processed.")
+    results = []
+    workers = max(1, min(int(max_workers or 1), len(todo) or 1, len(os.sched_getaffinity(0))))
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        futures = {ex.submit(process_folder_sync, f, tiles_path, pred_fold, output_path, shift, simplify_tolerance, logger): f
+                   for f in todo}
+        total = len(todo)
+        for i, fut in enumerate(as_completed(futures)):
+            results.append(futures[fut])
+            cur, prev = int(100 * (i + 1) / total), int(100 * i / total)
+            if logger and ((cur // 5) != (prev // 5) or i == 0 or cur == 100):
+                logger.info(f"Stitching file {i + 1}/{total} ({cur}%)")
+    save_stitching_recovery(output_path, list(completed) + results, logger)
+    return output_path
