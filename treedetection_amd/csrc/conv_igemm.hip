@@ -376,6 +376,10 @@ td_status dispatch(const ConvArgs& a, int cfg, hipStream_t stream) {
         case 8: return launch<T, TO, 2, 2, 2, 4, 2>(a, stream);     // 256 x 128, 8 waves
         case 9: return launch<T, TO, 2, 2, 2, 2, 4>(a, stream);     // 128 x 256, 8 waves
         case 10: return launch<T, TO, 2, 2, 2, 4, 4>(a, stream);    // 256 x 256, 16 waves
+        // 256 x 256 with bigger per-wave register tiles: fewer LDS fragment bytes per MFMA (the fp16 limiter)
+        case 11: return launch<T, TO, 4, 4, 2, 2, 2>(a, stream);    // 4 waves of 128 x 128 (256 accumulator registers)
+        case 12: return launch<T, TO, 4, 2, 2, 2, 4>(a, stream);    // 8 waves of 128 x 64
+        case 13: return launch<T, TO, 2, 4, 2, 4, 2>(a, stream);    // 8 waves of 64 x 128
         default: td_set_error("conv2d: bad tile_cfg %d", cfg); return TD_ERR_INVALID;
     }
 }

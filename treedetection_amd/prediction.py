@@ -13,6 +13,7 @@ import json
 import os
 import queue
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List, Optional
 
@@ -84,6 +85,9 @@ class Predictor:
         workers = host_workers or max(2, min(16, len(os.sched_getaffinity(0)) - 2))
         self._pool = ThreadPoolExecutor(max_workers=workers)
         self._slots = [_Slot() for _ in range(3)]
+        self._stats_lock = threading.Lock()
+        # seconds spent per stage of the last __call__ (reader thread, launcher thread, sum over epilogue workers)
+        self.stats = {"read": 0.0, "launch": 0.0, "launch_wait": 0.0, "epilogue": 0.0, "epilogue_wait": 0.0}
 
     def close(self) -> None:
         """Stops the host worker threads and releases the engine's device memory."""
@@ -216,7 +220,9 @@ class Predictor:
     def _process_and_save_single(self, b, i, slot: _Slot, pred_subdir, tifpath):
         """Reference prediction.py:198-266 for one tile: polygons of its instance masks → Prediction_<tile>.json."""
         try:
+            t0 = time.perf_counter()
             slot.event.synchronize()
+            t1 = time.perf_counter()
             host = slot.host
             output_file = os.path.join(pred_subdir, f"Prediction_{os.path.basename(b['tile_id'])}.json")
             n = int(host["count"][i])
@@ -224,7 +230,11 @@ class Predictor:
                                       host["scores"][i][:n], host["classes"][i], b["meta"]["transform"], tifpath)
             with open(output_file, "wb") as f:
                 f.write(text)
-            return json.loads(text) if self.return_predictions else []
+            res = json.loads(text) if self.return_predictions else []
+            with self._stats_lock:
+                self.stats["epilogue_wait"] += t1 - t0
+                self.stats["epilogue"] += time.perf_counter() - t1
+            return res
         finally:
             with slot.lock:
                 slot.pending -= 1
@@ -234,6 +244,7 @@ class Predictor:
     def _run_single(self, tiles, img: GeoTiff, pred_subdir, tifpath):
         B = self.max_batch_size
         rounds = [list(range(r * B, min((r + 1) * B, len(tiles)))) for r in range((len(tiles) + B - 1) // B)]
+        self.stats = dict.fromkeys(self.stats, 0.0)
         self._free = queue.Queue()
         for s in self._slots:
             self._free.put(s)
@@ -243,7 +254,10 @@ class Predictor:
             try:
                 for indices in rounds:
                     slot = self._free.get()
-                    ready.put((self._read_batch(tiles, indices, img, slot), slot))
+                    t0 = time.perf_counter()
+                    batch = self._read_batch(tiles, indices, img, slot)
+                    self.stats["read"] += time.perf_counter() - t0
+                    ready.put((batch, slot))
                 ready.put((None, None))
             except BaseException as e:      # surfaces in the launcher thread
                 ready.put((e, None))
@@ -252,7 +266,9 @@ class Predictor:
         t.start()
         futures, predictions = [], []
         while True:
+            t0 = time.perf_counter()
             batch, slot = ready.get()
+            self.stats["launch_wait"] += time.perf_counter() - t0
             if isinstance(batch, BaseException):
                 raise batch
             if batch is None:
@@ -260,7 +276,9 @@ class Predictor:
             if not batch:
                 self._free.put(slot)
                 continue
+            t0 = time.perf_counter()
             futures.extend(self._launch_batch(batch, slot, pred_subdir, tifpath))
+            self.stats["launch"] += time.perf_counter() - t0
         t.join()
         for f in futures:
             predictions.extend(f.result())
