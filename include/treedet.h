@@ -179,6 +179,16 @@ int td_tile_polygons_json(const int32_t* mask_region, const int64_t* mask_offset
                           int64_t mask_words, const float* scores, const int32_t* classes, int n,
                           const double* transform, const char* image_id, char* buf, int64_t cap, int64_t* needed);
 
+/* ---- raster input (reference prediction.py:61,164: rasterio.open / rasterio.mask.mask → GDAL → libtiff) ---- */
+/* Decompress one TIFF strip or tile: LZW (compression 5) and PackBits (32773) per TIFF 6.0; DEFLATE strips go
+ * through zlib on the host side. Return the number of bytes written to dst (capacity cap), or a negative status
+ * (TD_ERR_CAPACITY when the stream decodes to more than cap bytes, TD_ERR_INVALID for a corrupt stream). */
+int64_t td_tiff_lzw_decode(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap);
+int64_t td_tiff_packbits_decode(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap);
+/* Undo TIFF predictor 2 (horizontal differencing) in place on one decoded block of rows x cols pixels with
+ * `samples` interleaved samples of 1, 2 or 4 bytes (host byte order). */
+int td_tiff_unpredict(void* data, int64_t rows, int64_t cols, int samples, int bytes_per_sample);
+
 /* ---- stitching consumer of the prediction files (reference helpers.py:419-476) -------------- */
 /* `geometry.simplify(tolerance, preserve_topology=True)` (helpers.py:464-465) for one closed shell ring:
  * topology-preserving Douglas-Peucker as GEOS' TopologyPreservingSimplifier performs it. xy = n (x,y) pairs,

@@ -1,0 +1,101 @@
+"""Raster input formats of the tile loader (reference: rasterio/GDAL behind prediction.py:61,164): every layout and
+codec the reader claims must return exactly the pixels that were written — whole image and windows — whether the file
+was produced by our writer or by Pillow's libtiff."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from treedetection_amd import _lib  # noqa: E402
+from treedetection_amd.geotiff import GeoTiff, write_geotiff  # noqa: E402
+
+T = (0.2, 0, 412000.0, 0, -0.2, 5318100.0)
+
+
+def _image(rng, c, h, w, dtype):
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = (np.sin(xx / 17.0) + np.cos(yy / 11.0))[None] * np.arange(1, c + 1)[:, None, None]     # smooth → compressible
+    noise = rng.normal(0, 0.1, (c, h, w))
+    img = (base + noise - (base + noise).min())
+    img = img / img.max()
+    if dtype == np.float32:
+        return img.astype(np.float32)
+    return (img * np.iinfo(dtype).max).astype(dtype)
+
+
+@pytest.mark.parametrize("kw", [
+    {},                                                                     # one contiguous strip: the mmap fast path
+    {"rows_per_strip": 16},                                                 # contiguous strips: still one mapping
+    {"rows_per_strip": 7, "compression": "deflate"},
+    {"tile": (64, 48)},
+    {"tile": (32, 64), "compression": "deflate", "predictor": 2},
+    {"tile": (48, 48), "planar": True, "compression": "deflate"},
+    {"rows_per_strip": 33, "planar": True, "predictor": 2},
+])
+@pytest.mark.parametrize("dtype,bands", [(np.uint8, 4), (np.uint16, 3), (np.float32, 1)])
+def test_layouts_round_trip(tmp_path, kw, dtype, bands):
+    if dtype == np.float32 and kw.get("predictor") == 2:
+        pytest.skip("predictor 2 is defined for integer samples")
+    rng = np.random.default_rng(1)
+    img = _image(rng, bands, 131, 157, dtype)
+    path = str(tmp_path / "r.tif")
+    write_geotiff(path, img, T, 25832, **kw)
+    g = GeoTiff(path)
+    assert (g.width, g.height, g.count, g.epsg) == (157, 131, bands, 25832) and g.transform == T
+    assert np.array_equal(g.read(), img)
+    g = GeoTiff(path)                                    # fresh handle: windows without a whole-image decode
+    for (r0, c0, h, w) in [(0, 0, 1, 1), (5, 7, 60, 50), (100, 120, 31, 37), (63, 47, 3, 3), (0, 0, 131, 157)]:
+        win = g._window_hwc(r0, c0, h, w)
+        assert np.array_equal(win, img[:, r0:r0 + h, c0:c0 + w].transpose(1, 2, 0))
+    # geographic window with rasterio.mask semantics + staging buffer
+    b = (412003.0, 5318080.0, 412020.1, 5318095.0)
+    want = GeoTiff(path).read_bounds(b)
+    stage = np.zeros(want.size + 3, dtype=img.dtype)
+    got = g.read_bounds_hwc(b, out=stage, out_off=3)
+    assert np.array_equal(got.transpose(2, 0, 1), want) and np.shares_memory(got, stage)
+
+
+@pytest.mark.parametrize("compression", ["tiff_lzw", "tiff_adobe_deflate", "packbits", "raw"])
+@pytest.mark.parametrize("mode,bands", [("RGB", 3), ("RGBA", 4), ("L", 1)])
+def test_reads_files_written_by_libtiff(tmp_path, compression, mode, bands):
+    """Pillow (libtiff) as the independent producer: LZW and PackBits streams decoded by td_tiff_*_decode."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    img = _image(rng, bands, 300, 211, np.uint8)
+    img[:, 40:80, 50:120] = 200                         # long runs: LZW strings longer than a row of the table
+    path = str(tmp_path / "p.tif")
+    hwc = img.transpose(1, 2, 0)
+    Image.fromarray(hwc[:, :, 0] if bands == 1 else hwc, mode).save(path, compression=compression)
+    g = GeoTiff(path)
+    assert g.count == bands and np.array_equal(g.read(), img)
+    win = GeoTiff(path)._window_hwc(37, 11, 100, 150)
+    assert np.array_equal(win, hwc[37:137, 11:161])
+
+
+def test_lzw_predictor_16bit_from_libtiff(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(4)
+    img = _image(rng, 1, 97, 203, np.uint16)[0]
+    path = str(tmp_path / "p16.tif")
+    Image.fromarray(img).save(path, compression="tiff_lzw", tiffinfo={317: 2})
+    g = GeoTiff(path)
+    assert int(g.tags.get(317, [1])[0]) == 2 and np.array_equal(g.read()[0], img)
+
+
+def test_codec_errors():
+    lib = _lib.load()
+    dst = np.zeros(16, np.uint8)
+    bad = np.frombuffer(bytes([0x80, 0x7f, 0xff, 0xff]), np.uint8)       # Clear, then code 511 with an empty table
+    with pytest.raises(_lib.TdError, match="corrupt"):
+        _lib.check(lib.td_tiff_lzw_decode(bad.ctypes.data, bad.size, dst.ctypes.data, dst.size), "lzw")
+    pk = np.frombuffer(bytes([0xfe, 0xaa, 0x02, 0x01, 0x02, 0x03, 0x80]), np.uint8)   # 3 x 0xaa, literal 1 2 3, no-op
+    n = lib.td_tiff_packbits_decode(pk.ctypes.data, pk.size, dst.ctypes.data, dst.size)
+    assert n == 6 and dst[:6].tolist() == [0xaa, 0xaa, 0xaa, 1, 2, 3]
+    with pytest.raises(_lib.TdError, match="capacity"):
+        _lib.check(lib.td_tiff_packbits_decode(pk.ctypes.data, pk.size, dst.ctypes.data, 4), "packbits")
+    trunc = np.frombuffer(bytes([0x05, 0x01]), np.uint8)
+    with pytest.raises(_lib.TdError, match="truncated"):
+        _lib.check(lib.td_tiff_packbits_decode(trunc.ctypes.data, trunc.size, dst.ctypes.data, dst.size), "packbits")

@@ -69,6 +69,9 @@ SIGNATURES = {
     "td_paste_masks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "td_find_contours": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "td_tiff_lzw_decode": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
+    "td_tiff_packbits_decode": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
+    "td_tiff_unpredict": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "td_simplify_ring": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int]),
     "td_stitch_tile_json": (C.c_int, [C.c_char_p, C.c_int64, C.POINTER(C.c_double), C.c_double, C.c_int32, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),

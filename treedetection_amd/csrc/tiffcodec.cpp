@@ -1,0 +1,145 @@
+// Strip / tile decompressors for the GeoTIFF tile reader (the reference reads rasters through rasterio → GDAL →
+// libtiff: TreeDetection/prediction.py:61 `rasterio.open`, 164 `rasterio.mask.mask`; none of them is installed here).
+// Real orthophoto mosaics are almost always stored compressed; DEFLATE goes through Python's zlib, the two codecs
+// below cover what zlib cannot. Both follow the TIFF 6.0 specification (sections 13 "LZW" and 9 "PackBits").
+// Pure host code; called from the reader's decode threads with the GIL released.
+#include "common.h"
+
+#include <cstring>
+
+// TIFF LZW: MSB-first variable-width codes (9..12 bits), ClearCode 256, EndOfInformation 257, first free code 258,
+// code width grows one code EARLY (when the next free code reaches 2^width - 1).
+extern "C" int64_t td_tiff_lzw_decode(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap) {
+    if (!src || !dst || n < 0 || cap < 0) {
+        td_set_error("td_tiff_lzw_decode: bad argument");
+        return TD_ERR_INVALID;
+    }
+    constexpr int CLEAR = 256, EOI = 257, FIRST = 258, MAXC = 4096;
+    static thread_local uint16_t prefix[MAXC];
+    static thread_local uint8_t suffix[MAXC], first[MAXC];
+    static thread_local uint16_t length[MAXC];
+    for (int i = 0; i < 256; ++i) {
+        prefix[i] = 0;
+        suffix[i] = first[i] = (uint8_t)i;
+        length[i] = 1;
+    }
+    int nbits = 9, next = FIRST, old = -1;
+    uint64_t acc = 0;
+    int have = 0;
+    int64_t ip = 0, op = 0;
+    for (;;) {
+        while (have < nbits && ip < n) {
+            acc = (acc << 8) | src[ip++];
+            have += 8;
+        }
+        if (have < nbits) break;                       // ran out of input without an EOI: accept what was decoded
+        const int code = (int)((acc >> (have - nbits)) & ((1u << nbits) - 1));
+        have -= nbits;
+        if (code == EOI) break;
+        if (code == CLEAR) {
+            nbits = 9;
+            next = FIRST;
+            old = -1;
+            continue;
+        }
+        if (old < 0) {                                 // first code after a clear: a literal
+            if (code > 255) {
+                td_set_error("td_tiff_lzw_decode: corrupt stream (code %d after clear)", code);
+                return TD_ERR_INVALID;
+            }
+            if (op < cap) dst[op] = (uint8_t)code;
+            ++op;
+            old = code;
+            continue;
+        }
+        if (code > next || (code == next && next >= MAXC)) {
+            td_set_error("td_tiff_lzw_decode: corrupt stream (code %d, table size %d)", code, next);
+            return TD_ERR_INVALID;
+        }
+        if (next < MAXC) {                             // new entry = string(old) + first char of string(code | old)
+            prefix[next] = (uint16_t)old;
+            first[next] = first[old];
+            length[next] = (uint16_t)(length[old] + 1);
+            suffix[next] = code < next ? first[code] : first[old];
+            ++next;
+            if (next > (1 << nbits) - 2 && nbits < 12) ++nbits;
+        }
+        // write string(code) back to front
+        const int len = length[code];
+        if (op + len <= cap) {
+            uint8_t* w = dst + op + len;
+            int c = code;
+            for (int k = 0; k < len; ++k) {
+                *--w = suffix[c];
+                c = prefix[c];
+            }
+        }
+        op += len;
+        old = code;
+    }
+    if (op > cap) {
+        td_set_error("td_tiff_lzw_decode: %lld bytes decoded, capacity %lld", (long long)op, (long long)cap);
+        return TD_ERR_CAPACITY;
+    }
+    return op;
+}
+
+// PackBits (TIFF 6.0 section 9): header byte h: 0..127 → copy h+1 literal bytes; -127..-1 → repeat the next byte
+// 1-h times; -128 → no operation.
+extern "C" int64_t td_tiff_packbits_decode(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap) {
+    if (!src || !dst || n < 0 || cap < 0) {
+        td_set_error("td_tiff_packbits_decode: bad argument");
+        return TD_ERR_INVALID;
+    }
+    int64_t ip = 0, op = 0;
+    while (ip < n) {
+        const int h = (int8_t)src[ip++];
+        if (h >= 0) {
+            const int64_t cnt = h + 1;
+            if (ip + cnt > n) {
+                td_set_error("td_tiff_packbits_decode: truncated literal run");
+                return TD_ERR_INVALID;
+            }
+            if (op + cnt <= cap) std::memcpy(dst + op, src + ip, (size_t)cnt);
+            ip += cnt;
+            op += cnt;
+        } else if (h != -128) {
+            const int64_t cnt = 1 - h;
+            if (ip >= n) {
+                td_set_error("td_tiff_packbits_decode: truncated repeat run");
+                return TD_ERR_INVALID;
+            }
+            if (op + cnt <= cap) std::memset(dst + op, src[ip], (size_t)cnt);
+            ++ip;
+            op += cnt;
+        }
+    }
+    if (op > cap) {
+        td_set_error("td_tiff_packbits_decode: %lld bytes decoded, capacity %lld", (long long)op, (long long)cap);
+        return TD_ERR_CAPACITY;
+    }
+    return op;
+}
+
+// Predictor 2 (TIFF 6.0 section 14, horizontal differencing): each sample was stored as the difference to the same
+// sample of the pixel on its left, modulo the sample width; undo it in place, row by row.
+extern "C" int td_tiff_unpredict(void* data, int64_t rows, int64_t cols, int samples, int bytes_per_sample) {
+    if (!data || rows < 0 || cols < 0 || samples < 1 || (bytes_per_sample != 1 && bytes_per_sample != 2 && bytes_per_sample != 4)) {
+        td_set_error("td_tiff_unpredict: bad argument");
+        return TD_ERR_INVALID;
+    }
+    const int64_t row_elems = cols * samples;
+    for (int64_t r = 0; r < rows; ++r) {
+        if (bytes_per_sample == 1) {
+            uint8_t* p = static_cast<uint8_t*>(data) + r * row_elems;
+            for (int64_t i = samples; i < row_elems; ++i) p[i] = (uint8_t)(p[i] + p[i - samples]);
+        } else if (bytes_per_sample == 2) {
+            uint16_t* p = static_cast<uint16_t*>(data) + r * row_elems;
+            for (int64_t i = samples; i < row_elems; ++i) p[i] = (uint16_t)(p[i] + p[i - samples]);
+        } else {
+            uint32_t* p = static_cast<uint32_t*>(data) + r * row_elems;
+            for (int64_t i = samples; i < row_elems; ++i) p[i] = p[i] + p[i - samples];
+        }
+    }
+    return TD_OK;
+}

@@ -1,14 +1,20 @@
-"""Minimal GeoTIFF reader / writer for the tile loader of the prediction stage.
+"""GeoTIFF reader / writer for the tile loader of the prediction stage.
 
 The reference reads rasters through rasterio/GDAL (``rasterio.open`` + ``rasterio.mask.mask(img, shapes, crop=True)``,
-TreeDetection/prediction.py:61,164); neither is installed here, and the hot path only needs windowed reads of
-pixel-interleaved or planar, strip- or tile-organised, uncompressed rasters plus the three geo tags
-(ModelPixelScale / ModelTiepoint / GeoKeyDirectory). Compressed files fall back to Pillow.
+TreeDetection/prediction.py:61,164); neither is installed here. The tile loader needs windowed reads of classic or
+BigTIFF rasters — strips or tiles, pixel-interleaved or planar, 8/16/32-bit integer or float samples, uncompressed or
+DEFLATE (zlib) / LZW / PackBits (td_tiff_*_decode in libtreedet_hip.so), horizontal-differencing predictor — plus the
+three geo tags (ModelPixelScale / ModelTiepoint / GeoKeyDirectory). Other codecs (JPEG, ...) fall back to Pillow.
 """
 from __future__ import annotations
 
 import math
+import os
 import struct
+import threading
+import zlib
+from collections import OrderedDict
+from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
@@ -109,67 +115,153 @@ class GeoTiff:
                 tags[tag] = list(struct.unpack(e + str(cnt) + code, buf))
         return tags
 
-    def _load(self) -> np.ndarray:
-        """Whole raster as [bands, rows, cols] (memory-mapped when it is one contiguous uncompressed block)."""
-        if self._data is not None:
-            return self._data
+    # -- pixel access ---------------------------------------------------------------------------------
+    # The raster is a grid of blocks (strips = full-width blocks of RowsPerStrip rows; tiles = TileWidth x TileLength),
+    # chunky (one block holds all bands, pixel-interleaved) or planar (one grid per band). A window read touches only
+    # the blocks it overlaps; decoded blocks of compressed files are kept in a small LRU cache because neighbouring
+    # tile windows (buffer overlap) share them. Uncompressed chunky files whose strips are contiguous skip all of
+    # this: the window is a slice of one memory map.
+    _CACHE_BYTES = 256 << 20
+
+    def _setup_blocks(self) -> None:
+        if getattr(self, "_blocks_ready", False):
+            return
         t = self.tags
-        H, W, C = self.height, self.width, self.count
-        if self.compression != 1:
-            from PIL import Image
-            Image.MAX_IMAGE_PIXELS = None
-            arr = np.asarray(Image.open(self.path))
-            arr = arr[None] if arr.ndim == 2 else arr.transpose(2, 0, 1)
-            self._data = np.ascontiguousarray(arr)
-            return self._data
+        H, W = self.height, self.width
+        if 324 in t:
+            self._bw, self._bh = int(t[322][0]), int(t[323][0])
+            self._offs, self._counts = [int(v) for v in t[324]], [int(v) for v in t[325]]
+            self._strips = False
+        else:
+            self._bw, self._bh = W, min(int(t.get(278, [H])[0]), H)
+            self._offs = [int(v) for v in t[273]]
+            self._counts = [int(v) for v in t[279]] if 279 in t else None
+            self._strips = True
+        self._nx = (W + self._bw - 1) // self._bw
+        self._ny = (H + self._bh - 1) // self._bh
+        self._predictor = int(t.get(317, [1])[0])
+        self._mm = np.memmap(self.path, dtype=np.uint8, mode="r")
+        self._cache: "OrderedDict" = OrderedDict()
+        self._cache_bytes = 0
+        self._lock = threading.Lock()
+        self._pool = None
+        self._flat = None
         item = self.dtype.itemsize
-        if 324 in t:   # tiled
-            tw, th = int(t[322][0]), int(t[323][0])
-            offs = t[324]
-            nx, ny = (W + tw - 1) // tw, (H + th - 1) // th
-            out = np.zeros((C, H, W), dtype=self.dtype.newbyteorder("="))
-            mm = np.memmap(self.path, dtype=np.uint8, mode="r")
-            planes = C if self.planar == 2 else 1
-            for p in range(planes):
-                for ty in range(ny):
-                    for tx in range(nx):
-                        o = int(offs[(p * ny + ty) * nx + tx])
-                        if self.planar == 2:
-                            blk = np.frombuffer(mm[o:o + tw * th * item], dtype=self.dtype).reshape(th, tw)
-                            out[p, ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw] = blk[:H - ty * th, :W - tx * tw]
-                        else:
-                            blk = np.frombuffer(mm[o:o + tw * th * C * item], dtype=self.dtype).reshape(th, tw, C)
-                            out[:, ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw] = blk[:H - ty * th, :W - tx * tw].transpose(2, 0, 1)
-            self._data = out
+        if self.compression == 1 and self.planar == 1 and self._strips:
+            row_bytes = W * self.count * item
+            offs = self._offs
+            if all(offs[i + 1] - offs[i] == self._bh * row_bytes for i in range(len(offs) - 1)):
+                self._flat = np.memmap(self.path, dtype=self.dtype, mode="r", offset=offs[0], shape=(H, W, self.count))
+        if self.compression not in (1, 5, 8, 32946, 32773) or self._predictor not in (1, 2):
+            self._pil_fallback()
+        self._blocks_ready = True
+
+    def _pil_fallback(self) -> None:
+        """Codecs this reader does not implement (JPEG, floating-point predictor, ...): whole image through Pillow."""
+        from PIL import Image
+        Image.MAX_IMAGE_PIXELS = None
+        arr = np.asarray(Image.open(self.path))
+        arr = arr[:, :, None] if arr.ndim == 2 else arr
+        if arr.shape[2] != self.count:
+            raise ValueError(f"{self.path}: compression {self.compression} / predictor {self._predictor} is not supported "
+                             f"for {self.count}-band rasters")
+        self._flat = np.ascontiguousarray(arr)
+
+    def _block_rows(self, by: int) -> int:
+        return min(self._bh, self.height - by * self._bh) if self._strips else self._bh
+
+    def _decode_block(self, plane: int, by: int, bx: int) -> np.ndarray:
+        """→ [rows, bw, bands-in-block] in native byte order, predictor undone."""
+        idx = (plane * self._ny + by) * self._nx + bx
+        rows = self._block_rows(by)
+        cb = self.count if self.planar == 1 else 1
+        nbytes = rows * self._bw * cb * self.dtype.itemsize
+        off = self._offs[idx]
+        cnt = self._counts[idx] if self._counts is not None else nbytes
+        raw = self._mm[off:off + cnt]
+        comp = self.compression
+        if comp == 1:
+            buf = np.asarray(raw[:nbytes])
+        elif comp in (8, 32946):
+            buf = np.frombuffer(zlib.decompress(raw), dtype=np.uint8)
+        else:
+            from . import _lib
+            lib = _lib.load()
+            src = np.ascontiguousarray(raw)
+            buf = np.empty(nbytes, dtype=np.uint8)
+            fn = lib.td_tiff_lzw_decode if comp == 5 else lib.td_tiff_packbits_decode
+            n = fn(src.ctypes.data, src.size, buf.ctypes.data, nbytes)
+            _lib.check(n, "tiff block decode")
+            buf = buf[:n]
+        if buf.size < nbytes:
+            raise ValueError(f"{self.path}: block ({plane},{by},{bx}) decodes to {buf.size} bytes, expected {nbytes}")
+        blk = np.frombuffer(buf[:nbytes], dtype=self.dtype).reshape(rows, self._bw, cb)
+        if self.dtype.byteorder not in ("=", "|"):     # file byte order differs from the host's
+            blk = blk.astype(self.dtype.newbyteorder("="))
+        if self._predictor == 2:                      # horizontal differencing per sample, modulo the sample width
+            from . import _lib
+            if not blk.flags.writeable or not blk.flags.c_contiguous:
+                blk = np.array(blk)
+            _lib.check(_lib.load().td_tiff_unpredict(blk.ctypes.data, rows, self._bw, cb, blk.dtype.itemsize), "td_tiff_unpredict")
+        return blk
+
+    def _get_block(self, key) -> np.ndarray:
+        with self._lock:
+            blk = self._cache.get(key)
+            if blk is not None:
+                self._cache.move_to_end(key)
+                return blk
+        blk = self._decode_block(*key)
+        if self.compression != 1 or self._predictor != 1:
+            with self._lock:
+                if key not in self._cache:
+                    self._cache[key] = blk
+                    self._cache_bytes += blk.nbytes
+                    while self._cache_bytes > self._CACHE_BYTES and len(self._cache) > 1:
+                        _, old = self._cache.popitem(last=False)
+                        self._cache_bytes -= old.nbytes
+        return blk
+
+    def _window_hwc(self, r0: int, c0: int, h: int, w: int, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Pixels [r0:r0+h, c0:c0+w] of every band as [h, w, bands] (into ``out`` when given)."""
+        self._setup_blocks()
+        if self._flat is not None:
+            src = self._flat[r0:r0 + h, c0:c0 + w, :]
+            if out is None:
+                return np.ascontiguousarray(src)
+            np.copyto(out, src)
             return out
-        offs = [int(v) for v in t[273]]
-        rps = int(t.get(278, [H])[0])
-        if self.planar == 1:
-            row_bytes = W * C * item
-            contiguous = all(offs[i + 1] - offs[i] == rps * row_bytes for i in range(len(offs) - 1))
-            if contiguous:
-                mm = np.memmap(self.path, dtype=self.dtype, mode="r", offset=offs[0], shape=(H, W, C))
-                self._data = mm.transpose(2, 0, 1)
-                return self._data
-            mm = np.memmap(self.path, dtype=np.uint8, mode="r")
-            out = np.empty((H, W, C), dtype=self.dtype)
-            for i, o in enumerate(offs):
-                r0 = i * rps
-                r1 = min(r0 + rps, H)
-                out[r0:r1] = np.frombuffer(mm[o:o + (r1 - r0) * row_bytes], dtype=self.dtype).reshape(r1 - r0, W, C)
-            self._data = out.transpose(2, 0, 1)
-            return self._data
-        mm = np.memmap(self.path, dtype=np.uint8, mode="r")
-        out = np.empty((C, H, W), dtype=self.dtype)
-        spp = (H + rps - 1) // rps
-        for c in range(C):
-            for i in range(spp):
-                o = offs[c * spp + i]
-                r0 = i * rps
-                r1 = min(r0 + rps, H)
-                out[c, r0:r1] = np.frombuffer(mm[o:o + (r1 - r0) * W * item], dtype=self.dtype).reshape(r1 - r0, W)
-        self._data = out
+        if out is None:
+            out = np.empty((h, w, self.count), dtype=self.dtype.newbyteorder("="))
+        by0, by1 = r0 // self._bh, (r0 + h - 1) // self._bh
+        bx0, bx1 = c0 // self._bw, (c0 + w - 1) // self._bw
+        planes = self.count if self.planar == 2 else 1
+        keys = [(p, by, bx) for p in range(planes) for by in range(by0, by1 + 1) for bx in range(bx0, bx1 + 1)]
+        if len(keys) > 1 and self.compression != 1:
+            if self._pool is None:
+                self._pool = ThreadPoolExecutor(max_workers=min(8, max(2, len(os.sched_getaffinity(0)))))
+            # zlib / the C decoders release the GIL; a few blocks per task keep the executor overhead small
+            per = max(1, (len(keys) + 15) // 16)
+            chunks = [keys[i:i + per] for i in range(0, len(keys), per)]
+            blocks = [b for part in self._pool.map(lambda ks: [self._get_block(k) for k in ks], chunks) for b in part]
+        else:
+            blocks = [self._get_block(k) for k in keys]
+        for (p, by, bx), blk in zip(keys, blocks):
+            br0, bc0 = by * self._bh, bx * self._bw
+            rs, re = max(r0, br0), min(r0 + h, br0 + blk.shape[0])
+            cs, ce = max(c0, bc0), min(c0 + w, bc0 + self._bw)
+            piece = blk[rs - br0:re - br0, cs - bc0:ce - bc0, :]
+            if self.planar == 2:
+                out[rs - r0:re - r0, cs - c0:ce - c0, p] = piece[:, :, 0]
+            else:
+                out[rs - r0:re - r0, cs - c0:ce - c0, :] = piece
         return out
+
+    def _load(self) -> np.ndarray:
+        """Whole raster as [bands, rows, cols]."""
+        if self._data is None:
+            self._data = self._window_hwc(0, 0, self.height, self.width).transpose(2, 0, 1)
+        return self._data
 
     # -- rasterio-like surface ------------------------------------------------------------------------
     @property
@@ -197,24 +289,9 @@ class GeoTiff:
         a, b, c, d, e, f = self.transform
         return (a, b, c + a * col_off + b * row_off, d, e, f + d * col_off + e * row_off)
 
-    def read_bounds_hwc(self, bounds: Sequence[float], out: Optional[np.ndarray] = None, out_off: int = 0) -> np.ndarray:
-        """Same pixels as :meth:`read_bounds` but pixel-interleaved [rows, cols, bands] and contiguous — the layout
-        the device resize consumes; for chunky files this is a plain row-slab copy of the memory map. With ``out``
-        (a flat array of the raster's dtype, e.g. pinned staging memory) the window is written at ``out_off`` and the
-        returned array is a view of it."""
-        c0, r0, w, h = self.window_of_bounds(bounds)
-        if w <= 0 or h <= 0:
-            raise ValueError("Input shapes do not overlap raster.")
-        data = self._load()
-        if isinstance(data, np.ndarray) and data.ndim == 3 and data.strides[0] == data.dtype.itemsize:
-            src = data.transpose(1, 2, 0)[r0:r0 + h, c0:c0 + w, :]    # already HWC in memory
-        else:
-            src = np.asarray(data[:, r0:r0 + h, c0:c0 + w]).transpose(1, 2, 0)
-        if out is not None:
-            hwc = out[out_off:out_off + h * w * self.count].reshape(h, w, self.count)
-            np.copyto(hwc, src)
-        else:
-            hwc = np.ascontiguousarray(src)
+    def _mask_outside(self, hwc: np.ndarray, bounds, c0: int, r0: int) -> None:
+        """rasterio.mask semantics: pixels whose centre lies outside the bbox are set to 0."""
+        h, w = hwc.shape[:2]
         a, _, c, _, e, f = self.transform
         minx, miny, maxx, maxy = (float(v) for v in bounds[:4])
         xs = c + a * (np.arange(c0, c0 + w) + 0.5)
@@ -225,37 +302,63 @@ class GeoTiff:
             hwc[:, ~okx, :] = 0
         if not oky.all():
             hwc[~oky, :, :] = 0
-        return hwc
 
-    def read_bounds(self, bounds: Sequence[float]) -> np.ndarray:
-        """``rasterio.mask.mask(img, [bbox], crop=True)[0]``: the window covering the bbox, all bands, pixels whose
-        centre lies outside the bbox set to 0. Raises ValueError when the bbox does not overlap the raster."""
+    def read_bounds_hwc(self, bounds: Sequence[float], out: Optional[np.ndarray] = None, out_off: int = 0) -> np.ndarray:
+        """``rasterio.mask.mask(img, [bbox], crop=True)[0]`` as pixel-interleaved [rows, cols, bands] — the layout the
+        device resize consumes. With ``out`` (a flat array of the raster's dtype, e.g. pinned staging memory) the window
+        is written at ``out_off`` and the returned array is a view of it. Raises ValueError when the bbox does not
+        overlap the raster."""
         c0, r0, w, h = self.window_of_bounds(bounds)
         if w <= 0 or h <= 0:
             raise ValueError("Input shapes do not overlap raster.")
-        out = np.array(self._load()[:, r0:r0 + h, c0:c0 + w])
-        a, _, c, _, e, f = self.transform
-        minx, miny, maxx, maxy = (float(v) for v in bounds[:4])
-        xs = c + a * (np.arange(c0, c0 + w) + 0.5)
-        ys = f + e * (np.arange(r0, r0 + h) + 0.5)
-        okx = (xs >= minx) & (xs <= maxx)
-        oky = (ys >= miny) & (ys <= maxy)
-        if not okx.all():
-            out[:, :, ~okx] = 0
-        if not oky.all():
-            out[:, ~oky, :] = 0
-        return out
+        dst = None if out is None else out[out_off:out_off + h * w * self.count].reshape(h, w, self.count)
+        hwc = self._window_hwc(r0, c0, h, w, dst)
+        self._mask_outside(hwc, bounds, c0, r0)
+        return hwc
+
+    def read_bounds(self, bounds: Sequence[float]) -> np.ndarray:
+        """Same window as [bands, rows, cols] (rasterio's axis order)."""
+        return np.ascontiguousarray(self.read_bounds_hwc(bounds).transpose(2, 0, 1))
 
 
-def write_geotiff(path: str, data: np.ndarray, transform: Sequence[float], epsg: int = 25832) -> None:
-    """Uncompressed, pixel-interleaved, single-strip classic TIFF with the GeoTIFF tags the reader understands.
-    data: [bands, rows, cols] or [rows, cols]; uint8 / uint16 / float32."""
+def write_geotiff(path: str, data: np.ndarray, transform: Sequence[float], epsg: int = 25832, *,
+                  tile: Optional[Tuple[int, int]] = None, rows_per_strip: Optional[int] = None,
+                  compression: Optional[str] = None, predictor: int = 1, planar: bool = False) -> None:
+    """Classic little-endian TIFF with the GeoTIFF tags the reader understands. data: [bands, rows, cols] or
+    [rows, cols]; uint8 / uint16 / float32. Defaults: one uncompressed pixel-interleaved strip (what the tile reader
+    maps without copying). Options: ``tile=(tile_rows, tile_cols)`` (multiples of 16) or ``rows_per_strip``,
+    ``compression`` None / "deflate", ``predictor`` 1 / 2 (horizontal differencing, integer samples), ``planar``
+    (one block grid per band)."""
     arr = np.asarray(data)
     if arr.ndim == 2:
         arr = arr[None]
     C, H, W = arr.shape
     fmt = {np.dtype(np.uint8): (1, 8), np.dtype(np.uint16): (1, 16), np.dtype(np.float32): (3, 32)}[arr.dtype]
-    pix = np.ascontiguousarray(arr.transpose(1, 2, 0)).tobytes()
+    if compression not in (None, "deflate"):
+        raise ValueError("compression must be None or 'deflate'")
+    if predictor not in (1, 2) or (predictor == 2 and fmt[0] != 1):
+        raise ValueError("predictor 2 needs integer samples")
+    hwc = np.ascontiguousarray(arr.transpose(1, 2, 0)).astype(arr.dtype.newbyteorder("<"), copy=False)
+    if tile:
+        bh, bw = int(tile[0]), int(tile[1])
+        if bh % 16 or bw % 16:
+            raise ValueError("tile sides must be multiples of 16")
+    else:
+        bh, bw = int(rows_per_strip or H), W
+    ny, nx = (H + bh - 1) // bh, (W + bw - 1) // bw
+    blocks = []
+    for p in range(C if planar else 1):
+        src = hwc[:, :, p:p + 1] if planar else hwc
+        for by in range(ny):
+            for bx in range(nx):
+                rows = bh if tile else min(bh, H - by * bh)
+                blk = np.zeros((rows, bw, src.shape[2]), dtype=hwc.dtype)
+                piece = src[by * bh:by * bh + rows, bx * bw:(bx + 1) * bw]
+                blk[:piece.shape[0], :piece.shape[1]] = piece
+                if predictor == 2:
+                    blk[:, 1:] = blk[:, 1:] - blk[:, :-1]          # modulo the sample width
+                raw = blk.tobytes()
+                blocks.append(zlib.compress(raw, 6) if compression == "deflate" else raw)
     a, _, c, _, e, f = (float(v) for v in transform[:6])
     entries = []   # (tag, type, count, payload bytes)
 
@@ -266,13 +369,21 @@ def write_geotiff(path: str, data: np.ndarray, transform: Sequence[float], epsg:
     add(256, 4, [W])
     add(257, 4, [H])
     add(258, 3, [fmt[1]] * C)
-    add(259, 3, [1])
+    add(259, 3, [8 if compression == "deflate" else 1])
     add(262, 3, [2 if C >= 3 else 1])
-    add(273, 4, [0])   # patched below
     add(277, 3, [C])
-    add(278, 4, [H])
-    add(279, 4, [len(pix)])
-    add(284, 3, [1])
+    add(284, 3, [2 if planar else 1])
+    if predictor == 2:
+        add(317, 3, [2])
+    if tile:
+        add(322, 4, [bw])
+        add(323, 4, [bh])
+        add(324, 4, [0] * len(blocks))   # offsets, patched below
+        add(325, 4, [len(b) for b in blocks])
+    else:
+        add(273, 4, [0] * len(blocks))   # offsets, patched below
+        add(278, 4, [bh])
+        add(279, 4, [len(b) for b in blocks])
     if C > 3:
         add(338, 3, [0] * (C - 3))
     add(339, 3, [fmt[0]] * C)
@@ -283,24 +394,32 @@ def write_geotiff(path: str, data: np.ndarray, transform: Sequence[float], epsg:
     n = len(entries)
     ifd_off = 8
     extra_off = ifd_off + 2 + n * 12 + 4
-    extra = b""
-    recs = []
-    for tag, typ, cnt, payload in entries:
-        if len(payload) <= 4:
-            recs.append([tag, typ, cnt, payload.ljust(4, b"\0"), None])
-        else:
-            recs.append([tag, typ, cnt, None, len(extra)])
-            extra += payload + (b"\0" if len(payload) % 2 else b"")
-    data_off = extra_off + len(extra)
+    extra_len = sum(len(pl) + (len(pl) % 2) for _, _, _, pl in entries if len(pl) > 4)
+    data_off = extra_off + extra_len
+    offsets, pos = [], data_off
+    for b in blocks:
+        offsets.append(pos)
+        pos += len(b) + (len(b) % 2)
+    if pos >= 1 << 32:
+        raise ValueError("raster too large for a classic TIFF")
+    off_tag = 324 if tile else 273
     out = bytearray(struct.pack("<2sHI", b"II", 42, ifd_off))
     out += struct.pack("<H", n)
-    for tag, typ, cnt, inline, eoff in recs:
-        if tag == 273:
-            inline = struct.pack("<I", data_off)
-        val = inline if inline is not None else struct.pack("<I", extra_off + eoff)
+    extra = b""
+    for tag, typ, cnt, payload in entries:
+        if tag == off_tag:
+            payload = struct.pack("<" + str(cnt) + "I", *offsets)
+        if len(payload) <= 4:
+            val = payload.ljust(4, b"\0")
+        else:
+            val = struct.pack("<I", extra_off + len(extra))
+            extra += payload + (b"\0" if len(payload) % 2 else b"")
         out += struct.pack("<HHI", tag, typ, cnt) + val
     out += struct.pack("<I", 0)
     out += extra
-    out += pix
     with open(path, "wb") as fh:
         fh.write(bytes(out))
+        for b in blocks:
+            fh.write(b)
+            if len(b) % 2:
+                fh.write(b"\0")
