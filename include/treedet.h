@@ -207,6 +207,15 @@ int td_stitch_tile_json(const char* json, int64_t len, const double* box, double
                         uint8_t* blobs, int64_t blob_cap, int64_t* blob_offsets, double* scores, int max_features,
                         int64_t* needed_bytes, int* needed_features);
 
+/* ---- outline predicates (reference helpers.py:703-834 fuse_predictions; preprocessing.py:70-95 tile flags) ---- */
+/* Relates query rings to a region given as polygons with holes (the outline file's geometries, NOT unioned):
+ * ring r = ring_xy[ring_start[r] .. ring_start[r+1]) (x,y pairs, closed), ring_poly[r] = polygon it belongs to,
+ * rings of one polygon consecutive with the shell first. For each closed query ring q:
+ *   flags[q] bit 0 = query.intersects(union of the polygons), bit 1 = query.within(union of the polygons)
+ * (shapely/GEOS semantics for a simple query ring; exact-sign arithmetic). Host code only. */
+int td_region_relate(const double* ring_xy, const int64_t* ring_start, const int32_t* ring_poly, int n_rings,
+                     const double* query_xy, const int64_t* query_start, int n_queries, uint8_t* flags);
+
 #ifdef __cplusplus
 }
 #endif

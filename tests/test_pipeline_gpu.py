@@ -135,6 +135,18 @@ def test_two_model_flow_with_exclude_flags(tmp_path):
     assert forest == set(meta) - only_urban          # forest model skips urban-only tiles
     assert os.path.exists(root / "output" / "urban_geojson" / "1.gpkg")
     assert os.path.exists(root / "output" / "forrest_geojson" / "1.gpkg")
+    # fusion by the outline (reference helpers.py:703-834): forest-model crowns that intersect the forest + urban-model
+    # crowns that are not within it, one layer per image in geojson_predictions/
+    from treedetection_amd import gpkg
+    from treedetection_amd.vector import Region, read_polygon_layer
+    fused, cols, srs = gpkg.read_polygons(str(root / "output" / "geojson_predictions" / "1.gpkg"))
+    u_rings = gpkg.read_polygons(str(root / "output" / "urban_geojson" / "1.gpkg"))[0]
+    f_rings = gpkg.read_polygons(str(root / "output" / "forrest_geojson" / "1.gpkg"))[0]
+    region = Region(read_polygon_layer(str(root / "forest.geojson"))[0])
+    n_f = int(region.relate(f_rings)[0].sum()) if f_rings else 0
+    n_u = int((~region.relate(u_rings)[1]).sum()) if u_rings else 0
+    assert srs == 25832 and len(fused) == (n_f + n_u if (u_rings and f_rings) else len(u_rings) + len(f_rings))
+    assert os.path.exists(root / "output" / "geojson_predictions" / "fusion_recovery.yaml")
 
 
 def test_sixteen_bit_tiles_take_the_float_path(tmp_path):

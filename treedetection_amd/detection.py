@@ -20,6 +20,7 @@ from .config import Config, get_config, setup_model_cfg  # noqa: F401  (re-expor
 from .prediction import Predictor
 from .preprocessing import tile_data
 from .recoveries import load_prediction_recovery_data, save_prediction_recovery_data
+from .fusion import exclude_outlines, fuse_predictions  # noqa: F401
 from .stitching import process_and_stitch_predictions
 
 
@@ -92,8 +93,13 @@ def predict_tiles(config):
         t2 = time.time()
         _stitch(config, os.path.join(out, "urban_predictions"), os.path.join(out, "urban_geojson"))
         _stitch(config, os.path.join(out, "forrest_predictions"), os.path.join(out, "forrest_geojson"))
-        # fusion by forest outline (helpers.fuse_predictions) needs a geometry engine: both sets are kept side by side
-        logger.info("Predictions have been processed and stitched (fusion by outline is not part of this package yet).")
+        logger.info("Predictions have been processed and stitched. Begin fusing the predictions.")
+        t3 = time.time()
+        if D.rank() == 0:
+            fuse_predictions(os.path.join(out, "urban_geojson"), os.path.join(out, "forrest_geojson"), config["forrest_outline"],
+                             os.path.join(out, "geojson_predictions"), logger=logger)
+        logger.info("Fusion based on forest outline has been completed.")
+        logger.debug(f"fuse prediction took {time.time() - t3} seconds")
         logger.debug(f"predict on model for urban took {t1 - t0} seconds")
         logger.debug(f"predict on model for forrest took {t2 - t1} seconds")
     elif config.get("combined_model") and os.path.exists(config["combined_model"]):

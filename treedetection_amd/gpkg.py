@@ -172,3 +172,76 @@ def read_polygons(path: str) -> Tuple[List[np.ndarray], Dict[str, list], int]:
         return rings, cols, int(srs_id)
     finally:
         con.close()
+
+
+class Layer:
+    """A polygon layer held as GeoPackage geometry blobs + attribute columns (what fusion and the exclude filter pass
+    around: features are selected, never edited, so the blobs are written back untouched)."""
+
+    def __init__(self, blobs: List[bytes], columns: Dict[str, list], srs_id: int):
+        self.blobs, self.columns, self.srs_id = blobs, columns, int(srs_id)
+
+    def __len__(self) -> int:
+        return len(self.blobs)
+
+    def blob(self, i: int) -> bytes:
+        return self.blobs[i]
+
+    def rings(self) -> List[np.ndarray]:
+        """Shell of every feature (crowns are single-shell polygons)."""
+        from .vector import _gpkg_geom
+        out = []
+        for b in self.blobs:
+            parts = _gpkg_geom(b)
+            out.append(parts[0][0] if parts else np.zeros((0, 2)))
+        return out
+
+    def envelopes(self) -> np.ndarray:
+        """[n,4] minx, maxx, miny, maxy (from the blob header when it carries one, else from the shell)."""
+        env = np.zeros((len(self.blobs), 4))
+        for i, b in enumerate(self.blobs):
+            if (b[3] >> 1) & 7:
+                env[i] = np.frombuffer(b, dtype="<f8" if b[3] & 1 else ">f8", count=4, offset=8)
+            else:
+                r = self.rings()[i]
+                env[i] = (r[:, 0].min(), r[:, 0].max(), r[:, 1].min(), r[:, 1].max())
+        return env
+
+
+def read_layer(path: str) -> Layer:
+    """The single feature layer of a GeoPackage (or the features of a GeoJSON file) as a :class:`Layer`."""
+    if path.lower().endswith((".geojson", ".json")):
+        import json
+        from .vector import _read_geojson
+        polys, epsg, owner = _read_geojson(path)
+        with open(path) as f:
+            feats = json.load(f).get("features", [])
+        srs = epsg or 4326
+        names = sorted({k for ft in feats for k in (ft.get("properties") or {})})
+        blobs, cols = [], {n: [] for n in names}
+        for poly, fid in zip(polys, owner):
+            blobs.append(polygon_blob(poly[0], srs))
+            for n in names:
+                cols[n].append((feats[fid].get("properties") or {}).get(n))
+        return Layer(blobs, cols, srs)
+    con = sqlite3.connect(path)
+    try:
+        row = con.execute("SELECT table_name, srs_id FROM gpkg_contents WHERE data_type='features' LIMIT 1").fetchone()
+        if row is None:
+            return Layer([], {}, 4326)
+        layer, srs_id = row
+        gcol = con.execute("SELECT column_name FROM gpkg_geometry_columns WHERE table_name=?", (layer,)).fetchone()[0]
+        info = con.execute(f'PRAGMA table_info("{layer}")').fetchall()
+        pk = [r[1] for r in info if r[5]]
+        names = [r[1] for r in info if r[1] != gcol and r[1] not in pk]
+        sel = "".join(f', "{n}"' for n in names)
+        blobs, cols = [], {n: [] for n in names}
+        for row in con.execute(f'SELECT "{gcol}"{sel} FROM "{layer}" ORDER BY rowid'):
+            if row[0] is None:
+                continue
+            blobs.append(bytes(row[0]))
+            for n, v in zip(names, row[1:]):
+                cols[n].append(v)
+        return Layer(blobs, cols, int(srs_id))
+    finally:
+        con.close()

@@ -22,35 +22,31 @@ from .geotiff import GeoTiff
 
 
 def _load_outline(path: Optional[str]):
+    """Forest outline → list of polygons (each a list of closed rings, shell first) — reference preprocessing.py:153-163
+    (``gpd.read_file(forest_shapefile)``; GeoJSON, GeoPackage and Shapefile are read here)."""
     if not path:
         return None
-    if not path.lower().endswith((".json", ".geojson")):
-        raise ValueError(f"forest outline {path}: only GeoJSON is supported without geopandas")
-    with open(path) as f:
-        gj = json.load(f)
-    polys = []
-    for feat in gj.get("features", []):
-        g = feat.get("geometry") or {}
-        if g.get("type") == "Polygon":
-            polys.append(np.asarray(g["coordinates"][0], dtype=np.float64))
-        elif g.get("type") == "MultiPolygon":
-            polys.extend(np.asarray(p[0], dtype=np.float64) for p in g["coordinates"])
+    from .vector import read_polygon_layer
+    polys, _ = read_polygon_layer(path)
+    polys = [p for p in polys if p and len(p[0]) >= 4]
     if not polys:
         raise ValueError(f"No valid geometries found in the forest shapefile {path}.")
     return polys
 
 
-def _point_in_ring(px, py, ring) -> bool:
-    x, y = ring[:, 0], ring[:, 1]
-    x2, y2 = np.roll(x, -1), np.roll(y, -1)
-    cond = ((y > py) != (y2 > py)) & (px < (x2 - x) * (py - y) / np.where(y2 == y, 1e-300, (y2 - y)) + x)
-    return bool(np.count_nonzero(cond) % 2)
-
-
-def _ring_crosses_box(ring, minx, miny, maxx, maxy) -> bool:
-    x, y = ring[:, 0], ring[:, 1]
-    inside = (x > minx) & (x < maxx) & (y > miny) & (y < maxy)
-    return bool(inside.any())
+def _tile_flags(forest_polys, forest_boxes, minx, miny, tile_width, tile_height, bounds):
+    """only_forest / only_urban of one tile (reference preprocessing.py:70-95): candidates = outline polygons whose
+    envelope strictly overlaps the un-buffered tile; none of them intersects the buffered box → only_urban; the union
+    of those that do contains the box → only_forest."""
+    from .vector import Region, box_ring
+    fb = forest_boxes
+    cand = np.nonzero((fb[:, 2] > minx) & (fb[:, 0] < minx + tile_width) & (fb[:, 3] > miny) & (fb[:, 1] < miny + tile_height))[0]
+    if cand.size == 0:
+        return False, True
+    inter, within = Region([forest_polys[i] for i in cand]).relate([box_ring(*bounds)])
+    if not inter[0]:
+        return False, True
+    return bool(within[0]), False
 
 
 def tile_single_file(data_path: str, out_dir: str, buffer: int = 0, tile_width: int = 50, tile_height: int = 50,
@@ -63,6 +59,9 @@ def tile_single_file(data_path: str, out_dir: str, buffer: int = 0, tile_width: 
     tilename = Path(data_path).stem
     left, bottom, right, top = data.bounds
     meta = {}
+    forest_boxes = None
+    if forest_polys is not None:
+        forest_boxes = np.array([[p[0][:, 0].min(), p[0][:, 1].min(), p[0][:, 0].max(), p[0][:, 1].max()] for p in forest_polys])
     for minx in np.arange(left, right, tile_width):
         for miny in np.arange(bottom, top, tile_height):
             tile_id = f"{tilename}_{int(minx)}_{int(miny)}_{int(tile_width)}_{int(buffer)}_{crs}"
@@ -70,17 +69,7 @@ def tile_single_file(data_path: str, out_dir: str, buffer: int = 0, tile_width: 
                       float(miny + tile_height + buffer)]
             only_forest, only_urban = False, False
             if forest_polys is not None:
-                tb = (minx, miny, minx + tile_width, miny + tile_height)
-                over = [p for p in forest_polys
-                        if p[:, 0].max() > tb[0] and p[:, 0].min() < tb[2] and p[:, 1].max() > tb[1] and p[:, 1].min() < tb[3]]
-                if not over:
-                    only_urban = True
-                else:
-                    corners = [(bounds[0], bounds[1]), (bounds[2], bounds[1]), (bounds[2], bounds[3]), (bounds[0], bounds[3])]
-                    for p in over:
-                        if all(_point_in_ring(cx, cy, p) for cx, cy in corners) and not _ring_crosses_box(p, *bounds):
-                            only_forest = True
-                            break
+                only_forest, only_urban = _tile_flags(forest_polys, forest_boxes, minx, miny, tile_width, tile_height, bounds)
             c0, r0, w, h = data.window_of_bounds(bounds)
             if w <= 0 or h <= 0:
                 raise ValueError("Input shapes do not overlap raster, check geometry of incoming Tifs.")

@@ -101,3 +101,37 @@ def save_stitching_recovery(output_path, results, logger=None):
     except Exception as e:
         if logger:
             logger.error(f"Failed to save stitching recovery: {e}")
+
+
+# ---- fusion resume file (reference recoveries.py:251-284) --------------------------------------------------
+FUSION_RECOVERY_NAME = "fusion_recovery.yaml"
+
+
+def load_fusion_recovery(output_dir, logger=None):
+    recovery_file = os.path.join(output_dir, FUSION_RECOVERY_NAME)
+    completed = set()
+    if os.path.exists(recovery_file):
+        try:
+            with open(recovery_file) as f:
+                data = yaml.safe_load(f)
+            if data and "completed_files" in data:
+                completed = set(os.path.basename(p) for p in data["completed_files"])
+            if logger:
+                logger.info(f"Loaded {len(completed)} completed fusion files from recovery.")
+        except Exception as e:
+            if logger:
+                logger.warning(f"Failed to load fusion recovery: {e}")
+    return completed
+
+
+def save_fusion_recovery(output_dir, results, logger=None):
+    recovery_file = os.path.join(output_dir, FUSION_RECOVERY_NAME)
+    try:
+        stems = sorted({os.path.splitext(os.path.basename(r))[0] for r in results if r is not None})
+        with open(recovery_file, "w") as f:
+            yaml.safe_dump({"completed_files": stems}, f, sort_keys=False)
+        if logger:
+            logger.info(f"Saved fusion recovery with {len(stems)} files.")
+    except Exception as e:
+        if logger:
+            logger.warning(f"Failed to save fusion recovery: {e}")
