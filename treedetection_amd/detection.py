@@ -21,6 +21,7 @@ from .prediction import Predictor
 from .preprocessing import tile_data
 from .recoveries import load_prediction_recovery_data, save_prediction_recovery_data
 from .fusion import exclude_outlines, fuse_predictions  # noqa: F401
+from .merging import merge_and_crop_images
 from .stitching import process_and_stitch_predictions
 
 
@@ -116,7 +117,8 @@ def predict_tiles(config):
 
 
 def preprocess_files(config):
-    """Reference detection.py:256-339 without the neighbour-mosaic step (merging.py is raster I/O outside the scope)."""
+    """Reference detection.py:256-339: collect the rasters, seam strips between neighbours (``use_overlap``), tile
+    metadata for every image."""
     Config()._load_into_config(config)
     logger = config["logger"]
     for key, what in (("image_directory", "Image"), ("height_data_path", "Height")):
@@ -137,8 +139,8 @@ def preprocess_files(config):
     ids = {"".join(irx.search(os.path.basename(f)).groups()): f for f in images}
     hids = {"".join(hrx.search(os.path.basename(f)).groups()) for f in heights if hrx.search(os.path.basename(f))}
     if config["use_overlap"]:
-        logger.warning("use_overlap: neighbour mosaics (merging.merge_and_crop_images) are not built in this package; "
-                       "continuing without seam strips.")
+        logger.info("Using overlapping tiles for processing, do merging right now ...")
+        merge_and_crop_images(config, images, heights)
     for ident, path in ids.items():
         if ident not in hids:
             logger.warning(f"No corresponding height data found for image file {path}")
