@@ -159,6 +159,14 @@ td_status td_paste_masks(const float* mask_probs, const float* boxes, int n, int
                          float thresh, int32_t* mask_region, int64_t* mask_offset, uint32_t* mask_bits,
                          int64_t mask_words_cap, void* stream);
 
+/* Same for a batch of images, asynchronously on `stream` (no host synchronisation): mask_probs [batch][D][28*28],
+ * boxes [batch][D][4], counts [batch] — all DEVICE pointers; out_hw = host array of (height, width) per image.
+ * Outputs as in td_detections: mask_region [batch][D][4], mask_offset [batch][D], mask_bits
+ * [batch][mask_words_per_image]. This is how rank 0 pastes the detections gathered from the other ranks. */
+td_status td_paste_masks_batch(const float* mask_probs, const float* boxes, const int32_t* counts, const int32_t* out_hw,
+                               int batch, int dets_per_image, float thresh, int32_t* mask_region, int64_t* mask_offset,
+                               uint32_t* mask_bits, int64_t mask_words_per_image, void* stream);
+
 /* ---- host-side epilogue (reference prediction.py:232-245, utilities.py:182-207) ------------- */
 /* Border following on a binary image (row-major uint8, non-zero = foreground) equivalent to
  * cv2.findContours(RETR_TREE / RETR_LIST ordering, CHAIN_APPROX_SIMPLE): writes contour points as

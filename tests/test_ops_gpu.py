@@ -179,3 +179,45 @@ def test_resize_tile_pillow_exact(h, w, c):
     torch.cuda.synchronize()
     got = dst.cpu().numpy()[:, :ow, :]
     assert np.array_equal(got, ref)
+
+
+def test_paste_masks_batch_equals_per_image_paste():
+    """td_paste_masks_batch (rank 0's paste of gathered detections: ragged image sizes, device-side counts, one
+    asynchronous launch pair) against td_paste_masks image by image."""
+    from treedetection_amd.engine import unpack_masks
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    B, Dn = 3, 16
+    sizes = [(120, 200), (90, 64), (33, 150)]
+    counts = np.array([16, 5, 0], np.int32)
+    probs = rng.uniform(0, 1, (B, Dn, 28, 28)).astype(np.float32)
+    boxes = np.zeros((B, Dn, 4), np.float32)
+    for b, (h, w) in enumerate(sizes):
+        xy = rng.uniform(-10, 0.8 * w, (Dn, 2))
+        wh = rng.uniform(2, 80, (Dn, 2))
+        boxes[b] = R.clip_boxes(np.concatenate([xy, xy + wh], axis=1).astype(np.float32), h, w)
+    mh, mw = max(s[0] for s in sizes), max(s[1] for s in sizes)
+    words = Dn * ((mw + 2 + 31) // 32) * mh
+    region = torch.zeros((B, Dn, 4), dtype=torch.int32, device="cuda")
+    offset = torch.zeros((B, Dn), dtype=torch.int64, device="cuda")
+    bits = torch.zeros((B, words), dtype=torch.int32, device="cuda")
+    d_probs, d_boxes, d_counts = dev(probs), dev(boxes), torch.from_numpy(counts).cuda()
+    import ctypes as C
+    hw = (C.c_int32 * (2 * B))(*[v for s in sizes for v in s])
+    _lib.check(lib.td_paste_masks_batch(d_probs.data_ptr(), d_boxes.data_ptr(), d_counts.data_ptr(), hw, B, Dn, 0.5,
+                                        region.data_ptr(), offset.data_ptr(), bits.data_ptr(), words, _lib.stream_ptr()),
+               "td_paste_masks_batch")
+    torch.cuda.synchronize()
+    for b, (h, w) in enumerate(sizes):
+        n = int(counts[b])
+        got = unpack_masks(region[b].cpu().numpy(), offset[b].cpu().numpy(), bits[b].cpu().numpy(), n, h, w)
+        if n == 0:
+            assert got.shape == (0, h, w)
+            continue
+        keep = (boxes[b, :n, 2] > boxes[b, :n, 0]) & (boxes[b, :n, 3] > boxes[b, :n, 1])
+        want, _ = paste_hip(probs[b, :n][keep], boxes[b, :n][keep], h, w)
+        assert np.array_equal(got[keep], want)
+    hw_bad = (C.c_int32 * (2 * B))(*[v for s in [(4000, 4000)] * B for v in s])
+    with pytest.raises(_lib.TdError, match="mask words"):
+        _lib.check(lib.td_paste_masks_batch(d_probs.data_ptr(), d_boxes.data_ptr(), d_counts.data_ptr(), hw_bad, B, Dn, 0.5,
+                                            region.data_ptr(), offset.data_ptr(), bits.data_ptr(), words, _lib.stream_ptr()), "x")

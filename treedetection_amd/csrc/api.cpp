@@ -141,4 +141,25 @@ td_status td_paste_masks(const float* mask_probs, const float* boxes, int n, int
     return TD_OK;
 }
 
+td_status td_paste_masks_batch(const float* mask_probs, const float* boxes, const int32_t* counts, const int32_t* out_hw,
+                               int batch, int dets_per_image, float thresh, int32_t* mask_region, int64_t* mask_offset,
+                               uint32_t* mask_bits, int64_t mask_words_per_image, void* stream) {
+    TD_REQUIRE(mask_probs && boxes && counts && out_hw && mask_region && mask_offset && mask_bits,
+               "td_paste_masks_batch: null pointer");
+    TD_REQUIRE(batch >= 1 && batch <= TD_MAX_BATCH && dets_per_image >= 1 && dets_per_image <= 1024,
+               "td_paste_masks_batch: batch %d (max %d) / detections per image %d (max 1024)", batch, TD_MAX_BATCH, dets_per_image);
+    ImgSizes outsz{};
+    for (int i = 0; i < batch; ++i) {
+        TD_REQUIRE(out_hw[2 * i] >= 1 && out_hw[2 * i + 1] >= 1, "td_paste_masks_batch: bad output size of image %d", i);
+        outsz.h[i] = out_hw[2 * i];
+        outsz.w[i] = out_hw[2 * i + 1];
+        const int64_t need = (int64_t)dets_per_image * ((outsz.w[i] + 2 + 31) / 32) * outsz.h[i];
+        TD_REQUIRE(mask_words_per_image >= need, "td_paste_masks_batch: image %d needs %lld mask words, capacity %lld", i,
+                   (long long)need, (long long)mask_words_per_image);
+    }
+    return paste_masks_launch(mask_probs, boxes, counts, outsz, batch, dets_per_image, thresh, mask_region,
+                              reinterpret_cast<long long*>(mask_offset), mask_bits, mask_words_per_image,
+                              static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

@@ -217,6 +217,19 @@ class Engine:
         hw_out = [(int(t.shape[0]), int(t.shape[1])) for t in tiles]
         return batch, shapes, hw_out
 
+    def paste_masks_batch(self, probs: torch.Tensor, boxes: torch.Tensor, counts: torch.Tensor, hw: Sequence[Sequence[int]],
+                          out: Dict[str, torch.Tensor], thresh: float = 0.5) -> None:
+        """td_paste_masks_batch: the first ``len(hw)`` images of probs [B,D,28,28] / boxes [B,D,4] / counts [B] (CUDA
+        tensors) → out["mask_region" | "mask_offset" | "mask_bits"] rows, asynchronously on torch's current stream."""
+        n = len(hw)
+        assert probs.is_cuda and boxes.is_cuda and counts.is_cuda and probs.is_contiguous() and boxes.is_contiguous()
+        assert probs.dtype == torch.float32 and boxes.dtype == torch.float32 and counts.dtype == torch.int32
+        ohw = (C.c_int32 * (2 * n))(*[int(v) for p in hw for v in p])
+        _lib.check(self.lib.td_paste_masks_batch(probs.data_ptr(), boxes.data_ptr(), counts.data_ptr(), ohw, n, int(probs.shape[1]),
+                                                 thresh, out["mask_region"].data_ptr(), out["mask_offset"].data_ptr(),
+                                                 out["mask_bits"].data_ptr(), int(out["mask_bits"].shape[1]), _lib.stream_ptr()),
+                   "td_paste_masks_batch")
+
     def paste_masks_packed(self, probs: torch.Tensor, boxes: torch.Tensor, h: int, w: int, thresh: float = 0.5):
         """td_paste_masks for n detections of one tile (CUDA tensors) → (region [n,4] int32, offset [n] int64, packed
         bit rows int32) on the host. Used by rank 0 for detections gathered from other ranks."""

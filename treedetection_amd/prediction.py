@@ -57,6 +57,54 @@ class _Slot:
         return self.dev_out
 
 
+    # -- sharded runs: send / receive / paste buffers ------------------------------------------------------------
+    def gather_buffers(self, B: int, Dn: int, dev) -> Dict[str, torch.Tensor]:
+        if getattr(self, "_send", None) is None or self._send["count"].shape[0] != B:
+            self._send = {"count": torch.zeros((B,), dtype=torch.int32, device=dev),
+                          "boxes": torch.zeros((B, Dn, 4), dtype=torch.float32, device=dev),
+                          "scores": torch.zeros((B, Dn), dtype=torch.float32, device=dev),
+                          "mask_probs": torch.zeros((B, Dn, 28, 28), dtype=torch.float32, device=dev)}
+            self._classes = torch.zeros((B, Dn), dtype=torch.int32, device=dev)
+        return self._send
+
+    def classes_buffer(self, B: int, Dn: int, dev) -> torch.Tensor:
+        self.gather_buffers(B, Dn, dev)
+        return self._classes
+
+    def recv_buffers(self, W: int, B: int, Dn: int, dev, host: bool):
+        if getattr(self, "_recv", None) is None or len(self._recv) != W or self._recv[0]["count"].shape[0] != B:
+            where = torch.device("cpu") if host else dev
+            self._recv = [{"count": torch.zeros((B,), dtype=torch.int32, device=where),
+                           "boxes": torch.zeros((B, Dn, 4), dtype=torch.float32, device=where),
+                           "scores": torch.zeros((B, Dn), dtype=torch.float32, device=where),
+                           "mask_probs": torch.zeros((B, Dn, 28, 28), dtype=torch.float32, device=where)} for _ in range(W)]
+        return self._recv
+
+    def paste(self, engine: Engine, src: int, g: Dict[str, torch.Tensor], hw, B: int, Dn: int, dev):
+        """Pastes one rank's gathered batch (first len(hw) rows) on this device and queues the copies of what the
+        host epilogue reads — packed masks, counts, scores — into pinned memory. → the pinned numpy views."""
+        sets = self.__dict__.setdefault("_paste_sets", {})
+        mh, mw = max(h for h, _ in hw), max(w for _, w in hw)
+        cur = sets.get(src)
+        if cur is None or cur["key"][0] < B or cur["key"][1] < mh or cur["key"][2] < mw:
+            key = (B, max(mh, cur["key"][1]) if cur else mh, max(mw, cur["key"][2]) if cur else mw)
+            words = Dn * ((key[2] + 2 + 31) // 32) * key[1]
+            d = {"mask_region": torch.empty((B, Dn, 4), dtype=torch.int32, device=dev),
+                 "mask_offset": torch.empty((B, Dn), dtype=torch.int64, device=dev),
+                 "mask_bits": torch.empty((B, words), dtype=torch.int32, device=dev)}
+            p = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in d.items()}
+            p["count"] = torch.empty((B,), dtype=torch.int32, pin_memory=True)
+            p["scores"] = torch.empty((B, Dn), dtype=torch.float32, pin_memory=True)
+            cur = sets[src] = {"key": key, "dev": d, "pin": p, "np": {k: v.numpy() for k, v in p.items()}}
+        n = len(hw)
+        engine.paste_masks_batch(g["mask_probs"], g["boxes"], g["count"], hw, cur["dev"])
+        for k in ("mask_region", "mask_offset", "mask_bits"):
+            cur["pin"][k][:n].copy_(cur["dev"][k][:n], non_blocking=True)
+        cur["pin"]["count"][:n].copy_(g["count"][:n], non_blocking=True)
+        cur["pin"]["scores"][:n].copy_(g["scores"][:n], non_blocking=True)
+        return cur["np"]
+
+
 class Predictor:
     def __init__(self, cfg, device_type="cpu", max_batch_size=5, output_dir="./output", exclude_vars=None,
                  precision: str = "fp32", state_dict: Optional[Dict[str, np.ndarray]] = None,
@@ -184,8 +232,10 @@ class Predictor:
         return x, INPUT_F32_CHW, shapes, [(b["orig_height"], b["orig_width"]) for b in batch]
 
     # -- single process: reader thread → launcher (this thread) → epilogue workers --------------------------------
-    def _read_batch(self, tiles, indices, img: GeoTiff, slot: _Slot):
-        """Crops the tiles of one batch into the slot's pinned staging buffer (uint8 rasters) — reader thread."""
+    def _read_batch(self, tiles, indices, img: GeoTiff, slot: _Slot, keep_failed: bool = False):
+        """Crops the tiles of one batch into the slot's pinned staging buffer (uint8 rasters) — reader thread.
+        ``keep_failed`` (sharded runs, where every rank must see the same batch structure): a tile whose read fails
+        unexpectedly stays in the batch as a black tile instead of being dropped."""
         staging = None
         if img.dtype == np.uint8:
             need = 0
@@ -196,6 +246,15 @@ class Predictor:
         batch, off = [], 0
         for idx in indices:
             data, info = self._process_tile(tiles[idx], img, staging, off)
+            if data is None and keep_failed:
+                _, _, w, h = img.window_of_bounds(tiles[idx]["bounds"])
+                black = np.zeros((h, w, 3), np.uint8)
+                data = {"u8": torch.from_numpy(black)}
+                if staging is not None:
+                    staging[off:off + black.size] = 0
+                    data = {"staged": (off, black.shape)}
+                info = {"orig_height": h, "orig_width": w, "height": h, "width": w, "json_name": tiles[idx]["json_name"],
+                        "tile_id": tiles[idx]["tile_id"], "meta": tiles[idx]["meta"]}
             if data is None:
                 continue
             if "staged" in data:
@@ -285,41 +344,119 @@ class Predictor:
         return predictions
 
     # -- multi-GPU: tiles shard over ranks, detections gather to rank 0 ------------------------------------------
-    def _process_and_save_batch(self, batch, pred_subdir, tifpath):
-        """One (possibly empty, on a rank that ran out of tiles) batch: forward, fixed-shape gather (every rank pads
-        its batch to max_batch_size), and on rank 0 the host epilogue for every rank's detections."""
-        out = None
-        if batch:
-            images, fmt, hw_valid, hw_out = self._to_model_input(batch)
-            out = self.engine.alloc_outputs(len(batch), max(h for h, _ in hw_out), max(w for _, w in hw_out), paste=False)
-            self.engine.forward_raw(images, fmt, hw_valid, hw_out, out)
-            torch.cuda.synchronize()
-        B, Dn = self.max_batch_size, self.engine.D
+    def _tile_ok(self, tile, img: GeoTiff) -> bool:
+        """Whether a tile yields a model input at all (reference: a failing crop is skipped, prediction.py:174-176).
+        Decided from the raster's geometry alone, so every rank reaches the same verdict for every tile."""
+        _, _, w, h = img.window_of_bounds(tile["bounds"])
+        return w > 0 and h > 0 and img.count >= 3
+
+    def _run_sharded(self, tiles, img: GeoTiff, pred_subdir, tifpath):
+        """Rank r predicts tiles r, r+W, r+2W, ... in batches; after each forward the fixed-shape detection tensors
+        (count, boxes, scores, 28x28 probabilities) go to rank 0 with ``torch.distributed.gather`` (RCCL on GPUs: the
+        copy is ordered on the device, nobody waits on the host). Rank 0 pastes each rank's batch with one
+        td_paste_masks_batch launch, copies the packed masks to pinned memory and its worker threads write the
+        ``Prediction_*.json`` files — the same epilogue as the single-process path. Tiles that cannot be cropped are
+        left out by a rule every rank evaluates alike (:meth:`_tile_ok`), so rank 0 knows each batch's tiles without
+        any metadata exchange."""
+        import torch.distributed as dist
+        B, W, me = self.max_batch_size, D.world(), D.rank()
+        Dn = self.engine.D
         dev = torch.device(self.device)
-        pad = {"count": torch.zeros((B,), dtype=torch.int32, device=dev),
-               "boxes": torch.zeros((B, Dn, 4), dtype=torch.float32, device=dev),
-               "scores": torch.zeros((B, Dn), dtype=torch.float32, device=dev),
-               "mask_probs": torch.zeros((B, Dn, 28, 28), dtype=torch.float32, device=dev)}
-        if out is not None:
-            for k in pad:
-                pad[k][: len(batch)] = out[k]
-        gathered = D.gather_detections(pad, dst=0)
-        metas = D.gather_objects([{"tile_id": b["tile_id"], "h": b["orig_height"], "w": b["orig_width"],
-                                   "transform": b["meta"]["transform"]} for b in batch], dst=0)
-        preds = []
-        if D.rank() == 0:
-            for g, ms in zip(gathered, metas):
-                for i, m in enumerate(ms):
-                    n = int(g["count"][i].item())
-                    region, offset, bits = self.engine.paste_masks_packed(g["mask_probs"][i, :n].to(dev), g["boxes"][i, :n].to(dev),
-                                                                          m["h"], m["w"])
-                    text = tile_polygons_json(region, offset, bits, g["scores"][i, :n].cpu().numpy(), np.zeros(n, np.int32),
-                                              m["transform"], tifpath)
-                    with open(os.path.join(pred_subdir, f"Prediction_{os.path.basename(m['tile_id'])}.json"), "wb") as f:
-                        f.write(text)
-                    if self.return_predictions:
-                        preds.extend(json.loads(text))
-        return preds
+        host_backend = dist.get_backend() != "nccl"          # gloo (tests / one-GPU rehearsal) moves host tensors
+        ok = [self._tile_ok(t, img) for t in tiles]
+        shard = lambda r: [i for i in D.shard_indices(len(tiles), r, W) if ok[i]]       # noqa: E731
+        per_rank = max(len(D.shard_indices(len(tiles), r, W)) for r in range(W))
+        rounds = (per_rank + B - 1) // B
+        # batches are cut from the shard BEFORE dropping bad tiles, so the round structure is the same on every rank
+        def round_tiles(r, k):
+            return [i for i in D.shard_indices(len(tiles), r, W)[k * B:(k + 1) * B] if ok[i]]
+        self.stats = dict.fromkeys(self.stats, 0.0)
+        self._free = queue.Queue()
+        for s in self._slots:
+            self._free.put(s)
+        ready: "queue.Queue" = queue.Queue(maxsize=2)
+
+        def reader():
+            try:
+                for k in range(rounds):
+                    slot = self._free.get()
+                    t0 = time.perf_counter()
+                    batch = self._read_batch(tiles, round_tiles(me, k), img, slot, keep_failed=True)
+                    self.stats["read"] += time.perf_counter() - t0
+                    ready.put((batch, slot))
+            except BaseException as e:
+                ready.put((e, None))
+
+        th = threading.Thread(target=reader, name="td-tile-reader", daemon=True)
+        th.start()
+        futures, predictions = [], []
+        for k in range(rounds):
+            t0 = time.perf_counter()
+            batch, slot = ready.get()
+            self.stats["launch_wait"] += time.perf_counter() - t0
+            if isinstance(batch, BaseException):
+                raise batch
+            t0 = time.perf_counter()
+            n = len(batch)
+            send = slot.gather_buffers(B, Dn, dev)             # count / boxes / scores / mask_probs padded to B rows
+            if n:
+                images, fmt, hw_valid, hw_out = self._to_model_input(batch, slot)
+                view = {key: send[key][:n] for key in ("count", "boxes", "scores", "mask_probs")}
+                view["classes"] = slot.classes_buffer(B, Dn, dev)[:n]
+                self.engine.forward_raw(images, fmt, hw_valid, hw_out, view)
+            if n < B:
+                send["count"][n:].zero_()
+            recv = slot.recv_buffers(W, B, Dn, dev, host_backend) if me == 0 else None
+            for key in D.GATHER_KEYS:
+                t = send[key].cpu() if host_backend else send[key]
+                dist.gather(t, [g[key] for g in recv] if me == 0 else None, dst=0)
+            if me != 0:
+                # the slot (pinned staging included) may be refilled once this batch's copies and sends have run
+                slot.event.record()
+                self._pool.submit(self._release_when_done, slot)
+                self.stats["launch"] += time.perf_counter() - t0
+                continue
+            jobs = []
+            for src in range(W):
+                idx = round_tiles(src, k)
+                if not idx:
+                    continue
+                hw = [img.window_of_bounds(tiles[i]["bounds"]) for i in idx]
+                hw = [(h, w) for _, _, w, h in hw]
+                g = recv[src] if not host_backend else {key: v.to(dev, non_blocking=True) for key, v in recv[src].items()}
+                pin = slot.paste(self.engine, src, g, hw, B, Dn, dev)
+                jobs.append((src, idx, pin))
+            slot.event.record()
+            slot.pending = sum(len(idx) for _, idx, _ in jobs)
+            if slot.pending == 0:
+                self._pool.submit(self._release_when_done, slot)
+            for src, idx, pin in jobs:
+                for j, ti in enumerate(idx):
+                    futures.append(self._pool.submit(self._save_gathered, slot, pin, j, tiles[ti], pred_subdir, tifpath))
+            self.stats["launch"] += time.perf_counter() - t0
+        th.join()
+        for f in futures:
+            predictions.extend(f.result())
+        return predictions
+
+    def _release_when_done(self, slot: _Slot) -> None:
+        slot.event.synchronize()
+        self._free.put(slot)
+
+    def _save_gathered(self, slot: _Slot, pin, j, tile, pred_subdir, tifpath):
+        try:
+            slot.event.synchronize()
+            n = int(pin["count"][j])
+            text = tile_polygons_json(pin["mask_region"][j], pin["mask_offset"][j], pin["mask_bits"][j], pin["scores"][j][:n],
+                                      np.zeros(n, np.int32), tile["meta"]["transform"], tifpath)
+            with open(os.path.join(pred_subdir, f"Prediction_{os.path.basename(tile['tile_id'])}.json"), "wb") as f:
+                f.write(text)
+            return json.loads(text) if self.return_predictions else []
+        finally:
+            with slot.lock:
+                slot.pending -= 1
+                if slot.pending == 0:
+                    self._free.put(slot)
 
     def __call__(self, tifpath, tilepath):
         pred_subdir = os.path.join(self.output_dir, os.path.basename(tifpath).replace(".tif", "").replace(".json", ""))
@@ -328,17 +465,7 @@ class Predictor:
         img = GeoTiff(tifpath)
         if D.world() == 1:
             return self._run_single(tiles, img, pred_subdir, tifpath)
-        mine = D.shard_indices(len(tiles))
-        rounds = D.padded_rounds(len(tiles), self.max_batch_size)   # identical on every rank: collectives line up
-        predictions = []
-        for r in range(rounds):
-            batch = []
-            for idx in mine[r * self.max_batch_size:(r + 1) * self.max_batch_size]:
-                data, info = self._process_tile(tiles[idx], img)
-                if data is not None:
-                    batch.append({"data": data, **info})
-            predictions.extend(self._process_and_save_batch(batch, pred_subdir, tifpath))
-        return predictions
+        return self._run_sharded(tiles, img, pred_subdir, tifpath)
 
 
 def _ring_entries(sub: np.ndarray, x0: int, y0: int, score: float, cls: int, transform, tifpath, out: List[dict]) -> None:
