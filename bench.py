@@ -368,8 +368,17 @@ def main():
             if prof16 is not None:
                 c16 = prof16["conv_igemm"]
                 a16 = c16["flops"] / (c16["ms"] * 1e-3) / 1e12 if c16["ms"] > 0 else 0.0
+                t16, src16 = None, None
+                pmc16 = os.path.join(ROOT, "profiles", "r01_pmc_conv_igemm_fp16.json")
+                if args.depth == 50 and B == 8 and os.path.exists(pmc16):
+                    with open(pmc16) as f:
+                        pj = json.load(f)
+                    t16 = pj["hbm_traffic_gb_per_step"] * 1e9 / pj["launches"]
+                    src16 = "profiles/r01_pmc_conv_igemm_fp16.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
                 o["roofline"] = {"bound": "mfma", "achieved": a16, "peak": PEAK_F16_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": a16 / PEAK_F16_MATRIX_TFLOPS, "traffic": None}
+                                 "frac": a16 / PEAK_F16_MATRIX_TFLOPS, "traffic": t16, "traffic_unit": "bytes per launch (HBM, PMC)",
+                                 "traffic_source": src16,
+                                 "algorithmic_bytes_per_launch": c16["bytes"] / max(c16["launches"], 1)}
                 o["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof16.items()}
             line["fp16"] = o
         if piped is not None:
