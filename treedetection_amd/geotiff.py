@@ -167,6 +167,33 @@ class GeoTiff:
                              f"for {self.count}-band rasters")
         self._flat = np.ascontiguousarray(arr)
 
+    def close(self) -> None:
+        """Releases the decode threads, the block cache and the file mapping (the object can still be re-used: they are
+        rebuilt on the next read)."""
+        pool = getattr(self, "_pool", None)
+        if pool is not None:
+            pool.shutdown(wait=False)
+        self._pool = None
+        self._data = None
+        self._blocks_ready = False
+        for name in ("_cache", "_mm", "_flat"):
+            if hasattr(self, name):
+                setattr(self, name, None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            pool = getattr(self, "_pool", None)
+            if pool is not None:
+                pool.shutdown(wait=False)
+        except Exception:
+            pass
+
     def _block_rows(self, by: int) -> int:
         return min(self._bh, self.height - by * self._bh) if self._strips else self._bh
 

@@ -463,9 +463,12 @@ class Predictor:
         os.makedirs(pred_subdir, exist_ok=True)
         tiles = self._load_tiles(tilepath)
         img = GeoTiff(tifpath)
-        if D.world() == 1:
-            return self._run_single(tiles, img, pred_subdir, tifpath)
-        return self._run_sharded(tiles, img, pred_subdir, tifpath)
+        try:
+            if D.world() == 1:
+                return self._run_single(tiles, img, pred_subdir, tifpath)
+            return self._run_sharded(tiles, img, pred_subdir, tifpath)
+        finally:
+            img.close()
 
 
 def _ring_entries(sub: np.ndarray, x0: int, y0: int, score: float, cls: int, transform, tifpath, out: List[dict]) -> None:
