@@ -99,7 +99,7 @@ def test_conv_fp16_matches_torch(case):
     assert (err <= 2e-3 * np.maximum(np.abs(ref), 1.0)).all(), f"max err {err.max()}"
 
 
-@pytest.mark.parametrize("cfg", [4, 7, 8, 9, 10])
+@pytest.mark.parametrize("cfg", [4, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
 def test_conv_every_block_tile_variant(cfg):
     """The engine picks a block tile per layer by measurement; every variant must compute the same convolution.
     TD_CONV_CFG forces one variant for a whole process (diagnostic hook), so the cases above re-run in a child."""

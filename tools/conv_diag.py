@@ -12,7 +12,7 @@ def build(tag, defs):
     subprocess.run(cmd, check=True)
     return out
 
-def bench(lib, prec, B, H, W, Cin, Cout, k, cfg_name):
+def bench(lib, prec, B, H, W, Cin, Cout, k, cfg_name, residual=False):
     es = 4 if prec == 0 else 2
     dt = torch.float32 if prec == 0 else torch.float16
     x = torch.randn(B, H, W, Cin, device="cuda").to(dt)
@@ -22,7 +22,8 @@ def bench(lib, prec, B, H, W, Cin, Cout, k, cfg_name):
     f = lib.td_conv2d_nhwc
     f.restype = C.c_int
     f.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p] + [C.c_int] * 11 + [C.c_void_p]
-    args = (x.data_ptr(), w.data_ptr(), None, bias.data_ptr(), None, 0, y.data_ptr(), B, H, W, Cin, Cout, k, k, 1, k // 2, 1, prec, None)
+    res = torch.randn(B, H, W, Cout, device="cuda").to(dt) if residual else None
+    args = (x.data_ptr(), w.data_ptr(), None, bias.data_ptr(), res.data_ptr() if residual else None, 0, y.data_ptr(), B, H, W, Cin, Cout, k, k, 1, k // 2, 1, prec, None)
     for _ in range(3):
         assert f(*args) == 0
     torch.cuda.synchronize()
@@ -35,7 +36,8 @@ def bench(lib, prec, B, H, W, Cin, Cout, k, cfg_name):
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / n
     fl = 2.0 * B * H * W * Cout * Cin * k * k
-    print(f"{cfg_name:28s} prec={prec} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s", flush=True)
+    nbytes = es * (B * H * W * (Cin + Cout * (2 if residual else 1)) + Cout * Cin * k * k)
+    print(f"{cfg_name:34s} prec={prec} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s  {nbytes/ms/1e9:6.2f} TB/s", flush=True)
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "tiles":
@@ -47,6 +49,16 @@ if __name__ == "__main__":
             bench(lib, prec, 8, 100, 100, 128, 128, 3, tag + " 3x3 128->128 M=80k")
             bench(lib, prec, 8, 50, 50, 1024, 256, 1, tag + " 1x1 1024->256 M=20k")
             bench(lib, prec, 8000, 1, 1, 12544, 1024, 1, tag + " fc1 M=8000")
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "thin":
+        # the HBM-bound 1x1 layers of res2 / res3 / FPN (one or two k-steps)
+        lib = C.CDLL(os.path.join(ROOT, "treedetection_amd", "libtreedet_hip.so"))
+        tag = "cfg" + os.environ.get("TD_CONV_CFG", "-1")
+        for prec in (0, 1):
+            bench(lib, prec, 8, 200, 200, 64, 256, 1, tag + " res2.conv3 64->256 +res", residual=True)
+            bench(lib, prec, 8, 200, 200, 256, 64, 1, tag + " res2.conv1 256->64")
+            bench(lib, prec, 8, 100, 100, 128, 512, 1, tag + " res3.conv3 128->512 +res", residual=True)
+            bench(lib, prec, 8, 200, 200, 256, 256, 1, tag + " fpn_lateral2 256->256 +res", residual=True)
         sys.exit(0)
     libs = {"product": [], "no_loads": ["-DTD_DIAG_NO_LOADS"], "no_loads_no_barrier": ["-DTD_DIAG_NO_LOADS", "-DTD_DIAG_NO_BARRIER"]}
     for tag, defs in libs.items():

@@ -50,8 +50,8 @@ struct ConvArgs {
 };
 // tile_cfg ids: 0..3 4-wave tiles (2 LDS stages), 4..7 the same with 3 stages (measured no better: not tuned over),
 // 8 = 256x128 / 9 = 128x256 (8 waves), 10 = 256x256 (16 waves)
-#define TD_CONV_TILE_CFG_MAX 13
-static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10};   // 8 / 9 never won a layer (tools/conv_diag.py tiles)
+#define TD_CONV_TILE_CFG_MAX 16
+static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16};   // 15 / 16 (single LDS stage) only for <= 4 k-steps
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
 
 // ---- stem / pooling / resize (stem.hip) ---------------------------------------------------------

@@ -206,27 +206,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
         else if constexpr (INFLIGHT == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else static_assert(INFLIGHT < 0, "add the vmcnt immediate for this configuration");
     };
-#pragma unroll
-    for (int p = 0; p < NSTAGE - 1; ++p)
-        if (p < nit) stage(p);
-    // prologue: step 0 must have landed; with fewer than NSTAGE-1 steps issued simply drain
-    if (nit >= NSTAGE - 1) wait_stage();
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
     // fragment reads: row = lane & 31, piece = 2*kk + (lane >> 5), swizzled with the row's key (lane >> 1) & 7
     const unsigned frag_row = lane & 31;
     const unsigned swz = (lane >> 1) & 7, hi = lane >> 5;
     unsigned frag_off[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) frag_off[kk] = frag_row * CHUNK_BYTES + (((unsigned)(2 * kk) + hi) ^ swz) * 16;
-    int cur = 0, nxt = NSTAGE - 1;       // buffer of step it / buffer the DMA of step it+NSTAGE-1 goes to
-    for (int it = 0; it < nit; ++it) {
-#if !defined(TD_DIAG_NO_LOADS)     // diagnostic builds only (tools/conv_diag.py): never defined in the product
-        if (it + NSTAGE - 1 < nit) stage(nxt);
-#endif
-        const char* Ab = &As[(cur * BM + wm * 32 * MT) * CHUNK_BYTES];
-        const char* Bb = &Bs[(cur * BN + wn * 32 * NT) * CHUNK_BYTES];
+    // one k-step: MT + NT fragment reads per 16-B piece pair, MT x NT MFMA groups
+    auto compute = [&](int buf) {
+        const char* Ab = &As[(buf * BM + wm * 32 * MT) * CHUNK_BYTES];
+        const char* Bb = &Bs[(buf * BN + wn * 32 * NT) * CHUNK_BYTES];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             f32x4 fa[MT], fb[NT];
@@ -239,15 +228,43 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
 #pragma unroll
                 for (int j = 0; j < NT; ++j) Elem<T>::mma(fa[i], fb[j], acc[i][j]);
         }
-#if !defined(TD_DIAG_NO_BARRIER)
-        // retire step it+1 (younger DMA stays in flight while steps remain to be issued; the tail drains fully)
-        if (it + NSTAGE - 1 < nit) wait_stage();
+    };
+    if constexpr (NSTAGE == 1) {
+        // One LDS buffer: load, wait, compute, release — nothing overlaps inside the block, but the LDS footprint is
+        // half, so a second block shares the CU and ITS loads / stores overlap this one's MFMAs. For the thin 1x1
+        // layers (Cin 64..128: one to four k-steps), where a prefetch pipeline has nothing to run ahead of.
+        for (int it = 0; it < nit; ++it) {
+            stage(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            compute(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < NSTAGE - 1; ++p)
+            if (p < nit) stage(p);
+        // prologue: step 0 must have landed; with fewer than NSTAGE-1 steps issued simply drain
+        if (nit >= NSTAGE - 1) wait_stage();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of buf[cur] are done
         __builtin_amdgcn_s_barrier();
+        int cur = 0, nxt = NSTAGE - 1;       // buffer of step it / buffer the DMA of step it+NSTAGE-1 goes to
+        for (int it = 0; it < nit; ++it) {
+#if !defined(TD_DIAG_NO_LOADS)     // diagnostic builds only (tools/conv_diag.py): never defined in the product
+            if (it + NSTAGE - 1 < nit) stage(nxt);
 #endif
-        cur = cur + 1 == NSTAGE ? 0 : cur + 1;
-        nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+            compute(cur);
+#if !defined(TD_DIAG_NO_BARRIER)
+            // retire step it+1 (younger DMA stays in flight while steps remain to be issued; the tail drains fully)
+            if (it + NSTAGE - 1 < nit) wait_stage();
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of buf[cur] are done
+            __builtin_amdgcn_s_barrier();
+#endif
+            cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+            nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+        }
     }
 
     // ---- epilogue: accumulators → LDS tile → 4 channels per lane: scale/bias (+residual) (+ReLU), one IEEE op per
@@ -380,6 +397,10 @@ td_status dispatch(const ConvArgs& a, int cfg, hipStream_t stream) {
         case 11: return launch<T, TO, 4, 4, 2, 2, 2>(a, stream);    // 4 waves of 128 x 128 (256 accumulator registers)
         case 12: return launch<T, TO, 4, 2, 2, 2, 4>(a, stream);    // 8 waves of 128 x 64
         case 13: return launch<T, TO, 2, 4, 2, 4, 2>(a, stream);    // 8 waves of 64 x 128
+        // single LDS stage (half the LDS: two blocks per CU overlap each other) for layers with 1-2 k-steps
+        case 14: return launch<T, TO, 2, 2, 1, 4, 4>(a, stream);    // 256 x 256
+        case 15: return launch<T, TO, 2, 2, 1, 2, 2>(a, stream);    // 128 x 128
+        case 16: return launch<T, TO, 2, 2, 1, 2, 4>(a, stream);    // 128 x 256
         default: td_set_error("conv2d: bad tile_cfg %d", cfg); return TD_ERR_INVALID;
     }
 }
