@@ -21,6 +21,7 @@
 // staged through LDS so residual loads / stores are whole coalesced row segments.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -304,67 +305,82 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
                     }
         }
         __syncthreads();
-        for (int row = tid / CHUNKS; row < RWM * WROW; row += ROWS_PER_PASS) {
-            const int m = m0 + q * WROW + row;
-            if (m >= M || n >= a.Cout) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CS + c4 * 4]);
-            size_t yoff, roff = 0;
-            if (a.out_mode == 0) {
-                yoff = (size_t)m * a.Cout + n;
-                roff = yoff;
-                if (Rs && a.res_shift) {
+        // Each thread finishes ITERS rows of this round. The residual reads are the only loads left in the kernel and
+        // nothing hides their latency (the accumulators are already in LDS, the waves have no other work), so they are
+        // issued U rows ahead: U x 16 B per lane in flight instead of 16 B (the thin 1x1 layers with a shortcut add
+        // ran at 3.3 TB/s of HBM before, latency-bound right here).
+        constexpr int ITERS = (RWM * WROW) / ROWS_PER_PASS;
+        static_assert((RWM * WROW) % ROWS_PER_PASS == 0, "epilogue rows must split evenly over the threads");
+        constexpr int U = ITERS < 8 ? ITERS : 8;
+        static_assert(ITERS % U == 0, "epilogue batch must divide the rows per thread");
+        typedef typename std::conditional<sizeof(T) == 4, f32x4, f16x4>::type ResVec;
+        auto res_offset = [&](int m) -> size_t {
+            if (!a.res_shift) return (size_t)m * a.Cout + n;
+            const int b = m / hw;
+            const int rem = m - b * hw;
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            return ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout + n;
+        };
+        for (int it0 = 0; it0 < ITERS; it0 += U) {
+            ResVec rbuf[U];
+            if (Rs && vec) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int m = m0 + q * WROW + tid / CHUNKS + (it0 + u) * ROWS_PER_PASS;
+                    if (m < M) rbuf[u] = *reinterpret_cast<const ResVec*>(Rs + res_offset(m));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int row = tid / CHUNKS + (it0 + u) * ROWS_PER_PASS;
+                const int m = m0 + q * WROW + row;
+                if (m >= M || n >= a.Cout) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CS + c4 * 4]);
+                size_t yoff;
+                if (a.out_mode == 0) {
+                    yoff = (size_t)m * a.Cout + n;
+                } else {
+                    const int qq = n / Cq, co = n - qq * Cq;   // qq = dy*2+dx; a piece never straddles it (Cq % 4 == 0)
                     const int b = m / hw;
                     const int rem = m - b * hw;
                     const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-                    roff = ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout + n;
+                    yoff = ((size_t)(b * 2 * a.Ho + 2 * oy + (qq >> 1)) * (2 * a.Wo) + 2 * ox + (qq & 1)) * Cq + co;
                 }
-            } else {
-                const int qq = n / Cq, co = n - qq * Cq;   // qq = dy*2+dx; a piece never straddles it (Cq % 4 == 0)
-                const int b = m / hw;
-                const int rem = m - b * hw;
-                const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-                yoff = ((size_t)(b * 2 * a.Ho + 2 * oy + (qq >> 1)) * (2 * a.Wo) + 2 * ox + (qq & 1)) * Cq + co;
-            }
-            float rs[4] = {0.f, 0.f, 0.f, 0.f};
-            if (Rs) {
-                if (vec) {
-                    if constexpr (sizeof(T) == 4) {
-                        const f32x4 t = *reinterpret_cast<const f32x4*>(Rs + roff);
+                float rs[4] = {0.f, 0.f, 0.f, 0.f};
+                if (Rs) {
+                    if (vec) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) rs[e] = t[e];
+                        for (int e = 0; e < 4; ++e) rs[e] = (float)rbuf[u][e];
                     } else {
-                        const f16x4 t = *reinterpret_cast<const f16x4*>(Rs + roff);
+                        const size_t roff = res_offset(m);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) rs[e] = (float)t[e];
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < a.Cout) rs[e] = Elem<T>::to_f32(Rs[roff + e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = v[e];
+                    if (a.scale) t = __fmul_rn(t, sc[e]);
+                    if (a.bias) t = __fadd_rn(t, bi[e]);
+                    if (Rs) t = __fadd_rn(t, rs[e]);
+                    if (a.relu) t = t > 0.f ? t : 0.f;
+                    v[e] = t;
+                }
+                if (vec) {
+                    if constexpr (sizeof(TO) == 4) {
+                        *reinterpret_cast<f32x4*>(Y + yoff) = v;
+                    } else {
+                        f16x4 h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
+                        *reinterpret_cast<f16x4*>(Y + yoff) = h;
                     }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (n + e < a.Cout) rs[e] = Elem<T>::to_f32(Rs[roff + e]);
+                        if (n + e < a.Cout) Y[yoff + e] = (TO)v[e];
                 }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = v[e];
-                if (a.scale) t = __fmul_rn(t, sc[e]);
-                if (a.bias) t = __fadd_rn(t, bi[e]);
-                if (Rs) t = __fadd_rn(t, rs[e]);
-                if (a.relu) t = t > 0.f ? t : 0.f;
-                v[e] = t;
-            }
-            if (vec) {
-                if constexpr (sizeof(TO) == 4) {
-                    *reinterpret_cast<f32x4*>(Y + yoff) = v;
-                } else {
-                    f16x4 h;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
-                    *reinterpret_cast<f16x4*>(Y + yoff) = h;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < a.Cout) Y[yoff + e] = (TO)v[e];
             }
         }
     }
