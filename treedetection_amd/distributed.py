@@ -9,7 +9,7 @@ rank 0, which pastes / traces / writes the ``Prediction_*.json`` files — ``tor
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional
 
 import torch
 import torch.distributed as dist

@@ -13,8 +13,7 @@ from __future__ import annotations
 
 import os
 import shutil
-import sqlite3
-from typing import List, Optional
+from typing import List
 
 import numpy as np
 

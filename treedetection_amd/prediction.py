@@ -22,7 +22,7 @@ import torch
 
 from . import distributed as D
 from .contours import find_contours, tile_polygons_json, xy
-from .engine import Engine, INPUT_F32_CHW, INPUT_U8_HWC, unpack_masks
+from .engine import Engine, INPUT_F32_CHW, INPUT_U8_HWC
 from .geotiff import GeoTiff
 from .weights import load_checkpoint
 

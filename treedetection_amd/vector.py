@@ -8,7 +8,6 @@ there is no PROJ here, so callers compare EPSG codes and refuse mixed layers ins
 """
 from __future__ import annotations
 
-import ctypes as C
 import json
 import os
 import re
