@@ -220,21 +220,27 @@ def main():
         return float(tmax.item()), prof, ndet
 
     def run_pipelined(precision, profile):
-        """Three engines, two HIP streams: every tick enqueues, on the main stream, the mask-head convs of batch t-2,
-        the box-head FCs of batch t-1 and the trunk of batch t (contractions back to back, never overlapping each
-        other), and on the side stream the selection phase that follows each of them (top-k / NMS / RoIAlign /
-        detections / paste) — those low-occupancy kernels then run underneath the next contractions. K batches take
-        K + 2 ticks; the timed region covers all of them (fill and drain included)."""
-        log(f"creating 3 engines ({precision}, software pipeline over a main and a side stream)")
+        """Three engines, one main HIP stream and one side stream per engine: every tick enqueues, on the main stream,
+        the trunk of batch t, the mask-head convs of batch t-2 and the box-head FCs of batch t-1 (contractions back to
+        back, never overlapping each other), and on each batch's own side stream the selection phase that follows
+        (top-k / NMS / RoIAlign / detections / paste) — those low-occupancy kernels run underneath the next
+        contractions, and because every selection phase was enqueued a whole trunk before the contraction that
+        consumes it, the main stream does not stall on them. K batches take K + 2 ticks; the timed region covers all of
+        them (fill and drain included)."""
+        log(f"creating 3 engines ({precision}, software pipeline: one main stream, one side stream per engine)")
         engs = [Engine(sd, device=local_rank, precision=precision) for _ in range(3)]
         outs = [e.alloc_outputs(B, S, S, paste=True) for e in engs]
-        main, side = torch.cuda.Stream(), torch.cuda.Stream()
+        main = torch.cuda.Stream()
+        sides = [torch.cuda.Stream() for _ in range(3)]   # one per engine: a batch's selection phases only wait on that batch
         gl = None
         if world > 1 and rank == 0:
             gl = {k: [torch.empty_like(outs[0][k]) for _ in range(world)] for k in gather_keys}
 
         def tick(t, first, last):
-            for age, (pm, ps) in ((2, (4, 5)), (1, (2, 3)), (0, (0, 1))):
+            # main-stream order per tick: trunk of the new batch first, then the mask convs of batch t-2 and the FCs of
+            # batch t-1 — each of those waits on a selection phase that was enqueued a whole trunk earlier, so the main
+            # stream never stalls on the side stream
+            for age, (pm, ps) in ((0, (0, 1)), (2, (4, 5)), (1, (2, 3))):
                 i = t - age
                 if not first <= i < last:
                     continue
@@ -246,6 +252,7 @@ def main():
                     e.forward_phase(0, main, batch, INPUT_U8_HWC, hw_valid, hw_out, o)
                 else:
                     e.forward_phase(pm, main)
+                side = sides[i % 3]
                 e.forward_phase(ps, side)
                 if ps == 5 and world > 1:
                     with torch.cuda.stream(side):
@@ -333,7 +340,7 @@ def main():
                        "depth": args.depth, "batch_per_gpu": B, "tile": S, "net_input": "3x800x800",
                        "parallelism": f"tile-shard x{world} (replicated weights, RCCL gather of detections to rank 0)",
                        "schedule": "plain loop" if args.no_pipeline else "3 batches in flight per GPU: contraction phases on a main "
-                                   "HIP stream, selection phases (top-k/NMS/RoIAlign/paste) on a side stream",
+                                   "HIP stream, selection phases (top-k/NMS/RoIAlign/paste) on one side stream per batch in flight",
                        "detections_last_batch": ndet},
         }
         if prof is not None:
