@@ -101,7 +101,11 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
  * batches back to back on a main stream and the odd phases on a side stream, and the selection work of one batch
  * overlaps the contractions of the next. Phase 0 takes the arguments of td_engine_forward and stores them; phases 1-5
  * ignore everything but `e`, `phase` and `stream`. Each phase waits (hipStreamWaitEvent) for the previous phase of the
- * same batch and phase 0 for the engine's previous batch, so any stream assignment is correct. */
+ * same batch and phase 0 for the engine's previous batch, so any stream assignment is correct.
+ * Optional pre-phase TD_PHASE_STEM (6): stem convolution + max-pool of the NEXT batch (VALU / HBM work, no matrix
+ * cores) with the arguments of phase 0; the following phase 0 (images may be NULL) then starts at res2. Run it on a side
+ * stream while the previous batch's contractions hold the main stream. */
+#define TD_PHASE_STEM 6
 td_status td_engine_forward_phase(td_engine* e, int phase, const void* images, int input_format, const int32_t* hw_valid,
                                   const int32_t* hw_out, int B, int Hp, int Wp, void* stream, td_detections* out);
 /* Expose an internal activation of the last forward() for stage-wise parity tests: names

@@ -164,3 +164,76 @@ def test_phased_forward_on_two_streams_equals_plain_forward(full):
             assert torch.equal(outs[i][k], ref[i][k]), (i, k)
         used = int(ref[i]["mask_offset"].max().item()) + 1
         assert torch.equal(outs[i]["mask_bits"][:, :used], ref[i]["mask_bits"][:, :used]), i
+
+
+def test_stem_prephase_schedule_equals_plain_forward(full):
+    """The bench's schedule: resize + stem + pool of a batch as the TD_PHASE_STEM pre-phase on its engine's own side
+    stream (ahead of time, underneath other batches' contractions), trunk first on the main stream, then the mask convs
+    of batch t-2 and the FCs of batch t-1 — bit-identical to the single-stream forward, batch by batch."""
+    from treedetection_amd.engine import Engine, INPUT_U8_HWC, PHASE_STEM
+    sd = full["sd"]
+    engs = [Engine(sd) for _ in range(3)]
+    main = torch.cuda.Stream()
+    sides = [torch.cuda.Stream() for _ in range(3)]
+    tiles = full["tiles"]
+    batches = [[tiles[(i + j) % 3] for j in range(2)] for i in range(7)]
+    ref = []
+    for b in batches:
+        x, hv, ho = full["eng"].preprocess_tiles_u8(b)
+        o = full["eng"].alloc_outputs(2, 1000, 1000, paste=True)
+        full["eng"].forward_raw(x.clone(), INPUT_U8_HWC, hv, ho, o)
+        torch.cuda.synchronize()
+        ref.append({k: v.clone() for k, v in o.items()})
+    n = len(batches)
+    outs = [engs[i % 3].alloc_outputs(2, 1000, 1000, paste=True) for i in range(n)]
+    staged = set()
+
+    def same_bits(got, want):       # compare each image's packed rows up to what ITS detections wrote
+        for b in range(want["count"].shape[0]):
+            c = int(want["count"][b].item())
+            if c == 0:
+                continue
+            rg = want["mask_region"][b, c - 1].tolist()
+            used = int(want["mask_offset"][b, c - 1].item()) + ((rg[2] - rg[0] + 31) // 32) * (rg[3] - rg[1])
+            if not torch.equal(got["mask_bits"][b, :used], want["mask_bits"][b, :used]):
+                return False
+        return True
+
+    def pre_stage(i):
+        e, side = engs[i % 3], sides[i % 3]
+        with torch.cuda.stream(side):
+            x, hv, ho = e.preprocess_tiles_u8(batches[i])
+        e.forward_phase(PHASE_STEM, side, x, INPUT_U8_HWC, hv, ho, outs[i])
+        staged.add(i)
+
+    torch.cuda.synchronize()
+    for t in range(n + 2):
+        for age, (pm, ps) in ((0, (0, 1)), (2, (4, 5)), (1, (2, 3))):
+            i = t - age
+            if not 0 <= i < n:
+                continue
+            e, side = engs[i % 3], sides[i % 3]
+            if pm == 0:
+                if i not in staged:
+                    pre_stage(i)
+                e.forward_phase(0, main)
+            else:
+                e.forward_phase(pm, main)
+            e.forward_phase(ps, side)
+            if ps == 5 and i + 3 < n:
+                pre_stage(i + 3)
+    torch.cuda.synchronize()
+    for i in range(n):
+        for k in ("count", "boxes", "scores", "mask_probs", "mask_region", "mask_offset"):
+            assert torch.equal(outs[i][k], ref[i][k]), (i, k)
+        assert same_bits(outs[i], ref[i]), i
+    # a plain forward after a dangling pre-phase ignores it
+    e = engs[0]
+    x, hv, ho = e.preprocess_tiles_u8(batches[0])
+    o = e.alloc_outputs(2, 1000, 1000, paste=True)
+    e.forward_phase(PHASE_STEM, sides[0], x, INPUT_U8_HWC, hv, ho, o)
+    x2, hv2, ho2 = full["eng"].preprocess_tiles_u8(batches[1])
+    torch.cuda.synchronize()
+    e.forward_raw(x2.clone(), INPUT_U8_HWC, hv2, ho2, o)
+    torch.cuda.synchronize()
+    assert torch.equal(o["boxes"], ref[1]["boxes"]) and torch.equal(o["count"], ref[1]["count"])

@@ -118,8 +118,9 @@ struct td_engine {
         td_detections out{};
         bool valid_ctx = false;
     } ctx;
-    hipEvent_t phase_ev[6] = {};
-    bool phase_ev_recorded[6] = {};
+    hipEvent_t phase_ev[7] = {};           // [6] = the optional stem pre-phase (TD_PHASE_STEM)
+    bool phase_ev_recorded[7] = {};
+    bool stem_done = false;                // stem + pool of the current batch already ran in the pre-phase
 
     // optional per-category device timing (td_engine_profile_*)
     bool prof = false;
@@ -718,7 +719,8 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
     auto off = [&](void* p, size_t elems) -> void* { return static_cast<char*>(p) + elems * esz; };
     int sb = e->backbone_subbatch > 0 ? e->backbone_subbatch : B;
     if (sb > B) sb = B;
-    for (int b0 = 0; PH(0) && b0 < B; b0 += sb) {
+    const bool do_stem = PH(6) || (PH(0) && !e->stem_done);
+    for (int b0 = 0; (PH(0) || PH(6)) && b0 < B; b0 += sb) {
         const int nb_img = (B - b0) < sb ? (B - b0) : sb;
         ImgSizes vsub{};
         for (int i = 0; i < nb_img; ++i) {
@@ -729,11 +731,14 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         const void* img_sub = static_cast<const char*>(images) + (size_t)b0 * in_img;
         void* stem_sub = off(e->stem_out, (size_t)b0 * (Hp / 2) * (Wp / 2) * e->stem_c);
         void* pool_sub = off(e->pool_out, (size_t)b0 * hs[0] * wsz[0] * e->stem_c);
-        { ProfScope ps(e, s, 1);
-        if ((st = stem_launch(img_sub, input_format, vsub, nb_img, Hp, Wp, e->stem_w, e->stem_scale, e->stem_bias, stem_sub,
-                              e->stem_c, prec, s)) < 0) return st; }
-        { ProfScope ps(e, s, 2);
-        if ((st = maxpool3x3s2_launch(stem_sub, pool_sub, nb_img, Hp / 2, Wp / 2, e->stem_c, prec, s)) < 0) return st; }
+        if (do_stem) {
+            { ProfScope ps(e, s, 1);
+            if ((st = stem_launch(img_sub, input_format, vsub, nb_img, Hp, Wp, e->stem_w, e->stem_scale, e->stem_bias, stem_sub,
+                                  e->stem_c, prec, s)) < 0) return st; }
+            { ProfScope ps(e, s, 2);
+            if ((st = maxpool3x3s2_launch(stem_sub, pool_sub, nb_img, Hp / 2, Wp / 2, e->stem_c, prec, s)) < 0) return st; }
+        }
+        if (!PH(0)) continue;
         const void* x = pool_sub;
         int xh = hs[0], xw = wsz[0];
         ProfScope backbone_group(e, s, 0, 0.0, 0.0, true);
@@ -961,16 +966,29 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
                             const int32_t* hw_out, int B, int Hp, int Wp, void* stream_v, td_detections* out) {
     td_status st = set_forward_ctx(e, images, input_format, hw_valid, hw_out, B, Hp, Wp, out);
     if (st < 0) return st;
+    e->stem_done = false;
     return forward_impl(e, 0x3fu, static_cast<hipStream_t>(stream_v));
 }
 
 td_status td_engine_forward_phase(td_engine* e, int phase, const void* images, int input_format, const int32_t* hw_valid,
                                   const int32_t* hw_out, int B, int Hp, int Wp, void* stream_v, td_detections* out) {
-    TD_REQUIRE(e && phase >= 0 && phase < 6, "td_engine_forward_phase: bad phase %d", phase);
+    TD_REQUIRE(e && phase >= 0 && phase <= TD_PHASE_STEM, "td_engine_forward_phase: bad phase %d", phase);
     hipStream_t s = static_cast<hipStream_t>(stream_v);
     td_status st;
-    if (phase == 0) {
+    if (phase == TD_PHASE_STEM) {
+        // pre-phase of the NEXT batch: needs the engine's stem / pool buffers, which the previous batch's trunk read
         if ((st = set_forward_ctx(e, images, input_format, hw_valid, hw_out, B, Hp, Wp, out)) < 0) return st;
+        if (e->phase_ev_recorded[0]) TD_HIP_CHECK(hipStreamWaitEvent(s, e->phase_ev[0], 0));
+        if (e->phase_ev_recorded[5]) TD_HIP_CHECK(hipStreamWaitEvent(s, e->phase_ev[5], 0));
+        e->stem_done = false;
+    } else if (phase == 0) {
+        if (e->stem_done) {
+            TD_REQUIRE(e->ctx.valid_ctx && (!images || images == e->ctx.images),
+                       "td_engine_forward_phase: phase 0 after the stem pre-phase must continue the same batch");
+            TD_HIP_CHECK(hipStreamWaitEvent(s, e->phase_ev[TD_PHASE_STEM], 0));
+        } else if ((st = set_forward_ctx(e, images, input_format, hw_valid, hw_out, B, Hp, Wp, out)) < 0) {
+            return st;
+        }
         // the engine's previous batch must have left its buffers (its last selection phase ran on another stream)
         if (e->phase_ev_recorded[5]) TD_HIP_CHECK(hipStreamWaitEvent(s, e->phase_ev[5], 0));
     } else {
@@ -982,8 +1000,11 @@ td_status td_engine_forward_phase(td_engine* e, int phase, const void* images, i
     if (!e->phase_ev[phase]) TD_HIP_CHECK(hipEventCreateWithFlags(&e->phase_ev[phase], hipEventDisableTiming));
     TD_HIP_CHECK(hipEventRecord(e->phase_ev[phase], s));
     e->phase_ev_recorded[phase] = true;
-    if (phase == 0)
+    if (phase == TD_PHASE_STEM) e->stem_done = true;
+    if (phase == 0) {
+        e->stem_done = false;
         for (int k = 1; k < 6; ++k) e->phase_ev_recorded[k] = false;
+    }
     return TD_OK;
 }
 

@@ -20,6 +20,7 @@ from ._lib import Detections, ModelDesc, TensorDesc
 MASK_SIDE = 28
 INPUT_F32_CHW = 0
 INPUT_U8_HWC = 1
+PHASE_STEM = 6      # TD_PHASE_STEM
 PRECISIONS = {"fp32": 0, "fp16": 1}
 
 
@@ -138,8 +139,10 @@ class Engine:
 
     def forward_phase(self, phase: int, stream: torch.cuda.Stream, images: Optional[torch.Tensor] = None,
                       input_format: int = INPUT_U8_HWC, hw_valid=None, hw_out=None, out: Optional[Dict[str, torch.Tensor]] = None) -> None:
-        """One of the six phases of the forward on `stream` (see td_engine_forward_phase). Phase 0 takes the batch."""
-        if phase == 0:
+        """One of the six phases of the forward on `stream` (see td_engine_forward_phase). Phase 0 takes the batch;
+        ``PHASE_STEM`` (6) is the optional pre-phase (stem + pool of the next batch) with the same arguments, after which
+        phase 0 is called without a batch."""
+        if phase in (0, PHASE_STEM) and images is not None:
             B, Hp, Wp = (images.shape[0], images.shape[2], images.shape[3]) if input_format == INPUT_F32_CHW else images.shape[:3]
             self.reserve(B, Hp, Wp)
             hv = (C.c_int32 * (2 * B))(*[int(v) for p in hw_valid for v in p])
@@ -153,7 +156,7 @@ class Engine:
                 det.mask_bits = out["mask_bits"].data_ptr()
                 det.mask_words_per_image = out["mask_bits"].shape[1]
             self._phase_keep = (images, out)      # keep the buffers alive until the batch has drained
-            st = self.lib.td_engine_forward_phase(self._h, 0, images.data_ptr(), input_format, hv, ho, B, Hp, Wp,
+            st = self.lib.td_engine_forward_phase(self._h, phase, images.data_ptr(), input_format, hv, ho, B, Hp, Wp,
                                                   int(stream.cuda_stream), C.byref(det))
         else:
             st = self.lib.td_engine_forward_phase(self._h, phase, None, 0, None, None, 0, 0, 0, int(stream.cuda_stream), None)
