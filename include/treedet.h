@@ -94,12 +94,13 @@ td_status td_engine_reserve(td_engine* e, int max_batch, int max_hp, int max_wp)
  * Asynchronous on `stream`; results are complete once the stream has drained. */
 td_status td_engine_forward(td_engine* e, const void* images, int input_format, const int32_t* hw_valid,
                             const int32_t* hw_out, int B, int Hp, int Wp, void* stream, td_detections* out);
-/* The same forward cut into six phases for cross-batch software pipelining (three engines, two streams):
+/* The same forward cut into six phases for cross-batch software pipelining (three engines, a main stream and one
+ * side stream per engine):
  *   0 trunk (stem .. RPN heads)   1 RPN top-k / NMS / merge + RoIAlign 7x7   2 box-head FCs + predictors
  *   3 detections + RoIAlign 14x14 4 mask-head convolutions                   5 mask predictor, scatter, paste
  * Even phases are dense contractions, odd phases low-occupancy selection work: enqueue the even phases of successive
- * batches back to back on a main stream and the odd phases on a side stream, and the selection work of one batch
- * overlaps the contractions of the next. Phase 0 takes the arguments of td_engine_forward and stores them; phases 1-5
+ * batches back to back on a main stream and each batch's odd phases on its own side stream, and the selection work of
+ * one batch overlaps the contractions of the next (bench.py: per tick trunk(t), mask convs(t-2), FCs(t-1)). Phase 0 takes the arguments of td_engine_forward and stores them; phases 1-5
  * ignore everything but `e`, `phase` and `stream`. Each phase waits (hipStreamWaitEvent) for the previous phase of the
  * same batch and phase 0 for the engine's previous batch, so any stream assignment is correct.
  * Optional pre-phase TD_PHASE_STEM (6): stem convolution + max-pool of the NEXT batch (VALU / HBM work, no matrix
