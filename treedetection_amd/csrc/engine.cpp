@@ -319,6 +319,18 @@ struct ProfScope {
     }
 };
 
+// Measured block-tile choices shared between engines (and runs) through the TD_TUNE_CACHE file: read at creation and
+// again whenever a layer shape is missing, so engines created together pick up what the first one measured.
+void load_tune_cache(td_engine* e) {
+    if (e->tune_cache.empty()) return;
+    if (FILE* f = fopen(e->tune_cache.c_str(), "r")) {
+        int pr, a0, a1, a2, a3, a4, cfg;
+        while (fscanf(f, "%d %d %d %d %d %d %d", &pr, &a0, &a1, &a2, &a3, &a4, &cfg) == 7)
+            if (pr == e->desc.precision && cfg >= 0 && cfg <= TD_CONV_TILE_CFG_MAX) e->tuned[std::make_tuple(a0, a1, a2, a3, a4)] = cfg;
+        fclose(f);
+    }
+}
+
 void free_pool(std::vector<void*>& pool) {
     for (void* p : pool) (void)hipFree(p);
     pool.clear();
@@ -343,16 +355,9 @@ td_status td_engine_create(const td_model_desc* desc, int device, td_engine** ou
     TD_HIP_CHECK(hipSetDevice(device));
     td_engine* e = new td_engine();
     if (const char* sbenv = getenv("TD_BACKBONE_SUBBATCH")) e->backbone_subbatch = atoi(sbenv);
-    if (const char* tc = getenv("TD_TUNE_CACHE")) {
-        e->tune_cache = tc;
-        if (FILE* f = fopen(tc, "r")) {
-            int pr, a0, a1, a2, a3, a4, cfg;
-            while (fscanf(f, "%d %d %d %d %d %d %d", &pr, &a0, &a1, &a2, &a3, &a4, &cfg) == 7)
-                if (pr == d.precision && cfg >= 0 && cfg <= TD_CONV_TILE_CFG_MAX) e->tuned[std::make_tuple(a0, a1, a2, a3, a4)] = cfg;
-            fclose(f);
-        }
-    }
+    if (const char* tc = getenv("TD_TUNE_CACHE")) e->tune_cache = tc;
     e->desc = d;
+    load_tune_cache(e);
     e->device = device;
     *out = e;
     return TD_OK;
@@ -660,6 +665,10 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         if (e->autotune) {
             const auto key = std::make_tuple(L.cout, L.cin, L.kh * 16 + L.kw, B_ * Ho * Wo, stride * 4 + out_mode * 2 + (res_ ? 1 : 0));
             auto it = e->tuned.find(key);
+            if (it == e->tuned.end()) {
+                load_tune_cache(e);                   // another engine of this process may have measured it meanwhile
+                it = e->tuned.find(key);
+            }
             if (it == e->tuned.end()) {
                 // time every block-tile shape on this very launch (idempotent: same inputs, same output buffer)
                 float best = 1e30f;

@@ -38,7 +38,8 @@ def predict_on_model(config, model_path, tiles_path, output_path, batch_size=10,
     cfg = setup_model_cfg(update_model=model_path, device=config["device"])
     predictor = Predictor(cfg, device_type=config["device"], max_batch_size=batch_size, output_dir=output_path,
                           exclude_vars=exclude_vars, precision=config.get("precision", "fp32"),
-                          return_predictions=False)       # the files are the product; the list is unused here
+                          return_predictions=False,       # the files are the product; the list is unused here
+                          pipeline=config.get("pipeline", True))
     images_directory = Path(config["image_directory"])
     images_paths = sorted(str(f) for f in images_directory.glob("*.tif"))
     merged_directory = Path(f"{images_directory}/{config['merged_path']}")

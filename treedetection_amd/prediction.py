@@ -108,11 +108,14 @@ class _Slot:
 class Predictor:
     def __init__(self, cfg, device_type="cpu", max_batch_size=5, output_dir="./output", exclude_vars=None,
                  precision: str = "fp32", state_dict: Optional[Dict[str, np.ndarray]] = None,
-                 return_predictions: bool = True, host_workers: Optional[int] = None):
+                 return_predictions: bool = True, host_workers: Optional[int] = None, pipeline: bool = True):
         """cfg from ``setup_model_cfg``; ``device_type`` = GPU index ("0", 0) as config["device"] carries it.
         ``state_dict`` lets tests and the bench inject weights instead of reading cfg.MODEL.WEIGHTS.
         ``return_predictions=False`` skips rebuilding the Python list ``__call__`` returns (the reference's own caller
-        ignores it, detection.py:118); the per-tile files are written either way."""
+        ignores it, detection.py:118); the per-tile files are written either way. ``pipeline`` (single-process runs):
+        three engines keep three batches in flight — contraction phases back to back on a main stream, each batch's
+        selection phases on its own side stream (td_engine_forward_phase; same results bit for bit as one plain
+        forward per batch, tests/test_fullsize_gpu.py) — at the price of three weight / workspace replicas."""
         self.cfg = cfg
         if device_type == "cpu" or not torch.cuda.is_available():
             raise RuntimeError("treedetection_amd.Predictor runs on an MI355X only: the HIP path has no CPU fallback "
@@ -126,13 +129,20 @@ class Predictor:
         os.makedirs(self.output_dir, exist_ok=True)
         sd = state_dict if state_dict is not None else load_checkpoint(cfg.MODEL.WEIGHTS)
         rh = cfg.MODEL.ROI_HEADS
-        self.engine = Engine(sd, device=self.device_index, precision=precision, score_thresh=rh.SCORE_THRESH_TEST,
-                             nms_thresh=rh.NMS_THRESH_TEST, rpn_nms_thresh=cfg.MODEL.RPN.NMS_THRESH,
-                             pre_nms_topk=cfg.MODEL.RPN.PRE_NMS_TOPK_TEST, post_nms_topk=cfg.MODEL.RPN.POST_NMS_TOPK_TEST,
-                             detections_per_image=cfg.TEST.DETECTIONS_PER_IMAGE)
+        eng_args = dict(device=self.device_index, precision=precision, score_thresh=rh.SCORE_THRESH_TEST,
+                        nms_thresh=rh.NMS_THRESH_TEST, rpn_nms_thresh=cfg.MODEL.RPN.NMS_THRESH,
+                        pre_nms_topk=cfg.MODEL.RPN.PRE_NMS_TOPK_TEST, post_nms_topk=cfg.MODEL.RPN.POST_NMS_TOPK_TEST,
+                        detections_per_image=cfg.TEST.DETECTIONS_PER_IMAGE)
+        self.pipeline = bool(pipeline) and D.world() == 1
+        if self.pipeline and "TD_TUNE_CACHE" not in os.environ:
+            # the engines of one process share their measured block-tile choices through this file
+            import tempfile
+            os.environ["TD_TUNE_CACHE"] = os.path.join(tempfile.mkdtemp(prefix="td_tune_"), "tiles.txt")
+        self.engine = Engine(sd, **eng_args)
+        self._engines = [self.engine] + ([Engine(sd, **eng_args) for _ in range(2)] if self.pipeline else [])
         workers = host_workers or max(2, min(16, len(os.sched_getaffinity(0)) - 2))
         self._pool = ThreadPoolExecutor(max_workers=workers)
-        self._slots = [_Slot() for _ in range(3)]
+        self._slots = [_Slot() for _ in range(6 if self.pipeline else 3)]
         self._stats_lock = threading.Lock()
         # seconds spent per stage of the last __call__ (reader thread, launcher thread, sum over epilogue workers)
         self.stats = {"read": 0.0, "launch": 0.0, "launch_wait": 0.0, "epilogue": 0.0, "epilogue_wait": 0.0}
@@ -142,8 +152,8 @@ class Predictor:
         if getattr(self, "_pool", None) is not None:
             self._pool.shutdown(wait=True)
             self._pool = None
-        if getattr(self, "engine", None) is not None:
-            self.engine.close()
+        for eng in getattr(self, "_engines", []) or []:
+            eng.close()
 
     def __enter__(self):
         return self
@@ -202,9 +212,9 @@ class Predictor:
             print(f"Error processing tile {tile['json_name']}: {e}")
             return None, None
 
-    def _to_model_input(self, batch, slot: Optional[_Slot] = None):
+    def _to_model_input(self, batch, slot: Optional[_Slot] = None, engine: Optional[Engine] = None):
         """→ (images tensor on device, format, hw_valid, hw_out)."""
-        eng = self.engine
+        eng = engine or self.engine
         if slot is not None and batch and all("staged" in b["data"] for b in batch):
             used = max(b["data"]["staged"][0] + int(np.prod(b["data"]["staged"][1])) for b in batch)
             slot.dev_in[:used].copy_(slot.pin_in[:used], non_blocking=True)       # one H2D per batch, from pinned memory
@@ -300,6 +310,63 @@ class Predictor:
                 if slot.pending == 0:
                     self._free.put(slot)
 
+    def _launch_pipelined(self, ready, pred_subdir, tifpath, futures) -> None:
+        """Launcher loop of a pipelined run. Tick t enqueues, on the main stream, the trunk of batch t, the mask-head
+        convs of batch t-2 and the box-head FCs of batch t-1, and on each batch's own side stream the selection phase
+        that follows; after a batch's last phase the packed results are copied to pinned memory on that side stream
+        and its epilogue tasks are queued."""
+        if getattr(self, "_main", None) is None:
+            self._main = torch.cuda.Stream()
+            for slot in self._slots:
+                slot.side = torch.cuda.Stream()
+        main = self._main
+        window = []                 # batches in flight, oldest first: [batch, slot, next contraction phase, engine]
+        done = False
+        launched = 0
+        while not done or window:
+            if not done:
+                t0 = time.perf_counter()
+                batch, slot = ready.get()
+                self.stats["launch_wait"] += time.perf_counter() - t0
+                if isinstance(batch, BaseException):
+                    raise batch
+                if batch is None:
+                    done = True
+                elif not batch:
+                    self._free.put(slot)
+                    continue
+                else:
+                    # engines rotate over the batches: an engine is free for a new batch as soon as its previous
+                    # batch's last phase is ENQUEUED (phase 0 waits on that batch's events on the device); the slot —
+                    # pinned buffers the host epilogue reads — stays busy longer, hence more slots than engines
+                    window.append([batch, slot, 0, self._engines[launched % len(self._engines)]])
+                    launched += 1
+            t0 = time.perf_counter()
+            # the newest batch's trunk leads the tick, then the mask convs of the oldest, then the FCs of the middle one:
+            # every contraction then finds the selection phase it waits on enqueued a whole trunk earlier
+            for item in sorted(window, key=lambda it: (0, 2, 1)[it[2] // 2]):
+                batch, slot, phase, eng = item
+                if phase == 0:
+                    with torch.cuda.stream(main):      # allocations (and their fills) are ordered with the kernels
+                        images, fmt, hw_valid, hw_out = self._to_model_input(batch, slot, eng)
+                        dev_out = slot.outputs(eng, len(batch), max(h for h, _ in hw_out), max(w for _, w in hw_out))
+                    view = {k: v[: len(batch)] for k, v in dev_out.items()}
+                    eng.forward_phase(0, main, images, fmt, hw_valid, hw_out, view)
+                else:
+                    eng.forward_phase(phase, main)
+                eng.forward_phase(phase + 1, slot.side)
+                item[2] = phase + 2
+                if item[2] == 6:        # all six phases are enqueued: results → pinned memory, epilogue tasks
+                    with torch.cuda.stream(slot.side):
+                        for k, v in slot.dev_out.items():
+                            slot.pin_out[k][: len(batch)].copy_(v[: len(batch)], non_blocking=True)
+                        slot.event.record()
+                    slot.pending = len(batch)
+                    futures.extend(self._pool.submit(self._process_and_save_single, b, i, slot, pred_subdir, tifpath)
+                                   for i, b in enumerate(batch))
+            window = [it for it in window if it[2] < 6]
+            self.stats["launch"] += time.perf_counter() - t0
+
     def _run_single(self, tiles, img: GeoTiff, pred_subdir, tifpath):
         B = self.max_batch_size
         rounds = [list(range(r * B, min((r + 1) * B, len(tiles)))) for r in range((len(tiles) + B - 1) // B)]
@@ -324,7 +391,7 @@ class Predictor:
         t = threading.Thread(target=reader, name="td-tile-reader", daemon=True)
         t.start()
         futures, predictions = [], []
-        while True:
+        while not self.pipeline:
             t0 = time.perf_counter()
             batch, slot = ready.get()
             self.stats["launch_wait"] += time.perf_counter() - t0
@@ -338,6 +405,8 @@ class Predictor:
             t0 = time.perf_counter()
             futures.extend(self._launch_batch(batch, slot, pred_subdir, tifpath))
             self.stats["launch"] += time.perf_counter() - t0
+        if self.pipeline:
+            self._launch_pipelined(ready, pred_subdir, tifpath, futures)
         t.join()
         for f in futures:
             predictions.extend(f.result())
