@@ -229,6 +229,18 @@ int td_stitch_tile_json(const char* json, int64_t len, const double* box, double
 int td_region_relate(const double* ring_xy, const int64_t* ring_start, const int32_t* ring_poly, int n_rings,
                      const double* query_xy, const int64_t* query_start, int n_queries, uint8_t* flags);
 
+/* ---- crown post-processing (reference postprocessing.py:25-347) ----------------------------- */
+/* Raster statistics inside each crown's bounding circle. raster: device float32 [rows][cols]; transform: host
+ * (a,b,c,d,e,f) of the raster; window: host (row_lo, col_lo, row_hi, col_hi) = the reference's subset of the raster
+ * (its whole extent when the bounds passed are the raster's own); circles: device float32 [n][3] (centre x, y of
+ * the crown's bounding box and the largest vertex distance from it, computed from the float32 vertex arrays).
+ * mode 0 (get_height_within_polygon): out [n][3] = max value, x, y of its first occurrence (float64 membership test);
+ * mode 1 (get_ndvi_within_polygon / NDVI half of get_metadata_within_polygon with radius_scale 0.5): out [n][4] =
+ * min, max, mean, population variance (float32 membership test). -1 everywhere for a circle without pixels.
+ * Asynchronous on `stream`. */
+td_status td_crown_stats(const float* raster, int rows, int cols, const double* transform, const int32_t* window,
+                         const float* circles, int n, int mode, float radius_scale, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,11 +4,12 @@
 ``predict_tiles`` / ``predict_on_model`` are the hot path this package accelerates (model forward on the MI355X);
 ``preprocess_files`` produces the tile metadata; stitching writes one GeoPackage per image into the reference's
 ``*_geojson`` / ``geojson_predictions`` folders (treedetection_amd/stitching.py);
-``postprocess_files`` (crown filtering with nDSM / NDVI statistics, TreeDetection/postprocessing.py) is outside this
-round's scope and only hands the stitched files through.
+``postprocess_files`` filters the crowns with nDSM / NDVI statistics (treedetection_amd/postprocessing.py,
+``td_crown_stats``).
 """
 from __future__ import annotations
 
+import datetime
 import os
 import re
 import shutil
@@ -22,6 +23,7 @@ from .preprocessing import tile_data
 from .recoveries import load_prediction_recovery_data, save_prediction_recovery_data
 from .fusion import exclude_outlines, fuse_predictions  # noqa: F401
 from .merging import merge_and_crop_images
+from .postprocessing import process_files_in_directory
 from .stitching import process_and_stitch_predictions
 
 
@@ -156,18 +158,32 @@ def preprocess_files(config):
 
 
 def postprocess_files(config):
-    """Hand-through of the stitched predictions into ``output_directory`` (the reference's crown filtering —
-    postprocessing.py — is a later stage outside this round's scope)."""
+    """Reference detection.py:23-60: exclude-outline filter, crown post-processing of every stitched layer
+    (``processed_*.gpkg`` next to it), then the processed layers copied into ``output_directory`` under their plain
+    names (and into a time-stamped sub-folder with ``timestamped_output_directory``)."""
     Config()._load_into_config(config)
     logger = config["logger"]
-    src = os.path.join(config["output_directory"], "geojson_predictions")
-    if not os.path.isdir(src):
+    if D.rank() != 0:
+        return
+    logger.info("Postprocessing the predictions.")
+    pattern = (config.get("image_regex", "(\\d+)\\.tif"), config.get("height_data_regex", "(\\d+)\\.tif"))
+    logger.info("Excluding Outlines.")
+    exclude_outlines(config, logger)
+    pred_dir = os.path.join(config["output_directory"], "geojson_predictions")
+    if not os.path.isdir(pred_dir):
         logger.warning("No stitched predictions to post-process.")
         return
-    for name in sorted(os.listdir(src)):
-        if name.endswith(".gpkg"):
-            shutil.copy(os.path.join(src, name), os.path.join(config["output_directory"], name))
-    logger.info("Postprocessing: stitched predictions copied (height / NDVI crown filtering is not built yet).")
+    process_files_in_directory(pred_dir, config["height_data_path"], config["image_directory"], parallel=config.get("parallel", True),
+                               filename_pattern=pattern, config=config)
+    stamp = datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S")
+    for name in sorted(os.listdir(pred_dir)):
+        if not (name.endswith(".geojson") or name.endswith(".gpkg")) or not name.startswith("processed_"):
+            continue
+        plain = name.replace("processed_", "")
+        if config.get("timestamped_output_directory"):
+            os.makedirs(os.path.join(config["output_directory"], stamp), exist_ok=True)
+            shutil.copy(os.path.join(pred_dir, name), os.path.join(config["output_directory"], stamp, plain))
+        shutil.copy(os.path.join(pred_dir, name), os.path.join(config["output_directory"], plain))
 
 
 def cleanup_files(config):
