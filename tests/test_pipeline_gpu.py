@@ -180,3 +180,39 @@ def test_sixteen_bit_tiles_take_the_float_path(tmp_path):
     ref_scores = sorted({round(float(s), 4) for s in ref["scores"]})
     got_scores = sorted({round(e["score"], 4) for e in got})
     assert len(set(ref_scores) & set(got_scores)) >= len(ref_scores) - 1
+
+
+def test_process_files_end_to_end_with_overlap(tmp_path):
+    """The reference's top-level entry with its default ``use_overlap``: two adjacent RGBI images + nDSM rasters →
+    seam strip (merging) → tiles → predictions (plain images and the strip) → stitched layers → post-processed crowns
+    copied to the output directory; intermediate folders removed unless ``keep_intermediate``."""
+    import treedetection_amd as T
+    from treedetection_amd import gpkg
+    root = tmp_path
+    (root / "rgb").mkdir()
+    (root / "ndsm").mkdir()
+    np.savez(root / "model.npz", **make_synthetic_state_dict(50, seed=3, width_div=2))
+    for k, name in enumerate(("3241", "3242")):
+        rgb, ndsm = make_tile(200 + k, 400)
+        rgbi = np.concatenate([rgb, 255 - rgb[..., :1] // 2], axis=2).transpose(2, 0, 1)
+        t = (0.2, 0.0, 412000.0 + 80 * k, 0.0, -0.2, 5318080.0)                  # 80 m x 80 m, side by side
+        write_geotiff(str(root / "rgb" / f"{name}.tif"), np.ascontiguousarray(rgbi), t, 25832)
+        write_geotiff(str(root / "ndsm" / f"{name}.tif"), (ndsm[::5, ::5] + 5).copy(), (1.0, 0, t[2], 0, -1.0, t[5]), 25832)
+    cfg = {"image_directory": str(root / "rgb"), "height_data_path": str(root / "ndsm"), "combined_model": str(root / "model.npz"),
+           "output_directory": str(root / "output"), "tiles_path": str(root / "tiles"), "use_overlap": True,
+           "overlapping_tiles_width": 2, "overlapping_tiles_height": 2, "tile_width": 40, "tile_height": 40, "buffer": 10,
+           "batch_size": 4, "parallel": False, "num_workers": 2, "keep_intermediate": True, "device": "0", "height_threshold": 0}
+    (root / "config.yml").write_text(yaml.safe_dump(cfg))
+    config, _ = T.get_config(str(root / "config.yml"))
+    T.process_files(config)
+    strip = "3241_412000_5318080_412080_5318080_3241"
+    assert os.path.exists(root / "rgb" / "merged" / f"{strip}.tif") and os.path.exists(root / "ndsm" / "merged")
+    for name in ("3241", "3242", strip):
+        assert os.path.exists(root / "tiles" / f"{name}.json")
+        assert os.path.exists(root / "output" / "geojson_predictions" / f"{name}.gpkg")
+    for name in ("3241", "3242"):                        # plain images find their rasters; the strip's names do not match
+        rings, cols, srs = gpkg.read_polygons(str(root / "output" / f"{name}.gpkg"))       # the merged-file regex default
+        assert srs == 25832 and set(cols) >= {"TreeHeight", "Area", "Diameter", "Centroid", "is_contained", "num_contained"}
+        raw = gpkg.read_polygons(str(root / "output" / "geojson_predictions" / f"{name}.gpkg"))[0]
+        assert len(rings) <= len(raw)
+        assert all(h >= 5.0 or h == -1 for h in cols["TreeHeight"])                       # nDSM was offset by +5 m
