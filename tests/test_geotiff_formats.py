@@ -99,3 +99,79 @@ def test_codec_errors():
     trunc = np.frombuffer(bytes([0x05, 0x01]), np.uint8)
     with pytest.raises(_lib.TdError, match="truncated"):
         _lib.check(lib.td_tiff_packbits_decode(trunc.ctypes.data, trunc.size, dst.ctypes.data, dst.size), "packbits")
+
+
+def _rewrite(path_in, path_out, big_endian=False, bigtiff=False):
+    """Re-encodes a classic little-endian single-IFD TIFF (our writer's output) as big-endian and / or BigTIFF: same
+    tags, same pixel bytes (swapped per sample for big-endian), new offsets."""
+    import struct
+    raw = open(path_in, "rb").read()
+    (ifd,) = struct.unpack_from("<I", raw, 4)
+    (n,) = struct.unpack_from("<H", raw, ifd)
+    sizes = {1: 1, 2: 1, 3: 2, 4: 4, 12: 8, 16: 8}
+    codes = {1: "B", 2: "c", 3: "H", 4: "I", 12: "d", 16: "Q"}
+    tags = {}
+    for i in range(n):
+        tag, typ, cnt = struct.unpack_from("<HHI", raw, ifd + 2 + 12 * i)
+        total = sizes[typ] * cnt
+        off = ifd + 2 + 12 * i + 8 if total <= 4 else struct.unpack_from("<I", raw, ifd + 2 + 12 * i + 8)[0]
+        vals = struct.unpack_from("<" + str(cnt) + codes[typ], raw, off)
+        tags[tag] = [typ, list(vals)]
+    off_tag, cnt_tag = (324, 325) if 324 in tags else (273, 279)
+    blocks = [raw[o:o + c] for o, c in zip(tags[off_tag][1], tags[cnt_tag][1])]
+    e = ">" if big_endian else "<"
+    bits = tags[258][1][0]
+    if big_endian and bits > 8 and tags[259][1][0] == 1:
+        dt = {16: "u2", 32: "u4"}[bits]
+        blocks = [np.frombuffer(b, "<" + dt).astype(">" + dt).tobytes() for b in blocks]
+    if bigtiff:
+        tags[off_tag][0] = tags[cnt_tag][0] = 16
+        head, ent, inl, ocode, ncode = 16, 20, 8, "Q", "Q"
+    else:
+        head, ent, inl, ocode, ncode = 8, 12, 4, "I", "H"
+    items = sorted(tags.items())
+    extra_off = head + (8 if bigtiff else 2) + ent * len(items) + (8 if bigtiff else 4)
+    payloads, extra = [], b""
+    for tag, (typ, vals) in items:
+        payloads.append((tag, typ, len(vals), sizes[typ] * len(vals)))
+        if sizes[typ] * len(vals) > inl:
+            extra += b"\0" * (sizes[typ] * len(vals) + (sizes[typ] * len(vals)) % 2)
+    data_off = extra_off + len(extra)
+    offsets, pos = [], data_off
+    for b in blocks:
+        offsets.append(pos)
+        pos += len(b) + len(b) % 2
+    tags[off_tag][1] = offsets
+    out = bytearray((b"MM" if big_endian else b"II") + struct.pack(e + "H", 43 if bigtiff else 42))
+    out += struct.pack(e + "HHQ", 8, 0, head) if bigtiff else struct.pack(e + "I", head)
+    out += struct.pack(e + ncode, len(items))
+    extra, cursor = b"", extra_off
+    for tag, (typ, vals) in items:
+        payload = struct.pack(e + str(len(vals)) + codes[typ], *vals)
+        out += struct.pack(e + "HH" + ocode, tag, typ, len(vals))
+        if len(payload) <= inl:
+            out += payload.ljust(inl, b"\0")
+        else:
+            out += struct.pack(e + ocode, cursor + len(extra))
+            extra += payload + (b"\0" if len(payload) % 2 else b"")
+    out += struct.pack(e + ocode, 0) + extra
+    assert len(out) == data_off
+    with open(path_out, "wb") as f:
+        f.write(bytes(out))
+        for b in blocks:
+            f.write(b + (b"\0" if len(b) % 2 else b""))
+
+
+@pytest.mark.parametrize("big_endian,bigtiff", [(True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("kw", [{}, {"tile": (32, 48)}, {"rows_per_strip": 9, "compression": "deflate"}])
+def test_big_endian_and_bigtiff_headers(tmp_path, big_endian, bigtiff, kw):
+    if big_endian and kw.get("compression"):
+        pytest.skip("the rewriter does not re-compress byte-swapped samples")
+    rng = np.random.default_rng(2)
+    img = _image(rng, 3, 77, 101, np.uint16)
+    src, dst = str(tmp_path / "a.tif"), str(tmp_path / "b.tif")
+    write_geotiff(src, img, T, 25832, **kw)
+    _rewrite(src, dst, big_endian, bigtiff)
+    g = GeoTiff(dst)
+    assert (g.width, g.height, g.count, g.epsg) == (101, 77, 3, 25832) and g.transform == T
+    assert np.array_equal(g.read(), img) and np.array_equal(g._window_hwc(10, 20, 30, 40), img[:, 10:40, 20:60].transpose(1, 2, 0))
