@@ -53,6 +53,34 @@ def test_ndvi_and_helpers():
     assert c.dtype == np.float32 and c.shape == (1, 3) and c[0, 2] > 0
 
 
+def test_gdal_style_bilinear_decimation():
+    """resample_bilinear_gdal: GDAL's triangle-filter decimation (read(out_shape=..., resampling=bilinear))."""
+    const = np.full((2, 50, 35), 7, np.uint8)
+    assert (P.resample_bilinear_gdal(const, 10, 7) == 7).all() and P.resample_bilinear_gdal(const, 50, 35) is const
+    ramp = np.tile(np.arange(50, dtype=np.float32), (1, 20, 1))
+    out = P.resample_bilinear_gdal(ramp, 4, 10)
+    assert out.shape == (1, 4, 10) and np.allclose(out[0, :, 1:-1], [7, 12, 17, 22, 27, 32, 37, 42], atol=1e-4)   # block centres
+    assert 2.0 < out[0, 0, 0] < 2.6 and 46.4 < out[0, 0, -1] < 47.0          # truncated kernels at the borders
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (4, 40, 60), dtype=np.uint8)
+    got = P.resample_bilinear_gdal(img, 8, 12)
+    # against a direct evaluation of the same separable triangle filter in float64
+    def taps(n_src, n_dst):
+        sc = n_dst / n_src
+        m = np.zeros((n_dst, n_src))
+        for j in range(n_dst):
+            c = (j + 0.5) / sc
+            for i in range(max(int(np.floor(c - 1 / sc + 0.5)), 0), min(int(c + 1 / sc + 0.5), n_src)):
+                m[j, i] = max(0.0, 1 - abs(sc * (i - c + 0.5)))
+            m[j] /= m[j].sum()
+        return m
+    want = np.einsum("ih,bhw,jw->bij", taps(40, 8), img.astype(np.float64), taps(60, 12))
+    assert got.dtype == np.uint8 and np.abs(got.astype(np.float64) - np.floor(want + 0.5)).max() <= 1
+    assert (got == np.floor(want + 0.5)).mean() > 0.99
+    with pytest.raises(NotImplementedError):
+        P.resample_bilinear_gdal(img, 80, 60)
+
+
 def _scene(tmp_path, rng, same_grid):
     """An RGBI image (0.2 m) and an nDSM (1 m, or the RGBI grid) with blob crowns of known height, plus crowns."""
     H = W = 300
@@ -137,7 +165,8 @@ def test_postprocess_stage_end_to_end(tmp_path):
               "containment_threshold": 0.9, "height_threshold": 3, "ndvi_mean_threshold": 0.2, "ndvi_var_threshold": 0.5,
               "use_overlap": False, "tile_width": 50, "tile_height": 50, "buffer": 10, "overlapping_tiles_width": 3,
               "overlapping_tiles_height": 3, "device": "0", "parallel": False, "exclude_files": [],
-              "confidence_threshold_stitching": 0.3, "timestamped_output_directory": False}
+              "confidence_threshold_stitching": 0.3, "timestamped_output_directory": False,
+              "ndvi_scaling_factor": 1.0, "height_scaling_factor": 1.0}
     import treedetection_amd as T
     T.postprocess_files(config)
     rings, cols, srs = gpkg.read_polygons(str(pred / "processed_3241.gpkg"))
@@ -202,6 +231,7 @@ def test_containment_rules_as_in_the_reference(tmp_path):
     assert set(got) == {"two_a", "two_b", "three_a", "three_b", "three_c", "alone"}
     assert got["two_a"]["is_contained"] == "True" and got["alone"]["is_contained"] == "False" and got["alone"]["num_contained"] == 0
     assert all(p["TreeHeight"] == 12.0 for p in got.values()) and got["alone"]["Area"] == pytest.approx(36.0)
-    # defaults for the keys the reference leaves undefined: scaling 1 (anything else is refused), NDVI filter off
+    # the config above has no scaling keys: the NDVI raster was decimated by the documented default 0.2 (400 → 80 px);
+    # magnification is not restated
     with pytest.raises(NotImplementedError):
-        P.process_layer([crowns["alone"]], [0.9], dict(config, ndvi_scaling_factor=0.5), str(tmp_path / "ndsm" / "7.tif"), str(tmp_path / "img" / "7.tif"))
+        P.process_layer([crowns["alone"]], [0.9], dict(config, ndvi_scaling_factor=2.0), str(tmp_path / "ndsm" / "7.tif"), str(tmp_path / "img" / "7.tif"))

@@ -7,8 +7,9 @@ What runs where: the per-crown raster statistics — in the reference a cupy tes
 are one launch of ``td_crown_stats`` per raster (libtreedet_hip.so; a workgroup per crown over its circle's bounding
 box, same membership arithmetic); the N x N box filters and the selection rules are small host numpy, written to follow
 the reference line by line *including* its quirks, which are listed in DESIGN.md §7 and marked ``# ref:`` below.
-Not reproduced: reading the rasters through GDAL's bilinear decimation (``height_scaling_factor`` /
-``ndvi_scaling_factor`` other than 1 raise), fiona's schema handling (the layer is written by
+GDAL's bilinear decimation of the rasters (``ndvi_scaling_factor`` 0.2 in the example config) is restated from its
+published algorithm (:func:`resample_bilinear_gdal`). Not reproduced: magnification (factors above 1 raise), fiona's
+schema handling (the layer is written by
 :mod:`treedetection_amd.gpkg`), and cupy's float32 reduction order for mean / variance / centroid (accumulated in
 float64, rounded once). The reference holds no fixture for this stage: parity is unpinned (oracle/postprocess_ref.py).
 """
@@ -29,8 +30,10 @@ from .geotiff import GeoTiff
 from .gpkg import polygon_blob, read_layer, write_blobs
 from .stitching import simplify_ring
 
-DEFAULTS = {"height_scaling_factor": 1.0, "ndvi_scaling_factor": 1.0,
-            # the reference gives these two no default (postprocessing.py:612 would raise); neutral values = filter off
+# config.py of the reference defaults none of these four (the stage raises AttributeError without them); its
+# example/config.yml sets them and documents 0.2 / 1.0 as the scaling defaults. The NDVI thresholds have no documented
+# default: neutral values (filter off) are used when the keys are absent.
+DEFAULTS = {"height_scaling_factor": 1.0, "ndvi_scaling_factor": 0.2,
             "ndvi_mean_threshold": -1.0, "ndvi_var_threshold": float("inf")}
 
 
@@ -59,6 +62,46 @@ def _window(transform, n_rows, n_cols, bounds) -> Tuple[int, int, int, int]:
     c_lo, c_hi = sorted([min(c_a, n_cols - 1), max(c_b, 0)])
     r_lo, r_hi = sorted([min(r_a, n_rows - 1), max(r_b, 0)])
     return r_lo, c_lo, r_hi, c_hi
+
+
+def _decimation_weights(n_src: int, n_dst: int):
+    """Taps of GDAL's convolution resampler for a bilinear (triangle) kernel when shrinking n_src → n_dst pixels
+    (gcore/overview.cpp GDALResampleChunk_Convolution: kernel radius 1 stretched by the decimation ratio, weights
+    1 - |d| with d in destination-pixel units, normalised over the taps that fall inside the raster)."""
+    scale = n_dst / n_src
+    radius = 1.0 / scale
+    rows = []
+    for j in range(n_dst):
+        centre = (j + 0.5) / scale
+        start = max(int(math.floor(centre - radius + 0.5)), 0)
+        stop = min(int(centre + radius + 0.5), n_src)
+        idx = np.arange(start, stop)
+        w = np.maximum(0.0, 1.0 - np.abs(scale * (idx - centre + 0.5)))
+        rows.append((idx, w / w.sum()))
+    return rows
+
+
+def resample_bilinear_gdal(arr: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """``src.read(out_shape=(bands, out_h, out_w), resampling=Resampling.bilinear)`` for a SMALLER out_shape
+    (reference postprocessing.py:781-797 with a scaling factor below 1): separable triangle-filter decimation as GDAL's
+    RasterIO performs it, float32 working type, integer rasters rounded half up and clamped. Same shape = plain copy.
+    GDAL is not available here: restated from its published source, unpinned."""
+    bands, h, w = arr.shape
+    if (out_h, out_w) == (h, w):
+        return arr
+    if out_h > h or out_w > w or out_h < 1 or out_w < 1:
+        raise NotImplementedError("scaling factors above 1 (GDAL bilinear magnification) are not restated")
+    work = arr.astype(np.float32)
+    tmp = np.empty((bands, h, out_w), np.float32)
+    for j, (idx, wgt) in enumerate(_decimation_weights(w, out_w)):
+        tmp[:, :, j] = work[:, :, idx] @ wgt.astype(np.float32)
+    out = np.empty((bands, out_h, out_w), np.float32)
+    for i, (idx, wgt) in enumerate(_decimation_weights(h, out_h)):
+        out[:, i, :] = np.tensordot(wgt.astype(np.float32), tmp[:, idx, :], axes=([0], [1]))
+    if np.issubdtype(arr.dtype, np.integer):
+        info = np.iinfo(arr.dtype)
+        return np.clip(np.floor(out + 0.5), info.min, info.max).astype(arr.dtype)
+    return out.astype(arr.dtype)
 
 
 def ndvi_from_rgbi(rgbi: np.ndarray) -> np.ndarray:
@@ -175,8 +218,7 @@ def process_layer(rings: List[np.ndarray], scores: Sequence[Optional[float]], co
     """process_geojson + process_features (postprocessing.py:722-808, 478-720) for the crowns of one image → the list
     of output features ``{"ring": [m,2], "properties": {...}}`` in the reference's order (duplicates included)."""
     conf_thr, iou_thr, area_thr = _cfg(config, "confidence_threshold"), _cfg(config, "iou_threshold"), _cfg(config, "area_threshold")
-    if _cfg(config, "height_scaling_factor") != 1 or _cfg(config, "ndvi_scaling_factor") != 1:
-        raise NotImplementedError("height_scaling_factor / ndvi_scaling_factor other than 1 need GDAL's bilinear decimation")
+    h_scale, n_scale = float(_cfg(config, "height_scaling_factor")), float(_cfg(config, "ndvi_scaling_factor"))
     # 1-2: confidence filter, ids, areas of the simplify(2) polygons
     feats = []
     for ring, sc in zip(rings, scores):
@@ -190,13 +232,20 @@ def process_layer(rings: List[np.ndarray], scores: Sequence[Optional[float]], co
         return []
     id_to_area = {f["poly_id"]: f["area"] for f in feats}
     feats = [f for f in feats if area_thr <= f["area"] <= 1000]
-    # rasters (scaling factor 1: the arrays as they are in the files)
+    # rasters, decimated by the scaling factors (postprocessing.py:780-797): transform scaled by src / out size
     hg = GeoTiff(height_path)
-    height = hg.read()[0].astype(np.float32)
-    h_t, h_b = hg.transform, hg.bounds                    # bounds: left, bottom, right, top
+    hraw = hg.read()[:1]
+    height = resample_bilinear_gdal(hraw, int(hg.height * h_scale), int(hg.width * h_scale))[0].astype(np.float32)
+    h_t = (hg.transform[0] * (hg.width / height.shape[1]), hg.transform[1], hg.transform[2],
+           hg.transform[3], hg.transform[4] * (hg.height / height.shape[0]), hg.transform[5])
+    h_b = hg.bounds                                       # bounds: left, bottom, right, top
     rg = GeoTiff(rgbi_path)
-    ndvi = ndvi_from_rgbi(rg.read()).astype(np.float32)
-    n_t, n_b = rg.transform, rg.bounds
+    rraw = rg.read()
+    rgbi = resample_bilinear_gdal(rraw, int(rg.height * n_scale), int(rg.width * n_scale))
+    ndvi = ndvi_from_rgbi(rgbi).astype(np.float32)
+    orig_t = rg.transform
+    n_t = (orig_t[0] * (rg.width / ndvi.shape[1]), orig_t[1], orig_t[2], orig_t[3], orig_t[4] * (rg.height / ndvi.shape[0]), orig_t[5])
+    n_b = rg.bounds
     hg.close()
     rg.close()
     # 3: box-IoU / area de-duplication
@@ -230,7 +279,8 @@ def process_layer(rings: List[np.ndarray], scores: Sequence[Optional[float]], co
             if _near_border(pb, n_b, 1.0):
                 continue
             img_h, img_w = ndvi.shape
-            sx, sy = abs(n_t[0]), abs(n_t[4])
+            sx, sy = abs(orig_t[0]), abs(orig_t[4])      # ref: the ORIGINAL image's pixel size, while img_h / img_w are
+                                                         # the decimated NDVI raster's — kept as in the reference
             v_merged_h = ((config["tile_height"] + 2 * config["buffer"]) * config["overlapping_tiles_height"]) * sy
             h_merged_w = ((config["tile_width"] + 2 * config["buffer"]) * config["overlapping_tiles_width"]) * sx
             if not (img_h == v_merged_h or img_w == h_merged_w):
