@@ -27,6 +27,25 @@ from .geotiff import GeoTiff
 from .weights import load_checkpoint
 
 
+TILE_TABLE_VERSION = 3      # bump when the tile ids of csrc/conv_igemm.hip:dispatch() change meaning
+
+
+def _tune_cache_path(device_index: int) -> str:
+    try:
+        name = torch.cuda.get_device_name(device_index).replace(" ", "_").replace("/", "_")
+    except Exception:
+        name = "gpu"
+    base = os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "treedetection_amd")
+    try:
+        os.makedirs(base, exist_ok=True)
+        if not os.access(base, os.W_OK):
+            raise OSError(base)
+    except OSError:
+        import tempfile
+        base = tempfile.mkdtemp(prefix="td_tune_")
+    return os.path.join(base, f"tile_choices_v{TILE_TABLE_VERSION}_{name}.txt")
+
+
 class _Slot:
     """Buffers of one in-flight batch: pinned tile staging + its device copy, the engine's device outputs and their
     pinned host copies, and the event that marks the copies complete. A slot goes reader → launcher → epilogue
@@ -134,10 +153,11 @@ class Predictor:
                         pre_nms_topk=cfg.MODEL.RPN.PRE_NMS_TOPK_TEST, post_nms_topk=cfg.MODEL.RPN.POST_NMS_TOPK_TEST,
                         detections_per_image=cfg.TEST.DETECTIONS_PER_IMAGE)
         self.pipeline = bool(pipeline) and D.world() == 1
-        if self.pipeline and "TD_TUNE_CACHE" not in os.environ:
-            # the engines of one process share their measured block-tile choices through this file
-            import tempfile
-            os.environ["TD_TUNE_CACHE"] = os.path.join(tempfile.mkdtemp(prefix="td_tune_"), "tiles.txt")
+        if "TD_TUNE_CACHE" not in os.environ:
+            # Measured block-tile choices are shared between the engines of this process and kept for later runs (the
+            # first forward of a fresh process otherwise spends ~1.5 s timing tile variants per engine). The file is
+            # keyed by GPU name and the library's tile-table version; an unwritable cache directory just means no reuse.
+            os.environ["TD_TUNE_CACHE"] = _tune_cache_path(self.device_index)
         self.engine = Engine(sd, **eng_args)
         self._engines = [self.engine] + ([Engine(sd, **eng_args) for _ in range(2)] if self.pipeline else [])
         workers = host_workers or max(2, min(16, len(os.sched_getaffinity(0)) - 2))
