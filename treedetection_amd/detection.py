@@ -187,12 +187,21 @@ def postprocess_files(config):
 
 
 def cleanup_files(config):
-    if not config.get("keep_intermediate", False):
-        shutil.rmtree(config["tiles_path"], ignore_errors=True)
-        for folder in os.listdir(config["output_directory"]):
-            p = os.path.join(config["output_directory"], folder)
-            if os.path.isdir(p) and folder != "logs":
-                shutil.rmtree(p, ignore_errors=True)
+    """Reference detection.py:375-399: unless ``keep_intermediate``, remove the tile metadata, the seam-strip folders
+    next to the rasters, stray ``__`` files, and every sub-folder of the output directory except ``logs``."""
+    if config.get("keep_intermediate", False):
+        return
+    for path in (config["tiles_path"], os.path.join(config["image_directory"], config["merged_path"]),
+                 os.path.join(config["height_data_path"], config["merged_path"])):
+        shutil.rmtree(path, ignore_errors=True)
+    for key in ("image_directory", "height_data_path"):
+        for name in os.listdir(config[key]):
+            if "__" in name:
+                os.remove(os.path.join(config[key], name))
+    for folder in os.listdir(config["output_directory"]):
+        p = os.path.join(config["output_directory"], folder)
+        if os.path.isdir(p) and folder != "logs":
+            shutil.rmtree(p, ignore_errors=True)
 
 
 def process_files(config):
