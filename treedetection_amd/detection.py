@@ -42,33 +42,35 @@ def predict_on_model(config, model_path, tiles_path, output_path, batch_size=10,
                           exclude_vars=exclude_vars, precision=config.get("precision", "fp32"),
                           return_predictions=False,       # the files are the product; the list is unused here
                           pipeline=config.get("pipeline", True))
-    images_directory = Path(config["image_directory"])
-    images_paths = sorted(str(f) for f in images_directory.glob("*.tif"))
-    merged_directory = Path(f"{images_directory}/{config['merged_path']}")
-    images_paths.extend(sorted(str(f) for f in merged_directory.glob("*.tif")))
-    if not images_paths:
-        logger.warning("No TIF files found for prediction.")
-        return
-    file_list, processed_files = load_prediction_recovery_data(output_path, tiles_path, model_path, logger, exclude_vars)
-    if not file_list:
-        images_paths = [f for f in images_paths if f not in processed_files]
-    if not images_paths:
-        logger.info("All files have already been predicted. Exiting Prediction.")
-        return
-    total = len(images_paths)
-    for i, fp in enumerate(images_paths):
-        cur, prev = int(100 * (i + 1) / total), int(100 * i / total)
-        if logger and ((cur // 5) != (prev // 5) or cur == 100 or i == 0):
-            logger.info(f"Predicting file {i + 1}/{total} ({cur}%)")
-        tile_json = os.path.join(tiles_path, os.path.basename(fp).replace(".tif", ".json"))
-        try:
-            predictor(fp, tile_json)
-        except Exception as e:
-            logger.error(f"Error processing {fp}: {e}")
-    predictor.close()
-    logger.info(f"Completed prediction for {len(images_paths)} images.")
-    if D.rank() == 0:
-        save_prediction_recovery_data(output_path, tiles_path, model_path, processed_files, images_paths)
+    try:
+        images_directory = Path(config["image_directory"])
+        images_paths = sorted(str(f) for f in images_directory.glob("*.tif"))
+        merged_directory = Path(f"{images_directory}/{config['merged_path']}")
+        images_paths.extend(sorted(str(f) for f in merged_directory.glob("*.tif")))
+        if not images_paths:
+            logger.warning("No TIF files found for prediction.")
+            return
+        file_list, processed_files = load_prediction_recovery_data(output_path, tiles_path, model_path, logger, exclude_vars)
+        if not file_list:
+            images_paths = [f for f in images_paths if f not in processed_files]
+        if not images_paths:
+            logger.info("All files have already been predicted. Exiting Prediction.")
+            return
+        total = len(images_paths)
+        for i, fp in enumerate(images_paths):
+            cur, prev = int(100 * (i + 1) / total), int(100 * i / total)
+            if logger and ((cur // 5) != (prev // 5) or cur == 100 or i == 0):
+                logger.info(f"Predicting file {i + 1}/{total} ({cur}%)")
+            tile_json = os.path.join(tiles_path, os.path.basename(fp).replace(".tif", ".json"))
+            try:
+                predictor(fp, tile_json)
+            except Exception as e:
+                logger.error(f"Error processing {fp}: {e}")
+        logger.info(f"Completed prediction for {len(images_paths)} images.")
+        if D.rank() == 0:
+            save_prediction_recovery_data(output_path, tiles_path, model_path, processed_files, images_paths)
+    finally:
+        predictor.close()
 
 
 def _stitch(config, pred_dir, out_dir):
