@@ -243,3 +243,24 @@ def test_compressed_tiled_raster_gives_the_same_predictions(tmp_path):
         outs[tag] = {f: open(d / "out" / "9" / f, "rb").read().replace(tif.encode(), b"IMG") for f in files}
         assert len(files) == 9 and sum(len(json.loads(v)) for v in outs[tag].values()) == len(res) > 5
     assert outs["raw"] == outs["deflate"] == outs["deflate_plain"]
+
+
+def test_predictor_fp16_engine_end_to_end(tmp_path):
+    """config ``precision: fp16``: the same Predictor flow on the fp16 engine; per tile about the same crowns as fp32
+    (engine-level tolerances: tests/test_engine_fp16_gpu.py)."""
+    import treedetection_amd as T
+    from treedetection_amd.preprocessing import tile_single_file
+    sd = make_synthetic_state_dict(50, seed=3)          # full width: the fp16 kernels need Cin % 64 == 0
+    rgb, _ = make_tile(301, 500)
+    tif = str(tmp_path / "5.tif")
+    write_geotiff(tif, np.ascontiguousarray(rgb.transpose(2, 0, 1)), (0.2, 0.0, 412000.0, 0.0, -0.2, 5318100.0), 25832)
+    tile_single_file(tif, str(tmp_path / "tiles"), buffer=10, tile_width=40, tile_height=40)
+    counts = {}
+    for prec in ("fp32", "fp16"):
+        cfg = T.setup_model_cfg(update_model="x", device="0")
+        with T.Predictor(cfg, device_type="0", max_batch_size=4, output_dir=str(tmp_path / prec), state_dict=sd, precision=prec) as pred:
+            pred(tif, str(tmp_path / "tiles" / "5.json"))
+        counts[prec] = {f: len(json.load(open(tmp_path / prec / "5" / f))) for f in sorted(os.listdir(tmp_path / prec / "5"))}
+    assert counts["fp32"].keys() == counts["fp16"].keys() and sum(counts["fp32"].values()) > 5
+    a, b = sum(counts["fp32"].values()), sum(counts["fp16"].values())
+    assert abs(a - b) <= max(3, 0.15 * a), (a, b)
