@@ -172,6 +172,22 @@ td_status td_paste_masks_batch(const float* mask_probs, const float* boxes, cons
                                int batch, int dets_per_image, float thresh, int32_t* mask_region, int64_t* mask_offset,
                                uint32_t* mask_bits, int64_t mask_words_per_image, void* stream);
 
+/* Border following ON THE DEVICE for the packed masks of a batch (same contours, order and points as
+ * td_find_contours on each detection's region; prediction.py:232-236). Inputs: the mask_region / mask_offset /
+ * mask_bits / count arrays of td_detections (device). Outputs (device, caller-allocated):
+ *   points        int16 [batch][points_cap][2]   (x, y) in tile pixels
+ *   image_points  int32 [batch]                  points allocated per image (may exceed points_cap: see status 4)
+ *   det_info      int32 [batch][D][4]            status, contour count, first point, total points of the detection
+ *   contour_info  int32 [batch][D][TD_CONTOUR_MAX][2]   per contour in RETR_TREE order: (point offset inside the
+ *                                                detection's block, number of points)
+ * status: 0 traced; 1 region larger than the on-chip label image; 2 more than TD_CONTOUR_MAX contours; 4 point
+ * buffer full — such detections are left to td_find_contours on the host. Asynchronous on `stream`. */
+#define TD_CONTOUR_MAX 64
+td_status td_trace_contours_dev(const int32_t* mask_region, const int64_t* mask_offset, const uint32_t* mask_bits,
+                                int64_t mask_words_per_image, const int32_t* counts, int batch, int dets_per_image,
+                                int16_t* points, int points_cap, int32_t* image_points, int32_t* det_info,
+                                int32_t* contour_info, void* stream);
+
 /* ---- host-side epilogue (reference prediction.py:232-245, utilities.py:182-207) ------------- */
 /* Border following on a binary image (row-major uint8, non-zero = foreground) equivalent to
  * cv2.findContours(RETR_TREE / RETR_LIST ordering, CHAIN_APPROX_SIMPLE): writes contour points as

@@ -72,6 +72,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "td_crown_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p, C.c_int,
                                  C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "td_trace_contours_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "td_find_contours": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "td_tiff_lzw_decode": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
     "td_tiff_packbits_decode": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
