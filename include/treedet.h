@@ -182,7 +182,7 @@ td_status td_paste_masks_batch(const float* mask_probs, const float* boxes, cons
  *                                                detection's block, number of points)
  * status: 0 traced; 1 region larger than the on-chip label image; 2 more than TD_CONTOUR_MAX contours; 4 point
  * buffer full — such detections are left to td_find_contours on the host. Asynchronous on `stream`. */
-#define TD_CONTOUR_MAX 64
+#define TD_CONTOUR_MAX 256
 td_status td_trace_contours_dev(const int32_t* mask_region, const int64_t* mask_offset, const uint32_t* mask_bits,
                                 int64_t mask_words_per_image, const int32_t* counts, int batch, int dets_per_image,
                                 int16_t* points, int points_cap, int32_t* image_points, int32_t* det_info,
@@ -217,6 +217,15 @@ int64_t td_tiff_packbits_decode(const uint8_t* src, int64_t n, uint8_t* dst, int
 /* Undo TIFF predictor 2 (horizontal differencing) in place on one decoded block of rows x cols pixels with
  * `samples` interleaved samples of 1, 2 or 4 bytes (host byte order). */
 int td_tiff_unpredict(void* data, int64_t rows, int64_t cols, int samples, int bytes_per_sample);
+
+/* The same file text from contours traced on the device: points / det_info / contour_info are ONE image's slices of the
+ * td_trace_contours_dev outputs, copied to the host. Detections the device left to the host (status != 0) are traced
+ * from mask_bits as above; when such a detection exists and mask_bits is NULL the call returns TD_ERR_STATE and the
+ * caller repeats it with the image's mask rows. Byte-identical to td_tile_polygons_json on the same masks. */
+int td_tile_polygons_json_dev(const int16_t* points, int64_t points_cap, const int32_t* det_info, const int32_t* contour_info,
+                              const int32_t* mask_region, const int64_t* mask_offset, const uint32_t* mask_bits,
+                              int64_t mask_words, const float* scores, const int32_t* classes, int n,
+                              const double* transform, const char* image_id, char* buf, int64_t cap, int64_t* needed);
 
 /* ---- stitching consumer of the prediction files (reference helpers.py:419-476) -------------- */
 /* `geometry.simplify(tolerance, preserve_topology=True)` (helpers.py:464-465) for one closed shell ring:

@@ -14,7 +14,7 @@ from treedetection_amd import _lib  # noqa: E402
 from treedetection_amd.contours import find_contours  # noqa: E402
 
 pytestmark = pytest.mark.gpu
-CMAX = 64
+CMAX = 256
 
 
 def _pack(masks_per_image, Dn):
@@ -130,3 +130,29 @@ def test_limits_are_flagged_not_mis_traced():
     assert det_info[0, :, 0].tolist() == [1, 2, 0] and traced == 1
     det_info, _ = _check([[(0, 0, ok), (0, 0, ok)]], Dn=2, pts_cap=int(sum(len(c) for c in find_contours(ok.astype(np.uint8))) + 3))
     assert sorted(det_info[0, :, 0].tolist()) == [0, 4]               # the second block does not fit the point buffer
+
+
+def test_json_from_device_contours_is_bytewise_the_host_path():
+    """td_tile_polygons_json_dev on the traced points == td_tile_polygons_json on the packed rows, including tiles where
+    some detections were left to the host tracer (then the mask rows must be supplied)."""
+    from treedetection_amd.contours import tile_polygons_json, tile_polygons_json_dev
+    rng = np.random.default_rng(3)
+    many = np.zeros((30, 90), bool)
+    many[::2, ::2] = True
+    images = [[(int(rng.integers(0, 300)), int(rng.integers(0, 300)), _blob(rng, int(rng.integers(5, 120)), int(rng.integers(5, 120)))) for _ in range(9)],
+              [(10, 20, _blob(rng, 50, 70)), (40, 40, many), (0, 0, _blob(rng, 180, 190))]]
+    Dn = 9
+    region, offset, bits, counts = _pack(images, Dn)
+    pts, img_pts, det_info, cont_info = _trace(images, Dn=Dn)
+    t = (0.2, 0.0, 412000.0, 0.0, -0.2, 5319000.0)
+    for b, dets in enumerate(images):
+        n = len(dets)
+        scores = rng.random(n).astype(np.float32)
+        classes = np.zeros(n, np.int32)
+        want = tile_polygons_json(region[b], offset[b], bits[b].view(np.int32), scores, classes, t, "img.tif")
+        flagged = (det_info[b, :n, 0] != 0).any()
+        got = tile_polygons_json_dev(pts[b], det_info[b], cont_info[b], region[b], offset[b], None, scores, classes, t, "img.tif")
+        assert (got is None) == bool(flagged)
+        got = tile_polygons_json_dev(pts[b], det_info[b], cont_info[b], region[b], offset[b], bits[b].view(np.int32), scores, classes, t, "img.tif")
+        assert got == want and len(want) > 2
+    assert (det_info[1, :3, 0] != 0).sum() == 2 and (det_info[0, :, 0] == 0).all()

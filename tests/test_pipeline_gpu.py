@@ -221,7 +221,7 @@ def test_process_files_end_to_end_with_overlap(tmp_path):
 def test_compressed_tiled_raster_gives_the_same_predictions(tmp_path):
     """The same image stored as one raw strip (memory-mapped windows) and as DEFLATE-compressed 64x64 tiles with the
     horizontal predictor (block decode + cache in the reader thread): byte-identical prediction files, for the plain
-    and the pipelined launcher."""
+    and the pipelined launcher, with the borders followed on the host or on the GPU (``device_contours``)."""
     import treedetection_amd as T
     from treedetection_amd.preprocessing import tile_single_file
     sd = make_synthetic_state_dict(50, seed=3, width_div=2)
@@ -229,20 +229,22 @@ def test_compressed_tiled_raster_gives_the_same_predictions(tmp_path):
     rgbi = np.ascontiguousarray(np.concatenate([rgb, rgb[..., 1:2]], axis=2).transpose(2, 0, 1))
     t = (0.2, 0.0, 412000.0, 0.0, -0.2, 5318100.0)
     outs = {}
-    for tag, kw, pipe in (("raw", {}, True), ("deflate", {"tile": (64, 64), "compression": "deflate", "predictor": 2}, True),
-                          ("deflate_plain", {"tile": (64, 64), "compression": "deflate", "predictor": 2}, False)):
+    for tag, kw, pipe, devc in (("raw", {}, True, False), ("deflate", {"tile": (64, 64), "compression": "deflate", "predictor": 2}, True, False),
+                                ("deflate_plain", {"tile": (64, 64), "compression": "deflate", "predictor": 2}, False, False),
+                                ("gpu_contours", {}, True, True), ("gpu_contours_plain", {}, False, True)):
         d = tmp_path / tag
         (d / "rgb").mkdir(parents=True)
         tif = str(d / "rgb" / "9.tif")
         write_geotiff(tif, rgbi, t, 25832, **kw)
         tile_single_file(tif, str(d / "tiles"), buffer=10, tile_width=40, tile_height=40)
         cfg = T.setup_model_cfg(update_model="x", device="0")
-        with T.Predictor(cfg, device_type="0", max_batch_size=3, output_dir=str(d / "out"), state_dict=sd, pipeline=pipe) as pred:
+        with T.Predictor(cfg, device_type="0", max_batch_size=3, output_dir=str(d / "out"), state_dict=sd, pipeline=pipe,
+                         device_contours=devc) as pred:
             res = pred(tif, str(d / "tiles" / "9.json"))
         files = sorted(os.listdir(d / "out" / "9"))
         outs[tag] = {f: open(d / "out" / "9" / f, "rb").read().replace(tif.encode(), b"IMG") for f in files}
         assert len(files) == 9 and sum(len(json.loads(v)) for v in outs[tag].values()) == len(res) > 5
-    assert outs["raw"] == outs["deflate"] == outs["deflate_plain"]
+    assert outs["raw"] == outs["deflate"] == outs["deflate_plain"] == outs["gpu_contours"] == outs["gpu_contours_plain"]
 
 
 def test_predictor_fp16_engine_end_to_end(tmp_path):

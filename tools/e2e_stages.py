@@ -9,7 +9,7 @@ from treedetection_amd.preprocessing import tile_data
 from treedetection_amd.synth import make_tile
 from treedetection_amd.weights import make_synthetic_state_dict
 
-def main(size=5000, depth=50, batch=16, precision="fp32"):
+def main(size=5000, depth=50, batch=16, precision="fp32", device_contours=False):
     root = tempfile.mkdtemp(prefix="e2e_")
     os.makedirs(f"{root}/rgb")
     base, _ = make_tile(0, 1000)
@@ -21,7 +21,8 @@ def main(size=5000, depth=50, batch=16, precision="fp32"):
     ntiles = len(json.load(open(f"{root}/tiles/324125317.json")))
     cfg = T.setup_model_cfg(update_model="x", device="0")
     pred = T.Predictor(cfg, device_type="0", max_batch_size=batch, output_dir=f"{root}/out", precision=precision,
-                       state_dict=make_synthetic_state_dict(depth, seed=0), return_predictions=False)
+                       state_dict=make_synthetic_state_dict(depth, seed=0), return_predictions=False,
+                       device_contours=device_contours)
     for rep in range(3):
         t0 = time.time()
         pred(tif, f"{root}/tiles/324125317.json")
@@ -33,4 +34,4 @@ def main(size=5000, depth=50, batch=16, precision="fp32"):
     pred.close()
 
 if __name__ == "__main__":
-    main(precision=sys.argv[1] if len(sys.argv) > 1 else "fp32")
+    main(precision=sys.argv[1] if len(sys.argv) > 1 else "fp32", device_contours=len(sys.argv) > 2 and sys.argv[2] == "gpu_contours")

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libtreedet_hip.so")
 
 _lib: Optional[C.CDLL] = None
 ERR_CAPACITY = -4   # TD_ERR_CAPACITY
+ERR_STATE = -5      # TD_ERR_STATE
 
 
 class TdError(RuntimeError):
@@ -82,6 +83,9 @@ SIGNATURES = {
     "td_simplify_ring": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int]),
     "td_stitch_tile_json": (C.c_int, [C.c_char_p, C.c_int64, C.POINTER(C.c_double), C.c_double, C.c_int32, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "td_tile_polygons_json_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                            C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_void_p, C.c_int64,
+                                            C.POINTER(C.c_int64)]),
     "td_tile_polygons_json": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
                                         C.POINTER(C.c_double), C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
 }

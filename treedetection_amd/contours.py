@@ -60,3 +60,37 @@ def tile_polygons_json(regions: np.ndarray, offsets: np.ndarray, bits: np.ndarra
             continue
         _lib.check(st, "td_tile_polygons_json")
         return buf.raw[: need.value]
+
+
+def tile_polygons_json_dev(points: np.ndarray, det_info: np.ndarray, contour_info: np.ndarray, regions: np.ndarray,
+                           offsets: np.ndarray, bits, scores: np.ndarray, classes: np.ndarray, transform: Sequence[float],
+                           image_id: str):
+    """:func:`tile_polygons_json` from contours traced on the device (one image's slices of the td_trace_contours_dev
+    outputs, on the host). ``bits`` may be None; returns None when a detection was left to the host tracer and the mask
+    rows are needed — call again with them."""
+    lib = _lib.load()
+    n = int(len(scores))
+    points = np.ascontiguousarray(points, dtype=np.int16)
+    det_info = np.ascontiguousarray(det_info[:n], dtype=np.int32)
+    contour_info = np.ascontiguousarray(contour_info[:n], dtype=np.int32)
+    regions = np.ascontiguousarray(regions[:n], dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets[:n], dtype=np.int64)
+    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    classes = np.ascontiguousarray(classes[:n], dtype=np.int32)
+    words = None if bits is None else np.ascontiguousarray(bits).view(np.uint32).reshape(-1)
+    tr = (C.c_double * 6)(*[float(v) for v in transform[:6]])
+    need = C.c_int64(0)
+    cap = 1 << 20
+    while True:
+        buf = C.create_string_buffer(cap)
+        st = lib.td_tile_polygons_json_dev(points.ctypes.data, points.shape[0], det_info.ctypes.data, contour_info.ctypes.data,
+                                           regions.ctypes.data, offsets.ctypes.data, None if words is None else words.ctypes.data,
+                                           0 if words is None else words.size, scores.ctypes.data, classes.ctypes.data, n, tr,
+                                           image_id.encode("utf-8", "surrogateescape"), buf, cap, C.byref(need))
+        if st == _lib.ERR_CAPACITY:
+            cap = int(need.value)
+            continue
+        if st == _lib.ERR_STATE and words is None:
+            return None
+        _lib.check(st, "td_tile_polygons_json_dev")
+        return buf.raw[: need.value]

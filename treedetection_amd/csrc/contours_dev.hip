@@ -14,8 +14,9 @@
 
 namespace {
 
-constexpr int CMAX = 64;                 // contours per detection handled on the device (TD_CONTOUR_MAX)
-constexpr int LABEL_ELEMS = 30 * 1024;   // int16 label image: 60 KB of LDS → regions up to (h+2)*(w+2) <= 30720
+constexpr int CMAX = 256;                // contours per detection handled on the device (TD_CONTOUR_MAX)
+constexpr int LABEL_SMALL = 6 * 1024;    // int16 label images in LDS: 12 KB for crowns up to ~75 x 75 px (most of them),
+constexpr int LABEL_LARGE = 28 * 1024;   // 56 KB for regions up to (h+2)*(w+2) <= 28672; two launches, one per size class
 
 struct TraceArgs {
     const int32_t* region;      // [B][D][4]
@@ -77,6 +78,7 @@ __device__ int follow(int16_t* F, int step, const int* deltas, int i0, int x, in
     return -1;
 }
 
+template <int LABEL_ELEMS, int LABEL_MIN>
 __global__ __launch_bounds__(64) void contour_trace_kernel(const TraceArgs A) {
     const int d = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     int32_t* info = A.det_info + ((size_t)b * A.D + d) * 4;
@@ -91,8 +93,10 @@ __global__ __launch_bounds__(64) void contour_trace_kernel(const TraceArgs A) {
         return;
     }
     const int step = w + 2;
-    if ((long long)step * (h + 2) > LABEL_ELEMS) {
-        if (lane == 0) { info[0] = 1; info[1] = 0; info[2] = 0; info[3] = 0; }     // region too large for the LDS image
+    const long long need = (long long)step * (h + 2);
+    if (need <= LABEL_MIN) return;                   // the other size class handles (and reports) this detection
+    if (need > LABEL_ELEMS) {
+        if (LABEL_ELEMS == LABEL_LARGE && lane == 0) { info[0] = 1; info[1] = 0; info[2] = 0; info[3] = 0; }   // too large for LDS
         return;
     }
     __shared__ int16_t F[LABEL_ELEMS];
@@ -269,7 +273,9 @@ extern "C" td_status td_trace_contours_dev(const int32_t* mask_region, const int
     A.img_pts = image_points;
     A.det_info = det_info;
     A.cont_info = contour_info;
-    hipLaunchKernelGGL(contour_trace_kernel, dim3(dets_per_image, batch), dim3(64), 0, s, A);
+    hipLaunchKernelGGL((contour_trace_kernel<LABEL_SMALL, 0>), dim3(dets_per_image, batch), dim3(64), 0, s, A);
+    TD_KERNEL_CHECK();
+    hipLaunchKernelGGL((contour_trace_kernel<LABEL_LARGE, LABEL_SMALL>), dim3(dets_per_image, batch), dim3(64), 0, s, A);
     TD_KERNEL_CHECK();
     return TD_OK;
 }

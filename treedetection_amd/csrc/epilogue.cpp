@@ -121,15 +121,20 @@ void append_json_string(std::string& out, const char* s) {
 
 }  // namespace
 
-extern "C" int td_tile_polygons_json(const int32_t* mask_region, const int64_t* mask_offset, const uint32_t* mask_bits,
-                                     int64_t mask_words, const float* scores, const int32_t* classes, int n,
-                                     const double* transform, const char* image_id, char* buf, int64_t cap,
-                                     int64_t* needed) {
-    if (n < 0 || !transform || !image_id || !needed || (n > 0 && (!mask_region || !mask_offset || !mask_bits || !scores)) ||
-        (cap > 0 && !buf)) {
-        td_set_error("td_tile_polygons_json: bad argument");
-        return TD_ERR_INVALID;
-    }
+namespace {
+
+// Where the contours of one tile come from: the host tracer on the packed bit rows, or — for detections the device
+// tracer handled (status 0) — the points td_trace_contours_dev wrote (already in tile coordinates).
+struct DevContours {
+    const int16_t* points;       // this image's [points_cap][2]
+    int64_t points_cap;
+    const int32_t* det_info;     // [n][4] status, contour count, first point, total points
+    const int32_t* contour_info; // [n][TD_CONTOUR_MAX][2] (offset, count) in RETR_TREE order
+};
+
+int polygons_json_core(const int32_t* mask_region, const int64_t* mask_offset, const uint32_t* mask_bits, int64_t mask_words,
+                       const DevContours* dev, const float* scores, const int32_t* classes, int n, const double* transform,
+                       const char* image_id, char* buf, int64_t cap, int64_t* needed, const char* who) {
     const double a = transform[0], b = transform[1], c = transform[2], d = transform[3], e = transform[4], f = transform[5];
     // North-up rasters (b == d == 0, the usual case): x depends on the column only and y on the row only, so each
     // distinct column / row is converted to text once per tile and copied from then on (number formatting is
@@ -162,56 +167,111 @@ extern "C" int td_tile_polygons_json(const int32_t* mask_region, const int64_t* 
     out.reserve(1 << 16);
     out += '[';
     int entries = 0;
+    // one entry of the file: contour points (tile pixel corners) -> ring closed -> affine -> text
+    auto emit = [&](int k, int np, auto&& point) {
+        if (np < 4) return;
+        if (entries++) out += ", ";
+        out += "{\"image_id\": ";
+        out += id;
+        out += ", \"category_id\": ";
+        out += std::to_string(classes ? classes[k] : 0);
+        out += ", \"score\": ";
+        append_double(out, (double)scores[k]);
+        out += ", \"polygon_coords\": [[";
+        int fx, fy, lx, ly;
+        point(0, fx, fy);
+        point(np - 1, lx, ly);
+        const int total = np + ((fx == lx && fy == ly) ? 0 : 1);
+        for (int i = 0; i < total; ++i) {
+            int ic, ir;
+            point(i < np ? i : 0, ic, ir);
+            const double col = (double)ic, row = (double)ir;
+            const double gx = (a * col + b * row) + c;
+            const double gy = (d * col + e * row) + f;
+            if (i) out += ", ";
+            out += '[';
+            if (axis_aligned) cached(xcache, ic, gx, out);
+            else append_double(out, gx);
+            out += ", ";
+            if (axis_aligned) cached(ycache, ir, gy, out);
+            else append_double(out, gy);
+            out += ']';
+        }
+        out += "]]}";
+    };
     std::vector<int32_t> pts, starts;
     for (int k = 0; k < n; ++k) {
         const int x0 = mask_region[4 * k], y0 = mask_region[4 * k + 1], x1 = mask_region[4 * k + 2], y1 = mask_region[4 * k + 3];
         if (x1 <= x0 || y1 <= y0) continue;
+        if (dev && dev->det_info[4 * k] == 0) {                    // traced on the device
+            const int nc = dev->det_info[4 * k + 1];
+            const int64_t base = dev->det_info[4 * k + 2];
+            if (nc < 0 || nc > TD_CONTOUR_MAX || base < 0 || base + dev->det_info[4 * k + 3] > dev->points_cap) {
+                td_set_error("%s: detection %d has an inconsistent device contour record", who, k);
+                return TD_ERR_INVALID;
+            }
+            for (int ci = 0; ci < nc; ++ci) {
+                const int32_t* rec = dev->contour_info + ((size_t)k * TD_CONTOUR_MAX + ci) * 2;
+                const int16_t* p = dev->points + 2 * (base + rec[0]);
+                emit(k, rec[1], [&](int i, int& x, int& y) { x = p[2 * i]; y = p[2 * i + 1]; });
+            }
+            continue;
+        }
+        if (!mask_bits) {
+            td_set_error("%s: detection %d was left to the host tracer (device status %d) but no mask bits were passed", who, k,
+                         dev ? dev->det_info[4 * k] : -1);
+            return TD_ERR_STATE;
+        }
         const int w = x1 - x0, h = y1 - y0, wpr = (w + 31) / 32;
         const int64_t o = mask_offset[k];
         if (o < 0 || o + (int64_t)wpr * h > mask_words) {
-            td_set_error("td_tile_polygons_json: detection %d rows [%lld, +%lld) outside the %lld-word mask buffer", k,
-                         (long long)o, (long long)wpr * h, (long long)mask_words);
+            td_set_error("%s: detection %d rows [%lld, +%lld) outside the %lld-word mask buffer", who, k, (long long)o,
+                         (long long)wpr * h, (long long)mask_words);
             return TD_ERR_INVALID;
         }
         td_trace_contours_bits(mask_bits + o, wpr, h, w, pts, starts);
         const int nc = (int)starts.size() - 1;
         for (int ci = 0; ci < nc; ++ci) {
-            const int p0 = starts[ci], np = starts[ci + 1] - p0;
-            if (np < 4) continue;
-            if (entries++) out += ", ";
-            out += "{\"image_id\": ";
-            out += id;
-            out += ", \"category_id\": ";
-            out += std::to_string(classes ? classes[k] : 0);
-            out += ", \"score\": ";
-            append_double(out, (double)scores[k]);
-            out += ", \"polygon_coords\": [[";
-            const bool closed = pts[2 * p0] == pts[2 * (p0 + np - 1)] && pts[2 * p0 + 1] == pts[2 * (p0 + np - 1) + 1];
-            const int total = np + (closed ? 0 : 1);
-            for (int i = 0; i < total; ++i) {
-                const int j = p0 + (i < np ? i : 0);
-                const int ic = pts[2 * j] + x0, ir = pts[2 * j + 1] + y0;
-                const double col = (double)ic, row = (double)ir;
-                const double gx = (a * col + b * row) + c;
-                const double gy = (d * col + e * row) + f;
-                if (i) out += ", ";
-                out += '[';
-                if (axis_aligned) cached(xcache, ic, gx, out);
-                else append_double(out, gx);
-                out += ", ";
-                if (axis_aligned) cached(ycache, ir, gy, out);
-                else append_double(out, gy);
-                out += ']';
-            }
-            out += "]]}";
+            const int p0 = starts[ci];
+            emit(k, starts[ci + 1] - p0, [&](int i, int& x, int& y) { x = pts[2 * (p0 + i)] + x0; y = pts[2 * (p0 + i) + 1] + y0; });
         }
     }
     out += ']';
     *needed = (int64_t)out.size();
     if ((int64_t)out.size() > cap) {
-        td_set_error("td_tile_polygons_json: %lld bytes needed, capacity %lld", (long long)out.size(), (long long)cap);
+        td_set_error("%s: %lld bytes needed, capacity %lld", who, (long long)out.size(), (long long)cap);
         return TD_ERR_CAPACITY;
     }
     std::memcpy(buf, out.data(), out.size());
     return entries;
+}
+
+}  // namespace
+
+extern "C" int td_tile_polygons_json(const int32_t* mask_region, const int64_t* mask_offset, const uint32_t* mask_bits,
+                                     int64_t mask_words, const float* scores, const int32_t* classes, int n,
+                                     const double* transform, const char* image_id, char* buf, int64_t cap,
+                                     int64_t* needed) {
+    if (n < 0 || !transform || !image_id || !needed || (n > 0 && (!mask_region || !mask_offset || !mask_bits || !scores)) ||
+        (cap > 0 && !buf)) {
+        td_set_error("td_tile_polygons_json: bad argument");
+        return TD_ERR_INVALID;
+    }
+    return polygons_json_core(mask_region, mask_offset, mask_bits, mask_words, nullptr, scores, classes, n, transform, image_id, buf,
+                              cap, needed, "td_tile_polygons_json");
+}
+
+extern "C" int td_tile_polygons_json_dev(const int16_t* points, int64_t points_cap, const int32_t* det_info,
+                                         const int32_t* contour_info, const int32_t* mask_region, const int64_t* mask_offset,
+                                         const uint32_t* mask_bits, int64_t mask_words, const float* scores,
+                                         const int32_t* classes, int n, const double* transform, const char* image_id,
+                                         char* buf, int64_t cap, int64_t* needed) {
+    if (n < 0 || !transform || !image_id || !needed || (cap > 0 && !buf) ||
+        (n > 0 && (!points || !det_info || !contour_info || !mask_region || !scores || points_cap < 0))) {
+        td_set_error("td_tile_polygons_json_dev: bad argument");
+        return TD_ERR_INVALID;
+    }
+    const DevContours dev{points, points_cap, det_info, contour_info};
+    return polygons_json_core(mask_region, mask_offset, mask_bits, mask_words, &dev, scores, classes, n, transform, image_id, buf, cap,
+                              needed, "td_tile_polygons_json_dev");
 }

@@ -41,7 +41,7 @@ def predict_on_model(config, model_path, tiles_path, output_path, batch_size=10,
     predictor = Predictor(cfg, device_type=config["device"], max_batch_size=batch_size, output_dir=output_path,
                           exclude_vars=exclude_vars, precision=config.get("precision", "fp32"),
                           return_predictions=False,       # the files are the product; the list is unused here
-                          pipeline=config.get("pipeline", True))
+                          pipeline=config.get("pipeline", True), device_contours=config.get("device_contours", False))
     try:
         images_directory = Path(config["image_directory"])
         images_paths = sorted(str(f) for f in images_directory.glob("*.tif"))

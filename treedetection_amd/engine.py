@@ -220,6 +220,25 @@ class Engine:
         hw_out = [(int(t.shape[0]), int(t.shape[1])) for t in tiles]
         return batch, shapes, hw_out
 
+    CONTOUR_MAX = 256         # TD_CONTOUR_MAX
+
+    def alloc_contours(self, B: int, points_cap: int = 65536) -> Dict[str, torch.Tensor]:
+        """Device buffers of td_trace_contours_dev for a batch of B images."""
+        dev = torch.device("cuda", self.device)
+        return {"points": torch.empty((B, points_cap, 2), dtype=torch.int16, device=dev),
+                "image_points": torch.zeros((B,), dtype=torch.int32, device=dev),
+                "det_info": torch.zeros((B, self.D, 4), dtype=torch.int32, device=dev),
+                "contour_info": torch.empty((B, self.D, self.CONTOUR_MAX, 2), dtype=torch.int32, device=dev)}
+
+    def trace_contours(self, out: Dict[str, torch.Tensor], cont: Dict[str, torch.Tensor], B: int, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """td_trace_contours_dev on the pasted masks of ``out`` (first B images) — asynchronous on ``stream`` (default:
+        torch's current stream), to be enqueued after the forward's last phase."""
+        s = int(stream.cuda_stream) if stream is not None else _lib.stream_ptr()
+        _lib.check(self.lib.td_trace_contours_dev(out["mask_region"].data_ptr(), out["mask_offset"].data_ptr(), out["mask_bits"].data_ptr(),
+                                                  int(out["mask_bits"].shape[1]), out["count"].data_ptr(), B, self.D,
+                                                  cont["points"].data_ptr(), int(cont["points"].shape[1]), cont["image_points"].data_ptr(),
+                                                  cont["det_info"].data_ptr(), cont["contour_info"].data_ptr(), s), "td_trace_contours_dev")
+
     def paste_masks_batch(self, probs: torch.Tensor, boxes: torch.Tensor, counts: torch.Tensor, hw: Sequence[Sequence[int]],
                           out: Dict[str, torch.Tensor], thresh: float = 0.5) -> None:
         """td_paste_masks_batch: the first ``len(hw)`` images of probs [B,D,28,28] / boxes [B,D,4] / counts [B] (CUDA

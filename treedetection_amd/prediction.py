@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import distributed as D
-from .contours import find_contours, tile_polygons_json, xy
+from .contours import find_contours, tile_polygons_json, tile_polygons_json_dev, xy
 from .engine import Engine, INPUT_F32_CHW, INPUT_U8_HWC
 from .geotiff import GeoTiff
 from .weights import load_checkpoint
@@ -54,6 +54,7 @@ class _Slot:
     def __init__(self):
         self.pin_in = self.dev_in = None
         self.dev_out = self.pin_out = self.host = None
+        self.dev_cont = self.pin_cont = self.host_cont = None
         self.out_key = None
         self.event = torch.cuda.Event(blocking=True)
         self.pending = 0
@@ -65,7 +66,7 @@ class _Slot:
             self.dev_in = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         return self.pin_in.numpy()
 
-    def outputs(self, engine: Engine, B: int, h: int, w: int) -> Dict[str, torch.Tensor]:
+    def outputs(self, engine: Engine, B: int, h: int, w: int, device_contours: bool = False) -> Dict[str, torch.Tensor]:
         key = self.out_key
         if key is None or B > key[0] or h > key[1] or w > key[2]:
             key = (max(B, key[0]) if key else B, max(h, key[1]) if key else h, max(w, key[2]) if key else w)
@@ -73,6 +74,11 @@ class _Slot:
             self.pin_out = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in self.dev_out.items()}
             self.host = {k: v.numpy() for k, v in self.pin_out.items()}
             self.out_key = key
+            self.dev_cont = self.pin_cont = self.host_cont = None
+        if device_contours and self.dev_cont is None:
+            self.dev_cont = engine.alloc_contours(self.out_key[0])
+            self.pin_cont = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in self.dev_cont.items()}
+            self.host_cont = {k: v.numpy() for k, v in self.pin_cont.items()}
         return self.dev_out
 
 
@@ -124,10 +130,23 @@ class _Slot:
         return cur["np"]
 
 
+    def copy_results(self, n: int, device_contours: bool) -> None:
+        """Queues the D2H copies of what the host epilogue reads (current stream): with device contours the traced points
+        and records replace the packed mask rows (fetched only for detections the device tracer left to the host)."""
+        skip = ("mask_bits",) if device_contours else ()
+        for k, v in self.dev_out.items():
+            if k not in skip:
+                self.pin_out[k][:n].copy_(v[:n], non_blocking=True)
+        if device_contours:
+            for k, v in self.dev_cont.items():
+                self.pin_cont[k][:n].copy_(v[:n], non_blocking=True)
+
+
 class Predictor:
     def __init__(self, cfg, device_type="cpu", max_batch_size=5, output_dir="./output", exclude_vars=None,
                  precision: str = "fp32", state_dict: Optional[Dict[str, np.ndarray]] = None,
-                 return_predictions: bool = True, host_workers: Optional[int] = None, pipeline: bool = True):
+                 return_predictions: bool = True, host_workers: Optional[int] = None, pipeline: bool = True,
+                 device_contours: bool = False):
         """cfg from ``setup_model_cfg``; ``device_type`` = GPU index ("0", 0) as config["device"] carries it.
         ``state_dict`` lets tests and the bench inject weights instead of reading cfg.MODEL.WEIGHTS.
         ``return_predictions=False`` skips rebuilding the Python list ``__call__`` returns (the reference's own caller
@@ -145,6 +164,7 @@ class Predictor:
         self.output_dir = output_dir
         self.exclude_vars = exclude_vars or []
         self.return_predictions = return_predictions
+        self.device_contours = bool(device_contours) and D.world() == 1     # borders followed on the GPU (td_trace_contours_dev)
         os.makedirs(self.output_dir, exist_ok=True)
         sd = state_dict if state_dict is not None else load_checkpoint(cfg.MODEL.WEIGHTS)
         rh = cfg.MODEL.ROI_HEADS
@@ -296,11 +316,12 @@ class Predictor:
         """Forward + asynchronous copy of the packed results to pinned memory; the per-tile host epilogue is queued on
         the worker pool and waits on the slot's event, so this thread goes straight on to the next batch."""
         images, fmt, hw_valid, hw_out = self._to_model_input(batch, slot)
-        dev_out = slot.outputs(self.engine, len(batch), max(h for h, _ in hw_out), max(w for _, w in hw_out))
+        dev_out = slot.outputs(self.engine, len(batch), max(h for h, _ in hw_out), max(w for _, w in hw_out), self.device_contours)
         view = {k: v[: len(batch)] for k, v in dev_out.items()}     # leading-dim slices stay contiguous
         self.engine.forward_raw(images, fmt, hw_valid, hw_out, view)
-        for k, v in dev_out.items():
-            slot.pin_out[k][: len(batch)].copy_(v[: len(batch)], non_blocking=True)
+        if self.device_contours:
+            self.engine.trace_contours(view, slot.dev_cont, len(batch))
+        slot.copy_results(len(batch), self.device_contours)
         slot.event.record()
         slot.pending = len(batch)
         return [self._pool.submit(self._process_and_save_single, b, i, slot, pred_subdir, tifpath)
@@ -315,8 +336,16 @@ class Predictor:
             host = slot.host
             output_file = os.path.join(pred_subdir, f"Prediction_{os.path.basename(b['tile_id'])}.json")
             n = int(host["count"][i])
-            text = tile_polygons_json(host["mask_region"][i], host["mask_offset"][i], host["mask_bits"][i],
-                                      host["scores"][i][:n], host["classes"][i], b["meta"]["transform"], tifpath)
+            if self.device_contours:
+                hc = slot.host_cont
+                args = (hc["points"][i], hc["det_info"][i], hc["contour_info"][i], host["mask_region"][i], host["mask_offset"][i])
+                tail = (host["scores"][i][:n], host["classes"][i], b["meta"]["transform"], tifpath)
+                text = tile_polygons_json_dev(*args, None, *tail)
+                if text is None:        # a detection too large / too fragmented for the device tracer: fetch this tile's rows
+                    text = tile_polygons_json_dev(*args, slot.dev_out["mask_bits"][i].cpu().numpy(), *tail)
+            else:
+                text = tile_polygons_json(host["mask_region"][i], host["mask_offset"][i], host["mask_bits"][i],
+                                          host["scores"][i][:n], host["classes"][i], b["meta"]["transform"], tifpath)
             with open(output_file, "wb") as f:
                 f.write(text)
             res = json.loads(text) if self.return_predictions else []
@@ -369,7 +398,7 @@ class Predictor:
                 if phase == 0:
                     with torch.cuda.stream(main):      # allocations (and their fills) are ordered with the kernels
                         images, fmt, hw_valid, hw_out = self._to_model_input(batch, slot, eng)
-                        dev_out = slot.outputs(eng, len(batch), max(h for h, _ in hw_out), max(w for _, w in hw_out))
+                        dev_out = slot.outputs(eng, len(batch), max(h for h, _ in hw_out), max(w for _, w in hw_out), self.device_contours)
                     view = {k: v[: len(batch)] for k, v in dev_out.items()}
                     eng.forward_phase(0, main, images, fmt, hw_valid, hw_out, view)
                 else:
@@ -378,8 +407,9 @@ class Predictor:
                 item[2] = phase + 2
                 if item[2] == 6:        # all six phases are enqueued: results → pinned memory, epilogue tasks
                     with torch.cuda.stream(slot.side):
-                        for k, v in slot.dev_out.items():
-                            slot.pin_out[k][: len(batch)].copy_(v[: len(batch)], non_blocking=True)
+                        if self.device_contours:
+                            eng.trace_contours({k: v[: len(batch)] for k, v in slot.dev_out.items()}, slot.dev_cont, len(batch))
+                        slot.copy_results(len(batch), self.device_contours)
                         slot.event.record()
                     slot.pending = len(batch)
                     futures.extend(self._pool.submit(self._process_and_save_single, b, i, slot, pred_subdir, tifpath)
