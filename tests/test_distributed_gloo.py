@@ -77,3 +77,73 @@ def test_single_process_paths():
     assert D.world() == 1 and D.rank() == 0
     assert D.gather_detections(out)[0]["boxes"] is out["boxes"]
     assert D.gather_objects([1]) == [[1]]
+
+
+def _fs_worker(rank, world, port, root, q):
+    """File-system stages of process_files under 2 ranks (CPU only): preprocess_files writes on rank 0 alone and
+    hands every rank the same image list; the agreement helpers keep collective decisions paired."""
+    import logging
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = str(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from treedetection_amd import detection
+        config = {"image_directory": os.path.join(root, "rgb"), "height_data_path": os.path.join(root, "ndsm"),
+                  "tiles_path": os.path.join(root, "tiles"), "output_directory": os.path.join(root, "out"),
+                  "continue": os.path.join(root, "out", "continue.yml"), "use_overlap": False, "buffer": 10,
+                  "tile_width": 40, "tile_height": 40, "parallel": False, "num_workers": 2, "merged_path": "merged",
+                  "keep_intermediate": False, "logger": logging.getLogger(f"r{rank}")}
+        images = detection.preprocess_files(config)
+        # rank 0 has finished writing before any rank returns: the files are complete for everybody
+        import json
+        meta = json.load(open(os.path.join(root, "tiles", "7.json")))
+        assert len(meta) == 4 and images == [os.path.join(root, "rgb", "7.tif")]
+        assert D.all_ok(True) is True
+        assert D.all_ok(rank != 1) is False             # one rank's failure is everybody's
+        assert D.broadcast_object({"x": rank}) == {"x": 0}
+        # a failure on the writing rank surfaces on every rank (nobody is left waiting in a collective)
+        bad = dict(config, image_directory=os.path.join(root, "empty"))
+        try:
+            detection.preprocess_files(bad)
+            raised = False
+        except FileNotFoundError:
+            raised = True
+        assert raised
+        # cleanup: one rank removes, after everybody is done; afterwards the folders are gone for all
+        os.makedirs(config["output_directory"], exist_ok=True)
+        D.barrier()
+        if D.rank() == 0:
+            detection.cleanup_files(config)
+        D.barrier()
+        assert not os.path.exists(config["tiles_path"])
+        q.put((rank, len(meta)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_filesystem_stages_two_ranks(tmp_path):
+    import numpy as np
+    from treedetection_amd.geotiff import write_geotiff
+    root = str(tmp_path)
+    for d in ("rgb", "ndsm", "empty"):
+        os.makedirs(os.path.join(root, d))
+    rng = np.random.default_rng(0)
+    write_geotiff(os.path.join(root, "rgb", "7.tif"), rng.integers(0, 255, (3, 400, 400), dtype=np.uint8), (0.2, 0, 1000.0, 0, -0.2, 2080.0), 25832)
+    write_geotiff(os.path.join(root, "ndsm", "7.tif"), rng.random((80, 80), dtype=np.float32), (1.0, 0, 1000.0, 0, -1.0, 2080.0), 25832)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fs_worker, args=(r, 2, port, root, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=10) for _ in range(2))
+    assert got == [(0, 4), (1, 4)]
+
+
+def test_local_device_mapping(monkeypatch):
+    assert D.local_device("3") == 3          # single process: the configured device

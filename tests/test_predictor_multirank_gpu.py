@@ -1,5 +1,8 @@
 """N > 1 Predictor path on ONE GPU: 2 ranks (gloo rendezvous, both on cuda:0) shard the tiles of an image, gather the
-detections to rank 0, and rank 0 writes every Prediction_*.json — the files must equal the single-process run's."""
+detections to rank 0, and rank 0 writes every Prediction_*.json — the files must equal the single-process run's.
+Also: ``process_files`` end to end under 2 ranks with ``keep_intermediate: false`` (rank 0 alone touches the shared
+folders, nothing is removed under it), and BASELINE configs[3]'s shape — a 100 x 100 mosaic (10 000 tiles, reference
+tile-id scheme) sharded over 2 ranks at a reduced tile size, every tile written exactly once."""
 import json
 import os
 import socket
@@ -8,6 +11,7 @@ import sys
 
 import numpy as np
 import pytest
+import yaml
 
 from treedetection_amd.geotiff import write_geotiff
 from treedetection_amd.synth import make_tile
@@ -27,8 +31,25 @@ world = int(os.environ.get("WORLD_SIZE", "1"))
 if world > 1:
     dist.init_process_group("gloo")
 sd = load_checkpoint({model!r})
-pred = Predictor(setup_model_cfg(update_model="x", device="0"), device_type="0", max_batch_size=3, output_dir={out!r}, state_dict=sd)
+pred = Predictor(setup_model_cfg(update_model="x", device="0"), device_type="0", max_batch_size={batch}, output_dir={out!r},
+                 state_dict=sd, return_predictions=False, **{kw!r})
 pred({tif!r}, {meta!r})
+pred.close()
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+"""
+
+PROCESS_FILES_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+import treedetection_amd as T
+world = int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    dist.init_process_group("gloo")
+config, _ = T.get_config({cfg!r})
+T.process_files(config)
 if world > 1:
     dist.barrier()
     dist.destroy_process_group()
@@ -43,6 +64,16 @@ def _free_port():
     return p
 
 
+def _run(script, world, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if world == 1:
+        subprocess.run([sys.executable, str(script)], check=True, env=env, timeout=timeout)
+    else:
+        subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
+                       check=True, env=env, timeout=timeout)
+
+
 def test_two_ranks_write_the_same_files_as_one(tmp_path):
     from treedetection_amd.preprocessing import tile_single_file
     np.savez(tmp_path / "m.npz", **make_synthetic_state_dict(50, seed=3, width_div=2))
@@ -52,24 +83,94 @@ def test_two_ranks_write_the_same_files_as_one(tmp_path):
     tile_single_file(tif, str(tmp_path / "tiles"), buffer=20, tile_width=50, tile_height=50)
     meta = str(tmp_path / "tiles" / "img.json")
     outs = {}
+    runs = {"one": (1, {"pipeline": False}),
+            "two_plain": (2, {"pipeline": False}),
+            "two_pipelined": (2, {"pipeline": True}),              # three engines per rank, gather on the side stream
+            "two_local": (2, {"pipeline": True, "sharded_epilogue": "local"})}
+    for name, (world, kw) in runs.items():
+        out = str(tmp_path / f"out_{name}")
+        script = tmp_path / f"w_{name}.py"
+        script.write_text(WORKER.format(root=ROOT, model=str(tmp_path / "m.npz"), out=out, tif=tif, meta=meta, batch=3, kw=kw))
+        _run(script, world)
+        outs[name] = {f: open(os.path.join(out, "img", f), "rb").read() for f in sorted(os.listdir(os.path.join(out, "img")))}
+    assert len(outs["one"]) == 9
+    for name in runs:
+        assert sorted(outs[name]) == sorted(outs["one"]), name
+        for f in outs["one"]:
+            assert outs[name][f] == outs["one"][f], (name, f)       # byte for byte
+    assert sum(len(json.loads(v)) for v in outs["one"].values()) > 10
+
+
+def test_process_files_two_ranks_cleanup(tmp_path):
+    """``process_files`` under torch.distributed with the default ``keep_intermediate: false``: preprocess on rank 0
+    only, predict sharded, stitch + post-process on rank 0, and only then (barrier) the intermediate folders go —
+    the final layers must equal the single-process run's and nothing may be missing."""
+    root = tmp_path
+    np.savez(root / "model_combined.npz", **make_synthetic_state_dict(50, seed=3, width_div=2))
+    finals = {}
     for world in (1, 2):
-        out = str(tmp_path / f"out{world}")
-        script = tmp_path / f"w{world}.py"
-        script.write_text(WORKER.format(root=ROOT, model=str(tmp_path / "m.npz"), out=out, tif=tif, meta=meta))
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-        if world == 1:
-            subprocess.run([sys.executable, str(script)], check=True, env=env, timeout=300)
-        else:
-            subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
-                           check=True, env=env, timeout=300)
-        outs[world] = {f: json.load(open(os.path.join(out, "img", f))) for f in sorted(os.listdir(os.path.join(out, "img")))}
-    assert len(outs[1]) == 9 and sorted(outs[1]) == sorted(outs[2])
-    total = 0
-    for f in outs[1]:
-        a, b = outs[1][f], outs[2][f]
-        assert len(a) == len(b), f
-        for ea, eb in zip(a, b):
-            assert abs(ea["score"] - eb["score"]) <= 1e-6 and ea["polygon_coords"] == eb["polygon_coords"]
-        total += len(a)
-    assert total > 10
+        base = root / f"w{world}"
+        (base / "rgb").mkdir(parents=True)
+        (base / "ndsm").mkdir()
+        for k, name in enumerate(("3241", "3242")):
+            rgb, ndsm = make_tile(200 + k, 400)
+            rgbi = np.concatenate([rgb, 255 - rgb[..., :1] // 2], axis=2).transpose(2, 0, 1)
+            t = (0.2, 0.0, 412000.0 + 80 * k, 0.0, -0.2, 5318080.0)                  # 80 m x 80 m, side by side
+            write_geotiff(str(base / "rgb" / f"{name}.tif"), np.ascontiguousarray(rgbi), t, 25832)
+            write_geotiff(str(base / "ndsm" / f"{name}.tif"), (ndsm[::5, ::5] + 5).copy(), (1.0, 0, t[2], 0, -1.0, t[5]), 25832)
+        cfg = {"image_directory": str(base / "rgb"), "height_data_path": str(base / "ndsm"),
+               "combined_model": str(root / "model_combined.npz"), "output_directory": str(base / "output"),
+               "tiles_path": str(base / "tiles"), "use_overlap": True, "overlapping_tiles_width": 2,
+               "overlapping_tiles_height": 2, "tile_width": 40, "tile_height": 40, "buffer": 10,
+               "batch_size": 4, "parallel": False, "num_workers": 2, "keep_intermediate": False, "device": "0",
+               "height_threshold": 0}
+        (base / "config.yml").write_text(yaml.safe_dump(cfg))
+        script = base / "run.py"
+        script.write_text(PROCESS_FILES_WORKER.format(root=ROOT, cfg=str(base / "config.yml")))
+        _run(script, world)
+        out = base / "output"
+        assert not (base / "tiles").exists() and not (base / "rgb" / "merged").exists()   # intermediates are gone ...
+        assert not (out / "predictions").exists() and not (out / "geojson_predictions").exists()
+        layers = sorted(f for f in os.listdir(out) if f.endswith(".gpkg"))
+        assert layers, os.listdir(out)                                # ... and the final layers are there
+        finals[world] = {f: os.path.getsize(out / f) for f in layers}
+    assert sorted(finals[1]) == sorted(finals[2])
+    # same crowns either way: the GeoPackage payloads have the same size (feature bytes are deterministic)
+    assert finals[1] == finals[2]
+
+
+def test_config3_mosaic_10k_tiles_sharded(tmp_path):
+    """BASELINE configs[3] on one GPU: a 100 x 100 mosaic = 10 000 tiles with the reference's tile-id scheme
+    (TreeDetection/preprocessing.py:59), sharded i = r (mod W) over 2 ranks, padded rounds, gather to rank 0 — at a
+    reduced tile size (50 x 50 px; every tile still goes through the 800 x 800 network input) with a half-width
+    model, three engines per rank. Every tile must be written exactly once and carry valid JSON."""
+    from treedetection_amd import distributed as D
+    from treedetection_amd.preprocessing import tile_single_file
+    np.savez(tmp_path / "m.npz", **make_synthetic_state_dict(50, seed=3, width_div=2))
+    rgb, _ = make_tile(7, 1000)
+    mosaic = np.tile(rgb, (5, 5, 1))                                   # 5000 x 5000 px = 100 x 100 tiles of 50 px
+    tif = str(tmp_path / "mosaic.tif")
+    write_geotiff(tif, np.ascontiguousarray(mosaic.transpose(2, 0, 1)), (0.2, 0, 412000.0, 0, -0.2, 5319000.0), 25832)
+    tile_single_file(tif, str(tmp_path / "tiles"), buffer=0, tile_width=10, tile_height=10)
+    meta_path = str(tmp_path / "tiles" / "mosaic.json")
+    meta = json.load(open(meta_path))
+    assert len(meta) == 10000
+    first = next(iter(meta))
+    assert first == "mosaic_412000_5318000_10_0_25832"                 # {stem}_{minx}_{miny}_{tile_width}_{buffer}_{epsg}
+    B = 16
+    assert D.padded_rounds(10000, B, 2) == 313
+    assert len(D.shard_indices(10000, 0, 2)) == len(D.shard_indices(10000, 1, 2)) == 5000
+    out = str(tmp_path / "out")
+    script = tmp_path / "w.py"
+    script.write_text(WORKER.format(root=ROOT, model=str(tmp_path / "m.npz"), out=out, tif=tif, meta=meta_path, batch=B,
+                                    kw={"pipeline": True}))
+    _run(script, 2, timeout=1100)
+    files = sorted(os.listdir(os.path.join(out, "mosaic")))
+    assert files == sorted(f"Prediction_{k}.json" for k in meta)      # each of the 10 000 tiles exactly once
+    nonempty = 0
+    for f in files[::97]:
+        entries = json.load(open(os.path.join(out, "mosaic", f)))
+        for e in entries:
+            assert e["image_id"] == tif and 0.3 < e["score"] <= 1.0 and len(e["polygon_coords"][0]) >= 4
+        nonempty += bool(entries)
+    assert nonempty > 0

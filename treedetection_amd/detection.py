@@ -38,10 +38,14 @@ def predict_on_model(config, model_path, tiles_path, output_path, batch_size=10,
             raise NotADirectoryError(f"{name} is not a directory: {path}")
     os.makedirs(output_path, exist_ok=True)
     cfg = setup_model_cfg(update_model=model_path, device=config["device"])
-    predictor = Predictor(cfg, device_type=config["device"], max_batch_size=batch_size, output_dir=output_path,
+    # one process per GPU under torch.distributed: the shared config names one device, each rank takes its own
+    # (LOCAL_RANK), see distributed.local_device
+    device = config["device"] if D.world() == 1 else str(D.local_device(config["device"]))
+    predictor = Predictor(cfg, device_type=device, max_batch_size=batch_size, output_dir=output_path,
                           exclude_vars=exclude_vars, precision=config.get("precision", "fp32"),
                           return_predictions=False,       # the files are the product; the list is unused here
-                          pipeline=config.get("pipeline", True), device_contours=config.get("device_contours", False))
+                          pipeline=config.get("pipeline", True), device_contours=config.get("device_contours", False),
+                          sharded_epilogue=config.get("sharded_epilogue", "rank0"))
     try:
         images_directory = Path(config["image_directory"])
         images_paths = sorted(str(f) for f in images_directory.glob("*.tif"))
@@ -71,6 +75,7 @@ def predict_on_model(config, model_path, tiles_path, output_path, batch_size=10,
             save_prediction_recovery_data(output_path, tiles_path, model_path, processed_files, images_paths)
     finally:
         predictor.close()
+        D.barrier()      # rank 0 has written every Prediction_*.json and the resume file before anyone moves on
 
 
 def _stitch(config, pred_dir, out_dir):
@@ -143,19 +148,29 @@ def preprocess_files(config):
     images = [f for f in images if irx.search(os.path.basename(f))]
     ids = {"".join(irx.search(os.path.basename(f)).groups()): f for f in images}
     hids = {"".join(hrx.search(os.path.basename(f)).groups()) for f in heights if hrx.search(os.path.basename(f))}
-    if config["use_overlap"]:
-        logger.info("Using overlapping tiles for processing, do merging right now ...")
-        merge_and_crop_images(config, images, heights)
-    for ident, path in ids.items():
-        if ident not in hids:
-            logger.warning(f"No corresponding height data found for image file {path}")
-    if not images:
-        raise FileNotFoundError(f"No image TIF-files matching the pattern found in the directory: "
-                                f"{config['image_directory']} or all files have already been processed.")
-    logger.info(f"Found {len(images)} images for processing. Starting tiling...")
-    tile_data(images, config["tiles_path"], config["buffer"], config["tile_width"], config["tile_height"],
-              parallel=config["parallel"], max_workers=config["num_workers"], logger=logger,
-              forest_shapefile=config.get("forrest_outline", None))
+    # The seam strips and the tile metadata are files in folders every rank shares: rank 0 alone writes them, the
+    # others wait at the barrier and then see complete files (the reference is single-process, detection.py:313-337).
+    err = None
+    if D.rank() == 0:
+        try:
+            if config["use_overlap"]:
+                logger.info("Using overlapping tiles for processing, do merging right now ...")
+                merge_and_crop_images(config, images, heights)
+            for ident, path in ids.items():
+                if ident not in hids:
+                    logger.warning(f"No corresponding height data found for image file {path}")
+            if not images:
+                raise FileNotFoundError(f"No image TIF-files matching the pattern found in the directory: "
+                                        f"{config['image_directory']} or all files have already been processed.")
+            logger.info(f"Found {len(images)} images for processing. Starting tiling...")
+            tile_data(images, config["tiles_path"], config["buffer"], config["tile_width"], config["tile_height"],
+                      parallel=config["parallel"], max_workers=config["num_workers"], logger=logger,
+                      forest_shapefile=config.get("forrest_outline", None))
+        except Exception as e:      # every rank must leave this stage the same way
+            err = e
+    err, images = D.broadcast_object((err, images))
+    if err is not None:
+        raise err
     return images
 
 
@@ -165,7 +180,7 @@ def postprocess_files(config):
     names (and into a time-stamped sub-folder with ``timestamped_output_directory``)."""
     Config()._load_into_config(config)
     logger = config["logger"]
-    if D.rank() != 0:
+    if D.rank() != 0:       # one writer; the others wait in process_files' barrier before anything is cleaned up
         return
     logger.info("Postprocessing the predictions.")
     pattern = (config.get("image_regex", "(\\d+)\\.tif"), config.get("height_data_regex", "(\\d+)\\.tif"))
@@ -217,7 +232,12 @@ def process_files(config):
     t2 = time.time()
     postprocess_files(config)
     t3 = time.time()
-    cleanup_files(config)
+    # rank 0 stitched and post-processed out of the intermediate folders while the others idled: only once it is
+    # done may they be removed, and only one rank removes them (reference detection.py:366-368 is single-process)
+    D.barrier()
+    if D.rank() == 0:
+        cleanup_files(config)
+    D.barrier()
     logger.debug(f"preprocess step took {t1 - t0} seconds. ")
     logger.debug(f"predict step took {t2 - t1} seconds. ")
     logger.debug(f"postprocess step took {t3 - t2} seconds. ")

@@ -25,6 +25,57 @@ def rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def barrier() -> None:
+    """All ranks meet here (no-op in a single process). Used around the file-system stages of ``process_files``:
+    rank 0 alone writes / deletes the shared folders, the others wait."""
+    if world() > 1:
+        dist.barrier()
+
+
+def all_ok(ok: bool) -> bool:
+    """True iff ``ok`` holds on EVERY rank (one tiny all-reduce; the collective calls of the sharded predictor only
+    stay paired if all ranks take the same decision about an image or a round)."""
+    if world() == 1:
+        return bool(ok)
+    dev = "cpu"
+    if dist.get_backend() == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
+def broadcast_object(obj, src: int = 0):
+    """Small picklable object from ``src`` to every rank."""
+    if world() == 1:
+        return obj
+    box = [obj if rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def local_device(configured) -> int:
+    """GPU index of THIS rank. A single process keeps ``config['device']`` (reference config.py:112-142). Under
+    ``torch.distributed`` the shared config.yml cannot name one device per rank, so the index comes from LOCAL_RANK
+    (set by ``torch.distributed.run``), else ``rank % device_count``; with the nccl backend two ranks of a node on
+    one GPU abort inside RCCL ("Duplicate GPU detected"), so that case is refused here with a readable message.
+    (gloo rehearsal runs may share a GPU.)"""
+    import os
+    if world() == 1:
+        return int(configured)
+    n = torch.cuda.device_count()
+    if n < 1:
+        raise RuntimeError("no GPU visible to this rank")
+    lr = os.environ.get("LOCAL_RANK")
+    idx = int(lr) if lr is not None else rank()
+    if dist.get_backend() == "nccl":
+        lws = int(os.environ.get("LOCAL_WORLD_SIZE", world()))
+        if lws > n:
+            raise RuntimeError(f"{lws} ranks on this node but only {n} GPUs: one process per GPU (nccl backend)")
+        return idx
+    return idx % n
+
+
 def shard_indices(n: int, r: Optional[int] = None, w: Optional[int] = None) -> List[int]:
     """Indices of the ordered tile list that rank r processes (round-robin keeps per-rank work even)."""
     r = rank() if r is None else r

@@ -146,7 +146,7 @@ class Predictor:
     def __init__(self, cfg, device_type="cpu", max_batch_size=5, output_dir="./output", exclude_vars=None,
                  precision: str = "fp32", state_dict: Optional[Dict[str, np.ndarray]] = None,
                  return_predictions: bool = True, host_workers: Optional[int] = None, pipeline: bool = True,
-                 device_contours: bool = False):
+                 device_contours: bool = False, sharded_epilogue: str = "rank0"):
         """cfg from ``setup_model_cfg``; ``device_type`` = GPU index ("0", 0) as config["device"] carries it.
         ``state_dict`` lets tests and the bench inject weights instead of reading cfg.MODEL.WEIGHTS.
         ``return_predictions=False`` skips rebuilding the Python list ``__call__`` returns (the reference's own caller
@@ -164,7 +164,8 @@ class Predictor:
         self.output_dir = output_dir
         self.exclude_vars = exclude_vars or []
         self.return_predictions = return_predictions
-        self.device_contours = bool(device_contours) and D.world() == 1     # borders followed on the GPU (td_trace_contours_dev)
+        # borders followed on the GPU (td_trace_contours_dev); rank 0's gathered-batch epilogue uses the host tracer
+        self.device_contours = bool(device_contours) and (D.world() == 1 or sharded_epilogue == "local")
         os.makedirs(self.output_dir, exist_ok=True)
         sd = state_dict if state_dict is not None else load_checkpoint(cfg.MODEL.WEIGHTS)
         rh = cfg.MODEL.ROI_HEADS
@@ -172,7 +173,10 @@ class Predictor:
                         nms_thresh=rh.NMS_THRESH_TEST, rpn_nms_thresh=cfg.MODEL.RPN.NMS_THRESH,
                         pre_nms_topk=cfg.MODEL.RPN.PRE_NMS_TOPK_TEST, post_nms_topk=cfg.MODEL.RPN.POST_NMS_TOPK_TEST,
                         detections_per_image=cfg.TEST.DETECTIONS_PER_IMAGE)
-        self.pipeline = bool(pipeline) and D.world() == 1
+        self.pipeline = bool(pipeline)
+        if sharded_epilogue not in ("rank0", "local"):
+            raise ValueError(f"sharded_epilogue must be 'rank0' or 'local', got {sharded_epilogue!r}")
+        self.sharded_epilogue = sharded_epilogue     # torch.distributed runs only: who pastes / traces / writes the tile files
         if "TD_TUNE_CACHE" not in os.environ:
             # Measured block-tile choices are shared between the engines of this process and kept for later runs (the
             # first forward of a fresh process otherwise spends ~1.5 s timing tile variants per engine). The file is
@@ -359,17 +363,34 @@ class Predictor:
                 if slot.pending == 0:
                     self._free.put(slot)
 
-    def _launch_pipelined(self, ready, pred_subdir, tifpath, futures) -> None:
+    def _finish_local(self, item, pred_subdir, tifpath, futures, stream=None) -> None:
+        """A batch's last phase is enqueued: packed results → pinned memory (on ``stream``), epilogue tasks queued."""
+        batch, slot, eng = item["batch"], item["slot"], item["eng"]
+        ctx = torch.cuda.stream(stream) if stream is not None else _null_ctx()
+        with ctx:
+            if self.device_contours:
+                eng.trace_contours({k: v[: len(batch)] for k, v in slot.dev_out.items()}, slot.dev_cont, len(batch))
+            slot.copy_results(len(batch), self.device_contours)
+            slot.event.record()
+        slot.pending = len(batch)
+        futures.extend(self._pool.submit(self._process_and_save_single, b, i, slot, pred_subdir, tifpath)
+                       for i, b in enumerate(batch))
+
+    def _launch_pipelined(self, ready, prepare, finish, total_rounds: Optional[int] = None) -> None:
         """Launcher loop of a pipelined run. Tick t enqueues, on the main stream, the trunk of batch t, the mask-head
         convs of batch t-2 and the box-head FCs of batch t-1, and on each batch's own side stream the selection phase
-        that follows; after a batch's last phase the packed results are copied to pinned memory on that side stream
-        and its epilogue tasks are queued."""
+        that follows; after a batch's last phase ``finish(item)`` runs (single process: copy the packed results to
+        pinned memory on the side stream and queue the epilogue tasks; sharded: the gather to rank 0).
+        ``prepare(item, eng)`` → the engine-output views of a new batch. Batches arrive in order from ``ready``;
+        ``finish`` is called once per batch, in that same order, ALSO for empty or failed batches (``item["failed"]``)
+        — the sharded run pairs one collective with every round on every rank. With ``total_rounds`` the loop ends
+        after that many batches (no end marker is expected)."""
         if getattr(self, "_main", None) is None:
             self._main = torch.cuda.Stream()
             for slot in self._slots:
                 slot.side = torch.cuda.Stream()
         main = self._main
-        window = []                 # batches in flight, oldest first: [batch, slot, next contraction phase, engine]
+        window = []                 # batches in flight, oldest first
         done = False
         launched = 0
         while not done or window:
@@ -377,45 +398,74 @@ class Predictor:
                 t0 = time.perf_counter()
                 batch, slot = ready.get()
                 self.stats["launch_wait"] += time.perf_counter() - t0
-                if isinstance(batch, BaseException):
+                if isinstance(batch, BaseException) and total_rounds is None:
                     raise batch
                 if batch is None:
                     done = True
-                elif not batch:
+                elif not batch and total_rounds is None:
                     self._free.put(slot)
                     continue
                 else:
                     # engines rotate over the batches: an engine is free for a new batch as soon as its previous
                     # batch's last phase is ENQUEUED (phase 0 waits on that batch's events on the device); the slot —
                     # pinned buffers the host epilogue reads — stays busy longer, hence more slots than engines
-                    window.append([batch, slot, 0, self._engines[launched % len(self._engines)]])
+                    item = {"batch": batch, "slot": slot, "phase": 0, "eng": self._engines[launched % len(self._engines)],
+                            "failed": None, "round": launched}
+                    if isinstance(batch, BaseException):
+                        item["failed"], item["batch"] = batch, []
+                    window.append(item)
                     launched += 1
+                    if total_rounds is not None and launched == total_rounds:
+                        done = True
             t0 = time.perf_counter()
             # the newest batch's trunk leads the tick, then the mask convs of the oldest, then the FCs of the middle one:
             # every contraction then finds the selection phase it waits on enqueued a whole trunk earlier
-            for item in sorted(window, key=lambda it: (0, 2, 1)[it[2] // 2]):
-                batch, slot, phase, eng = item
-                if phase == 0:
-                    with torch.cuda.stream(main):      # allocations (and their fills) are ordered with the kernels
-                        images, fmt, hw_valid, hw_out = self._to_model_input(batch, slot, eng)
-                        dev_out = slot.outputs(eng, len(batch), max(h for h, _ in hw_out), max(w for _, w in hw_out), self.device_contours)
-                    view = {k: v[: len(batch)] for k, v in dev_out.items()}
-                    eng.forward_phase(0, main, images, fmt, hw_valid, hw_out, view)
-                else:
-                    eng.forward_phase(phase, main)
-                eng.forward_phase(phase + 1, slot.side)
-                item[2] = phase + 2
-                if item[2] == 6:        # all six phases are enqueued: results → pinned memory, epilogue tasks
-                    with torch.cuda.stream(slot.side):
-                        if self.device_contours:
-                            eng.trace_contours({k: v[: len(batch)] for k, v in slot.dev_out.items()}, slot.dev_cont, len(batch))
-                        slot.copy_results(len(batch), self.device_contours)
-                        slot.event.record()
-                    slot.pending = len(batch)
-                    futures.extend(self._pool.submit(self._process_and_save_single, b, i, slot, pred_subdir, tifpath)
-                                   for i, b in enumerate(batch))
-            window = [it for it in window if it[2] < 6]
+            for item in sorted(window, key=lambda it: (0, 2, 1)[it["phase"] // 2]):
+                batch, slot, phase, eng = item["batch"], item["slot"], item["phase"], item["eng"]
+                if batch and item["failed"] is None:
+                    try:
+                        if phase == 0:
+                            with torch.cuda.stream(main):      # allocations (and their fills) are ordered with the kernels
+                                images, fmt, hw_valid, hw_out = self._to_model_input(batch, slot, eng)
+                                view = prepare(item, eng, hw_out)
+                            eng.forward_phase(0, main, images, fmt, hw_valid, hw_out, view)
+                        else:
+                            eng.forward_phase(phase, main)
+                        eng.forward_phase(phase + 1, slot.side)
+                    except Exception as e:
+                        if total_rounds is None:
+                            raise
+                        item["failed"] = e       # sharded: the round still takes part in its gather, with no detections
+                item["phase"] = phase + 2
+            # batches finish in arrival order (a failed or empty one may be "ready" early: it waits for its elders)
+            while window and window[0]["phase"] >= 6:
+                finish(window.pop(0))
             self.stats["launch"] += time.perf_counter() - t0
+
+    def _drain(self, reader, ready, futures, stop) -> None:
+        """Leaves no work of this call behind (every exit path of ``__call__`` runs it): the reader thread is told to
+        stop and unblocked, and every epilogue task that was submitted is waited for — their slots' pinned buffers
+        must not be refilled by the next image while a worker of this one still reads them, and a late worker must
+        not hand a slot to the next call's free list a second time."""
+        stop.set()
+        while reader.is_alive():
+            try:
+                ready.get(timeout=0.05)
+            except queue.Empty:
+                pass
+            # the reader may also be waiting for a free slot: hand it one it will not use
+            if self._free.empty():
+                self._free.put(self._slots[0])
+        reader.join()
+        for f in futures:
+            try:
+                f.result()
+            except BaseException:
+                pass
+        try:
+            torch.cuda.synchronize(self.device_index)
+        except Exception:
+            pass
 
     def _run_single(self, tiles, img: GeoTiff, pred_subdir, tifpath):
         B = self.max_batch_size
@@ -425,11 +475,14 @@ class Predictor:
         for s in self._slots:
             self._free.put(s)
         ready: "queue.Queue" = queue.Queue(maxsize=2)
+        stop = threading.Event()
 
         def reader():
             try:
                 for indices in rounds:
                     slot = self._free.get()
+                    if stop.is_set():
+                        return
                     t0 = time.perf_counter()
                     batch = self._read_batch(tiles, indices, img, slot)
                     self.stats["read"] += time.perf_counter() - t0
@@ -441,26 +494,35 @@ class Predictor:
         t = threading.Thread(target=reader, name="td-tile-reader", daemon=True)
         t.start()
         futures, predictions = [], []
-        while not self.pipeline:
-            t0 = time.perf_counter()
-            batch, slot = ready.get()
-            self.stats["launch_wait"] += time.perf_counter() - t0
-            if isinstance(batch, BaseException):
-                raise batch
-            if batch is None:
-                break
-            if not batch:
-                self._free.put(slot)
-                continue
-            t0 = time.perf_counter()
-            futures.extend(self._launch_batch(batch, slot, pred_subdir, tifpath))
-            self.stats["launch"] += time.perf_counter() - t0
-        if self.pipeline:
-            self._launch_pipelined(ready, pred_subdir, tifpath, futures)
-        t.join()
-        for f in futures:
-            predictions.extend(f.result())
-        return predictions
+        try:
+            while not self.pipeline:
+                t0 = time.perf_counter()
+                batch, slot = ready.get()
+                self.stats["launch_wait"] += time.perf_counter() - t0
+                if isinstance(batch, BaseException):
+                    raise batch
+                if batch is None:
+                    break
+                if not batch:
+                    self._free.put(slot)
+                    continue
+                t0 = time.perf_counter()
+                futures.extend(self._launch_batch(batch, slot, pred_subdir, tifpath))
+                self.stats["launch"] += time.perf_counter() - t0
+            if self.pipeline:
+                def prepare(item, eng, hw_out):
+                    slot, n = item["slot"], len(item["batch"])
+                    dev_out = slot.outputs(eng, n, max(h for h, _ in hw_out), max(w for _, w in hw_out), self.device_contours)
+                    return {k: v[:n] for k, v in dev_out.items()}      # leading-dim slices stay contiguous
+                self._launch_pipelined(ready, prepare,
+                                       lambda item: self._finish_local(item, pred_subdir, tifpath, futures, item["slot"].side))
+            t.join()
+            for f in futures:
+                predictions.extend(f.result())
+            return predictions
+        except BaseException:
+            self._drain(t, ready, futures, stop)
+            raise
 
     # -- multi-GPU: tiles shard over ranks, detections gather to rank 0 ------------------------------------------
     def _tile_ok(self, tile, img: GeoTiff) -> bool:
@@ -470,20 +532,25 @@ class Predictor:
         return w > 0 and h > 0 and img.count >= 3
 
     def _run_sharded(self, tiles, img: GeoTiff, pred_subdir, tifpath):
-        """Rank r predicts tiles r, r+W, r+2W, ... in batches; after each forward the fixed-shape detection tensors
-        (count, boxes, scores, 28x28 probabilities) go to rank 0 with ``torch.distributed.gather`` (RCCL on GPUs: the
-        copy is ordered on the device, nobody waits on the host). Rank 0 pastes each rank's batch with one
-        td_paste_masks_batch launch, copies the packed masks to pinned memory and its worker threads write the
-        ``Prediction_*.json`` files — the same epilogue as the single-process path. Tiles that cannot be cropped are
-        left out by a rule every rank evaluates alike (:meth:`_tile_ok`), so rank 0 knows each batch's tiles without
-        any metadata exchange."""
+        """Rank r predicts tiles r, r+W, r+2W, ... in batches (the plain loop or, with ``pipeline``, three engines with
+        three batches in flight, exactly as a single process runs them); after a batch's last phase its fixed-shape
+        detection tensors (count, boxes, scores, 28x28 probabilities) go to rank 0 with ``torch.distributed.gather``
+        (RCCL on GPUs: enqueued on the batch's side stream and ordered on the device, nobody waits on the host).
+        Rank 0 pastes each rank's batch with one td_paste_masks_batch launch, copies the packed masks to pinned memory
+        and its worker threads write the ``Prediction_*.json`` files — the same epilogue as the single-process path.
+        Tiles that cannot be cropped are left out by a rule every rank evaluates alike (:meth:`_tile_ok`), so rank 0
+        knows each batch's tiles without any metadata exchange.
+
+        Every rank issues exactly ``rounds`` gathers per image whatever happens to it: a reader or launch failure
+        turns that round into an empty batch (count = 0), the error is kept, and after the last round all ranks agree
+        (one all-reduce) whether the image failed — then every rank raises, so the caller's log-and-continue
+        (detection.py:117-120) moves all of them to the next image together."""
         import torch.distributed as dist
         B, W, me = self.max_batch_size, D.world(), D.rank()
         Dn = self.engine.D
         dev = torch.device(self.device)
         host_backend = dist.get_backend() != "nccl"          # gloo (tests / one-GPU rehearsal) moves host tensors
         ok = [self._tile_ok(t, img) for t in tiles]
-        shard = lambda r: [i for i in D.shard_indices(len(tiles), r, W) if ok[i]]       # noqa: E731
         per_rank = max(len(D.shard_indices(len(tiles), r, W)) for r in range(W))
         rounds = (per_rank + B - 1) // B
         # batches are cut from the shard BEFORE dropping bad tiles, so the round structure is the same on every rank
@@ -494,69 +561,144 @@ class Predictor:
         for s in self._slots:
             self._free.put(s)
         ready: "queue.Queue" = queue.Queue(maxsize=2)
+        stop = threading.Event()
+        errors: List[BaseException] = []
 
         def reader():
+            k = 0
             try:
                 for k in range(rounds):
                     slot = self._free.get()
+                    if stop.is_set():
+                        return
                     t0 = time.perf_counter()
-                    batch = self._read_batch(tiles, round_tiles(me, k), img, slot, keep_failed=True)
+                    try:
+                        batch = self._read_batch(tiles, round_tiles(me, k), img, slot, keep_failed=True)
+                    except Exception as e:          # this round runs empty; the image is reported failed at the end
+                        batch = e
                     self.stats["read"] += time.perf_counter() - t0
                     ready.put((batch, slot))
-            except BaseException as e:
-                ready.put((e, None))
+            except BaseException as e:              # cannot get slots any more: fail the remaining rounds, keep the count
+                for _ in range(k, rounds):
+                    ready.put((e, self._slots[0]))
 
         th = threading.Thread(target=reader, name="td-tile-reader", daemon=True)
         th.start()
         futures, predictions = [], []
-        for k in range(rounds):
-            t0 = time.perf_counter()
-            batch, slot = ready.get()
-            self.stats["launch_wait"] += time.perf_counter() - t0
-            if isinstance(batch, BaseException):
-                raise batch
-            t0 = time.perf_counter()
-            n = len(batch)
-            send = slot.gather_buffers(B, Dn, dev)             # count / boxes / scores / mask_probs padded to B rows
-            if n:
-                images, fmt, hw_valid, hw_out = self._to_model_input(batch, slot)
-                view = {key: send[key][:n] for key in ("count", "boxes", "scores", "mask_probs")}
-                view["classes"] = slot.classes_buffer(B, Dn, dev)[:n]
-                self.engine.forward_raw(images, fmt, hw_valid, hw_out, view)
-            if n < B:
-                send["count"][n:].zero_()
-            recv = slot.recv_buffers(W, B, Dn, dev, host_backend) if me == 0 else None
-            for key in D.GATHER_KEYS:
-                t = send[key].cpu() if host_backend else send[key]
-                dist.gather(t, [g[key] for g in recv] if me == 0 else None, dst=0)
-            if me != 0:
-                # the slot (pinned staging included) may be refilled once this batch's copies and sends have run
+
+        def prepare(item, eng, hw_out):
+            slot, n = item["slot"], len(item["batch"])
+            send = slot.gather_buffers(B, Dn, dev)          # count / boxes / scores / mask_probs padded to B rows
+            view = {key: send[key][:n] for key in ("count", "boxes", "scores", "mask_probs")}
+            view["classes"] = slot.classes_buffer(B, Dn, dev)[:n]
+            return view
+
+        def finish(item, stream=None):
+            """Gather of round item["round"] (+ on rank 0: paste, copies, epilogue tasks) on ``stream``."""
+            slot, k = item["slot"], item["round"]
+            n = 0 if item["failed"] is not None else len(item["batch"])
+            if item["failed"] is not None:
+                errors.append(item["failed"])
+            ctx = torch.cuda.stream(stream) if stream is not None else _null_ctx()
+            with ctx:
+                send = slot.gather_buffers(B, Dn, dev)
+                if n < B:
+                    send["count"][n:].zero_()
+                recv = slot.recv_buffers(W, B, Dn, dev, host_backend) if me == 0 else None
+                for key in D.GATHER_KEYS:
+                    t = send[key].cpu() if host_backend else send[key]
+                    dist.gather(t, [g[key] for g in recv] if me == 0 else None, dst=0)
+                if me != 0:
+                    # the slot (pinned staging included) may be refilled once this batch's copies and sends have run
+                    slot.event.record()
+                    self._pool.submit(self._release_when_done, slot)
+                    return
+                jobs = []
+                try:
+                    for src in range(W):
+                        idx = round_tiles(src, k)
+                        if not idx:
+                            continue
+                        hw = [img.window_of_bounds(tiles[i]["bounds"]) for i in idx]
+                        hw = [(h, w) for _, _, w, h in hw]
+                        g = recv[src] if not host_backend else {key: v.to(dev, non_blocking=True) for key, v in recv[src].items()}
+                        pin = slot.paste(self.engine, src, g, hw, B, Dn, dev)
+                        jobs.append((src, idx, pin))
+                except Exception as e:      # rank 0 keeps receiving the later rounds; the image is reported failed
+                    errors.append(e)
+                    jobs = []
                 slot.event.record()
-                self._pool.submit(self._release_when_done, slot)
-                self.stats["launch"] += time.perf_counter() - t0
-                continue
-            jobs = []
-            for src in range(W):
-                idx = round_tiles(src, k)
-                if not idx:
-                    continue
-                hw = [img.window_of_bounds(tiles[i]["bounds"]) for i in idx]
-                hw = [(h, w) for _, _, w, h in hw]
-                g = recv[src] if not host_backend else {key: v.to(dev, non_blocking=True) for key, v in recv[src].items()}
-                pin = slot.paste(self.engine, src, g, hw, B, Dn, dev)
-                jobs.append((src, idx, pin))
-            slot.event.record()
             slot.pending = sum(len(idx) for _, idx, _ in jobs)
             if slot.pending == 0:
                 self._pool.submit(self._release_when_done, slot)
             for src, idx, pin in jobs:
                 for j, ti in enumerate(idx):
                     futures.append(self._pool.submit(self._save_gathered, slot, pin, j, tiles[ti], pred_subdir, tifpath))
-            self.stats["launch"] += time.perf_counter() - t0
-        th.join()
-        for f in futures:
-            predictions.extend(f.result())
+
+        try:
+            if self.pipeline:
+                self._launch_pipelined(ready, prepare, lambda item: finish(item, item["slot"].side), total_rounds=rounds)
+            else:
+                for k in range(rounds):
+                    t0 = time.perf_counter()
+                    batch, slot = ready.get()
+                    self.stats["launch_wait"] += time.perf_counter() - t0
+                    t0 = time.perf_counter()
+                    item = {"batch": batch, "slot": slot, "eng": self.engine, "failed": None, "round": k}
+                    if isinstance(batch, BaseException):
+                        item["failed"], item["batch"] = batch, []
+                    if item["batch"]:
+                        try:
+                            images, fmt, hw_valid, hw_out = self._to_model_input(item["batch"], slot)
+                            self.engine.forward_raw(images, fmt, hw_valid, hw_out, prepare(item, self.engine, hw_out))
+                        except Exception as e:
+                            item["failed"] = e
+                    finish(item)
+                    self.stats["launch"] += time.perf_counter() - t0
+            th.join()
+            for f in futures:
+                try:
+                    predictions.extend(f.result())
+                except Exception as e:
+                    errors.append(e)
+        except BaseException as e:          # not expected (every per-round failure is caught above): leave nothing behind
+            errors.append(e)
+            self._drain(th, ready, futures, stop)
+        if not D.all_ok(not errors):
+            if errors:
+                raise errors[0]
+            raise RuntimeError(f"another rank failed while predicting {tifpath}")
         return predictions
+
+    def _run_local_shard(self, tiles, img: GeoTiff, pred_subdir, tifpath):
+        """``sharded_epilogue="local"``: rank r predicts tiles r, r+W, ... with the single-process pipeline INCLUDING
+        paste, contours and the ``Prediction_*.json`` files of its own tiles (all ranks of a node share the output
+        folder), so no host, PCIe link or GPU carries another rank's masks; what rank 0 collects is a manifest —
+        (tile index, detections) per tile — and it checks that every tile of the image was written exactly once.
+        For nodes where rank 0's link cannot take every rank's packed masks (8 fp16 engines produce them faster than
+        one PCIe link moves them)."""
+        me, W = D.rank(), D.world()
+        mine = D.shard_indices(len(tiles), me, W)
+        err, preds = None, []
+        try:
+            preds = self._run_single([tiles[i] for i in mine], img, pred_subdir, tifpath)
+        except Exception as e:
+            err = e
+        written = []
+        for i in mine:
+            fn = os.path.join(pred_subdir, f"Prediction_{os.path.basename(tiles[i]['tile_id'])}.json")
+            if os.path.exists(fn):
+                written.append(i)
+        manifests = D.gather_objects(written)
+        if me == 0 and err is None:
+            seen = sorted(i for m in manifests for i in m)
+            expect = [i for i in range(len(tiles)) if self._tile_ok(tiles[i], img)]
+            if len(seen) != len(set(seen)) or not set(expect) <= set(seen):
+                err = RuntimeError(f"sharded prediction of {tifpath}: {len(set(expect) - set(seen))} tiles missing, "
+                                   f"{len(seen) - len(set(seen))} written twice")
+        if not D.all_ok(err is None):
+            raise err if err is not None else RuntimeError(f"another rank failed while predicting {tifpath}")
+        return preds
 
     def _release_when_done(self, slot: _Slot) -> None:
         slot.event.synchronize()
@@ -580,14 +722,38 @@ class Predictor:
     def __call__(self, tifpath, tilepath):
         pred_subdir = os.path.join(self.output_dir, os.path.basename(tifpath).replace(".tif", "").replace(".json", ""))
         os.makedirs(pred_subdir, exist_ok=True)
-        tiles = self._load_tiles(tilepath)
-        img = GeoTiff(tifpath)
-        try:
-            if D.world() == 1:
+        if D.world() == 1:
+            tiles = self._load_tiles(tilepath)
+            img = GeoTiff(tifpath)
+            try:
                 return self._run_single(tiles, img, pred_subdir, tifpath)
+            finally:
+                img.close()
+        # sharded: every rank must enter (or skip) the image together — the per-round gathers only pair up if all
+        # ranks read the same tile list from the same raster
+        tiles, img, err = None, None, None
+        try:
+            tiles = self._load_tiles(tilepath)
+            img = GeoTiff(tifpath)
+        except Exception as e:
+            err = e
+        try:
+            if not D.all_ok(err is None):
+                raise err if err is not None else RuntimeError(f"another rank could not open {tifpath} / {tilepath}")
+            if self.sharded_epilogue == "local":
+                return self._run_local_shard(tiles, img, pred_subdir, tifpath)
             return self._run_sharded(tiles, img, pred_subdir, tifpath)
         finally:
-            img.close()
+            if img is not None:
+                img.close()
+
+
+class _null_ctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
 
 
 def _ring_entries(sub: np.ndarray, x0: int, y0: int, score: float, cls: int, transform, tifpath, out: List[dict]) -> None:

@@ -76,8 +76,12 @@ def tile_single_file(data_path: str, out_dir: str, buffer: int = 0, tile_width: 
             t = data.window_transform(c0, r0)
             meta[tile_id] = {"crs": crs, "transform": [t[0], t[1], t[2], t[3], t[4], t[5], 0.0, 0.0, 1.0],
                              "bounds": bounds, "only_forest": only_forest, "only_urban": only_urban}
-    with open(Path(out_dir) / f"{tilename}.json", "w") as f:
+    # written under a temporary name and renamed: a reader (another rank, a resumed run) never sees half a file
+    final = Path(out_dir) / f"{tilename}.json"
+    tmp = Path(out_dir) / f".{tilename}.json.{os.getpid()}.tmp"
+    with open(tmp, "w") as f:
         f.write(json.dumps(meta))
+    os.replace(tmp, final)
 
 
 def load_recovery_data(file_list, buffer, tile_width, tile_height, logger, out_dir, recovery_file):
