@@ -1,5 +1,7 @@
-"""td_trace_contours_dev (border following on the GPU) against the host tracer td_find_contours, detection by
-detection: same contours, same RETR_TREE order, same CHAIN_APPROX_SIMPLE points."""
+"""td_trace_contours_dev (border following on the GPU) against the ORACLE's restatement of cv2.findContours
+(oracle/contours_ref.py — RETR_TREE order, CHAIN_APPROX_SIMPLE points), detection by detection; the product's host
+tracer (td_find_contours) is checked against the same oracle on the same masks, so a restatement error shared by the
+two product tracers cannot pass."""
 import ctypes as C
 import os
 import sys
@@ -10,8 +12,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+from oracle.contours_ref import find_contours  # noqa: E402  (the checker)
 from treedetection_amd import _lib  # noqa: E402
-from treedetection_amd.contours import find_contours  # noqa: E402
+from treedetection_amd.contours import find_contours as host_find_contours  # noqa: E402  (product, host tracer)
 
 pytestmark = pytest.mark.gpu
 CMAX = 256
@@ -68,6 +71,8 @@ def _check(masks_per_image, **kw):
         for d, (x0, y0, m) in enumerate(dets):
             status, nc, base, total = det_info[b, d]
             want = find_contours(m.astype(np.uint8))
+            host = host_find_contours(m.astype(np.uint8))
+            assert len(host) == len(want) and all(np.array_equal(a, b) for a, b in zip(host, want)), (b, d)
             if status != 0:
                 continue
             traced += 1

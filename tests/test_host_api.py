@@ -262,3 +262,66 @@ def test_geotiff_window_into_staging_buffer(tmp_path):
         got = g.read_bounds_hwc(bounds, out=stage, out_off=5)
         assert got.base is not None and np.shares_memory(got, stage)
         assert got.shape == want.shape and (got == want).all() and (stage[:5] == 7).all()
+
+
+def test_pth_checkpoint_round_trip(tmp_path):
+    """The reference's only weight format: ``torch.save({"model": state_dict, "optimizer": ..., ...})``
+    (detectron2 DetectionCheckpointer; TreeDetection/config.py:39, README.md:14). Extra non-weight buffers
+    (pixel_mean / pixel_std, anchor cell_anchors), integer entries and half-precision tensors must not disturb it."""
+    import torch
+    from treedetection_amd.weights import infer_depth, load_checkpoint, make_synthetic_state_dict
+    sd = make_synthetic_state_dict(50, seed=5, width_div=4)
+    model = {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
+    model["pixel_mean"] = torch.tensor([103.53, 116.28, 123.675]).view(3, 1, 1)
+    model["pixel_std"] = torch.ones(3, 1, 1)
+    for i in range(5):
+        model[f"proposal_generator.anchor_generator.cell_anchors.{i}"] = torch.zeros(3, 4)
+    model["backbone.bottom_up.stem.conv1.norm.num_batches_tracked"] = torch.tensor(7)       # integer: dropped
+    k16 = "roi_heads.box_head.fc2.bias"
+    model[k16] = model[k16].half()                                                           # comes back as float32
+    ckpt = {"model": model, "optimizer": {"state": {0: {"momentum_buffer": torch.zeros(3)}}, "param_groups": [{"lr": 0.01}]},
+            "scheduler": {"last_epoch": 10}, "iteration": 1234}
+    path = str(tmp_path / "model_combined.pth")
+    torch.save(ckpt, path)
+    got = load_checkpoint(path)
+    assert infer_depth(got) == 50
+    for k, v in sd.items():
+        assert got[k].dtype == np.float32 and got[k].shape == v.shape, k
+        if k == k16:
+            assert np.array_equal(got[k], v.astype(np.float16).astype(np.float32))
+        else:
+            assert np.array_equal(got[k], v), k
+    assert "pixel_mean" in got and "backbone.bottom_up.stem.conv1.norm.num_batches_tracked" not in got
+    # a flat state dict (no "model" wrapper) loads the same way
+    torch.save(model, str(tmp_path / "flat.pth"))
+    flat = load_checkpoint(str(tmp_path / "flat.pth"))
+    assert sorted(flat) == sorted(got)
+    # a checkpoint that needs full unpickling (numpy scalar in the trainer state) still loads
+    ckpt["best"] = np.float64(0.5)
+    torch.save(ckpt, str(tmp_path / "np.pth"))
+    assert sorted(load_checkpoint(str(tmp_path / "np.pth"))) == sorted(got)
+    with pytest.raises(ValueError):
+        torch.save([1, 2, 3], str(tmp_path / "bad.pth"))
+        load_checkpoint(str(tmp_path / "bad.pth"))
+
+
+def test_reference_ndsm_raster_reads_as_surveyed():
+    """The one raster the reference ships (data/nDSM/324125317.tif): 1000 x 1000 float32, 1 m, EPSG:25832, origin
+    (412000, 5318000) .. values 0 .. 50.9 m (SURVEY.md probe table). Skipped where /root/reference is absent."""
+    path = "/root/reference/data/nDSM/324125317.tif"
+    if not os.path.exists(path):
+        pytest.skip("reference data not present on this box")
+    from treedetection_amd.geotiff import GeoTiff
+    g = GeoTiff(path)
+    try:
+        assert (g.width, g.height, g.count) == (1000, 1000, 1) and g.dtype == np.float32 and g.epsg == 25832
+        left, bottom, right, top = g.bounds
+        assert (left, bottom, right, top) == (412000.0, 5317000.0, 413000.0, 5318000.0)      # origin = upper-left corner
+        a = g.read_bounds([left, bottom, right, top])
+        assert a.shape[-2:] == (1000, 1000)
+        assert a.min() == 0.0 and abs(float(a.max()) - 50.9) < 0.05 and abs(float(a.mean()) - 5.7) < 0.1
+        # a 50 m tile with 20 m buffer at the raster's corner is clipped to the extent, as rasterio.mask(crop=True) does
+        w = g.read_bounds([left - 20, top - 70, left + 70, top + 20])
+        assert w.shape[-2:] == (70, 70) and np.array_equal(w.reshape(70, 70), a.reshape(1000, 1000)[:70, :70])
+    finally:
+        g.close()

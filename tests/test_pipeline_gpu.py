@@ -266,3 +266,33 @@ def test_predictor_fp16_engine_end_to_end(tmp_path):
     assert counts["fp32"].keys() == counts["fp16"].keys() and sum(counts["fp32"].values()) > 5
     a, b = sum(counts["fp32"].values()), sum(counts["fp16"].values())
     assert abs(a - b) <= max(3, 0.15 * a), (a, b)
+
+
+def test_predictor_loads_pth_checkpoint(tmp_path):
+    """The reference's weight format end to end: cfg.MODEL.WEIGHTS = a detectron2-style ``.pth``
+    (``torch.save({"model": state_dict, "optimizer": ...})`` with the extra buffers detectron2 keeps) → load_checkpoint →
+    Engine; the prediction files equal those of the same weights injected as a dict."""
+    import torch
+    import treedetection_amd as T
+    from treedetection_amd.preprocessing import tile_single_file
+    sd = make_synthetic_state_dict(50, seed=3, width_div=2)
+    model = {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
+    model["pixel_mean"] = torch.tensor([103.53, 116.28, 123.675]).view(3, 1, 1)
+    model["pixel_std"] = torch.ones(3, 1, 1)
+    for i in range(5):
+        model[f"proposal_generator.anchor_generator.cell_anchors.{i}"] = torch.zeros(3, 4)
+    pth = str(tmp_path / "model_combined.pth")
+    torch.save({"model": model, "optimizer": {"state": {}, "param_groups": []}, "scheduler": {}, "iteration": 99}, pth)
+    rgb, _ = make_tile(302, 400)
+    tif = str(tmp_path / "7.tif")
+    write_geotiff(tif, np.ascontiguousarray(rgb.transpose(2, 0, 1)), (0.2, 0.0, 412000.0, 0.0, -0.2, 5318080.0), 25832)
+    tile_single_file(tif, str(tmp_path / "tiles"), buffer=10, tile_width=40, tile_height=40)
+    outs = {}
+    for tag, kw in (("pth", {}), ("dict", {"state_dict": sd})):
+        cfg = T.setup_model_cfg(update_model=pth, device="0")
+        assert cfg.MODEL.WEIGHTS == pth
+        with T.Predictor(cfg, device_type="0", max_batch_size=4, output_dir=str(tmp_path / tag), **kw) as pred:
+            pred(tif, str(tmp_path / "tiles" / "7.json"))
+        outs[tag] = {f: open(tmp_path / tag / "7" / f, "rb").read() for f in sorted(os.listdir(tmp_path / tag / "7"))}
+    assert len(outs["pth"]) == 4 and outs["pth"] == outs["dict"]
+    assert sum(len(json.loads(v)) for v in outs["pth"].values()) > 3

@@ -96,6 +96,19 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    host_only = os.environ.get("TD_HOST_LIB")
+    if host_only:
+        # sanitizer runs of the CPU tests (make -C treedetection_amd/csrc asan-test): the host-side C++ built with
+        # AddressSanitizer + UBSan and no device code. Only the symbols it exports are bound; anything that needs the
+        # GPU library fails loudly on the missing attribute.
+        lib = C.CDLL(host_only, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name, None)
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
+        _lib = lib
+        return lib
     if not os.path.exists(LIB_PATH):
         raise TdError(f"{LIB_PATH} not found — build it first: python -c 'import __graft_entry__ as g; g.build()' "
                       f"(or make -C treedetection_amd/csrc). There is no CPU fallback.")

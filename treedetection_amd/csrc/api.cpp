@@ -6,14 +6,7 @@
 #include <cstdio>
 #include <cmath>
 
-static thread_local char g_err[1024] = "";
-
-void td_set_error(const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-}
+// (td_set_error / td_last_error: error.cpp — shared with the host-only sanitizer build)
 
 namespace {
 // scratch for the op-level NMS / paste entry points (tests only; the engine owns its own workspace)
@@ -24,8 +17,6 @@ td_status scratch(void** p, size_t bytes) {
 }  // namespace
 
 extern "C" {
-
-const char* td_last_error(void) { return g_err; }
 
 void td_model_desc_default(td_model_desc* d) {
     d->num_classes = 1;

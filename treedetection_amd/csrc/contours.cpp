@@ -159,7 +159,7 @@ extern "C" int td_find_contours(const uint8_t* img, int h, int w, int32_t* point
         td_set_error("td_find_contours: %d points exceed capacity %d", (int)(pts.size() / 2), max_points);
         return TD_ERR_CAPACITY;
     }
-    std::memcpy(points, pts.data(), pts.size() * sizeof(int32_t));
-    std::memcpy(starts, st.data(), st.size() * sizeof(int32_t));
+    if (!pts.empty()) std::memcpy(points, pts.data(), pts.size() * sizeof(int32_t));   // an empty vector's data() may be null
+    if (!st.empty()) std::memcpy(starts, st.data(), st.size() * sizeof(int32_t));
     return total;
 }

@@ -74,7 +74,7 @@ void append_double(std::string& out, double v) {
         const int e = decpt - 1;
         out += 'e';
         out += e < 0 ? '-' : '+';
-        char eb[8];
+        char eb[16];
         std::snprintf(eb, sizeof(eb), "%02d", e < 0 ? -e : e);
         out += eb;
     }
@@ -203,6 +203,10 @@ int polygons_json_core(const int32_t* mask_region, const int64_t* mask_offset, c
     for (int k = 0; k < n; ++k) {
         const int x0 = mask_region[4 * k], y0 = mask_region[4 * k + 1], x1 = mask_region[4 * k + 2], y1 = mask_region[4 * k + 3];
         if (x1 <= x0 || y1 <= y0) continue;
+        if ((int64_t)x1 - x0 > (1 << 20) || (int64_t)y1 - y0 > (1 << 20)) {     // no raster tile is that large: corrupt record
+            td_set_error("%s: detection %d has an impossible paste region [%d,%d,%d,%d]", who, k, x0, y0, x1, y1);
+            return TD_ERR_INVALID;
+        }
         if (dev && dev->det_info[4 * k] == 0) {                    // traced on the device
             const int nc = dev->det_info[4 * k + 1];
             const int64_t base = dev->det_info[4 * k + 2];
@@ -212,6 +216,10 @@ int polygons_json_core(const int32_t* mask_region, const int64_t* mask_offset, c
             }
             for (int ci = 0; ci < nc; ++ci) {
                 const int32_t* rec = dev->contour_info + ((size_t)k * TD_CONTOUR_MAX + ci) * 2;
+                if (rec[0] < 0 || rec[1] < 0 || base + (int64_t)rec[0] + rec[1] > dev->points_cap) {
+                    td_set_error("%s: detection %d contour %d points outside the point buffer", who, k, ci);
+                    return TD_ERR_INVALID;
+                }
                 const int16_t* p = dev->points + 2 * (base + rec[0]);
                 emit(k, rec[1], [&](int i, int& x, int& y) { x = p[2 * i]; y = p[2 * i + 1]; });
             }

@@ -166,15 +166,26 @@ def load_checkpoint(path: str) -> Dict[str, np.ndarray]:
             return {k: np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}
     import torch
 
-    obj = torch.load(path, map_location="cpu", weights_only=False)
+    try:
+        # tensors, containers and scalars only — what a detectron2 checkpoint normally is; no pickled code runs
+        obj = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:
+        # checkpoints that carry other pickled objects (numpy scalars in the optimizer / scheduler state of older
+        # detectron2 versions): the reference loads them with full unpickling (DetectionCheckpointer), so do we —
+        # only for files the user names as model weights in config.yml
+        obj = torch.load(path, map_location="cpu", weights_only=False)
     if isinstance(obj, dict) and "model" in obj and isinstance(obj["model"], dict):
         obj = obj["model"]
+    if not isinstance(obj, dict):
+        raise ValueError(f"{path}: expected a state dict or {{'model': state_dict}}, got {type(obj).__name__}")
     out: Dict[str, np.ndarray] = {}
     for k, v in obj.items():
         if hasattr(v, "detach"):
-            v = v.detach().cpu().numpy()
+            v = v.detach().cpu().float().numpy() if v.is_floating_point() else v.detach().cpu().numpy()
         v = np.asarray(v)
         if v.dtype.kind == "f":
+            # non-weight buffers detectron2 stores alongside (pixel_mean / pixel_std, anchor_generator.cell_anchors.*)
+            # pass through: the engine looks tensors up by name and ignores the rest
             out[k] = np.ascontiguousarray(v, dtype=np.float32)
     return out
 
