@@ -1,9 +1,22 @@
 """fp16 engine (fp16 storage, v_mfma_f32_32x32x16_f16, fp32 accumulate / epilogue / selection) vs the fp32 oracle.
 
-Tolerances: boxes <= 0.5 px, scores <= 5e-3, mask probabilities <= 3e-2, pasted-mask
-IoU >= 0.95 (the seeded random mask head leaves many pixels within 1e-2 of the 0.5 cut, so the 0.97 proposed for
-trained weights is not reachable on this fixture), detections matched by IoU >= 0.9; a detection whose score sits within the score tolerance of the 0.3 threshold, or an NMS pair whose IoU
-sits at the threshold, may legitimately flip — the test requires >= 90 % one-to-one matches."""
+BASELINE.md §3 / SURVEY.md §8d PROPOSE for fp16: boxes <= 0.5 px, scores <= 5e-3, pasted-mask IoU >= 0.97, detections
+matched by IoU >= 0.9 ("proposed, to be stated with results"). What the fp16 engine measures on this fixture
+(tools/fp16_diag.py, round 2): every tensor is rounded to fp16 once per layer, so the relative RMS error of the
+features grows ~ sqrt(depth): stem 2.4e-4, res2 9e-4, res3 1.7e-3, res4 2.9e-3, res5 / p5 4e-3. A score
+s = sigmoid(logit) moves by s(1-s) * d(logit): at most a quarter of the logit error for s near 0.5, almost nothing for
+a saturated score. The synthetic classifier puts most detections in the steep part (quartiles 0.30 / 0.40 / 0.52 /
+0.73), a trained one near 1 — so the 5e-3 proposal is asserted where it is a statement about the ENGINE:
+  * boxes <= 0.5 px for every matched detection (measured max 0.24);
+  * |score error| <= 5e-3 * max(1, 4 s(1-s) / 0.36): i.e. 5e-3 for s outside [0.1, 0.9] and up to 1.4e-2 at s = 0.5,
+    AND median <= 2.5e-3, 90th percentile <= 6e-3 over all matched detections (measured: max 9.8e-3, p90 5.2e-3,
+    median 2.2e-3);
+  * mask probabilities <= 3e-2 (measured max 2.3e-2), and a pasted / 28x28 pixel may differ from the oracle ONLY where
+    the oracle's probability is within that 3e-2 of the 0.5 cut — this holds for every pixel of every detection;
+  * pasted-mask IoU >= 0.97 for masks with < 3 % of their pixels that close to the cut (what a trained mask head
+    produces), else >= 1 - 1.5 x that fraction: the seeded random mask head leaves ~10 % of the pixels within 3e-2 of
+    0.5 (median; up to 19 %), where IoU measures the fixture, not the engine (measured min 0.86, median 0.98).
+The measured distribution is printed by the test (pytest -s)."""
 import numpy as np
 import pytest
 import torch
@@ -46,29 +59,46 @@ def test_fp16_trunk_close_to_fp32(setup16):
         assert g.shape == r.shape
         assert eng.tensor(name).dtype == torch.float16
         rel = np.abs(g - r).max() / np.abs(r).max()
-        assert rel < 2e-2, (name, rel)
+        assert rel < 8e-3, (name, rel)          # measured: 3.5e-4 (stem) .. 4.3e-3 (p5)
 
 
-def test_fp16_detections_within_tolerance(setup16):
-    """Measured on this fixture (tests/fp16_stats.py): same detection sets (59/59, 78/79), boxes <= 0.25 px, scores
-    <= 0.0098, mask probabilities <= 0.0233, pasted-mask IoU 0.86 .. 1.0. The synthetic heads amplify rounding
-    (classifier gain x3, mask predictor gain x2, many mask pixels within 1e-2 of the 0.5 cut), so the bounds below
-    are this fixture's, looser than the fp16 row BASELINE.md proposes for trained weights."""
-    got, ref = setup16["got"], setup16["ref"]
-    for g, r in zip(got, ref):
+def check_fp16_detections(got, ref, label=""):
+    """Shared by the full-size / batch-32 test (tests/test_fullsize_gpu.py). → per-detection statistics."""
+    rows = []
+    for n, (g, r) in enumerate(zip(got, ref)):
         assert len(r["scores"]) > 5
-        matched, ious = 0, []
+        matched = 0
         for i in range(len(r["scores"])):
             v = [iou(r["pred_boxes"][i], g["pred_boxes"][j]) for j in range(len(g["scores"]))]
             bj = int(np.argmax(v))
-            if v[bj] >= 0.9:
-                matched += 1
-                assert abs(g["scores"][bj] - r["scores"][i]) <= 1.5e-2
-                assert np.abs(g["pred_boxes"][bj] - r["pred_boxes"][i]).max() <= 0.5
-                assert np.abs(g["mask_probs"][bj] - r["mask_probs"][i]).max() <= 3e-2
-                a, b = g["pred_masks"][bj], r["pred_masks"][i]
-                u = (a | b).sum()
-                ious.append((a & b).sum() / u if u else 1.0)
+            if v[bj] < 0.9:
+                continue
+            matched += 1
+            s = float(r["scores"][i])
+            es = abs(float(g["scores"][bj]) - s)
+            assert es <= 5e-3 * max(1.0, 4.0 * s * (1.0 - s) / 0.36), (label, n, i, s, es)
+            assert np.abs(g["pred_boxes"][bj] - r["pred_boxes"][i]).max() <= 0.5
+            pr, pg = r["mask_probs"][i], g["mask_probs"][bj]
+            assert np.abs(pg - pr).max() <= 3e-2
+            flip = (pg >= 0.5) != (pr >= 0.5)
+            assert (np.abs(pr - 0.5)[flip] <= 3e-2).all()                    # flips only where the oracle is undecided
+            near = float((np.abs(pr - 0.5) <= 3e-2).mean())
+            a, b = g["pred_masks"][bj], r["pred_masks"][i]
+            u = (a | b).sum()
+            m_iou = (a & b).sum() / u if u else 1.0
+            assert m_iou >= (0.97 if near < 0.03 else 1.0 - 1.5 * near) - 1e-9, (label, n, i, m_iou, near)
+            rows.append((es, m_iou, near, s))
         assert matched >= len(r["scores"]) - 2, (matched, len(r["scores"]), len(g["scores"]))
         assert abs(len(g["scores"]) - len(r["scores"])) <= 2
-        assert min(ious) >= 0.85 and np.mean(ious) >= 0.95, (min(ious), np.mean(ious))
+    rows = np.array(rows)
+    es = rows[:, 0]
+    print(f"\n[fp16 {label}] {len(rows)} matched detections: score err median {np.median(es):.4f} p90 {np.quantile(es, 0.9):.4f} "
+          f"max {es.max():.4f} | mask IoU min {rows[:, 1].min():.3f} median {np.median(rows[:, 1]):.3f} | "
+          f"near-cut pixel fraction median {np.median(rows[:, 2]):.3f} max {rows[:, 2].max():.3f}")
+    assert np.median(es) <= 2.5e-3 and np.quantile(es, 0.9) <= 6e-3
+    assert np.mean(rows[:, 1]) >= 0.95
+    return rows
+
+
+def test_fp16_detections_within_tolerance(setup16):
+    check_fp16_detections(setup16["got"], setup16["ref"], "fixture 256x320")

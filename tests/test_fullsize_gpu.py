@@ -237,3 +237,92 @@ def test_stem_prephase_schedule_equals_plain_forward(full):
     e.forward_raw(x2.clone(), INPUT_U8_HWC, hv2, ho2, o)
     torch.cuda.synchronize()
     assert torch.equal(o["boxes"], ref[1]["boxes"]) and torch.equal(o["count"], ref[1]["count"])
+
+
+def _same_bits(got, want):
+    """Packed mask rows of each image, up to what ITS detections wrote."""
+    for b in range(want["count"].shape[0]):
+        c = int(want["count"][b].item())
+        if c == 0:
+            continue
+        rg = want["mask_region"][b, c - 1].tolist()
+        used = int(want["mask_offset"][b, c - 1].item()) + ((rg[2] - rg[0] + 31) // 32) * (rg[3] - rg[1])
+        if not torch.equal(got["mask_bits"][b, :used], want["mask_bits"][b, :used]):
+            return False
+    return True
+
+
+def _invariants(got, hw_out):
+    for g, (h, w) in zip(got, hw_out):
+        n = len(g["scores"])
+        assert 0 < n <= 100
+        assert (np.diff(g["scores"]) <= 0).all() and (g["scores"] > 0.3).all()
+        b = g["pred_boxes"]
+        assert (b[:, 0] >= 0).all() and (b[:, 1] >= 0).all() and (b[:, 2] <= w).all() and (b[:, 3] <= h).all()
+        assert ((b[:, 2] - b[:, 0]) > 0).all() and ((b[:, 3] - b[:, 1]) > 0).all()
+        assert np.array_equal(R.nms(b, g["scores"], 0.5 + 1e-4), np.arange(n))      # NMS idempotence
+
+
+def test_batch8_equals_eight_single_tile_forwards(full):
+    """BASELINE configs[1] runs batch 8: the batch is 8 independent tiles, so the batched forward must equal eight
+    batch-1 forwards BIT FOR BIT (the block-tile choice differs between M = 8 x and 1 x, the k-order of every output
+    element does not)."""
+    from treedetection_amd.engine import INPUT_U8_HWC
+    eng = full["eng"]
+    tiles = [torch.from_numpy(make_tile(40 + i, 1000)[0]).cuda() for i in range(8)]
+    x, hv, ho = eng.preprocess_tiles_u8(tiles)
+    o8 = eng.alloc_outputs(8, 1000, 1000, paste=True)
+    eng.forward_raw(x.clone(), INPUT_U8_HWC, hv, ho, o8)
+    torch.cuda.synchronize()
+    assert int(o8["count"].min()) > 0
+    for i in range(8):
+        x1, hv1, ho1 = eng.preprocess_tiles_u8(tiles[i:i + 1])
+        o1 = eng.alloc_outputs(1, 1000, 1000, paste=True)
+        eng.forward_raw(x1.clone(), INPUT_U8_HWC, hv1, ho1, o1)
+        torch.cuda.synchronize()
+        for k in ("count", "boxes", "scores", "mask_probs", "mask_region"):
+            assert torch.equal(o1[k][0], o8[k][i]), (i, k)
+        assert _same_bits(o1, {k: v[i:i + 1] for k, v in o8.items()}), i
+
+
+def test_config4_fp16_batch32_full_size():
+    """BASELINE configs[4] on one GPU: the fp16 MFMA engine, full-width R50-FPN, 1000x1000 tiles, batch 32 — three tiles
+    of the batch against the fp32 oracle (tolerances: tests/test_engine_fp16_gpu.py), the output invariants on all 32,
+    and batch-32 == batch-8 == single-tile forwards bit for bit."""
+    from tests.test_engine_fp16_gpu import check_fp16_detections
+    from treedetection_amd.engine import Engine, INPUT_U8_HWC, unpack_outputs
+    torch.set_num_threads(8)
+    sd = make_synthetic_state_dict(50, seed=0)
+    tiles_np = [make_tile(100 + i, 1000)[0] for i in range(32)]
+    tiles = [torch.from_numpy(t).cuda() for t in tiles_np]
+    eng = Engine(sd, precision="fp16")
+    x, hv, ho = eng.preprocess_tiles_u8(tiles)
+    o32 = eng.alloc_outputs(32, 1000, 1000, paste=True)
+    eng.forward_raw(x.clone(), INPUT_U8_HWC, hv, ho, o32)
+    torch.cuda.synchronize()
+    got = unpack_outputs(o32, ho, True)
+    _invariants(got, ho)
+    oracle = MaskRCNNOracle(sd)
+    picks = (0, 13, 31)
+    ref = []
+    for i in picks:
+        xi, h, w = R.preprocess_tile_u8(tiles_np[i].transpose(2, 0, 1))
+        ref.append(oracle.forward([{"image": xi, "height": h, "width": w}])[0])
+    check_fp16_detections([got[i] for i in picks], ref, "configs[4] 1000x1000 batch 32")
+    # the same tiles in batches of 8 and alone
+    for lo in (0, 8, 24):
+        x8, hv8, ho8 = eng.preprocess_tiles_u8(tiles[lo:lo + 8])
+        o8 = eng.alloc_outputs(8, 1000, 1000, paste=True)
+        eng.forward_raw(x8.clone(), INPUT_U8_HWC, hv8, ho8, o8)
+        torch.cuda.synchronize()
+        for k in ("count", "boxes", "scores", "mask_probs", "mask_region"):
+            assert torch.equal(o8[k], o32[k][lo:lo + 8]), (lo, k)
+        assert _same_bits(o8, {k: v[lo:lo + 8] for k, v in o32.items()}), lo
+    for i in (5, 31):
+        x1, hv1, ho1 = eng.preprocess_tiles_u8(tiles[i:i + 1])
+        o1 = eng.alloc_outputs(1, 1000, 1000, paste=True)
+        eng.forward_raw(x1.clone(), INPUT_U8_HWC, hv1, ho1, o1)
+        torch.cuda.synchronize()
+        for k in ("count", "boxes", "scores", "mask_probs", "mask_region"):
+            assert torch.equal(o1[k][0], o32[k][i]), (i, k)
+    eng.close()
