@@ -145,7 +145,9 @@ void td_resize_shape(int h, int w, int short_edge, int max_size, int* out_h, int
 /* NHWC convolution: y = act(conv(x, w) * scale + bias [+ residual]).
  * x [B,H,W,Cin], w [Cout,KH,KW,Cin], scale/bias [Cout] (NULL = 1 / 0), residual [B,Ho>>rs,Wo>>rs,Cout]
  * (rs = res_shift: 1 = nearest-2x upsampled add, the FPN top-down path), y [B,Ho,Wo,Cout].
- * Cin must be a multiple of 32. precision selects float32 or float16 tensors (weights follow). */
+ * Cin must be a multiple of 32. precision selects float32 or float16 tensors (weights follow); bits 8..15 of
+ * `precision` may carry (block-tile id + 1) to force one kernel variant (parity tests of every variant; 0 = the
+ * library chooses). */
 td_status td_conv2d_nhwc(const void* x, const void* w, const float* scale, const float* bias,
                          const void* residual, int res_shift, void* y, int B, int H, int W, int Cin,
                          int Cout, int KH, int KW, int stride, int pad, int relu, int precision,

@@ -13,7 +13,7 @@ def dev(a, dtype=None):
 
 
 def conv2d_hip(x_nchw, w_oihw, scale=None, bias=None, residual_nchw=None, res_shift=0, stride=1, pad=0, relu=False,
-               precision=0):
+               precision=0, tile_cfg=-1):
     """x [B,C,H,W] np → y [B,Co,Ho,Wo] np through td_conv2d_nhwc."""
     lib = _lib.load()
     dt = torch.float32 if precision == 0 else torch.float16
@@ -29,7 +29,7 @@ def conv2d_hip(x_nchw, w_oihw, scale=None, bias=None, residual_nchw=None, res_sh
     rs = dev(np.transpose(residual_nchw, (0, 2, 3, 1)), dt) if residual_nchw is not None else None
     p = lambda t: t.data_ptr() if t is not None else None
     st = lib.td_conv2d_nhwc(p(x), p(w), p(sc), p(bi), p(rs), res_shift, p(y), B, H, W, Cin, Cout, KH, KW, stride, pad,
-                            int(relu), precision, _lib.stream_ptr())
+                            int(relu), precision | ((tile_cfg + 1) << 8), _lib.stream_ptr())
     _lib.check(st, "td_conv2d_nhwc")
     torch.cuda.synchronize()
     return y.float().cpu().numpy().transpose(0, 3, 1, 2)

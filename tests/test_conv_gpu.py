@@ -99,7 +99,44 @@ def test_conv_fp16_matches_torch(case):
     assert (err <= 2e-3 * np.maximum(np.abs(ref), 1.0)).all(), f"max err {err.max()}"
 
 
-@pytest.mark.parametrize("cfg", [4, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+PP8_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, res, relu   (fp16; 256 x 256 ping-pong tile = cfg 17)
+    (1, 64, 16, 16, 64, 1, 1, 0, 0, True),            # one k-chunk, one block, N tail
+    (1, 128, 20, 20, 256, 1, 1, 0, 1, True),          # two k-chunks
+    (2, 192, 23, 19, 300, 1, 1, 0, 0, False),         # three k-chunks, M and N tails, 2 x 4 blocks
+    (1, 256, 50, 50, 256, 3, 1, 1, 0, True),          # 36 k-chunks, zero padding, 10 M tiles
+    (2, 64, 64, 64, 512, 3, 1, 1, 1, True),           # 9 k-chunks, 32 x 2 blocks
+    (1, 256, 40, 40, 128, 1, 2, 0, 0, True),          # stride 2
+    (1, 512, 16, 16, 256, 1, 1, 0, 2, False),         # nearest-2x upsampled residual
+    (3, 1024, 13, 13, 2048, 1, 1, 0, 1, True),
+]
+
+
+@pytest.mark.parametrize("case", PP8_CASES)
+def test_conv_pp8_equals_the_reference_tile_bit_for_bit(case):
+    """conv_pp8_kernel (cfg 17) keeps the k order of conv_igemm_kernel, so on the same fp16 inputs its output must be
+    IDENTICAL to the 128 x 128 tile's (cfg 0), which test_conv_fp16_matches_torch checks against torch."""
+    B, Cin, H, W, Cout, k, stride, pad, res, relu = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.standard_normal((B, Cin, H, W), dtype=np.float32)
+    w = rng.standard_normal((Cout, Cin, k, k), dtype=np.float32) / np.float32(np.sqrt(Cin * k * k))
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    r = None
+    if res == 1:
+        r = rng.standard_normal((B, Cout, Ho, Wo), dtype=np.float32)
+    elif res == 2:
+        r = rng.standard_normal((B, Cout, Ho // 2, Wo // 2), dtype=np.float32)
+    kw = dict(scale=scale, bias=bias, residual_nchw=r, res_shift=1 if res == 2 else 0, stride=stride, pad=pad, relu=relu, precision=1)
+    ref = conv2d_hip(x, w, tile_cfg=0, **kw)
+    for _ in range(3):                                  # a racy schedule would not repeat
+        got = conv2d_hip(x, w, tile_cfg=17, **kw)
+        assert got.shape == ref.shape and np.array_equal(got, ref)
+    assert np.abs(ref).max() > 0.5
+
+
+@pytest.mark.parametrize("cfg", [4, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
 def test_conv_every_block_tile_variant(cfg):
     """The engine picks a block tile per layer by measurement; every variant must compute the same convolution.
     TD_CONV_CFG forces one variant for a whole process (diagnostic hook), so the cases above re-run in a child."""

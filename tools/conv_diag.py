@@ -7,7 +7,7 @@ CS = os.path.join(ROOT, "treedetection_amd", "csrc")
 
 def build(tag, defs):
     out = f"/tmp/libdiag_{tag}.so"
-    srcs = [os.path.join(CS, f) for f in ("conv_igemm.hip", "api.cpp", "stem.hip", "rpn.hip", "roi.hip", "engine.cpp", "contours.cpp")]
+    srcs = [os.path.join(CS, f) for f in ("conv_igemm.hip", "api.cpp", "error.cpp", "stem.hip", "rpn.hip", "roi.hip", "engine.cpp", "contours.cpp")]
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", "-x", "hip"] + defs + srcs + ["-o", out]
     subprocess.run(cmd, check=True)
     return out
@@ -59,6 +59,25 @@ if __name__ == "__main__":
             bench(lib, prec, 8, 200, 200, 256, 64, 1, tag + " res2.conv1 256->64")
             bench(lib, prec, 8, 100, 100, 128, 512, 1, tag + " res3.conv3 128->512 +res", residual=True)
             bench(lib, prec, 8, 200, 200, 256, 256, 1, tag + " fpn_lateral2 256->256 +res", residual=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pp8":
+        # where does conv_pp8_kernel (cfg 17) spend its time? builds without its in-loop DMA / fragment reads / barriers
+        os.environ["TD_CONV_CFG"] = "17"
+        variants = {"pp8 product": [], "pp8 no_dma": ["-DTD_DIAG_PP8_NO_DMA"],
+                    "pp8 no_dma_no_reads": ["-DTD_DIAG_PP8_NO_DMA", "-DTD_DIAG_PP8_NO_READS"],
+                    "pp8 no_reads": ["-DTD_DIAG_PP8_NO_READS"],
+                    "pp8 mfma_only": ["-DTD_DIAG_PP8_NO_DMA", "-DTD_DIAG_PP8_NO_READS", "-DTD_DIAG_PP8_NO_BARRIER"],
+                    "pp8 no_epilogue": ["-DTD_DIAG_PP8_NO_EPILOGUE"],
+                    "pp8 balanced": ["-DTD_PP8_BAL"],
+                    "pp8 mfma16": ["-DTD_DIAG_MFMA16"],
+                    "pp8 mfma16_loop_only": ["-DTD_DIAG_MFMA16", "-DTD_DIAG_PP8_NO_DMA", "-DTD_DIAG_PP8_NO_READS", "-DTD_DIAG_PP8_NO_EPILOGUE"],
+                    "pp8 loop_only": ["-DTD_DIAG_PP8_NO_DMA", "-DTD_DIAG_PP8_NO_READS", "-DTD_DIAG_PP8_NO_EPILOGUE"]}
+        if len(sys.argv) > 2:
+            variants = {k: v for k, v in variants.items() if any(a in k for a in sys.argv[2:])}
+        for tag, defs in variants.items():
+            lib = C.CDLL(build(tag.replace(" ", "_"), defs))
+            bench(lib, 1, 8, 200, 200, 256, 256, 3, tag + " 3x3 256->256 M=320k")
+            bench(lib, 1, 8, 100, 100, 512, 512, 1, tag + " 1x1 512->512 M=80k")
         sys.exit(0)
     libs = {"product": [], "no_loads": ["-DTD_DIAG_NO_LOADS"], "no_loads_no_barrier": ["-DTD_DIAG_NO_LOADS", "-DTD_DIAG_NO_BARRIER"]}
     for tag, defs in libs.items():

@@ -43,8 +43,9 @@ td_status td_conv2d_nhwc(const void* x, const void* w, const float* scale, const
     a.Ho = (H + 2 * pad - KH) / stride + 1;
     a.Wo = (W + 2 * pad - KW) / stride + 1;
     a.res_shift = res_shift; a.relu = relu; a.out_mode = 0;
-    a.M = B * a.Ho * a.Wo; a.m_dyn = nullptr; a.m_mul = 1; a.tile_cfg = -1; a.out_f32 = 0;
-    return conv2d_launch(a, precision, static_cast<hipStream_t>(stream));
+    a.M = B * a.Ho * a.Wo; a.m_dyn = nullptr; a.m_mul = 1; a.out_f32 = 0;
+    a.tile_cfg = ((precision >> 8) & 0xff) - 1;          // tests: force one block-tile variant (0 = the library chooses)
+    return conv2d_launch(a, precision & 0xff, static_cast<hipStream_t>(stream));
 }
 
 td_status td_resize_tile_u8(const uint8_t* src, int h, int w, int c, uint8_t* dst, int out_h, int out_w,

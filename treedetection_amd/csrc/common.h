@@ -48,10 +48,12 @@ struct ConvArgs {
     int tile_cfg;         // -1 = heuristic; 0..3 = block tile 128x128, 128x64, 64x128, 64x64 with 2 LDS stages,
                           // 4..7 = the same tiles with 3 stages (engine autotunes)
 };
-// tile_cfg ids: 0..3 4-wave tiles (2 LDS stages), 4..7 the same with 3 stages (measured no better: not tuned over),
-// 8 = 256x128 / 9 = 128x256 (8 waves), 10 = 256x256 (16 waves)
-#define TD_CONV_TILE_CFG_MAX 16
-static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16};   // 15 / 16 (single LDS stage) only for <= 4 k-steps
+// tile_cfg ids (conv_igemm.hip:dispatch): 0..3 4-wave tiles 128x128 / 128x64 / 64x128 / 64x64 (2 LDS stages), 4..7 the same
+// with 3 stages (measured no better: not tuned over), 8 = 256x128 / 9 = 128x256 (8 waves), 10 = 256x256 (16 waves),
+// 11..13 = 256x256 with larger per-wave tiles, 14..16 = single-LDS-stage 256x256 / 128x128 / 128x256 (thin 1x1 layers),
+// 17 = conv_pp8_kernel: 256x256, 8 waves, ping-pong phases, DMA 1.5 k-chunks ahead (fp16 only)
+#define TD_CONV_TILE_CFG_MAX 17
+static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
 
 // ---- stem / pooling / resize (stem.hip) ---------------------------------------------------------

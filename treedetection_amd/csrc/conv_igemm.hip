@@ -56,10 +56,235 @@ template <>
 struct Elem<_Float16> {
     static constexpr int PER_CHUNK = 64;
     static __device__ __forceinline__ void mma(const f32x4& fa, const f32x4& fb, f32x16& acc) {
+#if defined(TD_DIAG_MFMA16)     // timing experiment only (tools/conv_diag.py): same FLOPs and registers as four 16x16x32
+        f32x4 q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            q[k] = f32x4{acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]};
+            q[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa), __builtin_bit_cast(f16x8, fb), q[k], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * k + e] = q[k][e];
+        }
+#else
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa), __builtin_bit_cast(f16x8, fb), acc, 0, 0, 0);
+#endif
     }
     static __device__ __forceinline__ float to_f32(_Float16 v) { return (float)v; }
 };
+
+// ---- epilogue ---------------------------------------------------------------------------------------------------------
+// y = act(acc * scale + bias (+ residual)), one IEEE op per step (no fma contraction), identical in both paths below.
+// The MFMA layout (a lane = one column, 16 scattered rows of a 32 x 32 tile) is turned into whole row segments through
+// LDS, so residual loads and stores are 16-B accesses of contiguous channels and fully coalesced.
+//  * fp16 output without residual (every 3x3, the stride / first 1x1 of a block, FC layers): scale / bias / ReLU and
+//    the fp16 rounding happen in REGISTERS, neighbouring lanes swap one value (DPP quad_perm) so that each lane owns a
+//    packed channel pair, and the whole block tile is staged as fp16 in ONE round: half the ds_write instructions and
+//    LDS bytes of the fp32 staging, no second barrier round, 16-B (8-channel) stores. The epilogue of the 256 x 256
+//    fp16 tile cost 20 us of a 95-us tile before (store-issue bound at 8 B per lane).
+//  * otherwise (residual add, fp32 output, odd channel counts): fp32 tile staged RWM wave-rows at a time; fp16 outputs
+//    leave as 8 channels (16 B) per lane with 16-B residual loads issued U rows ahead.
+// `lds` must hold the staged tile (conv_epilogue_lds_bytes) and every wave must be past its last LDS read of the k-loop
+// (the caller's final barrier).
+template <typename TO, int MT, int NT, int WM, int WN, int RWM>
+constexpr int conv_epilogue_lds_bytes() {
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+    constexpr int f32 = RWM * 32 * MT * (BN + 4) * 4;
+    constexpr int f16 = sizeof(TO) == 2 ? BM * (BN + 8) * 2 : 0;
+    return f32 > f16 ? f32 : f16;
+}
+
+template <typename T, typename TO, int MT, int NT, int WM, int WN, int RWM>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], char* lds, int M, int m0, int n0,
+                                              int tid, int lane, int wm, int wn) {
+    constexpr int THREADS = 64 * WM * WN;
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+    constexpr int CS = BN + 4;                        // padded row stride (floats) of the staged fp32 tile
+    constexpr int WROW = 32 * MT;                     // rows of one wave-row
+    TO* __restrict__ Y = static_cast<TO*>(a.y);
+    const T* __restrict__ Rs = static_cast<const T*>(a.res);
+    const int hw = a.Ho * a.Wo;
+
+    if constexpr (sizeof(TO) == 2) {
+        if (!Rs && a.out_mode == 0 && (a.Cout & 7) == 0) {
+            // ---- fp16 fast path: finish in registers, stage packed fp16, one round ----
+            constexpr int HS = BN + 8;                // row stride in halves: 16-B aligned rows, 4-dword skew between rows
+            _Float16* Hs = reinterpret_cast<_Float16*>(lds);
+            const int odd = lane & 1;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = wn * 32 * NT + j * 32 + (lane & 31);
+                const int nn = n0 + col;
+                float sc = 1.f, bi = 0.f;
+                if (nn < a.Cout) {
+                    if (a.scale) sc = a.scale[nn];
+                    if (a.bias) bi = a.bias[nn];
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        float t0 = acc[i][j][r], t1 = acc[i][j][r + 1];     // rows R and R + 1 of this lane's column
+                        if (a.scale) { t0 = __fmul_rn(t0, sc); t1 = __fmul_rn(t1, sc); }
+                        if (a.bias) { t0 = __fadd_rn(t0, bi); t1 = __fadd_rn(t1, bi); }
+                        if (a.relu) { t0 = t0 > 0.f ? t0 : 0.f; t1 = t1 > 0.f ? t1 : 0.f; }
+                        // even lanes keep row R (and get the right neighbour's R value), odd lanes keep row R + 1
+                        const float give = odd ? t0 : t1;
+                        const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                            0, __builtin_bit_cast(int, give), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false));
+                        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                        f16x2 pk;
+                        pk[0] = (_Float16)(odd ? got : t0);
+                        pk[1] = (_Float16)(odd ? t1 : got);
+                        const int row = wm * WROW + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) + odd;
+                        *reinterpret_cast<f16x2*>(&Hs[row * HS + (col & ~1)]) = pk;
+                    }
+                }
+            }
+            __syncthreads();
+            constexpr int PIECES = BN / 8;            // 16-B pieces per tile row
+            constexpr int ROWS_PER_PASS = THREADS / PIECES;
+            static_assert(BM % ROWS_PER_PASS == 0, "fp16 epilogue rows must split evenly over the threads");
+            const int pc = tid % PIECES, pr = tid / PIECES;
+            const int n = n0 + pc * 8;
+            if (n < a.Cout) {                         // Cout % 8 == 0: a piece is in range as a whole
+#pragma unroll 4
+                for (int it = 0; it < BM / ROWS_PER_PASS; ++it) {
+                    const int row = pr + it * ROWS_PER_PASS;
+                    const int m = m0 + row;
+                    if (m >= M) break;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&Hs[row * HS + pc * 8]);
+                    *reinterpret_cast<f32x4*>(Y + (size_t)m * a.Cout + n) = v;
+                }
+            }
+            return;
+        }
+    }
+
+    // ---- general path: fp32 tile, RWM wave-rows per round ----
+    float* Cs = reinterpret_cast<float*>(lds);
+    const int Cq = a.out_mode == 1 ? a.Cout >> 2 : a.Cout;
+    constexpr int CPL = sizeof(TO) == 2 ? 8 : 4;      // channels per lane: 16-B stores either way
+    constexpr int CHUNKS = BN / CPL;                   // pieces per tile row
+    constexpr int ROWS_PER_PASS = THREADS / CHUNKS;
+    const int c4 = tid % CHUNKS;
+    const int n = n0 + c4 * CPL;
+    const bool vec = (a.Cout % CPL) == 0 && n + CPL - 1 < a.Cout;   // aligned, whole piece in range
+    float sc[CPL], bi[CPL];
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) {
+        sc[e] = 1.f;
+        bi[e] = 0.f;
+        if (n + e < a.Cout) {
+            const int co = a.out_mode == 1 ? (n + e) % Cq : n + e;
+            if (a.scale) sc[e] = a.scale[co];
+            if (a.bias) bi[e] = a.bias[co];
+        }
+    }
+    for (int q = 0; q < WM; q += RWM) {
+        if (q > 0) __syncthreads();                    // the previous round's readers are done with Cs
+        if (wm >= q && wm < q + RWM) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (wm - q) * WROW + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const int col = wn * 32 * NT + j * 32 + (lane & 31);
+                        Cs[row * CS + col] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        // Each thread finishes ITERS rows of this round. The residual reads are the only loads left in the kernel and
+        // nothing hides their latency (the accumulators are already in LDS, the waves have no other work), so they are
+        // issued U rows ahead: U x 16 B per lane in flight instead of 16 B (the thin 1x1 layers with a shortcut add
+        // ran at 3.3 TB/s of HBM before, latency-bound right here).
+        constexpr int ITERS = (RWM * WROW) / ROWS_PER_PASS;
+        static_assert((RWM * WROW) % ROWS_PER_PASS == 0 && ITERS >= 1, "epilogue rows must split evenly over the threads");
+        constexpr int U = ITERS < 8 ? ITERS : 8;
+        static_assert(ITERS % U == 0, "epilogue batch must divide the rows per thread");
+        typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+        typedef typename std::conditional<sizeof(T) == 4, f32x4, typename std::conditional<CPL == 8, f16x8v, f16x4>::type>::type ResVec;
+        auto res_offset = [&](int m) -> size_t {
+            if (!a.res_shift) return (size_t)m * a.Cout + n;
+            const int b = m / hw;
+            const int rem = m - b * hw;
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            return ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout + n;
+        };
+        for (int it0 = 0; it0 < ITERS; it0 += U) {
+            ResVec rbuf[U];
+            if (Rs && vec) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int m = m0 + q * WROW + tid / CHUNKS + (it0 + u) * ROWS_PER_PASS;
+                    if (m < M) rbuf[u] = *reinterpret_cast<const ResVec*>(Rs + res_offset(m));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int row = tid / CHUNKS + (it0 + u) * ROWS_PER_PASS;
+                const int m = m0 + q * WROW + row;
+                if (m >= M || n >= a.Cout) continue;
+                float v[CPL];
+#pragma unroll
+                for (int g = 0; g < CPL / 4; ++g) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(&Cs[row * CS + c4 * CPL + 4 * g]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * g + e] = t[e];
+                }
+                size_t yoff;
+                if (a.out_mode == 0) {
+                    yoff = (size_t)m * a.Cout + n;
+                } else {
+                    const int qq = n / Cq, co = n - qq * Cq;   // qq = dy*2+dx; a piece never straddles it (Cq % CPL == 0)
+                    const int b = m / hw;
+                    const int rem = m - b * hw;
+                    const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+                    yoff = ((size_t)(b * 2 * a.Ho + 2 * oy + (qq >> 1)) * (2 * a.Wo) + 2 * ox + (qq & 1)) * Cq + co;
+                }
+                float rs[CPL];
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) rs[e] = 0.f;
+                if (Rs) {
+                    if (vec) {
+#pragma unroll
+                        for (int e = 0; e < CPL; ++e) rs[e] = (float)rbuf[u][e];
+                    } else {
+                        const size_t roff = res_offset(m);
+#pragma unroll
+                        for (int e = 0; e < CPL; ++e)
+                            if (n + e < a.Cout) rs[e] = Elem<T>::to_f32(Rs[roff + e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) {
+                    float t = v[e];
+                    if (a.scale) t = __fmul_rn(t, sc[e]);
+                    if (a.bias) t = __fadd_rn(t, bi[e]);
+                    if (Rs) t = __fadd_rn(t, rs[e]);
+                    if (a.relu) t = t > 0.f ? t : 0.f;
+                    v[e] = t;
+                }
+                if (vec) {
+                    if constexpr (sizeof(TO) == 4) {
+                        f32x4 o = {v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(Y + yoff) = o;
+                    } else {
+                        f16x8v h;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h[e] = (_Float16)v[e];
+                        *reinterpret_cast<f16x8v*>(Y + yoff) = h;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < CPL; ++e)
+                        if (n + e < a.Cout) Y[yoff + e] = (TO)v[e];
+                }
+            }
+        }
+    }
+}
 
 // T = element type of x / w / residual; TO = element type of y (float outputs are kept for the RPN / box heads)
 // WM x WN waves per block (each wave owns a (32*MT) x (32*NT) output sub-tile): 2x2 = the 4-wave tiles above;
@@ -80,7 +305,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
     // the epilogue stages RWM wave-rows at a time through LDS (all of them when the k-loop's LDS is large enough)
     constexpr int FIT = STAGE_BYTES / (WROW * CS * 4);
     constexpr int RWM = FIT >= WM ? WM : (FIT >= 2 && WM % 2 == 0 ? 2 : 1);
-    constexpr int EPI_BYTES = RWM * WROW * CS * 4;
+    constexpr int EPI_BYTES = conv_epilogue_lds_bytes<TO, MT, NT, WM, WN, RWM>();
     __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES];
     char* As = lds;                                   // [NSTAGE][BM][128 B]   piece c of row r sits at slot c ^ ((r>>1)&7)
     char* Bs = lds + NSTAGE * BM * CHUNK_BYTES;       // [NSTAGE][BN][128 B]
@@ -268,122 +493,304 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
         }
     }
 
-    // ---- epilogue: accumulators → LDS tile → 4 channels per lane: scale/bias (+residual) (+ReLU), one IEEE op per
-    // step (no fma contraction). Staging through LDS turns the MFMA layout (32 lanes x 4 B per row) into whole row
-    // segments, so residual loads and stores are vector accesses and fully coalesced (HBM-bound 1x1 layers).
-    float* Cs = reinterpret_cast<float*>(lds);
-    TO* __restrict__ Y = static_cast<TO*>(a.y);
-    const T* __restrict__ Rs = static_cast<const T*>(a.res);
-    const int Cq = a.out_mode == 1 ? a.Cout >> 2 : a.Cout;
-    constexpr int CHUNKS = BN / 4;                     // 4-channel pieces per tile row
-    constexpr int ROWS_PER_PASS = THREADS / CHUNKS;
-    const int c4 = tid % CHUNKS;
-    const int n = n0 + c4 * 4;
-    const bool vec = (a.Cout & 3) == 0 && n + 3 < a.Cout;   // aligned, whole piece in range
-    float sc[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (n + e < a.Cout) {
-            const int co = a.out_mode == 1 ? (n + e) % Cq : n + e;
-            if (a.scale) sc[e] = a.scale[co];
-            if (a.bias) bi[e] = a.bias[co];
-        }
+    conv_epilogue<T, TO, MT, NT, WM, WN, RWM>(a, acc, lds, M, m0, n0, tid, lane, wm, wn);
+}
+
+// ---- conv_pp8_kernel: 256 x 256 block tile, 8 waves, ping-pong schedule (fp16 only) ---------------------------------
+// The k-loop of conv_igemm_kernel ends every 128-B k-chunk with a block-wide barrier that all 16 waves reach with
+// empty pipelines: at the fp16 MFMA rate the refill (DMA issue, first fragment reads) is a quarter of the step. This
+// kernel keeps the same data path (LDS-DMA staging of 128-B rows, XOR-swizzled image, v_mfma_f32_32x32x16_f16, same
+// k order → bit-identical sums) and changes the schedule (cdna_hip_programming.md §5 "256² 8-phase template"):
+//   * 8 waves as 2 (M) x 4 (N); a wave owns 128 x 64 outputs = 4 x 2 MFMA tiles (128 accumulator registers), so an A
+//     fragment feeds 2 MFMAs and a B fragment 4 (24 ds_read_b128 per 32 MFMAs; the 16-wave tile needs 32).
+//   * a k-chunk is computed in 4 PHASES, one output quadrant (64 x 32 = 2 MFMA tiles x 4 k-sub-steps = 8 MFMAs) each:
+//     (A0,B0) (A0,B1) (A1,B1) (A1,B0). A phase = load segment (issue this phase's fragment reads and 2 DMA
+//     instructions, counted vmcnt) | s_barrier | compute segment (lgkmcnt(0), 8 MFMAs) | s_barrier.
+//   * the two wave-rows run ONE BARRIER APART (wave-row 1 takes an extra s_barrier first): the SIMD partners (wave w
+//     and w + 4) are always in opposite segments, so the matrix pipe of every SIMD is fed by one wave while the other
+//     issues its LDS reads and DMA — nobody meets the barrier with an empty pipeline.
+//   * the quadrant order frees LDS rows early (A0 and B0 rows are dead after phase 0, B1 after phase 1, A1 after
+//     phase 2), so with only two 64-KB stages the DMA runs SIX phases (1.5 k-chunks) ahead of the MFMAs: the DMA
+//     "pair" m (2 instructions per wave = 128 rows: pair 0 = A0 rows, 1 = B0, 2 = B1, 3 = A1 of chunk m / 4) is issued
+//     in load segment m - 6 and waited for (s_waitcnt vmcnt(8): four younger pairs stay in flight) in load segment
+//     m - 2 — one barrier before the first wave reads it (RAW: counted vmcnt, then a barrier, then the read; WAR: a
+//     slot is re-filled at least two phases after its last read). vmcnt never drains to 0 inside the loop.
+// Rows / taps in the zero padding read beyond num_records and land as zeros, as in conv_igemm_kernel.
+template <typename TO>
+__global__ __launch_bounds__(512) void conv_pp8_kernel(const ConvArgs a) {
+    typedef _Float16 T;
+    constexpr int MT = 4, NT = 2, WM = 2, WN = 4;
+    constexpr int BM = 256, BN = 256;
+    constexpr int STAGE = (BM + BN) * CHUNK_BYTES;            // 64 KB: A rows then B rows
+    constexpr int EPI_BYTES = conv_epilogue_lds_bytes<TO, MT, NT, WM, WN, 1>();   // fp32: one wave-row per round; fp16: whole tile
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES];
+
+    int M = a.M;
+    if (a.m_dyn) {
+        const int md = *a.m_dyn * a.m_mul;
+        M = md < M ? md : M;
     }
-    const int hw = a.Ho * a.Wo;
-    for (int q = 0; q < WM; q += RWM) {
-        if (q > 0) __syncthreads();                    // the previous round's readers are done with Cs
-        if (wm >= q && wm < q + RWM) {
+    const int tiles_n = (a.Cout + BN - 1) / BN;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int nblk = tiles_m * tiles_n;
+    if ((int)blockIdx.x >= nblk) return;
+    const int pid = xcd_remap(blockIdx.x, nblk);
+    const int tm = pid / tiles_n, tn = pid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                  // wave-row = ping-pong group
+
+    const int K = a.KH * a.KW * a.Cin;
+    const int cchunks = a.Cin / 64;
+    const int ntaps = a.KH * a.KW;
+    const int nchunks = ntaps * cchunks;
+    const unsigned pix_bytes = (unsigned)a.Cin * 2;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.x), 0, (int)((size_t)a.B * a.H * a.W * pix_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.w), 0, (int)((size_t)a.Cout * K * 2), 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+
+    // ---- staged rows of this thread: 2 per pair (lane = 8 rows x 8 pieces of one DMA instruction) -----------------
+    // pair 0 (A0): tile rows i*128 + wave*8 + r          pair 3 (A1): the same + 64
+    // pair 1 (B0): tile rows (2i + wave/4)*64 + (wave%4)*8 + r   pair 2 (B1): the same + 32      (i = 0, 1; r = lane/8)
+    const int ld_c = lane & 7, ld_r = lane >> 3;
+    unsigned a_off[4], a_ok[4];              // [pair 0: i=0,1 | pair 3: i=0,1]
+    unsigned a_lds[4];                       // LDS byte offset (inside a stage) of the instruction's first row
+    unsigned b_off[4], b_lds[4];             // [pair 1: i=0,1 | pair 2: i=0,1]
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (wm - q) * WROW + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        const int col = wn * 32 * NT + j * 32 + (lane & 31);
-                        Cs[row * CS + col] = acc[i][j][r];
-                    }
-        }
-        __syncthreads();
-        // Each thread finishes ITERS rows of this round. The residual reads are the only loads left in the kernel and
-        // nothing hides their latency (the accumulators are already in LDS, the waves have no other work), so they are
-        // issued U rows ahead: U x 16 B per lane in flight instead of 16 B (the thin 1x1 layers with a shortcut add
-        // ran at 3.3 TB/s of HBM before, latency-bound right here).
-        constexpr int ITERS = (RWM * WROW) / ROWS_PER_PASS;
-        static_assert((RWM * WROW) % ROWS_PER_PASS == 0, "epilogue rows must split evenly over the threads");
-        constexpr int U = ITERS < 8 ? ITERS : 8;
-        static_assert(ITERS % U == 0, "epilogue batch must divide the rows per thread");
-        typedef typename std::conditional<sizeof(T) == 4, f32x4, f16x4>::type ResVec;
-        auto res_offset = [&](int m) -> size_t {
-            if (!a.res_shift) return (size_t)m * a.Cout + n;
+    for (int k = 0; k < 4; ++k) {
+        const int i = k & 1, hi = k >> 1;
+        const int row0 = i * 128 + hi * 64 + wave * 8;        // first row of the instruction (multiple of 8)
+        const int row = row0 + ld_r;
+        a_lds[k] = (unsigned)row0 * CHUNK_BYTES;
+        const unsigned piece = (unsigned)(ld_c ^ ((row >> 1) & 7)) * 16;
+        const int m = m0 + row;
+        a_off[k] = 0;
+        a_ok[k] = 0;
+        if (m < M) {
+            const int hw = a.Ho * a.Wo;
             const int b = m / hw;
             const int rem = m - b * hw;
-            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-            return ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout + n;
-        };
-        for (int it0 = 0; it0 < ITERS; it0 += U) {
-            ResVec rbuf[U];
-            if (Rs && vec) {
+            const int oy = rem / a.Wo;
+            const int ox = rem - oy * a.Wo;
+            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+            a_off[k] = (unsigned)((b * a.H + iy0) * a.W + ix0) * pix_bytes + piece;
+            for (int ky = 0; ky < a.KH; ++ky)
+                for (int kx = 0; kx < a.KW; ++kx)
+                    if ((unsigned)(iy0 + ky) < (unsigned)a.H && (unsigned)(ix0 + kx) < (unsigned)a.W)
+                        a_ok[k] |= 1u << (ky * a.KW + kx);
+        }
+        const int brow0 = (2 * i + (wave >> 2)) * 64 + hi * 32 + (wave & 3) * 8;
+        const int brow = brow0 + ld_r;
+        b_lds[k] = (unsigned)(BM + brow0) * CHUNK_BYTES;
+        const unsigned bpiece = (unsigned)(ld_c ^ ((brow >> 1) & 7)) * 16;
+        const int n = n0 + brow;
+        b_off[k] = n < a.Cout ? (unsigned)n * (unsigned)K * 2 + bpiece : OOB;
+    }
+
+    typedef __attribute__((address_space(3))) void lds_void;
+    // DMA cursor: pair index dm (0 .. 4*nchunks-1), its chunk's filter tap / channel chunk (scalar walk, chunk outer)
+    int dm = 0, d_tap = 0, d_ky = 0, d_kx = 0, d_cc = 0;
+    const int dm_end = 4 * nchunks;
+    // pr = dm & 3 is passed as a compile-time constant (every call site knows it): the per-thread row tables are then
+    // indexed statically and stay in registers
+    auto issue_pair = [&](auto pr_c) {
+        constexpr int pr = decltype(pr_c)::value;
+        if (dm >= dm_end) return;
+#if defined(TD_DIAG_PP8_NO_DMA)            // diagnostic builds only (tools/conv_diag.py pp8): prologue DMA only
+        if (dm >= 6) { ++dm; return; }
+#endif
+        char* st = lds + ((dm >> 2) & 1) * STAGE;
+        if constexpr (pr == 0 || pr == 3) {
+            const unsigned xs = (unsigned)(d_ky * a.W + d_kx) * pix_bytes + (unsigned)d_cc * CHUNK_BYTES;
+            constexpr int k0 = pr == 0 ? 0 : 2;
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int m = m0 + q * WROW + tid / CHUNKS + (it0 + u) * ROWS_PER_PASS;
-                    if (m < M) rbuf[u] = *reinterpret_cast<const ResVec*>(Rs + res_offset(m));
-                }
+            for (int i = 0; i < 2; ++i) {
+                const unsigned off = ((a_ok[k0 + i] >> d_tap) & 1u) ? a_off[k0 + i] + xs : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(st + a_lds[k0 + i]), 16, off, 0, 0, 0);
             }
+        } else {
+            const unsigned ws = (unsigned)d_tap * pix_bytes + (unsigned)d_cc * CHUNK_BYTES;
+            constexpr int k0 = pr == 1 ? 0 : 2;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int row = tid / CHUNKS + (it0 + u) * ROWS_PER_PASS;
-                const int m = m0 + q * WROW + row;
-                if (m >= M || n >= a.Cout) continue;
-                f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CS + c4 * 4]);
-                size_t yoff;
-                if (a.out_mode == 0) {
-                    yoff = (size_t)m * a.Cout + n;
-                } else {
-                    const int qq = n / Cq, co = n - qq * Cq;   // qq = dy*2+dx; a piece never straddles it (Cq % 4 == 0)
-                    const int b = m / hw;
-                    const int rem = m - b * hw;
-                    const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-                    yoff = ((size_t)(b * 2 * a.Ho + 2 * oy + (qq >> 1)) * (2 * a.Wo) + 2 * ox + (qq & 1)) * Cq + co;
-                }
-                float rs[4] = {0.f, 0.f, 0.f, 0.f};
-                if (Rs) {
-                    if (vec) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) rs[e] = (float)rbuf[u][e];
-                    } else {
-                        const size_t roff = res_offset(m);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < a.Cout) rs[e] = Elem<T>::to_f32(Rs[roff + e]);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = v[e];
-                    if (a.scale) t = __fmul_rn(t, sc[e]);
-                    if (a.bias) t = __fadd_rn(t, bi[e]);
-                    if (Rs) t = __fadd_rn(t, rs[e]);
-                    if (a.relu) t = t > 0.f ? t : 0.f;
-                    v[e] = t;
-                }
-                if (vec) {
-                    if constexpr (sizeof(TO) == 4) {
-                        *reinterpret_cast<f32x4*>(Y + yoff) = v;
-                    } else {
-                        f16x4 h;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
-                        *reinterpret_cast<f16x4*>(Y + yoff) = h;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < a.Cout) Y[yoff + e] = (TO)v[e];
-                }
+            for (int i = 0; i < 2; ++i) {
+                const unsigned off = b_off[k0 + i] == OOB ? OOB : b_off[k0 + i] + ws;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(st + b_lds[k0 + i]), 16, off, 0, 0, 0);
             }
         }
-    }
+        ++dm;
+        if constexpr (pr == 3) {             // next chunk: tap inner, channel chunk outer
+            if (++d_kx == a.KW) {
+                d_kx = 0;
+                ++d_ky;
+            }
+            if (++d_tap == ntaps) {
+                d_tap = 0;
+                d_ky = 0;
+                d_kx = 0;
+                ++d_cc;
+            }
+        }
+    };
+    typedef std::integral_constant<int, 0> P0;
+    typedef std::integral_constant<int, 1> P1;
+    typedef std::integral_constant<int, 2> P2;
+    typedef std::integral_constant<int, 3> P3;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment reads: row = lane & 31, piece = 2*kk + (lane >> 5), swizzled with the row's key (lane >> 1) & 7
+    const unsigned swz = (lane >> 1) & 7, hi5 = lane >> 5;
+    unsigned frag_off[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) frag_off[kk] = (unsigned)(lane & 31) * CHUNK_BYTES + (((unsigned)(2 * kk) + hi5) ^ swz) * 16;
+    const unsigned a_base = (unsigned)(wm * 128) * CHUNK_BYTES;
+    const unsigned b_base = (unsigned)(BM + wn * 64) * CHUNK_BYTES;
+    auto rd = [&](const char* st, unsigned base, int tile, int kk) -> f32x4 {
+#if defined(TD_DIAG_PP8_NO_READS)
+        f32x4 z = {1.f, 2.f, 3.f, (float)kk};
+        asm volatile("" : "+v"(z));
+        return z;
+#else
+        return *reinterpret_cast<const f32x4*>(st + base + tile * 32 * CHUNK_BYTES + frag_off[kk]);
+#endif
+    };
+#if defined(TD_DIAG_PP8_NO_BARRIER)
+#define TD_PP8_BARRIER() do {} while (0)
+#else
+#define TD_PP8_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+
+    // ---- prologue: pairs 0..5 in flight, pairs 0 and 1 (A0, B0 of chunk 0) landed ------------------------------------
+    issue_pair(P0{}); issue_pair(P1{}); issue_pair(P2{}); issue_pair(P3{}); issue_pair(P0{}); issue_pair(P1{});
+    if (dm >= 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // four younger pairs stay in flight
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");               // a single chunk: pairs 2, 3 are the younger ones
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();         // wave-row 1 runs one barrier behind wave-row 0
+
+    f32x4 fa[2][4], fb0[4], fb1[4];
+#if defined(TD_PP8_BAL)
+    // fragment reads spread 8 / 4 / 8 / 4 over the phases: B0 of the NEXT chunk is read in phase 3 (which has no reads of
+    // its own) into fb0n and becomes fb0 at the chunk boundary; chunk 0's B0 is read here
+    f32x4 fb0n[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fb0[kk] = rd(lds, b_base, 0, kk);
+#endif
+    // The compute segment. hipcc treats MFMAs as pure register arithmetic and would sink them past the closing barrier
+    // into the next load segment (or hoist them above the wait): the empty asm statements make the fragments
+    // "produced" after the lgkmcnt wait and the two accumulators "consumed" before the barrier, which pins the
+    // cluster between the two s_barriers without hiding the MFMAs from the scheduler's hazard handling.
+#define TD_PIN4(x) "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])
+#if !defined(TD_PP8_BAL)
+#define TD_PIN_EXTRA() do {} while (0)
+#else
+#define TD_PIN_EXTRA() asm volatile("" : TD_PIN4(fb0n))
+#endif
+#define TD_COMPUTE(FB, AI0, AI1, NJ)                                                                         \
+    do {                                                                                                     \
+        TD_PP8_BARRIER();                                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+        asm volatile("" : TD_PIN4(fa[0]), TD_PIN4(fa[1]), TD_PIN4(FB));                                      \
+        TD_PIN_EXTRA();                                                                                      \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                   \
+            Elem<T>::mma(fa[0][kk], FB[kk], acc[AI0][NJ]);                                                   \
+            Elem<T>::mma(fa[1][kk], FB[kk], acc[AI1][NJ]);                                                   \
+        }                                                                                                    \
+        asm volatile("" : "+v"(acc[AI0][NJ]), "+v"(acc[AI1][NJ]));                                           \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
+        TD_PP8_BARRIER();                                                                                    \
+    } while (0)
+    // mode 0: steady state (every phase issues its pair; vmcnt(8) = the pair issued four phases ago has landed);
+    // mode 1: second-to-last chunk (pairs remain for phases 0 and 1 only); mode 2: last chunk (nothing left to issue)
+    auto run_chunk = [&](int c, auto mode_c) {
+        constexpr int mode = decltype(mode_c)::value;
+        const char* st = lds + (c & 1) * STAGE;
+        // ---- phase 0: quadrant (A0, B0) ----
+#if !defined(TD_PP8_BAL)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fb0[kk] = rd(st, b_base, 0, kk);
+#endif
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fa[0][kk] = rd(st, a_base, 0, kk);
+            fa[1][kk] = rd(st, a_base, 1, kk);
+        }
+        if constexpr (mode <= 1) issue_pair(P2{});
+        if constexpr (mode <= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        TD_COMPUTE(fb0, 0, 1, 0);
+        // ---- phase 1: quadrant (A0, B1) ----
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fb1[kk] = rd(st, b_base, 1, kk);
+        if constexpr (mode <= 1) issue_pair(P3{});
+        if constexpr (mode <= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TD_COMPUTE(fb1, 0, 1, 1);
+        // ---- phase 2: quadrant (A1, B1) ----
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fa[0][kk] = rd(st, a_base, 2, kk);
+            fa[1][kk] = rd(st, a_base, 3, kk);
+        }
+        if constexpr (mode == 0) issue_pair(P0{});
+#if !defined(TD_PP8_BAL)
+        if constexpr (mode == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (mode == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#else   // B0 of the next chunk (pair n + 3) is read one phase from here: one pair fewer may stay in flight
+        if constexpr (mode == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (mode == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#endif
+        TD_COMPUTE(fb1, 2, 3, 1);
+        // ---- phase 3: quadrant (A1, B0): no new fragments of its own ----
+#if defined(TD_PP8_BAL)
+        if constexpr (mode <= 1) {
+            const char* stn = lds + ((c + 1) & 1) * STAGE;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) fb0n[kk] = rd(stn, b_base, 0, kk);
+        }
+#endif
+        if constexpr (mode == 0) issue_pair(P1{});
+        if constexpr (mode == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (mode == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        TD_COMPUTE(fb0, 2, 3, 0);
+#if defined(TD_PP8_BAL)
+        if constexpr (mode <= 1) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) fb0[kk] = fb0n[kk];
+        }
+#endif
+    };
+    int c = 0;
+    for (; c + 2 < nchunks; ++c) run_chunk(c, std::integral_constant<int, 0>{});
+    if (nchunks >= 2) run_chunk(c++, std::integral_constant<int, 1>{});
+    run_chunk(c, std::integral_constant<int, 2>{});
+#undef TD_COMPUTE
+#undef TD_PIN_EXTRA
+#undef TD_PIN4
+#undef TD_PP8_BARRIER
+    if (wm == 0) __builtin_amdgcn_s_barrier();         // the barrier wave-row 1 took in the prologue
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // every wave is past its last fragment read: LDS is the epilogue's
+#if defined(TD_DIAG_PP8_NO_EPILOGUE)                   // diagnostic builds only: keep the accumulators live, store one value
+    float keep = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) keep += acc[i][j][0] + acc[i][j][15];
+    if (keep == 12345.678f) static_cast<TO*>(a.y)[tid] = (TO)keep;
+    return;
+#endif
+    conv_epilogue<T, TO, MT, NT, WM, WN, 1>(a, acc, lds, M, m0, n0, tid, lane, wm, wn);
 }
 
 template <typename T, typename TO, int MT, int NT, int NSTAGE, int WM = 2, int WN = 2>
@@ -417,6 +824,16 @@ td_status dispatch(const ConvArgs& a, int cfg, hipStream_t stream) {
         case 14: return launch<T, TO, 2, 2, 1, 4, 4>(a, stream);    // 256 x 256
         case 15: return launch<T, TO, 2, 2, 1, 2, 2>(a, stream);    // 128 x 128
         case 16: return launch<T, TO, 2, 2, 1, 2, 4>(a, stream);    // 128 x 256
+        case 17:                                                     // 256 x 256, 8 waves, ping-pong phases (fp16 only)
+            if constexpr (std::is_same<T, _Float16>::value) {
+                const int tiles = td_cdiv(a.M, 256) * td_cdiv(a.Cout, 256);
+                hipLaunchKernelGGL((conv_pp8_kernel<TO>), dim3(tiles), dim3(512), 0, stream, a);
+                TD_KERNEL_CHECK();
+                return TD_OK;
+            } else {
+                td_set_error("conv2d: tile_cfg 17 is an fp16 kernel");
+                return TD_ERR_INVALID;
+            }
         default: td_set_error("conv2d: bad tile_cfg %d", cfg); return TD_ERR_INVALID;
     }
 }
@@ -432,12 +849,13 @@ td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream) {
     TD_REQUIRE((size_t)a.B * a.H * a.W * (size_t)a.Cin * es < 0xfffffff0ull - (1u << 20), "conv2d: input tensor must stay below 4 GB (32-bit buffer offsets)");
     TD_REQUIRE((size_t)a.Cout * a.KH * a.KW * a.Cin * es < 0xfffffff0ull - (1u << 20), "conv2d: weight tensor must stay below 4 GB");
     TD_REQUIRE(a.KH * a.KW <= 32, "conv2d: at most 32 filter taps (got %dx%d)", a.KH, a.KW);
-    TD_REQUIRE(a.out_mode == 0 || (a.Cout % 16 == 0 && !a.res), "conv2d: bad deconv configuration");
+    TD_REQUIRE(a.out_mode == 0 || (a.Cout % 32 == 0 && !a.res), "conv2d: bad deconv configuration");
     int cfg = a.tile_cfg;
     if (cfg < 0) {
         static const char* forced = getenv("TD_CONV_CFG");     // diagnostics only (tools/conv_diag.py)
         if (forced) cfg = atoi(forced);
     }
+    if (cfg == 17 && (precision != TD_PRECISION_FP16 || a.out_mode != 0)) cfg = -1;      // fp16-only variant
     if (cfg < 0) {
         // heuristic (the engine replaces it by a measured choice per layer shape): wide N for wide layers, 64-row
         // tiles when there is less than one 128-row tile per CU

@@ -678,7 +678,8 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                 TD_HIP_CHECK(hipEventCreate(&eb));
                 const int ksteps = L.kh * L.kw * L.cin / (prec_ == TD_PRECISION_FP16 ? 64 : 32);
                 for (int c : TD_CONV_TUNE_CANDIDATES) {
-                    if (c >= 14 && ksteps > 4) continue;      // single-stage tiles only pay on the thin 1x1 layers
+                    if (c >= 14 && c <= 16 && ksteps > 4) continue;      // single-stage tiles only pay on the thin 1x1 layers
+                    if (c == 17 && (prec_ != TD_PRECISION_FP16 || out_mode != 0 || L.cout < 128)) continue;   // fp16 256x256 ping-pong tile
                     td_status st2 = run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, c);
                     if (st2 < 0) return st2;
                     // per-launch time over `reps` back-to-back launches; launches shorter than ~100 us are timed again
