@@ -85,15 +85,15 @@ struct Elem<_Float16> {
 //    leave as 8 channels (16 B) per lane with 16-B residual loads issued U rows ahead.
 // `lds` must hold the staged tile (conv_epilogue_lds_bytes) and every wave must be past its last LDS read of the k-loop
 // (the caller's final barrier).
-template <typename TO, int MT, int NT, int WM, int WN, int RWM>
+template <typename TO, int MT, int NT, int WM, int WN, int RWM, bool WIDE_OK = true>
 constexpr int conv_epilogue_lds_bytes() {
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     constexpr int f32 = RWM * 32 * MT * (BN + 4) * 4;
-    constexpr int f16 = sizeof(TO) == 2 ? BM * (BN + 8) * 2 : 0;
+    constexpr int f16 = sizeof(TO) == 2 && WM * WN >= 8 && WIDE_OK ? BM * (BN + 8) * 2 : 0;
     return f32 > f16 ? f32 : f16;
 }
 
-template <typename T, typename TO, int MT, int NT, int WM, int WN, int RWM>
+template <typename T, typename TO, int MT, int NT, int WM, int WN, int RWM, bool WIDE_OK = true>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], char* lds, int M, int m0, int n0,
                                               int tid, int lane, int wm, int wn) {
     constexpr int THREADS = 64 * WM * WN;
@@ -104,7 +104,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
     const T* __restrict__ Rs = static_cast<const T*>(a.res);
     const int hw = a.Ho * a.Wo;
 
-    if constexpr (sizeof(TO) == 2) {
+    // The wide paths (fp16 tile staged in one round, 8 channels per lane) cost ~35 more live registers than the plain
+    // one: worth it on the 8- and 16-wave tiles that own a CU anyway, not on the 4-wave tiles whose thin layers live on
+    // three or four co-resident blocks per CU.
+    constexpr bool WIDE = sizeof(TO) == 2 && THREADS >= 512 && WIDE_OK;
+    if constexpr (WIDE) {
         if (!Rs && a.out_mode == 0 && (a.Cout & 7) == 0) {
             // ---- fp16 fast path: finish in registers, stage packed fp16, one round ----
             constexpr int HS = BN + 8;                // row stride in halves: 16-B aligned rows, 4-dword skew between rows
@@ -137,6 +141,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                         pk[1] = (_Float16)(odd ? t1 : got);
                         const int row = wm * WROW + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) + odd;
                         *reinterpret_cast<f16x2*>(&Hs[row * HS + (col & ~1)]) = pk;
+                        // keep the pairs sequential: hoisting all conversions ahead of the stores costs ~35 live registers
+                        // (and with them a block per CU on the small tiles)
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
@@ -163,7 +170,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
     // ---- general path: fp32 tile, RWM wave-rows per round ----
     float* Cs = reinterpret_cast<float*>(lds);
     const int Cq = a.out_mode == 1 ? a.Cout >> 2 : a.Cout;
-    constexpr int CPL = sizeof(TO) == 2 ? 8 : 4;      // channels per lane: 16-B stores either way
+    constexpr int CPL = WIDE ? 8 : 4;                  // channels per lane
     constexpr int CHUNKS = BN / CPL;                   // pieces per tile row
     constexpr int ROWS_PER_PASS = THREADS / CHUNKS;
     const int c4 = tid % CHUNKS;
@@ -201,7 +208,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
         // ran at 3.3 TB/s of HBM before, latency-bound right here).
         constexpr int ITERS = (RWM * WROW) / ROWS_PER_PASS;
         static_assert((RWM * WROW) % ROWS_PER_PASS == 0 && ITERS >= 1, "epilogue rows must split evenly over the threads");
-        constexpr int U = ITERS < 8 ? ITERS : 8;
+        constexpr int UMAX = CPL == 8 ? 4 : 8;         // 64 B per lane in flight either way
+        constexpr int U = ITERS < UMAX ? ITERS : UMAX;
         static_assert(ITERS % U == 0, "epilogue batch must divide the rows per thread");
         typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
         typedef typename std::conditional<sizeof(T) == 4, f32x4, typename std::conditional<CPL == 8, f16x8v, f16x4>::type>::type ResVec;
@@ -270,11 +278,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                     if constexpr (sizeof(TO) == 4) {
                         f32x4 o = {v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4*>(Y + yoff) = o;
-                    } else {
+                    } else if constexpr (CPL == 8) {
                         f16x8v h;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) h[e] = (_Float16)v[e];
                         *reinterpret_cast<f16x8v*>(Y + yoff) = h;
+                    } else {
+                        f16x4 h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
+                        *reinterpret_cast<f16x4*>(Y + yoff) = h;
                     }
                 } else {
 #pragma unroll
@@ -291,7 +304,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
 // 4x2 / 2x4 / 4x4 = 256x128 / 128x256 / 256x256 block tiles whose larger operand reuse cuts the DMA instructions and
 // the L2 traffic per flop (what bounds the fp16 path).
 template <typename T, typename TO, int MT, int NT, int NSTAGE, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 && MT * NT <= 4 ? 4 : 1)     // single-stage tiles: >= 4 waves per SIMD (<= 128 registers)
+void conv_igemm_kernel(const ConvArgs a) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     constexpr int LDROWS = THREADS / 8;               // rows staged per pass (8 lanes x 16 B per row)
@@ -305,7 +319,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
     // the epilogue stages RWM wave-rows at a time through LDS (all of them when the k-loop's LDS is large enough)
     constexpr int FIT = STAGE_BYTES / (WROW * CS * 4);
     constexpr int RWM = FIT >= WM ? WM : (FIT >= 2 && WM % 2 == 0 ? 2 : 1);
-    constexpr int EPI_BYTES = conv_epilogue_lds_bytes<TO, MT, NT, WM, WN, RWM>();
+    constexpr bool WIDE_OK = NSTAGE > 1;      // the single-stage tiles trade everything for blocks per CU
+    constexpr int EPI_BYTES = conv_epilogue_lds_bytes<TO, MT, NT, WM, WN, RWM, WIDE_OK>();
     __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES];
     char* As = lds;                                   // [NSTAGE][BM][128 B]   piece c of row r sits at slot c ^ ((r>>1)&7)
     char* Bs = lds + NSTAGE * BM * CHUNK_BYTES;       // [NSTAGE][BN][128 B]
@@ -493,7 +508,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
         }
     }
 
-    conv_epilogue<T, TO, MT, NT, WM, WN, RWM>(a, acc, lds, M, m0, n0, tid, lane, wm, wn);
+    conv_epilogue<T, TO, MT, NT, WM, WN, RWM, WIDE_OK>(a, acc, lds, M, m0, n0, tid, lane, wm, wn);
 }
 
 // ---- conv_pp8_kernel: 256 x 256 block tile, 8 waves, ping-pong schedule (fp16 only) ---------------------------------
