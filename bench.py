@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-fp16", action="store_true", help="skip the second timed region with the fp16 engine")
     ap.add_argument("--no-pipeline", action="store_true", help="plain loop: one batch at a time on one stream")
     ap.add_argument("--no-serial", action="store_true", help="skip the extra informational single-stream region")
+    ap.add_argument("--no-r101", action="store_true", help="skip the extra timed region with the reference's own depth (R101-FPN)")
+    ap.add_argument("--no-fp16-b32", action="store_true", help="skip the fp16 region at BASELINE configs[4]'s batch (32 per GPU)")
     ap.add_argument("--streams", type=int, default=1, help="engines / HIP streams the batches alternate over (the "
                     "low-occupancy selection tail of one batch overlaps the next batch's convolutions)")
     return ap.parse_args()
@@ -152,6 +154,8 @@ def main():
     ndsm = torch.from_numpy(ndsm_np).to(dev)          # side band: travels with the tile, not a network input
     gather_keys = ("boxes", "scores", "count", "mask_probs")
 
+    nsteps = args.steps      # the extra regions below re-bind sd / B / nsteps before calling run_pipelined again
+
     def run(precision, ns, profile):
         """Warm-up + timed region for one engine precision over `ns` engines / HIP streams → (seconds max over
         ranks, profile dict or None, detections)."""
@@ -191,7 +195,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(nsteps):
             step(args.warmup + i)
         t_enq = time.perf_counter() - t0          # host time to enqueue everything (launch-bound if close to dt)
         torch.cuda.synchronize()
@@ -303,7 +307,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_batches(nw, nw + args.steps)
+        run_batches(nw, nw + nsteps)
         t_enq = time.perf_counter() - t0
         torch.cuda.synchronize()
         if world > 1:
@@ -342,6 +346,22 @@ def main():
         extra = run("fp16", 1, not args.no_profile) if args.no_pipeline else run_pipelined("fp16", not args.no_profile)
     if not args.no_pipeline and not args.no_serial:
         piped = run(args.precision, 1, False)      # informational: the plain one-batch-at-a-time loop
+    r101 = b32 = None
+    if args.precision == "fp32" and args.depth == 50 and not args.no_pipeline and world == 1:
+        if not args.no_r101:
+            # the reference's own depth (TreeDetection/config.py:25 hard-codes R101-FPN): same stream, same schedule
+            log("generating R101 weights")
+            sd = make_synthetic_state_dict(101, seed=0)
+            nsteps = max(4, args.steps // 2)
+            r101 = {"fp32": run_pipelined("fp32", not args.no_profile) + (nsteps,)}
+            if not args.no_fp16:
+                r101["fp16"] = run_pipelined("fp16", not args.no_profile) + (nsteps,)
+            sd = make_synthetic_state_dict(args.depth, seed=0)
+        if not args.no_fp16 and not args.no_fp16_b32:
+            # BASELINE configs[4]: the fp16 MFMA path at batch 32 per GPU (same tiles, four times the rows per launch)
+            B, nsteps = 32, max(4, args.steps // 4)
+            b32 = run_pipelined("fp16", not args.no_profile) + (nsteps,)
+            B, nsteps = args.batch, args.steps
 
     if rank == 0:
         tiles_total = args.steps * B * world
@@ -412,6 +432,25 @@ def main():
                                  "algorithmic_bytes_per_launch": c16["bytes"] / max(c16["launches"], 1)}
                 o["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof16.items()}
             line["fp16"] = o
+        def sub(res, batch, peak, depth):
+            dtx, profx, ndetx, k = res
+            o = {"value": k * batch * world / dtx, "unit": "tiles/s", "ms_per_step": 1000.0 * dtx / k, "steps": k,
+                 "batch_per_gpu": batch, "depth": depth, "detections_last_batch": ndetx}
+            if profx is not None:
+                cx = profx["conv_igemm"]
+                ax = cx["flops"] / (cx["ms"] * 1e-3) / 1e12 if cx["ms"] > 0 else 0.0
+                o["roofline"] = {"bound": "mfma", "achieved": ax, "peak": peak, "unit": "TFLOP/s", "frac": ax / peak,
+                                 "traffic": None, "gflop_per_step": cx["flops"] / k / 1e9}
+                o["breakdown_ms_per_step"] = {kk: v["ms"] / k for kk, v in profx.items()}
+            return o
+        if r101 is not None:
+            line["r101"] = {"note": "the reference's own depth (config.py:25: mask_rcnn_R_101_FPN_3x), same stream and schedule",
+                            "f32": sub(r101["fp32"], args.batch, PEAK_F32_MATRIX_TFLOPS, 101)}
+            if "fp16" in r101:
+                line["r101"]["f16"] = sub(r101["fp16"], args.batch, PEAK_F16_MATRIX_TFLOPS, 101)
+        if b32 is not None:
+            line["fp16_batch32"] = sub(b32, 32, PEAK_F16_MATRIX_TFLOPS, args.depth)
+            line["fp16_batch32"]["note"] = "BASELINE configs[4]: fp16 MFMA conv path at batch 32 per GPU, R50-FPN, same tile stream"
         if piped is not None:
             line["single_stream"] = {"value": tiles_total / piped[0], "unit": "tiles/s", "ms_per_step": 1000.0 * piped[0] / args.steps,
                                      "note": "same K steps as a plain loop, one batch at a time on one stream (informational)"}

@@ -326,3 +326,37 @@ def test_config4_fp16_batch32_full_size():
         for k in ("count", "boxes", "scores", "mask_probs", "mask_region"):
             assert torch.equal(o1[k][0], o32[k][i]), (i, k)
     eng.close()
+
+
+def test_full_width_r101_tile_matches_oracle():
+    """The reference's only depth (TreeDetection/config.py:25: mask_rcnn_R_101_FPN_3x, blocks [3,4,23,3]) at full width on
+    one 1000x1000 tile through the bench's device path (resize → forward → paste), against the oracle: same detections
+    one-to-one, boxes <= 1e-2 px, scores <= 1e-4, mask probabilities <= 1e-3, pasted masks IoU >= 0.995."""
+    from treedetection_amd.engine import Engine, INPUT_U8_HWC, unpack_outputs
+    torch.set_num_threads(8)
+    sd = make_synthetic_state_dict(101, seed=0)
+    tile_np = make_tile(3, 1000)[0]
+    eng = Engine(sd)
+    tiles = [torch.from_numpy(tile_np).cuda()]
+    batch, hw_valid, hw_out = eng.preprocess_tiles_u8(tiles)
+    out = eng.alloc_outputs(1, 1000, 1000, paste=True)
+    eng.forward_raw(batch, INPUT_U8_HWC, hw_valid, hw_out, out)
+    torch.cuda.synchronize()
+    g = unpack_outputs(out, hw_out, True)[0]
+    x, h, w = R.preprocess_tile_u8(tile_np.transpose(2, 0, 1))
+    oracle = MaskRCNNOracle(sd)
+    assert oracle.blocks == [3, 4, 23, 3]
+    ref = oracle.forward([{"image": x, "height": h, "width": w}])[0]
+    assert len(ref["scores"]) >= 5 and abs(len(g["scores"]) - len(ref["scores"])) <= 1
+    matched = 0
+    for j in range(len(ref["scores"])):
+        d = np.abs(g["pred_boxes"] - ref["pred_boxes"][j]).max(axis=1)
+        k = int(np.argmin(d))
+        if d[k] <= 1e-2 and abs(g["scores"][k] - ref["scores"][j]) <= 1e-4:
+            a, b = g["pred_masks"][k], ref["pred_masks"][j]
+            u = (a | b).sum()
+            assert u == 0 or (a & b).sum() / u >= 0.995
+            assert np.abs(g["mask_probs"][k] - ref["mask_probs"][j]).max() <= 1e-3
+            matched += 1
+    assert matched >= len(ref["scores"]) - 1, (matched, len(ref["scores"]))
+    eng.close()

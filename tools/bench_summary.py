@@ -1,11 +1,23 @@
-"""Pretty-print a bench.py JSON line from stdin: tools/bench_summary.py [label]"""
-import json, sys
-d = json.loads(sys.stdin.read())
-lab = sys.argv[1] if len(sys.argv) > 1 else ""
-r = d.get("roofline", {})
-print(lab, "fp32" if d["dtype"] == "f32" else d["dtype"], round(d["value"], 1), "tiles/s  conv", round(r.get("achieved", 0), 1), "TF/s",
-      {k: round(v, 2) for k, v in d.get("breakdown_ms_per_step", {}).items()})
-if "fp16" in d:
-    f = d["fp16"]
-    print(lab, "fp16", round(f["value"], 1), "tiles/s  conv", round(f.get("roofline", {}).get("achieved", 0), 1), "TF/s",
-          {k: round(v, 2) for k, v in f.get("breakdown_ms_per_step", {}).items()})
+"""One-line-per-region view of bench.py's JSON line (stdin)."""
+import json
+import sys
+
+j = json.loads(sys.stdin.read().strip().splitlines()[-1])
+
+
+def show(tag, o):
+    r = o.get("roofline") or {}
+    b = {k: round(v, 2) for k, v in (o.get("breakdown_ms_per_step") or {}).items()}
+    print(f" {tag:14s} {o['value']:8.1f} tiles/s  {o['ms_per_step']:7.2f} ms/step  conv {r.get('achieved', 0):7.1f} TF/s (frac {r.get('frac', 0):.3f})  {b}")
+
+
+show("fp32", j)
+for k, tag in (("fp16", "fp16"), ("fp16_batch32", "fp16 b32"), ("single_stream", "fp32 plain")):
+    if k in j:
+        show(tag, j[k])
+if "r101" in j:
+    for k, o in j["r101"].items():
+        if isinstance(o, dict):
+            show("r101 " + k, o)
+if "cpu_baseline" in j:
+    print(" cpu_baseline", j["cpu_baseline"]["value"], j["cpu_baseline"]["unit"], j["cpu_baseline"]["cores"], "cores")

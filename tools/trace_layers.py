@@ -39,7 +39,7 @@ def schedule(depth=50, B=8, Hp=800, Wp=800, P=1000):
 
 
 def main(path, depth=50):
-    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"] or "conv_pp8" in r["Kernel_Name"]]
     L = schedule(depth)
     n = len(L)
     last = rows[-n:]
@@ -47,7 +47,8 @@ def main(path, depth=50):
     for (name, M, N, K), r in zip(L, last):
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         gf = 2.0 * M * N * K / 1e9
-        kern = r["Kernel_Name"].split("conv_igemm_")[1].split("(")[0]
+        kn = r["Kernel_Name"]
+        kern = "pp8" if "conv_pp8" in kn else kn.split("conv_igemm_")[1].split("(")[0]
         print(f"{name:24s} M={M:7d} N={N:5d} K={K:6d} {kern:14s} grid={int(r['Grid_Size_X'])//256:5d} {us:9.1f} us {gf:8.2f} GF {gf/us*1e3 if us else 0:7.1f} TF/s")
         if M:
             tot_f += gf
