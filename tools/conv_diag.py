@@ -8,7 +8,7 @@ CS = os.path.join(ROOT, "treedetection_amd", "csrc")
 def build(tag, defs):
     out = f"/tmp/libdiag_{tag}.so"
     srcs = [os.path.join(CS, f) for f in ("conv_igemm.hip", "api.cpp", "error.cpp", "stem.hip", "rpn.hip", "roi.hip", "engine.cpp", "contours.cpp")]
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", "-x", "hip"] + defs + srcs + ["-o", out]
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form", "-x", "hip"] + defs + srcs + ["-o", out]
     subprocess.run(cmd, check=True)
     return out
 
@@ -68,7 +68,7 @@ if __name__ == "__main__":
                     "pp8 no_reads": ["-DTD_DIAG_PP8_NO_READS"],
                     "pp8 mfma_only": ["-DTD_DIAG_PP8_NO_DMA", "-DTD_DIAG_PP8_NO_READS", "-DTD_DIAG_PP8_NO_BARRIER"],
                     "pp8 no_epilogue": ["-DTD_DIAG_PP8_NO_EPILOGUE"],
-                    "pp8 balanced": ["-DTD_PP8_BAL"],
+                    "pp8 v1_dma_first": ["-DTD_PP8_V1"], "pp8 v2_dma_light_phases": ["-DTD_PP8_V2"],
                     "pp8 mfma16": ["-DTD_DIAG_MFMA16"],
                     "pp8 mfma16_loop_only": ["-DTD_DIAG_MFMA16", "-DTD_DIAG_PP8_NO_DMA", "-DTD_DIAG_PP8_NO_READS", "-DTD_DIAG_PP8_NO_EPILOGUE"],
                     "pp8 loop_only": ["-DTD_DIAG_PP8_NO_DMA", "-DTD_DIAG_PP8_NO_READS", "-DTD_DIAG_PP8_NO_EPILOGUE"]}

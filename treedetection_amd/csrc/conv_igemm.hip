@@ -89,7 +89,7 @@ template <typename TO, int MT, int NT, int WM, int WN, int RWM, bool WIDE_OK = t
 constexpr int conv_epilogue_lds_bytes() {
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     constexpr int f32 = RWM * 32 * MT * (BN + 4) * 4;
-    constexpr int f16 = sizeof(TO) == 2 && WM * WN >= 8 && WIDE_OK ? BM * (BN + 8) * 2 : 0;
+    constexpr int f16 = sizeof(TO) == 2 && WIDE_OK ? BM * (BN + 8) * 2 : 0;
     return f32 > f16 ? f32 : f16;
 }
 
@@ -104,11 +104,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
     const T* __restrict__ Rs = static_cast<const T*>(a.res);
     const int hw = a.Ho * a.Wo;
 
-    // The wide paths (fp16 tile staged in one round, 8 channels per lane) cost ~35 more live registers than the plain
-    // one: worth it on the 8- and 16-wave tiles that own a CU anyway, not on the 4-wave tiles whose thin layers live on
-    // three or four co-resident blocks per CU.
-    constexpr bool WIDE = sizeof(TO) == 2 && THREADS >= 512 && WIDE_OK;
-    if constexpr (WIDE) {
+    // The 8-channel-per-lane general path costs ~30 more live registers than the 4-channel one: worth it on the 8- and
+    // 16-wave tiles that own a CU anyway, not on the 4-wave tiles whose thin layers live on three or four co-resident
+    // blocks per CU. The register-finished fp16 staging is cheap in registers as long as the accumulators live in VGPRs
+    // (the Makefile builds this file with -mllvm -amdgpu-mfma-vgpr-form: with AGPR accumulators hipcc copies all of
+    // them to VGPRs ahead of this code, +64 registers).
+    constexpr bool WIDE = sizeof(TO) == 2 && THREADS >= 512 && WIDE_OK;      // 8 channels per lane in the general path
+    constexpr bool E16 = sizeof(TO) == 2 && WIDE_OK;                         // register-finished fp16 staging
+    if constexpr (E16) {
         if (!Rs && a.out_mode == 0 && (a.Cout & 7) == 0) {
             // ---- fp16 fast path: finish in registers, stage packed fp16, one round ----
             constexpr int HS = BN + 8;                // row stride in halves: 16-B aligned rows, 4-dword skew between rows
@@ -693,29 +696,16 @@ __global__ __launch_bounds__(512) void conv_pp8_kernel(const ConvArgs a) {
     if (wm == 1) __builtin_amdgcn_s_barrier();         // wave-row 1 runs one barrier behind wave-row 0
 
     f32x4 fa[2][4], fb0[4], fb1[4];
-#if defined(TD_PP8_BAL)
-    // fragment reads spread 8 / 4 / 8 / 4 over the phases: B0 of the NEXT chunk is read in phase 3 (which has no reads of
-    // its own) into fb0n and becomes fb0 at the chunk boundary; chunk 0's B0 is read here
-    f32x4 fb0n[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) fb0[kk] = rd(lds, b_base, 0, kk);
-#endif
     // The compute segment. hipcc treats MFMAs as pure register arithmetic and would sink them past the closing barrier
     // into the next load segment (or hoist them above the wait): the empty asm statements make the fragments
     // "produced" after the lgkmcnt wait and the two accumulators "consumed" before the barrier, which pins the
     // cluster between the two s_barriers without hiding the MFMAs from the scheduler's hazard handling.
 #define TD_PIN4(x) "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])
-#if !defined(TD_PP8_BAL)
-#define TD_PIN_EXTRA() do {} while (0)
-#else
-#define TD_PIN_EXTRA() asm volatile("" : TD_PIN4(fb0n))
-#endif
 #define TD_COMPUTE(FB, AI0, AI1, NJ)                                                                         \
     do {                                                                                                     \
         TD_PP8_BARRIER();                                                                                    \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
         asm volatile("" : TD_PIN4(fa[0]), TD_PIN4(fa[1]), TD_PIN4(FB));                                      \
-        TD_PIN_EXTRA();                                                                                      \
         __builtin_amdgcn_s_setprio(1);                                                                       \
         _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                   \
             Elem<T>::mma(fa[0][kk], FB[kk], acc[AI0][NJ]);                                                   \
@@ -730,59 +720,86 @@ __global__ __launch_bounds__(512) void conv_pp8_kernel(const ConvArgs a) {
     auto run_chunk = [&](int c, auto mode_c) {
         constexpr int mode = decltype(mode_c)::value;
         const char* st = lds + (c & 1) * STAGE;
-        // ---- phase 0: quadrant (A0, B0) ----
-#if !defined(TD_PP8_BAL)
+#if defined(TD_PP8_V2)
+        // experiment: DMA only in the light phases — [P2,P3] of chunk c+1 in phase 1, [P0,P1] of chunk c+2 in phase 3
+        // ---- phase 0 ----
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) fb0[kk] = rd(st, b_base, 0, kk);
-#endif
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             fa[0][kk] = rd(st, a_base, 0, kk);
             fa[1][kk] = rd(st, a_base, 1, kk);
         }
-        if constexpr (mode <= 1) issue_pair(P2{});
-        if constexpr (mode <= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if constexpr (mode <= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         TD_COMPUTE(fb0, 0, 1, 0);
-        // ---- phase 1: quadrant (A0, B1) ----
+        // ---- phase 1 ----
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) fb1[kk] = rd(st, b_base, 1, kk);
-        if constexpr (mode <= 1) issue_pair(P3{});
-        if constexpr (mode <= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (mode <= 1) { issue_pair(P2{}); issue_pair(P3{}); }
         TD_COMPUTE(fb1, 0, 1, 1);
-        // ---- phase 2: quadrant (A1, B1) ----
+        // ---- phase 2 ----
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             fa[0][kk] = rd(st, a_base, 2, kk);
             fa[1][kk] = rd(st, a_base, 3, kk);
         }
+        TD_COMPUTE(fb1, 2, 3, 1);
+        // ---- phase 3 ----
+        if constexpr (mode == 0) { issue_pair(P0{}); issue_pair(P1{}); }
+        if constexpr (mode == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (mode == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        TD_COMPUTE(fb0, 2, 3, 0);
+#else
+        // ---- phase 0: quadrant (A0, B0) ----
+#if defined(TD_PP8_V1)
+        if constexpr (mode <= 1) issue_pair(P2{});
+#endif
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fb0[kk] = rd(st, b_base, 0, kk);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fa[0][kk] = rd(st, a_base, 0, kk);
+            fa[1][kk] = rd(st, a_base, 1, kk);
+        }
+#if !defined(TD_PP8_V1)
+        if constexpr (mode <= 1) issue_pair(P2{});
+#endif
+        if constexpr (mode <= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        TD_COMPUTE(fb0, 0, 1, 0);
+        // ---- phase 1: quadrant (A0, B1) ----
+#if defined(TD_PP8_V1)
+        if constexpr (mode <= 1) issue_pair(P3{});
+#endif
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fb1[kk] = rd(st, b_base, 1, kk);
+#if !defined(TD_PP8_V1)
+        if constexpr (mode <= 1) issue_pair(P3{});
+#endif
+        if constexpr (mode <= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TD_COMPUTE(fb1, 0, 1, 1);
+        // ---- phase 2: quadrant (A1, B1) ----
+#if defined(TD_PP8_V1)
         if constexpr (mode == 0) issue_pair(P0{});
-#if !defined(TD_PP8_BAL)
+#endif
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fa[0][kk] = rd(st, a_base, 2, kk);
+            fa[1][kk] = rd(st, a_base, 3, kk);
+        }
+#if !defined(TD_PP8_V1)
+        if constexpr (mode == 0) issue_pair(P0{});
+#endif
         if constexpr (mode == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if constexpr (mode == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-#else   // B0 of the next chunk (pair n + 3) is read one phase from here: one pair fewer may stay in flight
-        if constexpr (mode == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if constexpr (mode == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#endif
         TD_COMPUTE(fb1, 2, 3, 1);
-        // ---- phase 3: quadrant (A1, B0): no new fragments of its own ----
-#if defined(TD_PP8_BAL)
-        if constexpr (mode <= 1) {
-            const char* stn = lds + ((c + 1) & 1) * STAGE;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fb0n[kk] = rd(stn, b_base, 0, kk);
-        }
-#endif
+        // ---- phase 3: quadrant (A1, B0): no new fragments ----
         if constexpr (mode == 0) issue_pair(P1{});
         if constexpr (mode == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if constexpr (mode == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         TD_COMPUTE(fb0, 2, 3, 0);
-#if defined(TD_PP8_BAL)
-        if constexpr (mode <= 1) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fb0[kk] = fb0n[kk];
-        }
 #endif
     };
     int c = 0;
@@ -790,7 +807,6 @@ __global__ __launch_bounds__(512) void conv_pp8_kernel(const ConvArgs a) {
     if (nchunks >= 2) run_chunk(c++, std::integral_constant<int, 1>{});
     run_chunk(c, std::integral_constant<int, 2>{});
 #undef TD_COMPUTE
-#undef TD_PIN_EXTRA
 #undef TD_PIN4
 #undef TD_PP8_BARRIER
     if (wm == 0) __builtin_amdgcn_s_barrier();         // the barrier wave-row 1 took in the prologue
