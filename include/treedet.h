@@ -152,6 +152,12 @@ td_status td_conv2d_nhwc(const void* x, const void* w, const float* scale, const
                          const void* residual, int res_shift, void* y, int B, int H, int W, int Cin,
                          int Cout, int KH, int KW, int stride, int pad, int relu, int precision,
                          void* stream);
+/* The same 3x3 / stride 1 / pad 1 convolution (float32) through the Winograd F(2x2,3x3) path the fp32 engine uses where it
+ * measures faster (input transform, 16 batched plane contractions on the MFMA kernel, output transform): x [B,H,W,Cin],
+ * w [Cout,3,3,Cin], y [B,H,W,Cout] = act(conv * scale + bias), all DEVICE pointers; Cin % 32 == 0, Cout % 4 == 0.
+ * Synchronous (allocates its own scratch): parity tests only. */
+td_status td_conv2d_winograd_nhwc(const float* x, const float* w, const float* scale, const float* bias, float* y, int B,
+                                  int H, int W, int Cin, int Cout, int relu, void* stream);
 /* Greedy NMS of n boxes (dev [n,4], scores dev [n]); keep_idx dev int32 [n] receives the kept
  * indices in descending-score order (ties: lower index first), *keep_count (dev) their number. */
 td_status td_nms(const float* boxes, const float* scores, int n, float iou_thresh, int32_t* keep_idx,

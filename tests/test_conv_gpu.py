@@ -149,3 +149,52 @@ def test_conv_every_block_tile_variant(cfg):
                         "-k", "matches_torch"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "18 passed" in r.stdout
+
+
+WINO_CASES = [
+    # B, Cin, H, W, Cout, scale, bias, relu
+    (1, 32, 8, 8, 16, False, True, False),
+    (2, 64, 20, 24, 64, True, True, True),
+    (1, 128, 25, 25, 128, True, True, True),          # odd sizes: the last tile row / column is half outside
+    (3, 96, 14, 14, 100, False, True, True),          # the mask head's 14 x 14 RoIs
+    (1, 256, 50, 50, 256, False, True, False),
+    (1, 64, 1, 7, 32, False, False, False),
+    (2, 256, 13, 13, 256, False, True, True),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_winograd_conv_matches_torch(case):
+    """Winograd F(2x2,3x3) path of the fp32 engine vs torch CPU F.conv2d: same tolerance as the direct kernel
+    (|err| <= 5e-5 * max|ref|; the transforms add a few roundings per output)."""
+    from treedetection_amd import _lib
+    from tests.gpu_util import dev
+    B, Cin, H, W, Cout, use_scale, use_bias, relu = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.standard_normal((B, Cin, H, W), dtype=np.float32)
+    w = rng.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) / np.float32(np.sqrt(Cin * 9))
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32) if use_scale else None
+    bias = rng.standard_normal(Cout).astype(np.float32) if use_bias else None
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), None, stride=1, padding=1)
+    if use_scale:
+        ref = ref * torch.from_numpy(scale).reshape(1, -1, 1, 1)
+    if use_bias:
+        ref = ref + torch.from_numpy(bias).reshape(1, -1, 1, 1)
+    if relu:
+        ref = F.relu(ref)
+    ref = ref.numpy()
+    lib = _lib.load()
+    xd, wd = dev(x.transpose(0, 2, 3, 1)), dev(w.transpose(0, 2, 3, 1))
+    sd = dev(scale) if use_scale else None
+    bd = dev(bias) if use_bias else None
+    y = torch.full((B, H, W, Cout), float("nan"), dtype=torch.float32, device="cuda")
+    p = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
+    _lib.check(lib.td_conv2d_winograd_nhwc(p(xd), p(wd), p(sd), p(bd), y.data_ptr(), B, H, W, Cin, Cout, int(relu), _lib.stream_ptr()),
+               "td_conv2d_winograd_nhwc")
+    got = y.cpu().numpy().transpose(0, 3, 1, 2)
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref).max()
+    assert err <= 5e-5 * max(1.0, np.abs(ref).max()), f"max abs err {err}"
+    # and against the direct MFMA kernel on the same inputs
+    direct = conv2d_hip(x, w, scale, bias, None, stride=1, pad=1, relu=relu)
+    assert np.abs(got - direct).max() <= 5e-5 * max(1.0, np.abs(ref).max())

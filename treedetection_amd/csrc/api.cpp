@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
+#include <vector>
 
 // (td_set_error / td_last_error: error.cpp — shared with the host-only sanitizer build)
 
@@ -46,6 +47,39 @@ td_status td_conv2d_nhwc(const void* x, const void* w, const float* scale, const
     a.M = B * a.Ho * a.Wo; a.m_dyn = nullptr; a.m_mul = 1; a.out_f32 = 0;
     a.tile_cfg = ((precision >> 8) & 0xff) - 1;          // tests: force one block-tile variant (0 = the library chooses)
     return conv2d_launch(a, precision & 0xff, static_cast<hipStream_t>(stream));
+}
+
+td_status td_conv2d_winograd_nhwc(const float* x, const float* w, const float* scale, const float* bias, float* y, int B, int H,
+                                  int W, int Cin, int Cout, int relu, void* stream) {
+    TD_REQUIRE(x && w && y && B >= 1 && H >= 1 && W >= 1, "td_conv2d_winograd_nhwc: bad arguments");
+    TD_REQUIRE(Cin % 32 == 0 && Cout % 4 == 0, "td_conv2d_winograd_nhwc: Cin must be a multiple of 32, Cout of 4");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t T = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+    std::vector<float> wh((size_t)Cout * 9 * Cin), uh((size_t)16 * Cout * Cin);
+    TD_HIP_CHECK(hipMemcpy(wh.data(), w, wh.size() * sizeof(float), hipMemcpyDeviceToHost));
+    wino_filter_transform(wh.data(), Cout, Cin, uh.data());
+    void *U = nullptr, *V = nullptr, *Mb = nullptr;
+    td_status st;
+    if ((st = scratch(&U, uh.size() * 4)) < 0 || (st = scratch(&V, 16 * T * Cin * 4)) < 0 || (st = scratch(&Mb, 16 * T * Cout * 4)) < 0) {
+        (void)hipFree(U); (void)hipFree(V); (void)hipFree(Mb);
+        return st;
+    }
+    TD_HIP_CHECK(hipMemcpy(U, uh.data(), uh.size() * 4, hipMemcpyHostToDevice));
+    st = wino_input_launch(x, B, H, W, Cin, static_cast<float*>(V), nullptr, 1, s);
+    if (st == TD_OK) {
+        ConvArgs a{};
+        a.x = V; a.w = U; a.y = Mb;
+        a.B = 1; a.H = 1; a.W = (int)T; a.Cin = Cin; a.Cout = Cout; a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.Ho = 1; a.Wo = (int)T;
+        a.M = (int)T; a.m_mul = 1; a.tile_cfg = -1;
+        a.batch_count = 16; a.x_bs = (long long)T * Cin; a.w_bs = (long long)Cout * Cin; a.y_bs = (long long)T * Cout;
+        st = conv2d_launch(a, TD_PRECISION_FP32, s);
+    }
+    if (st == TD_OK) st = wino_output_launch(static_cast<float*>(Mb), B, H, W, Cout, scale, bias, relu, y, nullptr, 1, s);
+    hipError_t herr = hipStreamSynchronize(s);
+    (void)hipFree(U); (void)hipFree(V); (void)hipFree(Mb);
+    if (st < 0) return st;
+    TD_HIP_CHECK(herr);
+    return TD_OK;
 }
 
 td_status td_resize_tile_u8(const uint8_t* src, int h, int w, int c, uint8_t* dst, int out_h, int out_w,

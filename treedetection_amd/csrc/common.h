@@ -45,6 +45,10 @@ struct ConvArgs {
     const int* m_dyn;     // optional device scalar: effective rows = min(M, *m_dyn * m_mul)
     int m_mul;
     int out_f32;          // fp16 path only: write y as float32 (RPN / box-predictor heads feed the fp32 selection kernels)
+    // batched launch (blockIdx.y = 0 .. batch_count-1): per-batch element offsets of x / w / y. Used by the Winograd path,
+    // whose 16 transform planes are 16 independent 1x1 contractions (winograd.hip). 0 / 1 = a plain launch.
+    int batch_count;
+    long long x_bs, w_bs, y_bs;
     int tile_cfg;         // -1 = heuristic; 0..3 = block tile 128x128, 128x64, 64x128, 64x64 with 2 LDS stages,
                           // 4..7 = the same tiles with 3 stages (engine autotunes)
 };
@@ -55,6 +59,12 @@ struct ConvArgs {
 #define TD_CONV_TILE_CFG_MAX 17
 static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
+
+// ---- Winograd F(2x2,3x3) transforms (winograd.hip; fp32 engine) ---------------------------------
+td_status wino_input_launch(const float* x, int B, int H, int W, int C, float* V, const int* m_dyn, int m_mul, hipStream_t s);
+td_status wino_output_launch(const float* Mb, int B, int H, int W, int N, const float* scale, const float* bias, int relu,
+                             float* y, const int* m_dyn, int m_mul, hipStream_t s);
+void wino_filter_transform(const float* w_ohwi, int N, int C, float* U);     // host: U [16][N][C]
 
 // ---- stem / pooling / resize (stem.hip) ---------------------------------------------------------
 struct ImgSizes {           // per-image valid sizes, passed by value (B <= TD_MAX_BATCH)

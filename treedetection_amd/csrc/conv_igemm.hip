@@ -308,7 +308,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
 // the L2 traffic per flop (what bounds the fp16 path).
 template <typename T, typename TO, int MT, int NT, int NSTAGE, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 && MT * NT <= 4 ? 4 : 1)     // single-stage tiles: >= 4 waves per SIMD (<= 128 registers)
-void conv_igemm_kernel(const ConvArgs a) {
+void conv_igemm_kernel(const ConvArgs a_in) {
+    ConvArgs a = a_in;
+    if (a.batch_count > 1) {                         // batched contraction: plane blockIdx.y of x / w / y
+        const long long bz = blockIdx.y;
+        a.x = static_cast<const T*>(a.x) + bz * a.x_bs;
+        a.w = static_cast<const T*>(a.w) + bz * a.w_bs;
+        a.y = static_cast<TO*>(a.y) + bz * a.y_bs;
+    }
     constexpr int THREADS = 64 * WM * WN;
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     constexpr int LDROWS = THREADS / 8;               // rows staged per pass (8 lanes x 16 B per row)
@@ -828,7 +835,8 @@ template <typename T, typename TO, int MT, int NT, int NSTAGE, int WM = 2, int W
 td_status launch(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     const int tiles = td_cdiv(a.M, BM) * td_cdiv(a.Cout, BN);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, TO, MT, NT, NSTAGE, WM, WN>), dim3(tiles), dim3(64 * WM * WN), 0, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, TO, MT, NT, NSTAGE, WM, WN>), dim3(tiles, a.batch_count > 1 ? a.batch_count : 1),
+                       dim3(64 * WM * WN), 0, stream, a);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
@@ -886,7 +894,8 @@ td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream) {
         static const char* forced = getenv("TD_CONV_CFG");     // diagnostics only (tools/conv_diag.py)
         if (forced) cfg = atoi(forced);
     }
-    if (cfg == 17 && (precision != TD_PRECISION_FP16 || a.out_mode != 0)) cfg = -1;      // fp16-only variant
+    if (cfg == 17 && (precision != TD_PRECISION_FP16 || a.out_mode != 0 || a.batch_count > 1)) cfg = -1;      // fp16-only variant
+    TD_REQUIRE(a.batch_count <= 1 || (a.KH == 1 && a.KW == 1 && !a.res), "conv2d: batched launches are 1x1 contractions");
     if (cfg < 0) {
         // heuristic (the engine replaces it by a measured choice per layer shape): wide N for wide layers, 64-row
         // tiles when there is less than one 128-row tile per CU

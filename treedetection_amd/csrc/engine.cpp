@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <tuple>
@@ -35,6 +36,7 @@ struct ConvLayer {
     float* scale = nullptr;   // [cout] or null
     float* bias = nullptr;    // [cout] or null
     bool out_f32 = false;     // fp16 engine: this layer still writes float32 (feeds the fp32 selection kernels)
+    float* wino_u = nullptr;  // fp32 engine, 3x3 layers: Winograd-transformed filters U [16][cout][cin] (winograd.hip)
 };
 
 struct Block {
@@ -108,6 +110,12 @@ struct td_engine {
     int backbone_subbatch = 0;    // 0 = whole batch; else images per backbone pass (TD_BACKBONE_SUBBATCH)
     // key: (cout, cin, kh*16+kw, rows, stride*4 + out_mode*2 + has_residual) — layers of identical shape share it
     std::map<std::tuple<int, int, int, int, int>, int> tuned;
+    // direct (0) or Winograd (1) per 3x3 layer, keyed by (cout, cin, H, W) WITHOUT the batch: one engine then treats a
+    // tile the same way whatever batch it arrives in (batch-8 == 8 x batch-1 bit for bit, tests/test_fullsize_gpu.py)
+    std::map<std::tuple<int, int, int, int>, int> algo;
+    bool winograd = true;         // TD_WINOGRAD=0 disables the Winograd path (diagnostics)
+    float *wino_v = nullptr, *wino_m = nullptr;
+    size_t wino_elems = 0;
     std::string tune_cache;       // TD_TUNE_CACHE: load / append measured choices (keeps profiled runs free of tuning launches)
 
     // forward context (kept between the phases of td_engine_forward_phase) and the per-phase completion events
@@ -221,6 +229,16 @@ td_status bn_fold(const TensorMap& tm, const std::string& p, int c, std::vector<
     return TD_OK;
 }
 
+// fp32 engine: Winograd F(2x2,3x3) filter bank of a 3x3 layer (used where the engine measures it faster, run_conv)
+td_status upload_wino(td_engine* e, const std::vector<float>& w_ohwi, ConvLayer& L) {
+    L.wino_u = nullptr;
+    if (e->desc.precision != TD_PRECISION_FP32 || !e->winograd || L.kh != 3 || L.kw != 3 || L.cin % 32 != 0 || L.cout % 4 != 0)
+        return TD_OK;
+    std::vector<float> u((size_t)16 * L.cout * L.cin);
+    wino_filter_transform(w_ohwi.data(), L.cout, L.cin, u.data());
+    return upload(e, u, &L.wino_u);
+}
+
 td_status load_conv_bn(td_engine* e, const TensorMap& tm, const std::string& p, ConvLayer& L) {
     const HostTensor* w;
     td_status st = need(tm, p + ".weight", 4, &w);
@@ -229,7 +247,9 @@ td_status load_conv_bn(td_engine* e, const TensorMap& tm, const std::string& p, 
     L.cin = (int)w->shape[1];
     L.kh = (int)w->shape[2];
     L.kw = (int)w->shape[3];
-    if ((st = upload_w(e, pack_ohwi(*w), &L.w)) < 0) return st;
+    const std::vector<float> packed = pack_ohwi(*w);
+    if ((st = upload_w(e, packed, &L.w)) < 0) return st;
+    if ((st = upload_wino(e, packed, L)) < 0) return st;
     std::vector<float> s, b;
     if ((st = bn_fold(tm, p, L.cout, s, b)) < 0) return st;
     if ((st = upload(e, s, &L.scale)) < 0) return st;
@@ -249,7 +269,9 @@ td_status load_conv_bias(td_engine* e, const TensorMap& tm, const std::string& p
         td_set_error("load_weights: bias of '%s' has wrong length", p.c_str());
         return TD_ERR_WEIGHTS;
     }
-    if ((st = upload_w(e, pack_ohwi(*w), &L.w)) < 0) return st;
+    const std::vector<float> packed = pack_ohwi(*w);
+    if ((st = upload_w(e, packed, &L.w)) < 0) return st;
+    if ((st = upload_wino(e, packed, L)) < 0) return st;
     L.scale = nullptr;
     return upload(e, std::vector<float>(b->data, b->data + L.cout), &L.bias);
 }
@@ -325,8 +347,10 @@ void load_tune_cache(td_engine* e) {
     if (e->tune_cache.empty()) return;
     if (FILE* f = fopen(e->tune_cache.c_str(), "r")) {
         int pr, a0, a1, a2, a3, a4, cfg;
-        while (fscanf(f, "%d %d %d %d %d %d %d", &pr, &a0, &a1, &a2, &a3, &a4, &cfg) == 7)
+        while (fscanf(f, "%d %d %d %d %d %d %d", &pr, &a0, &a1, &a2, &a3, &a4, &cfg) == 7) {
             if (pr == e->desc.precision && cfg >= 0 && cfg <= TD_CONV_TILE_CFG_MAX) e->tuned[std::make_tuple(a0, a1, a2, a3, a4)] = cfg;
+            if (pr == 100 + e->desc.precision && (cfg == 0 || cfg == 1)) e->algo[std::make_tuple(a0, a1, a2, a3)] = cfg;   // direct / Winograd
+        }
         fclose(f);
     }
 }
@@ -356,6 +380,7 @@ td_status td_engine_create(const td_model_desc* desc, int device, td_engine** ou
     td_engine* e = new td_engine();
     if (const char* sbenv = getenv("TD_BACKBONE_SUBBATCH")) e->backbone_subbatch = atoi(sbenv);
     if (const char* tc = getenv("TD_TUNE_CACHE")) e->tune_cache = tc;
+    if (const char* wg = getenv("TD_WINOGRAD")) e->winograd = atoi(wg) != 0;
     e->desc = d;
     load_tune_cache(e);
     e->device = device;
@@ -628,6 +653,20 @@ td_status td_engine_reserve(td_engine* e, int B, int Hp, int Wp) {
     if ((st = A(&e->o_classes, b * D)) < 0) return st;
     if ((st = A(&e->o_count, b)) < 0) return st;
     if ((st = A(&e->o_mask_probs, mrows * 784)) < 0) return st;
+    e->wino_v = e->wino_m = nullptr;
+    e->wino_elems = 0;
+    if (e->desc.precision == TD_PRECISION_FP32 && e->winograd) {
+        // Winograd workspace: 16 planes of [tiles][channels] for the largest 3x3 layer (FPN / RPN at p2, the bottleneck
+        // conv2 of every stage, the mask head over B*D RoIs of 14x14)
+        auto tiles = [](int h, int w) { return (size_t)((h + 1) / 2) * ((w + 1) / 2); };
+        size_t need = 0;
+        for (int l = 0; l < 5; ++l) need = std::max(need, b * tiles(hs[l], wsz[l]) * (size_t)e->fpn_c);
+        for (int s = 0; s < 4; ++s) need = std::max(need, b * tiles(hs[s], wsz[s]) * (size_t)e->stages[s][0].c2.cout);
+        need = std::max(need, mrows * tiles(14, 14) * (size_t)e->fpn_c);
+        e->wino_elems = 16 * need;
+        if ((st = A(&e->wino_v, e->wino_elems)) < 0) return st;
+        if ((st = A(&e->wino_m, e->wino_elems)) < 0) return st;
+    }
     e->rB = B;
     e->rHp = Hp;
     e->rWp = Wp;
@@ -653,6 +692,85 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
     auto PH = [&](int k) { return (phase_mask >> k) & 1u; };
     if (PH(0)) e->named.clear();
     td_status st;
+    // Times `launch(cfg)` for every candidate block tile on the live buffers (idempotent: same inputs, same outputs) and
+    // returns the fastest; launches shorter than ~100 us are timed again over a longer run (event granularity and clock
+    // ramps otherwise pick the wrong tile for them).
+    auto time_launch = [&](hipStream_t s_, hipEvent_t ea, hipEvent_t eb, auto&& launch, float* ms_out) -> td_status {
+        td_status st2 = launch();
+        if (st2 < 0) return st2;
+        float ms = 1e30f;
+        for (int round = 0, reps = 2; round < 2; ++round, reps = 8) {
+            TD_HIP_CHECK(hipEventRecord(ea, s_));
+            for (int rep = 0; rep < reps; ++rep)
+                if ((st2 = launch()) < 0) return st2;
+            TD_HIP_CHECK(hipEventRecord(eb, s_));
+            TD_HIP_CHECK(hipEventSynchronize(eb));
+            float t = 0.f;
+            TD_HIP_CHECK(hipEventElapsedTime(&t, ea, eb));
+            t /= (float)reps;
+            if (t < ms) ms = t;
+            if (ms > 0.1f) break;
+        }
+        *ms_out = ms;
+        return TD_OK;
+    };
+    // measured block tile of one launch shape (cached per engine, shared through the TD_TUNE_CACHE file)
+    auto tuned_cfg = [&](const std::tuple<int, int, int, int, int>& key, int prec_, int ksteps, bool pp8_ok, hipStream_t s_,
+                         auto&& launch_cfg, int* cfg_out, float* best_ms) -> td_status {
+        auto it = e->tuned.find(key);
+        if (it == e->tuned.end()) {
+            load_tune_cache(e);                   // another engine of this process may have measured it meanwhile
+            it = e->tuned.find(key);
+        }
+        if (it != e->tuned.end() && !best_ms) {
+            *cfg_out = it->second;
+            return TD_OK;
+        }
+        float best = 1e30f;
+        int best_cfg = -1;
+        hipEvent_t ea, eb;
+        TD_HIP_CHECK(hipEventCreate(&ea));
+        TD_HIP_CHECK(hipEventCreate(&eb));
+        for (int c : TD_CONV_TUNE_CANDIDATES) {
+            if (it != e->tuned.end() && c != it->second) continue;       // known choice: only its time is wanted
+            if (c >= 14 && c <= 16 && ksteps > 4) continue;      // single-stage tiles only pay on the thin 1x1 layers
+            if (c == 17 && !pp8_ok) continue;                    // fp16 256x256 ping-pong tile
+            float ms = 1e30f;
+            td_status st2 = time_launch(s_, ea, eb, [&]() { return launch_cfg(c); }, &ms);
+            if (st2 < 0) return st2;
+            if (ms < best) { best = ms; best_cfg = c; }
+        }
+        (void)hipEventDestroy(ea);
+        (void)hipEventDestroy(eb);
+        if (it == e->tuned.end()) {
+            e->tuned.emplace(key, best_cfg);
+            if (!e->tune_cache.empty()) {
+                if (FILE* f = fopen(e->tune_cache.c_str(), "a")) {
+                    fprintf(f, "%d %d %d %d %d %d %d\n", prec_, std::get<0>(key), std::get<1>(key), std::get<2>(key), std::get<3>(key), std::get<4>(key), best_cfg);
+                    fclose(f);
+                }
+            }
+        }
+        *cfg_out = best_cfg;
+        if (best_ms) *best_ms = best;
+        return TD_OK;
+    };
+    // Winograd F(2x2,3x3) path of a stride-1 3x3 layer (fp32 engine): input transform → ONE batched launch of the 16
+    // plane contractions through conv_igemm_kernel → output transform with the layer's scale / bias / ReLU (winograd.hip)
+    auto run_wino = [&](const ConvLayer& L, const void* x_, int B_, int H_, int W_, bool relu, void* y_, hipStream_t s_,
+                        const int* m_dyn, int m_mul, int gemm_cfg) -> td_status {
+        const int T = B_ * ((H_ + 1) / 2) * ((W_ + 1) / 2);
+        td_status st2 = wino_input_launch(static_cast<const float*>(x_), B_, H_, W_, L.cin, e->wino_v, m_dyn, m_mul, s_);
+        if (st2 < 0) return st2;
+        ConvArgs a{};
+        a.x = e->wino_v; a.w = L.wino_u; a.y = e->wino_m;
+        a.B = 1; a.H = 1; a.W = T; a.Cin = L.cin; a.Cout = L.cout; a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.Ho = 1; a.Wo = T;
+        a.M = T; a.m_dyn = m_dyn; a.m_mul = m_dyn ? m_mul / 4 : 1;        // even H, W with a device row count: tiles = rows / 4
+        a.batch_count = 16; a.x_bs = (long long)T * L.cin; a.w_bs = (long long)L.cout * L.cin; a.y_bs = (long long)T * L.cout;
+        a.tile_cfg = gemm_cfg;
+        if ((st2 = conv2d_launch(a, TD_PRECISION_FP32, s_)) < 0) return st2;
+        return wino_output_launch(e->wino_m, B_, H_, W_, L.cout, L.scale, L.bias, relu ? 1 : 0, static_cast<float*>(y_), m_dyn, m_mul, s_);
+    };
     auto run_conv = [&](const ConvLayer& L, const void* x_, int B_, int H_, int W_, int stride, int pad, bool relu,
                         void* y_, const void* res_, int res_shift, hipStream_t s_, int prec_,
                         const int* m_dyn = nullptr, int m_mul = 1, int out_mode = 0) -> td_status {
@@ -661,57 +779,48 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         const double flops = 2.0 * M * L.cout * K;
         const double es = prec_ == TD_PRECISION_FP16 ? 2.0 : 4.0;
         const double bytes = es * ((double)B_ * H_ * W_ * L.cin / (stride * stride) + M * L.cout * (res_ ? 2.0 : 1.0) + L.cout * K);
-        int cfg = -1;
+        int cfg = -1, wino_cfg = -1;
+        bool use_wino = false;
+        td_status st2;
         if (e->autotune) {
             const auto key = std::make_tuple(L.cout, L.cin, L.kh * 16 + L.kw, B_ * Ho * Wo, stride * 4 + out_mode * 2 + (res_ ? 1 : 0));
-            auto it = e->tuned.find(key);
-            if (it == e->tuned.end()) {
-                load_tune_cache(e);                   // another engine of this process may have measured it meanwhile
-                it = e->tuned.find(key);
-            }
-            if (it == e->tuned.end()) {
-                // time every block-tile shape on this very launch (idempotent: same inputs, same output buffer)
-                float best = 1e30f;
-                int best_cfg = -1;
-                hipEvent_t ea, eb;
-                TD_HIP_CHECK(hipEventCreate(&ea));
-                TD_HIP_CHECK(hipEventCreate(&eb));
-                const int ksteps = L.kh * L.kw * L.cin / (prec_ == TD_PRECISION_FP16 ? 64 : 32);
-                for (int c : TD_CONV_TUNE_CANDIDATES) {
-                    if (c >= 14 && c <= 16 && ksteps > 4) continue;      // single-stage tiles only pay on the thin 1x1 layers
-                    if (c == 17 && (prec_ != TD_PRECISION_FP16 || out_mode != 0 || L.cout < 128)) continue;   // fp16 256x256 ping-pong tile
-                    td_status st2 = run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, c);
-                    if (st2 < 0) return st2;
-                    // per-launch time over `reps` back-to-back launches; launches shorter than ~100 us are timed again
-                    // over a longer run (event granularity and clock ramps otherwise pick the wrong tile for them)
-                    float ms = 1e30f;
-                    for (int round = 0, reps = 2; round < 2; ++round, reps = 8) {
-                        TD_HIP_CHECK(hipEventRecord(ea, s_));
-                        for (int rep = 0; rep < reps; ++rep)
-                            if ((st2 = run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, c)) < 0) return st2;
-                        TD_HIP_CHECK(hipEventRecord(eb, s_));
-                        TD_HIP_CHECK(hipEventSynchronize(eb));
-                        float t = 0.f;
-                        TD_HIP_CHECK(hipEventElapsedTime(&t, ea, eb));
-                        t /= (float)reps;
-                        if (t < ms) ms = t;
-                        if (ms > 0.1f) break;
-                    }
-                    if (ms < best) { best = ms; best_cfg = c; }
+            const int ksteps = L.kh * L.kw * L.cin / (prec_ == TD_PRECISION_FP16 ? 64 : 32);
+            const bool pp8_ok = prec_ == TD_PRECISION_FP16 && out_mode == 0 && L.cout >= 128;
+            auto direct = [&](int c) { return run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, c); };
+            const bool wino_ok = prec_ == TD_PRECISION_FP32 && L.wino_u && e->wino_v && stride == 1 && pad == 1 && !res_ && out_mode == 0 &&
+                                 (!m_dyn || ((H_ | W_) & 1) == 0) &&
+                                 (size_t)16 * B_ * ((H_ + 1) / 2) * ((W_ + 1) / 2) * (size_t)std::max(L.cin, L.cout) <= e->wino_elems;
+            if (wino_ok) {
+                // the batched plane contraction is a launch shape of its own (1x1, rows = tiles, flag 32 = batched x16)
+                const int T = B_ * ((H_ + 1) / 2) * ((W_ + 1) / 2);
+                const auto wkey = std::make_tuple(L.cout, L.cin, 1 * 16 + 1, T, 4 + 32);
+                auto wino = [&](int c) { return run_wino(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, m_mul, c); };
+                const auto akey = std::make_tuple(L.cout, L.cin, H_, W_);
+                auto ia = e->algo.find(akey);
+                if (ia == e->algo.end()) {
+                    load_tune_cache(e);
+                    ia = e->algo.find(akey);
                 }
-                (void)hipEventDestroy(ea);
-                (void)hipEventDestroy(eb);
-                it = e->tuned.emplace(key, best_cfg).first;
-                if (!e->tune_cache.empty()) {
-                    if (FILE* f = fopen(e->tune_cache.c_str(), "a")) {
-                        fprintf(f, "%d %d %d %d %d %d %d\n", prec_, std::get<0>(key), std::get<1>(key), std::get<2>(key), std::get<3>(key), std::get<4>(key), best_cfg);
-                        fclose(f);
+                if (ia == e->algo.end()) {
+                    // direct vs Winograd, each at its best tile, timed on this very launch
+                    float ms_d = 1e30f, ms_w = 1e30f;
+                    if ((st2 = tuned_cfg(key, prec_, ksteps, pp8_ok, s_, direct, &cfg, &ms_d)) < 0) return st2;
+                    if ((st2 = tuned_cfg(wkey, prec_, L.cin / 32, false, s_, wino, &wino_cfg, &ms_w)) < 0) return st2;
+                    ia = e->algo.emplace(akey, ms_w < ms_d ? 1 : 0).first;
+                    if (!e->tune_cache.empty()) {
+                        if (FILE* f = fopen(e->tune_cache.c_str(), "a")) {
+                            fprintf(f, "%d %d %d %d %d %d %d\n", 100 + prec_, L.cout, L.cin, H_, W_, 0, ia->second);
+                            fclose(f);
+                        }
                     }
                 }
+                use_wino = ia->second == 1;
+                if (use_wino && (st2 = tuned_cfg(wkey, prec_, L.cin / 32, false, s_, wino, &wino_cfg, nullptr)) < 0) return st2;
             }
-            cfg = it->second;
+            if (!use_wino && (st2 = tuned_cfg(key, prec_, ksteps, pp8_ok, s_, direct, &cfg, nullptr)) < 0) return st2;
         }
         ProfScope ps(e, s_, m_dyn ? 7 : 0, m_dyn ? 0.0 : flops, m_dyn ? 0.0 : bytes);
+        if (use_wino) return run_wino(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, m_mul, wino_cfg);
         return run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, cfg);
     };
     // ---- backbone ------------------------------------------------------------------------------------------
