@@ -392,14 +392,14 @@ def main():
             peak = PEAK_F32_MATRIX_TFLOPS if args.precision == "fp32" else PEAK_F16_MATRIX_TFLOPS
             ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
             traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_igemm.json")
+            pmc = os.path.join(ROOT, "profiles", "r02_pmc_conv_fp32.json")
             if args.precision == "fp32" and args.depth == 50 and B == 8 and os.path.exists(pmc):
                 # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE x2
                 # gfx950 correction + WRITE_SIZE; tools/pmc_summary.py) — counters cannot be read from inside bench.py
                 with open(pmc) as f:
                     pj = json.load(f)
                 traffic = pj["hbm_traffic_gb_per_step"] * 1e9 / pj["launches"]
-                traffic_src = "profiles/r01_pmc_conv_igemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                traffic_src = "profiles/r02_pmc_conv_fp32.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; conv family)"
             line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                 "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
                                 "algorithmic_bytes_per_launch": conv["bytes"] / max(conv["launches"], 1),
@@ -409,7 +409,14 @@ def main():
                                 "avg_launch_us": 1e3 * conv["ms"] / max(conv["launches"], 1),
                                 "gflop_per_step": conv["flops"] / args.steps / 1e9,
                                 "algorithmic_gbytes_per_step": conv["bytes"] / args.steps / 1e9}
-            line["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items()}
+            ex = prof.get("executed", {"flops": conv["flops"], "launches": 0})
+            line["roofline"]["note"] = ("achieved = ALGORITHMIC FLOPs (2 x MACs of the direct convolution, SURVEY.md §8d) / time of the conv family "
+                                        "(conv_igemm_kernel + the two Winograd transform kernels of the layers that take that path); "
+                                        "executed_tflops = FLOPs the MFMA pipe really issued (Winograd F(2x2,3x3) layers run 4/9 of theirs) / the same time")
+            line["roofline"]["executed_tflops"] = ex["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+            line["roofline"]["executed_frac"] = line["roofline"]["executed_tflops"] / peak
+            line["roofline"]["winograd_layers_per_step"] = ex["launches"] / args.steps
+            line["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items() if k != "executed"}
         if extra is not None:
             dt16, prof16, ndet16 = extra
             o = {"value": tiles_total / dt16, "unit": "tiles/s", "ms_per_step": 1000.0 * dt16 / args.steps, "dtype": "f16",
@@ -420,17 +427,17 @@ def main():
                 c16 = prof16["conv_igemm"]
                 a16 = c16["flops"] / (c16["ms"] * 1e-3) / 1e12 if c16["ms"] > 0 else 0.0
                 t16, src16 = None, None
-                pmc16 = os.path.join(ROOT, "profiles", "r01_pmc_conv_igemm_fp16.json")
+                pmc16 = os.path.join(ROOT, "profiles", "r02_pmc_conv_fp16.json")
                 if args.depth == 50 and B == 8 and os.path.exists(pmc16):
                     with open(pmc16) as f:
                         pj = json.load(f)
                     t16 = pj["hbm_traffic_gb_per_step"] * 1e9 / pj["launches"]
-                    src16 = "profiles/r01_pmc_conv_igemm_fp16.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                    src16 = "profiles/r02_pmc_conv_fp16.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; conv family)"
                 o["roofline"] = {"bound": "mfma", "achieved": a16, "peak": PEAK_F16_MATRIX_TFLOPS, "unit": "TFLOP/s",
                                  "frac": a16 / PEAK_F16_MATRIX_TFLOPS, "traffic": t16, "traffic_unit": "bytes per launch (HBM, PMC)",
                                  "traffic_source": src16,
                                  "algorithmic_bytes_per_launch": c16["bytes"] / max(c16["launches"], 1)}
-                o["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof16.items()}
+                o["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof16.items() if k != "executed"}
             line["fp16"] = o
         def sub(res, batch, peak, depth):
             dtx, profx, ndetx, k = res
@@ -441,7 +448,9 @@ def main():
                 ax = cx["flops"] / (cx["ms"] * 1e-3) / 1e12 if cx["ms"] > 0 else 0.0
                 o["roofline"] = {"bound": "mfma", "achieved": ax, "peak": peak, "unit": "TFLOP/s", "frac": ax / peak,
                                  "traffic": None, "gflop_per_step": cx["flops"] / k / 1e9}
-                o["breakdown_ms_per_step"] = {kk: v["ms"] / k for kk, v in profx.items()}
+                o["breakdown_ms_per_step"] = {kk: v["ms"] / k for kk, v in profx.items() if kk != "executed"}
+                if "executed" in profx:
+                    o["roofline"]["executed_tflops"] = profx["executed"]["flops"] / (cx["ms"] * 1e-3) / 1e12 if cx["ms"] > 0 else 0.0
             return o
         if r101 is not None:
             line["r101"] = {"note": "the reference's own depth (config.py:25: mask_rcnn_R_101_FPN_3x), same stream and schedule",

@@ -119,10 +119,13 @@ td_status td_engine_read_tensor(td_engine* e, const char* name, void* dst_dev, i
 /* Per-category device timing of forward(): when enabled, every kernel launch is bracketed by HIP events on the
  * forward's stream. Categories: 0 conv_igemm (all MFMA contractions), 1 stem, 2 pool/subsample, 3 rpn_select
  * (top-k, decode, NMS, merge), 4 roi_align, 5 detect (decode/sort/NMS/finalize), 6 mask_tail (predictor, scatter,
- * paste), 7 mask-head contractions (row count lives on the device: flops/bytes are left 0 for the caller to fill). td_engine_profile_read synchronises the recorded events and ACCUMULATES since the last reset:
+ * paste), 7 mask-head contractions (row count lives on the device: flops/bytes are left 0 for the caller to fill),
+ * 8 "executed": no time of its own — flops[8] = multiply-adds x 2 the category-0 launches really issued (the Winograd
+ * path of the fp32 engine runs 4/9 of a 3x3 layer's algorithmic FLOPs; its two transform kernels are timed inside
+ * category 0, the conv family), launches[8] = layers that took the Winograd path. td_engine_profile_read synchronises the recorded events and ACCUMULATES since the last reset:
  * ms[c] device milliseconds, launches[c], flops[c] algorithmic FLOPs (2*M*N*K, conv only), bytes[c] algorithmic
  * HBM bytes (inputs read once + outputs written once). Arrays hold TD_PROF_CATEGORIES entries. */
-#define TD_PROF_CATEGORIES 8
+#define TD_PROF_CATEGORIES 9
 td_status td_engine_profile_enable(td_engine* e, int enable);
 td_status td_engine_profile_read(td_engine* e, double* ms, int64_t* launches, double* flops, double* bytes, int reset);
 const char* td_last_error(void);

@@ -146,9 +146,10 @@ def test_conv_every_block_tile_variant(cfg):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TD_CONV_CFG=str(cfg))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_conv_gpu.py"), "-m", "gpu", "-q", "-x",
-                        "-k", "matches_torch"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+                        "-k", "test_conv_matches_torch or test_conv_fp16_matches_torch"], env=env, cwd=root, capture_output=True,
+                       text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "18 passed" in r.stdout
+    assert f"{len(CASES) + len(FP16_CASES)} passed" in r.stdout
 
 
 WINO_CASES = [

@@ -162,8 +162,7 @@ def test_phased_forward_on_two_streams_equals_plain_forward(full):
     for i in range(n):
         for k in ("count", "boxes", "scores", "mask_probs", "mask_region", "mask_offset"):
             assert torch.equal(outs[i][k], ref[i][k]), (i, k)
-        used = int(ref[i]["mask_offset"].max().item()) + 1
-        assert torch.equal(outs[i]["mask_bits"][:, :used], ref[i]["mask_bits"][:, :used]), i
+        assert _same_bits(outs[i], ref[i]), i        # each image's packed rows, up to what its detections wrote
 
 
 def test_stem_prephase_schedule_equals_plain_forward(full):

@@ -1,20 +1,28 @@
-# Regenerates the judged artefacts of profiles/ on the GPU box (run as: bash tools/profile_round.sh).
+# Regenerates the judged artefacts of profiles/ on the GPU box: bash tools/profile_round.sh [round tag, default r02]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_final
+TAG=${1:-r02}
+O=$R/gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
 export TD_TUNE_CACHE=$O/tune.txt
-python3 $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-serial > $O/warm.json 2> $O/warm.err || exit 1      # fills the tile-choice cache
-rocprofv3 --kernel-trace --stats -d $O/stats -o s --output-format csv -- python3 $R/bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-serial > $O/bench_profiled.json 2> $O/bench_profiled.err || exit 1
+python3 $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-serial --no-r101 --no-fp16-b32 > $O/warm.json 2> $O/warm.err || exit 1      # fills the tile-choice cache
+python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-serial --no-r101 --no-fp16-b32 --no-pipeline > $O/warm2.json 2> $O/warm2.err || exit 1
+rocprofv3 --kernel-trace --stats -d $O/stats -o s --output-format csv -- python3 $R/bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-serial --no-r101 --no-fp16-b32 > $O/bench_profiled.json 2> $O/bench_profiled.err || exit 1
 echo stats done
-for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
-  tag=$(echo $set | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $set -d $O/pmc_$tag -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-fp16 --no-pipeline > $O/pmc_$tag.log 2>&1 || exit 1
-  echo pmc $tag done
+for prec in fp32 fp16; do
+  for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
+    tag=$(echo $set | cut -d' ' -f1)
+    rocprofv3 --kernel-trace --pmc $set -d $O/pmc_${prec}_$tag -o p --output-format csv -- python3 $R/bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-fp16 --no-pipeline --no-serial > $O/pmc_${prec}_$tag.log 2>&1 || exit 1
+    echo pmc $prec $tag done
+  done
 done
 cd $R
-python tools/pmc_summary.py $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES/p_counter_collection.csv $O/pmc_FETCH_SIZE/p_counter_collection.csv $O/pmc_WRITE_SIZE/p_counter_collection.csv 50 4 > $O/r01_pmc_conv_igemm.json
-cp $O/tune.txt $O/r01_tile_choices.txt
-python3 bench.py > $O/r01_bench_n1.json 2> $O/bench_final.err
-python tools/bench_summary.py < $O/r01_bench_n1.json
-grep -c conv_igemm $O/stats/s_kernel_stats.csv
+ALG32=$(python3 -c "import json;print(json.load(open('$O/warm.json'))['roofline']['algorithmic_gbytes_per_step'])")
+ALG16=$(python3 -c "print($ALG32/2)")
+python3 tools/pmc_summary2.py $O/pmc_fp32_SQ_VALU_MFMA_BUSY_CYCLES/p_counter_collection.csv $O/pmc_fp32_FETCH_SIZE/p_counter_collection.csv $O/pmc_fp32_WRITE_SIZE/p_counter_collection.csv 2 $ALG32 > $O/${TAG}_pmc_conv_fp32.json
+python3 tools/pmc_summary2.py $O/pmc_fp16_SQ_VALU_MFMA_BUSY_CYCLES/p_counter_collection.csv $O/pmc_fp16_FETCH_SIZE/p_counter_collection.csv $O/pmc_fp16_WRITE_SIZE/p_counter_collection.csv 2 $ALG16 > $O/${TAG}_pmc_conv_fp16.json
+cp $O/tune.txt $O/${TAG}_tile_choices.txt
+cp $O/stats/s_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv 2>/dev/null || cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_kernel_stats.csv
+cp $O/bench_profiled.json $O/${TAG}_bench_profiled_run.json
+python3 -c "import json;d=json.load(open('$O/${TAG}_pmc_conv_fp32.json'));print('fp32 conv family', d['conv_family'])"
+python3 -c "import json;d=json.load(open('$O/${TAG}_pmc_conv_fp16.json'));print('fp16 conv family', d['conv_family'])"

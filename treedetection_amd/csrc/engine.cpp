@@ -110,9 +110,6 @@ struct td_engine {
     int backbone_subbatch = 0;    // 0 = whole batch; else images per backbone pass (TD_BACKBONE_SUBBATCH)
     // key: (cout, cin, kh*16+kw, rows, stride*4 + out_mode*2 + has_residual) — layers of identical shape share it
     std::map<std::tuple<int, int, int, int, int>, int> tuned;
-    // direct (0) or Winograd (1) per 3x3 layer, keyed by (cout, cin, H, W) WITHOUT the batch: one engine then treats a
-    // tile the same way whatever batch it arrives in (batch-8 == 8 x batch-1 bit for bit, tests/test_fullsize_gpu.py)
-    std::map<std::tuple<int, int, int, int>, int> algo;
     bool winograd = true;         // TD_WINOGRAD=0 disables the Winograd path (diagnostics)
     float *wino_v = nullptr, *wino_m = nullptr;
     size_t wino_elems = 0;
@@ -349,7 +346,6 @@ void load_tune_cache(td_engine* e) {
         int pr, a0, a1, a2, a3, a4, cfg;
         while (fscanf(f, "%d %d %d %d %d %d %d", &pr, &a0, &a1, &a2, &a3, &a4, &cfg) == 7) {
             if (pr == e->desc.precision && cfg >= 0 && cfg <= TD_CONV_TILE_CFG_MAX) e->tuned[std::make_tuple(a0, a1, a2, a3, a4)] = cfg;
-            if (pr == 100 + e->desc.precision && (cfg == 0 || cfg == 1)) e->algo[std::make_tuple(a0, a1, a2, a3)] = cfg;   // direct / Winograd
         }
         fclose(f);
     }
@@ -795,31 +791,21 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                 const int T = B_ * ((H_ + 1) / 2) * ((W_ + 1) / 2);
                 const auto wkey = std::make_tuple(L.cout, L.cin, 1 * 16 + 1, T, 4 + 32);
                 auto wino = [&](int c) { return run_wino(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, m_mul, c); };
-                const auto akey = std::make_tuple(L.cout, L.cin, H_, W_);
-                auto ia = e->algo.find(akey);
-                if (ia == e->algo.end()) {
-                    load_tune_cache(e);
-                    ia = e->algo.find(akey);
-                }
-                if (ia == e->algo.end()) {
-                    // direct vs Winograd, each at its best tile, timed on this very launch
-                    float ms_d = 1e30f, ms_w = 1e30f;
-                    if ((st2 = tuned_cfg(key, prec_, ksteps, pp8_ok, s_, direct, &cfg, &ms_d)) < 0) return st2;
-                    if ((st2 = tuned_cfg(wkey, prec_, L.cin / 32, false, s_, wino, &wino_cfg, &ms_w)) < 0) return st2;
-                    ia = e->algo.emplace(akey, ms_w < ms_d ? 1 : 0).first;
-                    if (!e->tune_cache.empty()) {
-                        if (FILE* f = fopen(e->tune_cache.c_str(), "a")) {
-                            fprintf(f, "%d %d %d %d %d %d %d\n", 100 + prec_, L.cout, L.cin, H_, W_, 0, ia->second);
-                            fclose(f);
-                        }
-                    }
-                }
-                use_wino = ia->second == 1;
+                // Which path a layer takes must not depend on a measurement: the two differ in rounding, and a timing
+                // decision would make the results vary between processes (sharded ranks, resumed runs). The rule is the
+                // measured outcome on the R50/R101 layer set (profiles/r02_tile_choices.txt): every 3x3 layer with at least
+                // 128 channels on both sides is faster through Winograd at every map size from 13x13 to 200x200
+                // (1.3-1.9x); 64 -> 64 (res2) is HBM-bound on the transforms and stays direct.
+                use_wino = L.cin >= 128 && L.cout >= 128;
                 if (use_wino && (st2 = tuned_cfg(wkey, prec_, L.cin / 32, false, s_, wino, &wino_cfg, nullptr)) < 0) return st2;
             }
             if (!use_wino && (st2 = tuned_cfg(key, prec_, ksteps, pp8_ok, s_, direct, &cfg, nullptr)) < 0) return st2;
         }
         ProfScope ps(e, s_, m_dyn ? 7 : 0, m_dyn ? 0.0 : flops, m_dyn ? 0.0 : bytes);
+        if (e->prof && !m_dyn) {          // category 8: FLOPs the MFMA pipe really executes
+            e->prof_flops[8] += use_wino ? flops * 4.0 / 9.0 : flops;
+            e->prof_launches[8] += use_wino ? 1 : 0;
+        }
         if (use_wino) return run_wino(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, m_mul, wino_cfg);
         return run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, cfg);
     };

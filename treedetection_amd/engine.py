@@ -279,7 +279,7 @@ class Engine:
         return rg, unpack_masks(rg, off, bits, n, h, w)
 
     # -- device timing ------------------------------------------------------------------------------------
-    PROF_NAMES = ("conv_igemm", "stem", "pool", "rpn_select", "roi_align", "detect", "mask_tail", "mask_convs")
+    PROF_NAMES = ("conv_igemm", "stem", "pool", "rpn_select", "roi_align", "detect", "mask_tail", "mask_convs", "executed")
 
     def profile_enable(self, on: bool = True) -> None:
         _lib.check(self.lib.td_engine_profile_enable(self._h, int(on)), "td_engine_profile_enable")
