@@ -65,7 +65,7 @@ td_status td_conv2d_winograd_nhwc(const float* x, const float* w, const float* s
         return st;
     }
     TD_HIP_CHECK(hipMemcpy(U, uh.data(), uh.size() * 4, hipMemcpyHostToDevice));
-    st = wino_input_launch(x, B, H, W, Cin, static_cast<float*>(V), nullptr, 1, s);
+    st = wino_input_launch(x, B, H, W, Cin, static_cast<float*>(V), nullptr, 1, 0, (int)T, s);
     if (st == TD_OK) {
         ConvArgs a{};
         a.x = V; a.w = U; a.y = Mb;
@@ -74,7 +74,7 @@ td_status td_conv2d_winograd_nhwc(const float* x, const float* w, const float* s
         a.batch_count = 16; a.x_bs = (long long)T * Cin; a.w_bs = (long long)Cout * Cin; a.y_bs = (long long)T * Cout;
         st = conv2d_launch(a, TD_PRECISION_FP32, s);
     }
-    if (st == TD_OK) st = wino_output_launch(static_cast<float*>(Mb), B, H, W, Cout, scale, bias, relu, y, nullptr, 1, s);
+    if (st == TD_OK) st = wino_output_launch(static_cast<float*>(Mb), B, H, W, Cout, scale, bias, relu, y, nullptr, 1, 0, (int)T, s);
     hipError_t herr = hipStreamSynchronize(s);
     (void)hipFree(U); (void)hipFree(V); (void)hipFree(Mb);
     if (st < 0) return st;

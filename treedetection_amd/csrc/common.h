@@ -42,8 +42,9 @@ struct ConvArgs {
     int relu;
     int out_mode;         // 0 plain, 1 deconv2x2 pixel shuffle: n = (dy*2+dx)*Cq + co, Cq = Cout/4
     int M;                // B*Ho*Wo
-    const int* m_dyn;     // optional device scalar: effective rows = min(M, *m_dyn * m_mul)
+    const int* m_dyn;     // optional device scalar: effective rows = min(M, *m_dyn * m_mul - m_off)
     int m_mul;
+    int m_off;            // rows of the dynamic count that belong to earlier launches (Winograd slabs); 0 otherwise
     int out_f32;          // fp16 path only: write y as float32 (RPN / box-predictor heads feed the fp32 selection kernels)
     // batched launch (blockIdx.y = 0 .. batch_count-1): per-batch element offsets of x / w / y. Used by the Winograd path,
     // whose 16 transform planes are 16 independent 1x1 contractions (winograd.hip). 0 / 1 = a plain launch.
@@ -61,9 +62,11 @@ static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17};   // 
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
 
 // ---- Winograd F(2x2,3x3) transforms (winograd.hip; fp32 engine) ---------------------------------
-td_status wino_input_launch(const float* x, int B, int H, int W, int C, float* V, const int* m_dyn, int m_mul, hipStream_t s);
+// tiles [t0, t0 + Ts) of the layer ("slab"): V / Mb hold 16 planes of [Ts][C]
+td_status wino_input_launch(const float* x, int B, int H, int W, int C, float* V, const int* m_dyn, int m_mul, long long t0, int Ts,
+                            hipStream_t s);
 td_status wino_output_launch(const float* Mb, int B, int H, int W, int N, const float* scale, const float* bias, int relu,
-                             float* y, const int* m_dyn, int m_mul, hipStream_t s);
+                             float* y, const int* m_dyn, int m_mul, long long t0, int Ts, hipStream_t s);
 void wino_filter_transform(const float* w_ohwi, int N, int C, float* U);     // host: U [16][N][C]
 
 // ---- stem / pooling / resize (stem.hip) ---------------------------------------------------------

@@ -337,7 +337,8 @@ void conv_igemm_kernel(const ConvArgs a_in) {
 
     int M = a.M;
     if (a.m_dyn) {
-        const int md = *a.m_dyn * a.m_mul;
+        int md = *a.m_dyn * a.m_mul - a.m_off;
+        md = md < 0 ? 0 : md;
         M = md < M ? md : M;
     }
     // the grid is sized for a.M; with a device-side row count only the first `nblk` blocks have work, and the
@@ -552,7 +553,8 @@ __global__ __launch_bounds__(512) void conv_pp8_kernel(const ConvArgs a) {
 
     int M = a.M;
     if (a.m_dyn) {
-        const int md = *a.m_dyn * a.m_mul;
+        int md = *a.m_dyn * a.m_mul - a.m_off;
+        md = md < 0 ? 0 : md;
         M = md < M ? md : M;
     }
     const int tiles_n = (a.Cout + BN - 1) / BN;

@@ -113,6 +113,7 @@ struct td_engine {
     bool winograd = true;         // TD_WINOGRAD=0 disables the Winograd path (diagnostics)
     float *wino_v = nullptr, *wino_m = nullptr;
     size_t wino_elems = 0;
+    int wino_slab = 0;            // TD_WINO_SLAB: tiles per slab (diagnostics); 0 = sized for the Infinity Cache
     std::string tune_cache;       // TD_TUNE_CACHE: load / append measured choices (keeps profiled runs free of tuning launches)
 
     // forward context (kept between the phases of td_engine_forward_phase) and the per-phase completion events
@@ -224,6 +225,15 @@ td_status bn_fold(const TensorMap& tm, const std::string& p, int c, std::vector<
         bias[i] = b->data[i] - ms;
     }
     return TD_OK;
+}
+
+// Tiles per Winograd slab. A layer can be walked in slabs of tiles whose V and M planes would stay inside the 256 MiB
+// Infinity Cache (TD_WINO_SLAB = tiles per slab); measured on the bench (round 2, fp32, 3 batches in flight): 4096-tile
+// slabs 425 tiles/s, 8192 441, whole layers 456 — the shorter launches lose more to their tails and boundaries than the
+// on-die hand-over of V / M saves, so the default is one slab = the whole layer.
+int wino_slab_tiles(const td_engine* e, const ConvLayer& L) {
+    (void)L;
+    return e->wino_slab > 0 ? e->wino_slab : (1 << 30);
 }
 
 // fp32 engine: Winograd F(2x2,3x3) filter bank of a 3x3 layer (used where the engine measures it faster, run_conv)
@@ -377,6 +387,7 @@ td_status td_engine_create(const td_model_desc* desc, int device, td_engine** ou
     if (const char* sbenv = getenv("TD_BACKBONE_SUBBATCH")) e->backbone_subbatch = atoi(sbenv);
     if (const char* tc = getenv("TD_TUNE_CACHE")) e->tune_cache = tc;
     if (const char* wg = getenv("TD_WINOGRAD")) e->winograd = atoi(wg) != 0;
+    if (const char* ws = getenv("TD_WINO_SLAB")) e->wino_slab = atoi(ws);
     e->desc = d;
     load_tune_cache(e);
     e->device = device;
@@ -652,8 +663,8 @@ td_status td_engine_reserve(td_engine* e, int B, int Hp, int Wp) {
     e->wino_v = e->wino_m = nullptr;
     e->wino_elems = 0;
     if (e->desc.precision == TD_PRECISION_FP32 && e->winograd) {
-        // Winograd workspace: 16 planes of [tiles][channels] for the largest 3x3 layer (FPN / RPN at p2, the bottleneck
-        // conv2 of every stage, the mask head over B*D RoIs of 14x14)
+        // Winograd workspace: 16 planes of [tiles][channels] for V and for M of the largest 3x3 layer that takes the path
+        // (FPN / RPN at p2, the bottleneck conv2 of every stage, the mask head over B*D RoIs of 14x14)
         auto tiles = [](int h, int w) { return (size_t)((h + 1) / 2) * ((w + 1) / 2); };
         size_t need = 0;
         for (int l = 0; l < 5; ++l) need = std::max(need, b * tiles(hs[l], wsz[l]) * (size_t)e->fpn_c);
@@ -755,17 +766,24 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
     // plane contractions through conv_igemm_kernel → output transform with the layer's scale / bias / ReLU (winograd.hip)
     auto run_wino = [&](const ConvLayer& L, const void* x_, int B_, int H_, int W_, bool relu, void* y_, hipStream_t s_,
                         const int* m_dyn, int m_mul, int gemm_cfg) -> td_status {
-        const int T = B_ * ((H_ + 1) / 2) * ((W_ + 1) / 2);
-        td_status st2 = wino_input_launch(static_cast<const float*>(x_), B_, H_, W_, L.cin, e->wino_v, m_dyn, m_mul, s_);
-        if (st2 < 0) return st2;
-        ConvArgs a{};
-        a.x = e->wino_v; a.w = L.wino_u; a.y = e->wino_m;
-        a.B = 1; a.H = 1; a.W = T; a.Cin = L.cin; a.Cout = L.cout; a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.Ho = 1; a.Wo = T;
-        a.M = T; a.m_dyn = m_dyn; a.m_mul = m_dyn ? m_mul / 4 : 1;        // even H, W with a device row count: tiles = rows / 4
-        a.batch_count = 16; a.x_bs = (long long)T * L.cin; a.w_bs = (long long)L.cout * L.cin; a.y_bs = (long long)T * L.cout;
-        a.tile_cfg = gemm_cfg;
-        if ((st2 = conv2d_launch(a, TD_PRECISION_FP32, s_)) < 0) return st2;
-        return wino_output_launch(e->wino_m, B_, H_, W_, L.cout, L.scale, L.bias, relu ? 1 : 0, static_cast<float*>(y_), m_dyn, m_mul, s_);
+        const long long T = (long long)B_ * ((H_ + 1) / 2) * ((W_ + 1) / 2);
+        const int Ts = wino_slab_tiles(e, L);                 // tiles per slab: V + M of a slab stay in the Infinity Cache
+        for (long long t0 = 0; t0 < T; t0 += Ts) {
+            const int n = (int)std::min<long long>(Ts, T - t0);
+            td_status st2 = wino_input_launch(static_cast<const float*>(x_), B_, H_, W_, L.cin, e->wino_v, m_dyn, m_mul, t0, n, s_);
+            if (st2 < 0) return st2;
+            ConvArgs a{};
+            a.x = e->wino_v; a.w = L.wino_u; a.y = e->wino_m;
+            a.B = 1; a.H = 1; a.W = n; a.Cin = L.cin; a.Cout = L.cout; a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.Ho = 1; a.Wo = n;
+            a.M = n; a.m_dyn = m_dyn; a.m_mul = m_dyn ? m_mul / 4 : 1;    // even H, W with a device row count: tiles = rows / 4
+            a.m_off = (int)t0;
+            a.batch_count = 16; a.x_bs = (long long)n * L.cin; a.w_bs = (long long)L.cout * L.cin; a.y_bs = (long long)n * L.cout;
+            a.tile_cfg = gemm_cfg;
+            if ((st2 = conv2d_launch(a, TD_PRECISION_FP32, s_)) < 0) return st2;
+            if ((st2 = wino_output_launch(e->wino_m, B_, H_, W_, L.cout, L.scale, L.bias, relu ? 1 : 0, static_cast<float*>(y_), m_dyn,
+                                          m_mul, t0, n, s_)) < 0) return st2;
+        }
+        return TD_OK;
     };
     auto run_conv = [&](const ConvLayer& L, const void* x_, int B_, int H_, int W_, int stride, int pad, bool relu,
                         void* y_, const void* res_, int res_shift, hipStream_t s_, int prec_,
@@ -785,10 +803,11 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
             auto direct = [&](int c) { return run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, c); };
             const bool wino_ok = prec_ == TD_PRECISION_FP32 && L.wino_u && e->wino_v && stride == 1 && pad == 1 && !res_ && out_mode == 0 &&
                                  (!m_dyn || ((H_ | W_) & 1) == 0) &&
-                                 (size_t)16 * B_ * ((H_ + 1) / 2) * ((W_ + 1) / 2) * (size_t)std::max(L.cin, L.cout) <= e->wino_elems;
+                                 (size_t)16 * std::min<long long>((long long)B_ * ((H_ + 1) / 2) * ((W_ + 1) / 2), wino_slab_tiles(e, L)) *
+                                         (size_t)std::max(L.cin, L.cout) <= e->wino_elems;
             if (wino_ok) {
                 // the batched plane contraction is a launch shape of its own (1x1, rows = tiles, flag 32 = batched x16)
-                const int T = B_ * ((H_ + 1) / 2) * ((W_ + 1) / 2);
+                const int T = (int)std::min<long long>((long long)B_ * ((H_ + 1) / 2) * ((W_ + 1) / 2), wino_slab_tiles(e, L));
                 const auto wkey = std::make_tuple(L.cout, L.cin, 1 * 16 + 1, T, 4 + 32);
                 auto wino = [&](int c) { return run_wino(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, m_mul, c); };
                 // Which path a layer takes must not depend on a measurement: the two differ in rounding, and a timing

@@ -4,8 +4,10 @@
 // The element-wise products summed over the input channels are 16 independent contractions
 //   M_xi[t][n] = sum_c V_xi[t][c] * U_xi[n][c]        xi = 0..15, t = output tile (b, y/2, x/2)
 // with 4/9 of the direct convolution's multiplies; they run as ONE batched launch of conv_igemm_kernel (blockIdx.y =
-// xi, 1x1 "convolution" over the plane V_xi), so the MFMA path, its tiles and its tuner are reused. This file holds the
-// two HBM-bound transforms either side of it:
+// xi, 1x1 "convolution" over the plane V_xi), so the MFMA path, its tiles and its tuner are reused. V and M are four
+// times the size of the layer's input / output: the engine therefore walks a layer in SLABS of a few thousand tiles
+// (engine.cpp run_wino) whose V and M planes together stay inside the 256 MiB Infinity Cache — the transforms then hand
+// over on-die and only the layer's own input and output cross HBM. This file holds the two transforms:
 //   wino_input_kernel   x [B,H,W,C]      → V [16][T][C]      (32 add/sub per patch and channel)
 //   wino_output_kernel  M [16][T][N]     → y [B,H,W,N] = act((A^T M A) * scale + bias)   (24 add/sub per tile and channel)
 // Standard matrices (Lavin & Gray): B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],
@@ -17,8 +19,10 @@
 namespace {
 
 // one thread = one tile x 4 channels
+// Tiles [t0, t0 + Ts) of the layer form one SLAB: its 16 planes are [16][Ts][C], indexed by the tile's position in the slab.
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int B, int H, int W, int C,
-                                                         float* __restrict__ V, const int* __restrict__ m_dyn, int m_mul) {
+                                                         float* __restrict__ V, const int* __restrict__ m_dyn, int m_mul,
+                                                         long long t0, int Ts) {
     const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
     int nimg = B;
     if (m_dyn) {
@@ -26,11 +30,12 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         nimg = n < B ? n : B;
     }
     const int c4n = C >> 2;
-    const long long T = (long long)B * TH * TW;                       // plane stride is in ALL tiles (fixed layout)
+    const long long T = Ts;                                           // plane stride: tiles of one slab
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long t = idx / c4n;
-    const int c = (int)(idx - t * c4n) * 4;
-    if (t >= (long long)nimg * TH * TW) return;
+    const long long tl = idx / c4n;                                   // tile inside the slab
+    const int c = (int)(idx - tl * c4n) * 4;
+    const long long t = t0 + tl;
+    if (tl >= Ts || t >= (long long)nimg * TH * TW) return;
     const int tx = (int)(t % TW);
     const int ty = (int)((t / TW) % TH);
     const int b = (int)(t / ((long long)TW * TH));
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         const float4 v1 = TD_ADD(r[i][1], r[i][2]);
         const float4 v2 = TD_SUB(r[i][2], r[i][1]);
         const float4 v3 = TD_SUB(r[i][1], r[i][3]);
-        float* p = V + ((size_t)(4 * i) * T + t) * C + c;
+        float* p = V + ((size_t)(4 * i) * T + tl) * C + c;
         *reinterpret_cast<float4*>(p) = v0;
         *reinterpret_cast<float4*>(p + (size_t)T * C) = v1;
         *reinterpret_cast<float4*>(p + (size_t)2 * T * C) = v2;
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, int B, int H, int W, int N,
                                                           const float* __restrict__ scale, const float* __restrict__ bias,
                                                           int relu, float* __restrict__ y, const int* __restrict__ m_dyn,
-                                                          int m_mul) {
+                                                          int m_mul, long long t0, int Ts) {
     const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
     int nimg = B;
     if (m_dyn) {
@@ -83,11 +88,12 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         nimg = n < B ? n : B;
     }
     const int c4n = N >> 2;
-    const long long T = (long long)B * TH * TW;
+    const long long T = Ts;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long t = idx / c4n;
-    const int c = (int)(idx - t * c4n) * 4;
-    if (t >= (long long)nimg * TH * TW) return;
+    const long long tl = idx / c4n;
+    const int c = (int)(idx - tl * c4n) * 4;
+    const long long t = t0 + tl;
+    if (tl >= Ts || t >= (long long)nimg * TH * TW) return;
     const int tx = (int)(t % TW);
     const int ty = (int)((t / TW) % TH);
     const int b = (int)(t / ((long long)TW * TH));
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m[i][j] = *reinterpret_cast<const float4*>(Mb + ((size_t)(4 * i + j) * T + t) * N + c);
+        for (int j = 0; j < 4; ++j) m[i][j] = *reinterpret_cast<const float4*>(Mb + ((size_t)(4 * i + j) * T + tl) * N + c);
     float4 s[2][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {            // A^T M
@@ -128,20 +134,21 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 
 }  // namespace
 
-td_status wino_input_launch(const float* x, int B, int H, int W, int C, float* V, const int* m_dyn, int m_mul, hipStream_t s) {
-    TD_REQUIRE(x && V && B >= 1 && H >= 1 && W >= 1 && C >= 4 && (C & 3) == 0, "winograd input transform: bad arguments");
-    const long long threads = (long long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, B, H, W, C, V, m_dyn, m_mul);
+td_status wino_input_launch(const float* x, int B, int H, int W, int C, float* V, const int* m_dyn, int m_mul, long long t0,
+                            int Ts, hipStream_t s) {
+    TD_REQUIRE(x && V && B >= 1 && H >= 1 && W >= 1 && C >= 4 && (C & 3) == 0 && Ts >= 1 && t0 >= 0, "winograd input transform: bad arguments");
+    const long long threads = (long long)Ts * (C / 4);
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, B, H, W, C, V, m_dyn, m_mul, t0, Ts);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
 
 td_status wino_output_launch(const float* Mb, int B, int H, int W, int N, const float* scale, const float* bias, int relu,
-                             float* y, const int* m_dyn, int m_mul, hipStream_t s) {
-    TD_REQUIRE(Mb && y && B >= 1 && H >= 1 && W >= 1 && N >= 4 && (N & 3) == 0, "winograd output transform: bad arguments");
-    const long long threads = (long long)B * ((H + 1) / 2) * ((W + 1) / 2) * (N / 4);
+                             float* y, const int* m_dyn, int m_mul, long long t0, int Ts, hipStream_t s) {
+    TD_REQUIRE(Mb && y && B >= 1 && H >= 1 && W >= 1 && N >= 4 && (N & 3) == 0 && Ts >= 1 && t0 >= 0, "winograd output transform: bad arguments");
+    const long long threads = (long long)Ts * (N / 4);
     hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, Mb, B, H, W, N, scale, bias,
-                       relu, y, m_dyn, m_mul);
+                       relu, y, m_dyn, m_mul, t0, Ts);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
