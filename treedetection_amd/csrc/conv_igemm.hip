@@ -15,10 +15,12 @@
 // Two element types share the structure (everything is addressed in bytes; a k-chunk is 128 B either way):
 //   float    — v_mfma_f32_32x32x2_f32: exact f32 fmaf chains; one 16-B fragment read feeds 4 MFMAs (k-pairs {e,e+4})
 //   _Float16 — v_mfma_f32_32x32x16_f16: f32 accumulate; one 16-B fragment read (8 halves) feeds 1 MFMA
-// Block tile 128x128 (also 128x64, 64x128, 64x64; the engine measures which is fastest per layer), 4 waves as 2x2,
-// LDS rows padded to 144 B so every ds_read_b128 lane group hits 16 distinct 16-B slots, global→register→LDS double
-// buffering with one barrier per k-step, bijective XCD-aware block remap over the live tile count, and an epilogue
-// staged through LDS so residual loads / stores are whole coalesced row segments.
+// Block tiles 64x64 .. 256x256 with 4 / 8 / 16 waves (dispatch() lists them; the engine measures which is fastest per
+// layer shape), global → LDS by LDS-DMA (buffer_load ... lds, no VGPR round trip) into a lane-linear image whose bank
+// conflicts are removed by an XOR swizzle on the SOURCE piece and again on the ds_read_b128 fragment reads, two LDS
+// stages with one raw s_barrier per k-step (single-stage variants for the thin 1x1 layers), bijective XCD-aware block
+// remap over the live tile count, an epilogue staged through LDS (conv_epilogue), batched launches (blockIdx.y) for the
+// Winograd plane contractions, and conv_pp8_kernel: the fp16 256x256 ping-pong schedule.
 #include "common.h"
 #include <cstdlib>
 #include <type_traits>
