@@ -199,3 +199,14 @@ def test_winograd_conv_matches_torch(case):
     # and against the direct MFMA kernel on the same inputs
     direct = conv2d_hip(x, w, scale, bias, None, stride=1, pad=1, relu=relu)
     assert np.abs(got - direct).max() <= 5e-5 * max(1.0, np.abs(ref).max())
+    # the fused form (input transform inside the contraction's A staging, the default) and the three-kernel form
+    # (wino_input_kernel + batched conv_igemm launch) associate identically: bit for bit
+    import os
+    os.environ["TD_WINO_FUSED"] = "0"
+    try:
+        y2 = torch.full((B, H, W, Cout), float("nan"), dtype=torch.float32, device="cuda")
+        _lib.check(lib.td_conv2d_winograd_nhwc(p(xd), p(wd), p(sd), p(bd), y2.data_ptr(), B, H, W, Cin, Cout, int(relu), _lib.stream_ptr()),
+                   "td_conv2d_winograd_nhwc")
+    finally:
+        del os.environ["TD_WINO_FUSED"]
+    assert torch.equal(y, y2)

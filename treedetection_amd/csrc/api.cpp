@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 // (td_set_error / td_last_error: error.cpp — shared with the host-only sanitizer build)
@@ -65,14 +66,23 @@ td_status td_conv2d_winograd_nhwc(const float* x, const float* w, const float* s
         return st;
     }
     TD_HIP_CHECK(hipMemcpy(U, uh.data(), uh.size() * 4, hipMemcpyHostToDevice));
-    st = wino_input_launch(x, B, H, W, Cin, static_cast<float*>(V), nullptr, 1, 0, (int)T, s);
-    if (st == TD_OK) {
-        ConvArgs a{};
-        a.x = V; a.w = U; a.y = Mb;
-        a.B = 1; a.H = 1; a.W = (int)T; a.Cin = Cin; a.Cout = Cout; a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.Ho = 1; a.Wo = (int)T;
-        a.M = (int)T; a.m_mul = 1; a.tile_cfg = -1;
-        a.batch_count = 16; a.x_bs = (long long)T * Cin; a.w_bs = (long long)Cout * Cin; a.y_bs = (long long)T * Cout;
-        st = conv2d_launch(a, TD_PRECISION_FP32, s);
+    const char* fenv = getenv("TD_WINO_FUSED");           // tests compare the two forms of the contraction (bit-identical)
+    const bool fused = !fenv || atoi(fenv) != 0;
+    ConvArgs a{};
+    a.w = U; a.y = Mb;
+    a.Cin = Cin; a.Cout = Cout; a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
+    a.M = (int)T; a.m_mul = 1; a.tile_cfg = -1;
+    a.w_bs = (long long)Cout * Cin; a.y_bs = (long long)T * Cout;
+    if (fused) {
+        a.x = x; a.B = B; a.H = H; a.W = W;
+        st = wino_gemm_launch(a, s);
+    } else {
+        st = wino_input_launch(x, B, H, W, Cin, static_cast<float*>(V), nullptr, 1, 0, (int)T, s);
+        if (st == TD_OK) {
+            a.x = V; a.B = 1; a.H = 1; a.W = (int)T; a.Ho = 1; a.Wo = (int)T;
+            a.batch_count = 16; a.x_bs = (long long)T * Cin;
+            st = conv2d_launch(a, TD_PRECISION_FP32, s);
+        }
     }
     if (st == TD_OK) st = wino_output_launch(static_cast<float*>(Mb), B, H, W, Cout, scale, bias, relu, y, nullptr, 1, 0, (int)T, s);
     hipError_t herr = hipStreamSynchronize(s);

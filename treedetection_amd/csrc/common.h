@@ -60,6 +60,7 @@ struct ConvArgs {
 #define TD_CONV_TILE_CFG_MAX 17
 static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
+td_status wino_gemm_launch(const ConvArgs& a, hipStream_t stream);     // Winograd plane contractions, input transform fused (fp32)
 
 // ---- Winograd F(2x2,3x3) transforms (winograd.hip; fp32 engine) ---------------------------------
 // tiles [t0, t0 + Ts) of the layer ("slab"): V / Mb hold 16 planes of [Ts][C]

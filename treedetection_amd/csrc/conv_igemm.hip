@@ -524,6 +524,184 @@ void conv_igemm_kernel(const ConvArgs a_in) {
     conv_epilogue<T, TO, MT, NT, WM, WN, RWM, WIDE_OK>(a, acc, lds, M, m0, n0, tid, lane, wm, wn);
 }
 
+// ---- wino_gemm_kernel: the 16 plane contractions of Winograd F(2x2,3x3) with the INPUT TRANSFORM FUSED into the A
+// staging (fp32 engine; winograd.hip holds the algebra and the output transform) ------------------------------------------
+//   M_xi[t][n] = sum_c V_xi[t][c] * U_xi[n][c],   V_xi[t][c] = (B^T d B)[xi] of tile t's 4x4 input patch
+// Every V element is a signed sum of FOUR input pixels (B^T has two non-zeros per row): V = (p[a1][b1] (+-) p[a2][b1])
+// (+-) (p[a1][b2] (+-) p[a2][b2]), in exactly the association wino_input_kernel uses — so instead of writing V (4x the
+// layer input) to HBM and reading it back, the A tile of a k-step is built on the way into LDS: four 16-B loads per row
+// piece (zero padding = out-of-range buffer offsets), three packed add/sub, one ds_write_b128 into the same XOR-swizzled
+// image the LDS-DMA path produces. The fp32 MFMA loop has the slack for it (a k-step is 2048 MFMA cycles per wave; the
+// staging is 8 loads + 24 VALU + 2 ds_writes per thread). Register double buffering: the loads of step it+1 are issued
+// before the MFMAs of step it and combined after them. The weights U_xi still arrive by LDS-DMA. Block ids run plane-
+// fastest, so the 16 planes of one tile range execute together and share the patch rows in L2 (the XCD remap keeps
+// them on one XCD). Tile 128 (tiles) x 128 (channels), 8 waves as 4 x 2, two LDS stages, 2 blocks per CU.
+// Results are bit-identical to wino_input_kernel + the batched conv_igemm launch (tests/test_conv_gpu.py).
+__global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const ConvArgs a) {
+    typedef float T;
+    constexpr int MT = 1, NT = 2, WM = 4, WN = 2;
+    constexpr int BM = 128, BN = 128, THREADS = 512;
+    constexpr int LDROWS = THREADS / 8;               // 64 rows per staging pass
+    constexpr int AROWS = BM / LDROWS, BROWS = BN / LDROWS;
+    constexpr int STAGE_BYTES = 2 * (BM + BN) * CHUNK_BYTES;
+    constexpr int RWM = 2;
+    constexpr int EPI_BYTES = conv_epilogue_lds_bytes<float, MT, NT, WM, WN, RWM>();
+    __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES];
+    char* As = lds;
+    char* Bs = lds + 2 * BM * CHUNK_BYTES;
+
+    int M = a.M;                                      // tiles of this slab (a.m_off = first tile of the slab)
+    if (a.m_dyn) {
+        int md = *a.m_dyn * a.m_mul - a.m_off;
+        md = md < 0 ? 0 : md;
+        M = md < M ? md : M;
+    }
+    const int tiles_n = (a.Cout + BN - 1) / BN;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int nblk = tiles_m * tiles_n * 16;
+    if ((int)blockIdx.x >= nblk) return;
+    const int pid = xcd_remap(blockIdx.x, nblk);
+    const int plane = pid & 15;
+    const int rest = pid >> 4;
+    const int tm = rest / tiles_n, tn = rest - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    // B^T rows: i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3   (first operand, second operand, subtract?)
+    const int pi = plane >> 2, pj = plane & 3;
+    const int ra1 = pi == 0 ? 0 : (pi == 2 ? 2 : 1), ra2 = pi == 0 ? 2 : (pi == 1 ? 2 : (pi == 2 ? 1 : 3));
+    const int cb1 = pj == 0 ? 0 : (pj == 2 ? 2 : 1), cb2 = pj == 0 ? 2 : (pj == 1 ? 2 : (pj == 2 ? 1 : 3));
+    const bool row_sub = pi != 1, col_sub = pj != 1;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ld_c = tid & 7, ld_r = tid >> 3;
+    const int cchunks = a.Cin / 32;
+    const unsigned pix_bytes = (unsigned)a.Cin * 4;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.x), 0, (int)((size_t)a.B * a.H * a.W * pix_bytes), 0x00020000);
+    const float* wplane = static_cast<const float*>(a.w) + (size_t)plane * a.w_bs;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(wplane), 0, (int)((size_t)a.Cout * a.Cin * 4), 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+    const unsigned src_piece = (unsigned)(ld_c ^ ((ld_r >> 1) & 7)) * 16;
+    const int TH = (a.H + 1) >> 1, TW = (a.W + 1) >> 1;
+
+    unsigned p_off[AROWS][4];                 // the four pixels of this plane, per staged row (OOB = zero padding / past M)
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+        const int m = m0 + ld_r + LDROWS * i;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p_off[i][q] = OOB;
+        if (m < M) {
+            const long long t = (long long)a.m_off + m;
+            const int tx = (int)(t % TW);
+            const int ty = (int)((t / TW) % TH);
+            const int b = (int)(t / ((long long)TW * TH));
+            const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+            const int ys[2] = {y0 + ra1, y0 + ra2}, xs[2] = {x0 + cb1, x0 + cb2};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {      // q = 2 * column + row:  (a1,b1) (a2,b1) (a1,b2) (a2,b2)
+                const int yy = ys[q & 1], xx = xs[q >> 1];
+                if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
+                    p_off[i][q] = (unsigned)((b * a.H + yy) * a.W + xx) * pix_bytes + src_piece;
+            }
+        }
+    }
+    unsigned b_off[BROWS];
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) {
+        const int n = n0 + ld_r + LDROWS * i;
+        b_off[i] = n < a.Cout ? (unsigned)n * (unsigned)a.Cin * 4 + src_piece : OOB;
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    const unsigned wave_rows = (unsigned)__builtin_amdgcn_readfirstlane(wave) * 8u;
+
+    f32x4 px[AROWS][4];                       // the k-step in flight: 4 pixel pieces per staged row
+    auto load_a = [&](int cc) {
+        const unsigned xs = (unsigned)cc * CHUNK_BYTES;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned off = p_off[i][q] == OOB ? OOB : p_off[i][q] + xs;
+                px[i][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0));
+            }
+    };
+    auto stage_b = [&](int buf, int cc) {
+        const unsigned ws = (unsigned)cc * CHUNK_BYTES;
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            const unsigned off = b_off[i] == OOB ? OOB : b_off[i] + ws;
+            char* dst = Bs + ((unsigned)buf * BN + (unsigned)LDROWS * i + wave_rows) * CHUNK_BYTES;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)dst, 16, off, 0, 0, 0);
+        }
+    };
+    auto combine_store = [&](int buf) {       // V piece = (p0 rs p1) cs (p2 rs p3), IEEE add / sub in wino_input_kernel's order
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c0 = row_sub ? __fsub_rn(px[i][0][e], px[i][1][e]) : __fadd_rn(px[i][0][e], px[i][1][e]);
+                const float c1 = row_sub ? __fsub_rn(px[i][2][e], px[i][3][e]) : __fadd_rn(px[i][2][e], px[i][3][e]);
+                v[e] = col_sub ? __fsub_rn(c0, c1) : __fadd_rn(c0, c1);
+            }
+            *reinterpret_cast<f32x4*>(As + ((unsigned)buf * BM + (unsigned)LDROWS * i + (unsigned)ld_r) * CHUNK_BYTES + ld_c * 16) = v;
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+    const unsigned frag_row = lane & 31;
+    const unsigned swz = (lane >> 1) & 7, hi = lane >> 5;
+    unsigned frag_off[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) frag_off[kk] = frag_row * CHUNK_BYTES + (((unsigned)(2 * kk) + hi) ^ swz) * 16;
+    auto compute = [&](int buf) {
+        const char* Ab = &As[(buf * BM + wm * 32 * MT) * CHUNK_BYTES];
+        const char* Bb = &Bs[(buf * BN + wn * 32 * NT) * CHUNK_BYTES];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const f32x4 fa = *reinterpret_cast<const f32x4*>(Ab + frag_off[kk]);
+            f32x4 fb[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * CHUNK_BYTES + frag_off[kk]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) Elem<T>::mma(fa, fb[j], acc[0][j]);
+        }
+    };
+
+    load_a(0);
+    stage_b(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    combine_store(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int it = 0; it < cchunks; ++it) {
+        const int cur = it & 1, nxt = cur ^ 1;
+        const bool more = it + 1 < cchunks;
+        if (more) {
+            load_a(it + 1);
+            stage_b(nxt, it + 1);
+        }
+        compute(cur);
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            combine_store(nxt);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    ConvArgs e = a;                           // plain store of the plane's accumulators: M_xi [tiles][Cout]
+    e.y = static_cast<float*>(a.y) + (size_t)plane * a.y_bs;
+    e.scale = nullptr; e.bias = nullptr; e.res = nullptr; e.relu = 0; e.out_mode = 0; e.res_shift = 0;
+    e.Ho = 1; e.Wo = M > 0 ? M : 1;
+    conv_epilogue<float, float, MT, NT, WM, WN, RWM>(e, acc, lds, M, m0, n0, tid, lane, wm, wn);
+}
+
 // ---- conv_pp8_kernel: 256 x 256 block tile, 8 waves, ping-pong schedule (fp16 only) ---------------------------------
 // The k-loop of conv_igemm_kernel ends every 128-B k-chunk with a block-wide barrier that all 16 waves reach with
 // empty pipelines: at the fp16 MFMA rate the refill (DMA issue, first fragment reads) is a quarter of the step. This
@@ -882,6 +1060,18 @@ td_status dispatch(const ConvArgs& a, int cfg, hipStream_t stream) {
 }
 
 }  // namespace
+
+// Winograd plane contractions with the input transform fused (fp32): x = layer input [B,H,W,Cin], w = U [16][Cout][Cin]
+// (w_bs = Cout*Cin), y = M planes [16][M][Cout] (y_bs = M*Cout), M = tiles of this slab starting at tile m_off.
+td_status wino_gemm_launch(const ConvArgs& a, hipStream_t stream) {
+    TD_REQUIRE(a.Cin % 32 == 0 && a.Cout % 4 == 0 && a.M > 0, "winograd contraction: Cin %% 32, Cout %% 4, M > 0 required");
+    TD_REQUIRE((size_t)a.B * a.H * a.W * (size_t)a.Cin * 4 < 0xfffffff0ull - (1u << 20), "winograd contraction: input tensor must stay below 4 GB");
+    const long long nblk = (long long)td_cdiv(a.M, 128) * td_cdiv(a.Cout, 128) * 16;
+    TD_REQUIRE(nblk < (1ll << 31), "winograd contraction: grid too large");
+    hipLaunchKernelGGL(wino_gemm_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, a);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
 
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream) {
     const int ke = precision == TD_PRECISION_FP16 ? 64 : 32;

@@ -113,6 +113,7 @@ struct td_engine {
     bool winograd = true;         // TD_WINOGRAD=0 disables the Winograd path (diagnostics)
     float *wino_v = nullptr, *wino_m = nullptr;
     size_t wino_elems = 0;
+    bool wino_fused = true;       // TD_WINO_FUSED=0: separate input-transform kernel + batched conv_igemm launch (diagnostics)
     int wino_slab = 0;            // TD_WINO_SLAB: tiles per slab (diagnostics); 0 = sized for the Infinity Cache
     std::string tune_cache;       // TD_TUNE_CACHE: load / append measured choices (keeps profiled runs free of tuning launches)
 
@@ -388,6 +389,7 @@ td_status td_engine_create(const td_model_desc* desc, int device, td_engine** ou
     if (const char* tc = getenv("TD_TUNE_CACHE")) e->tune_cache = tc;
     if (const char* wg = getenv("TD_WINOGRAD")) e->winograd = atoi(wg) != 0;
     if (const char* ws = getenv("TD_WINO_SLAB")) e->wino_slab = atoi(ws);
+    if (const char* wf = getenv("TD_WINO_FUSED")) e->wino_fused = atoi(wf) != 0;
     e->desc = d;
     load_tune_cache(e);
     e->device = device;
@@ -770,16 +772,24 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         const int Ts = wino_slab_tiles(e, L);                 // tiles per slab: V + M of a slab stay in the Infinity Cache
         for (long long t0 = 0; t0 < T; t0 += Ts) {
             const int n = (int)std::min<long long>(Ts, T - t0);
-            td_status st2 = wino_input_launch(static_cast<const float*>(x_), B_, H_, W_, L.cin, e->wino_v, m_dyn, m_mul, t0, n, s_);
-            if (st2 < 0) return st2;
+            td_status st2;
             ConvArgs a{};
-            a.x = e->wino_v; a.w = L.wino_u; a.y = e->wino_m;
-            a.B = 1; a.H = 1; a.W = n; a.Cin = L.cin; a.Cout = L.cout; a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.Ho = 1; a.Wo = n;
+            a.w = L.wino_u; a.y = e->wino_m;
+            a.Cin = L.cin; a.Cout = L.cout; a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
             a.M = n; a.m_dyn = m_dyn; a.m_mul = m_dyn ? m_mul / 4 : 1;    // even H, W with a device row count: tiles = rows / 4
             a.m_off = (int)t0;
-            a.batch_count = 16; a.x_bs = (long long)n * L.cin; a.w_bs = (long long)L.cout * L.cin; a.y_bs = (long long)n * L.cout;
-            a.tile_cfg = gemm_cfg;
-            if ((st2 = conv2d_launch(a, TD_PRECISION_FP32, s_)) < 0) return st2;
+            a.w_bs = (long long)L.cout * L.cin; a.y_bs = (long long)n * L.cout;
+            if (e->wino_fused) {
+                // input transform fused into the contraction's A staging (wino_gemm_kernel): V never exists in memory
+                a.x = x_; a.B = B_; a.H = H_; a.W = W_;
+                if ((st2 = wino_gemm_launch(a, s_)) < 0) return st2;
+            } else {
+                if ((st2 = wino_input_launch(static_cast<const float*>(x_), B_, H_, W_, L.cin, e->wino_v, m_dyn, m_mul, t0, n, s_)) < 0) return st2;
+                a.x = e->wino_v; a.B = 1; a.H = 1; a.W = n; a.Ho = 1; a.Wo = n;
+                a.batch_count = 16; a.x_bs = (long long)n * L.cin;
+                a.tile_cfg = gemm_cfg;
+                if ((st2 = conv2d_launch(a, TD_PRECISION_FP32, s_)) < 0) return st2;
+            }
             if ((st2 = wino_output_launch(e->wino_m, B_, H_, W_, L.cout, L.scale, L.bias, relu ? 1 : 0, static_cast<float*>(y_), m_dyn,
                                           m_mul, t0, n, s_)) < 0) return st2;
         }
@@ -816,7 +826,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                 // 128 channels on both sides is faster through Winograd at every map size from 13x13 to 200x200
                 // (1.3-1.9x); 64 -> 64 (res2) is HBM-bound on the transforms and stays direct.
                 use_wino = L.cin >= 128 && L.cout >= 128;
-                if (use_wino && (st2 = tuned_cfg(wkey, prec_, L.cin / 32, false, s_, wino, &wino_cfg, nullptr)) < 0) return st2;
+                if (use_wino && !e->wino_fused && (st2 = tuned_cfg(wkey, prec_, L.cin / 32, false, s_, wino, &wino_cfg, nullptr)) < 0) return st2;
             }
             if (!use_wino && (st2 = tuned_cfg(key, prec_, ksteps, pp8_ok, s_, direct, &cfg, nullptr)) < 0) return st2;
         }
