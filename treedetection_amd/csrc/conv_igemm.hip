@@ -695,11 +695,28 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const ConvArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+#if !defined(TD_WINO_EPI_DIRECT)   // staged epilogue; the direct register stores below measured no faster (475-477 vs 478-485 tiles/s)
     ConvArgs e = a;                           // plain store of the plane's accumulators: M_xi [tiles][Cout]
     e.y = static_cast<float*>(a.y) + (size_t)plane * a.y_bs;
     e.scale = nullptr; e.bias = nullptr; e.res = nullptr; e.relu = 0; e.out_mode = 0; e.res_shift = 0;
     e.Ho = 1; e.Wo = M > 0 ? M : 1;
     conv_epilogue<float, float, MT, NT, WM, WN, RWM>(e, acc, lds, M, m0, n0, tid, lane, wm, wn);
+#else
+    // M_xi [tiles][Cout] gets the raw accumulators: a register of a 32 x 32 tile is 32 consecutive floats of one row per
+    // half-wave = one whole 128-B line (rows are Cout * 4 B apart, columns start at multiples of 32), so the plane is
+    // stored straight from registers — no LDS round trip, no barriers
+    float* __restrict__ Y = static_cast<float*>(a.y) + (size_t)plane * a.y_bs;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * 32 * NT + j * 32 + (lane & 31);
+        if (n >= a.Cout) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < M) Y[(size_t)m * a.Cout + n] = acc[0][j][r];
+        }
+    }
+#endif
 }
 
 // ---- conv_pp8_kernel: 256 x 256 block tile, 8 waves, ping-pong schedule (fp16 only) ---------------------------------
