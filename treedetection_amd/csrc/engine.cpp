@@ -1112,8 +1112,9 @@ td_status td_engine_forward_phase(td_engine* e, int phase, const void* images, i
     if (phase == TD_PHASE_STEM) {
         // pre-phase of the NEXT batch: needs the engine's stem / pool buffers, which the previous batch's trunk read
         if ((st = set_forward_ctx(e, images, input_format, hw_valid, hw_out, B, Hp, Wp, out)) < 0) return st;
+        // (the previous batch's LATER phases do not touch stem_out / pool_out: waiting for its phase 5 here put the
+        // pre-phase behind the whole selection tail and stalled the next trunk 0.8 ms per fp16 step)
         if (e->phase_ev_recorded[0]) TD_HIP_CHECK(hipStreamWaitEvent(s, e->phase_ev[0], 0));
-        if (e->phase_ev_recorded[5]) TD_HIP_CHECK(hipStreamWaitEvent(s, e->phase_ev[5], 0));
         e->stem_done = false;
     } else if (phase == 0) {
         if (e->stem_done) {
@@ -1123,8 +1124,12 @@ td_status td_engine_forward_phase(td_engine* e, int phase, const void* images, i
         } else if ((st = set_forward_ctx(e, images, input_format, hw_valid, hw_out, B, Hp, Wp, out)) < 0) {
             return st;
         }
-        // the engine's previous batch must have left its buffers (its last selection phase ran on another stream)
-        if (e->phase_ev_recorded[5]) TD_HIP_CHECK(hipStreamWaitEvent(s, e->phase_ev[5], 0));
+        // The engine's previous batch must have left the buffers the trunk writes: the FPN levels and RPN head maps are
+        // read last by RoIAlign 14x14 in phase 3 (phases 4 and 5 — mask convs, predictor, paste — only touch the mask
+        // buffers and the caller's outputs). Waiting for phase 5 instead chained every trunk behind the previous-but-two
+        // batch's mask tail, which starts only after that batch's mask convs earlier in the same tick: 0.5-0.8 ms of idle
+        // main stream per fp16 step (rocprof trace, round 2).
+        if (e->phase_ev_recorded[3]) TD_HIP_CHECK(hipStreamWaitEvent(s, e->phase_ev[3], 0));
     } else {
         TD_REQUIRE(e->ctx.valid_ctx, "td_engine_forward_phase: phase %d before phase 0", phase);
         TD_REQUIRE(e->phase_ev_recorded[phase - 1], "td_engine_forward_phase: phase %d before phase %d", phase, phase - 1);
