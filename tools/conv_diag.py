@@ -57,6 +57,7 @@ if __name__ == "__main__":
         for prec in (0, 1):
             bench(lib, prec, 8, 200, 200, 64, 256, 1, tag + " res2.conv3 64->256 +res", residual=True)
             bench(lib, prec, 8, 200, 200, 256, 64, 1, tag + " res2.conv1 256->64")
+            bench(lib, prec, 8, 200, 200, 64, 256, 1, tag + " res2.shortcut 64->256")
             bench(lib, prec, 8, 100, 100, 128, 512, 1, tag + " res3.conv3 128->512 +res", residual=True)
             bench(lib, prec, 8, 200, 200, 256, 256, 1, tag + " fpn_lateral2 256->256 +res", residual=True)
         sys.exit(0)

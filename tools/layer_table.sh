@@ -8,6 +8,6 @@ export TD_TUNE_CACHE=$O/tune.txt
 python3 $R/bench.py --precision $P --depth $D --steps 2 --warmup 2 --no-cpu-baseline --no-serial --no-fp16 --no-pipeline --no-profile > $O/warm.json 2> $O/warm.err || exit 1
 rocprofv3 --kernel-trace -d $O/trace -o t --output-format csv -- python3 $R/bench.py --precision $P --depth $D --steps 3 --warmup 1 --no-cpu-baseline --no-serial --no-fp16 --no-pipeline --no-profile > $O/bench.json 2> $O/bench.err || exit 1
 F=$(find $O/trace -name "*kernel_trace.csv" | head -1)
-python3 $R/tools/trace_layers.py $F $D > $O/layers.txt
+python3 $R/tools/trace_layers.py $F $D $P > $O/layers.txt
 cp $O/tune.txt $O/tile_choices.txt
 tail -80 $O/layers.txt

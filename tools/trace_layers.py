@@ -38,23 +38,36 @@ def schedule(depth=50, B=8, Hp=800, Wp=800, P=1000):
     return L
 
 
-def main(path, depth=50):
-    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"] or "conv_pp8" in r["Kernel_Name"]]
+def is_wino(name, N, K, fp32):
+    """fp32 engine: 3x3 stride-1 layers with >= 128 channels on both sides take the Winograd path (engine.cpp run_conv):
+    two launches (wino_gemm_kernel + wino_output_kernel) instead of one."""
+    three = ("conv2" in name or "fpn_output" in name or "rpn_conv" in name or "mask_fcn" in name)
+    return fp32 and three and N >= 128 and K // 9 >= 128
+
+
+def main(path, depth=50, fp32=False):
+    fam = ("conv_igemm", "conv_pp8", "wino_gemm", "wino_output", "wino_input")
+    rows = [r for r in csv.DictReader(open(path)) if any(f in r["Kernel_Name"] for f in fam)]
     L = schedule(depth)
-    n = len(L)
-    last = rows[-n:]
+    need = sum(2 if is_wino(n, N, K, fp32) else 1 for n, M, N, K in L)
+    last = rows[-need:]
     tot_f = tot_t = 0.0
-    for (name, M, N, K), r in zip(L, last):
-        us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    i = 0
+    for name, M, N, K in L:
+        k = 2 if is_wino(name, N, K, fp32) else 1
+        rs = last[i:i + k]
+        i += k
+        us = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rs)
         gf = 2.0 * M * N * K / 1e9
-        kn = r["Kernel_Name"]
-        kern = "pp8" if "conv_pp8" in kn else kn.split("conv_igemm_")[1].split("(")[0]
-        print(f"{name:24s} M={M:7d} N={N:5d} K={K:6d} {kern:14s} grid={int(r['Grid_Size_X'])//256:5d} {us:9.1f} us {gf:8.2f} GF {gf/us*1e3 if us else 0:7.1f} TF/s")
+        kn = rs[0]["Kernel_Name"]
+        kern = "winograd" if k == 2 else ("pp8" if "conv_pp8" in kn else kn.split("conv_igemm_")[1].split("(")[0][:28])
+        assert (k == 2) == ("wino_gemm" in kn), (name, kn)
+        print(f"{name:24s} M={M:7d} N={N:5d} K={K:6d} {kern:30s} {us:9.1f} us {gf:8.2f} GF {gf/us*1e3 if us else 0:7.1f} TF/s")
         if M:
             tot_f += gf
             tot_t += us
-    print(f"static convs: {tot_f:.1f} GF in {tot_t/1e3:.2f} ms = {tot_f/tot_t*1e3:.1f} TF/s")
+    print(f"static convs: {tot_f:.1f} algorithmic GF in {tot_t/1e3:.2f} ms = {tot_f/tot_t*1e3:.1f} TF/s")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 50)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 50, len(sys.argv) > 3 and sys.argv[3] == "fp32")

@@ -5,6 +5,8 @@
 // HBM-gather bound (RoIAlign reads whole 1-KB channel rows per bilinear corner) or trivially small: no MFMA.
 #include "common.h"
 #include "detect.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -30,13 +32,28 @@ __device__ __forceinline__ int fpn_level(float x1, float y1, float x2, float y2)
     return (int)lv - 2;
 }
 
-// One block (256 threads = 4 waves) per RoI; each wave walks bins w, w+4, ...; lane = channel quad.
-template <typename T>
+// raw 4-channel piece as it sits in memory (converted to float when it is consumed, not when it is loaded)
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef float4 type; };
+template <> struct Raw4<_Float16> { typedef h4 type; };
+__device__ __forceinline__ float4 widen4(const float4& v) { return v; }
+__device__ __forceinline__ float4 widen4(const h4& v) { return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]); }
+
+// One block (256 threads = 4 waves) per (RoI, part); wave g = part * 4 + wave walks bins g, g + 4 * parts, ...; lane =
+// channel quad. A bin is the mean of gh x gw bilinear samples = 4 corner loads each; summed one sample after the other
+// (the oracle's order: iy outer, ix inner, ((w1 v1 + w2 v2) + w3 v3) + w4 v4 per sample) the loop is a chain of
+// dependent rounds "table lookup → 4 loads → wait → add", ≈ 2 µs each next to the trunk's contractions: 66 rounds per
+// wave for the box head (12 bins x 5.4 samples), 113 for the mask head when one block owned all 196 bins. The sums keep
+// that order, the LOADS do not wait for it: the wave's samples form one flat sequence across its bins, and a ring of D
+// samples (4 D raw corner pieces in registers) is kept in flight — sample s + D is issued right after sample s is
+// consumed, so the compiler's counted vmcnt leaves 4 (D - 1) loads outstanding at every add. Same arithmetic, same
+// order → bit-identical outputs (tests/test_ops_gpu.py, tests/test_engine_gpu.py).
+template <typename T, int D>
 __global__ __launch_bounds__(256) void roi_align_kernel(FeatLevels fl, const float* __restrict__ rois,
                                                         const int* __restrict__ counts, int items, int roi_stride,
                                                         int pooled, int compact, T* __restrict__ out,
-                                                        int* __restrict__ total_rows, int single_level) {
-    const int item = blockIdx.y, r = blockIdx.x;
+                                                        int* __restrict__ total_rows, int single_level, int parts) {
+    const int item = blockIdx.y, r = blockIdx.x / parts, part = blockIdx.x - r * parts;
     const int cnt = counts ? counts[item] : roi_stride;
     int prefix = 0;
     if (compact) {
@@ -100,32 +117,104 @@ __global__ __launch_bounds__(256) void roi_align_kernel(FeatLevels fl, const flo
         __syncthreads();
     }
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nbins = pooled * pooled;
-    for (int bin = wave; bin < nbins; bin += 4) {
+    const int g0 = part * 4 + wave, gstride = 4 * parts;
+#define TD_RA(f) acc.f = __fadd_rn(acc.f, __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w1, v1.f), __fmul_rn(w2, v2.f)), __fmul_rn(w3, v3.f)), __fmul_rn(w4, v4.f)))
+    if (tab && ghw > 0) {
+        typedef typename Raw4<T>::type R4;
+        const int nb_w = g0 < nbins ? (nbins - 1 - g0) / gstride + 1 : 0;     // bins of this wave
+        const int total = nb_w * ghw;                                         // its samples, bin after bin
+        for (int cb = 0; cb < C; cb += 256) {
+            const int c0 = cb + lane * 4;
+            const bool act = c0 < C;
+            // issue cursor (sample s + D) and consume cursor (sample s): both walk bin → iy → ix
+            int i_bin = g0, i_iy = 0, i_ix = 0, i_ph = g0 / pooled, i_pw = g0 - (g0 / pooled) * pooled;
+            int c_bin = g0, c_n = 0;
+            R4 v[D][4];
+            float wgt[D][4];
+            int ok[D];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int c0l = act ? c0 : 0;                 // idle lanes (C < 256) load a valid address and drop the value
+            const int nb_all = nbins;
+            auto issue = [&](int d) {
+                // past the wave's last sample the cursor keeps walking (at most D - 1 dummy samples: clamped bin, never consumed)
+                const int ph = i_bin < nb_all ? i_ph : 0, pw = i_bin < nb_all ? i_pw : 0;
+                const int yi = ph * gh + i_iy, xi = pw * gw + i_ix;
+                // every lane reads the same table entry: the indices go to scalar registers (scalar address arithmetic), the
+                // weights stay per lane
+                const int yl = __builtin_amdgcn_readfirstlane(t_lo[0][yi]), xl = __builtin_amdgcn_readfirstlane(t_lo[1][xi]);
+                const int yh = __builtin_amdgcn_readfirstlane(t_hi[0][yi]), xh = __builtin_amdgcn_readfirstlane(t_hi[1][xi]);
+                ok[d] = yl >= 0 && xl >= 0;
+                const float ly = t_l[0][yi], hy = t_h[0][yi], lx = t_l[1][xi], hx = t_h[1][xi];
+                wgt[d][0] = __fmul_rn(hy, hx);
+                wgt[d][1] = __fmul_rn(hy, lx);
+                wgt[d][2] = __fmul_rn(ly, hx);
+                wgt[d][3] = __fmul_rn(ly, lx);
+                // the loads are UNCONDITIONAL (a sample outside the map reads pixel (0, 0) and is dropped at the add): with a
+                // branch around them the compiler cannot count what is in flight and drains vmcnt to 0 at every add
+                const int syl = ok[d] ? yl : 0, syh = ok[d] ? yh : 0, sxl = ok[d] ? xl : 0, sxh = ok[d] ? xh : 0;
+                v[d][0] = *reinterpret_cast<const R4*>(feat + ((size_t)syl * W + sxl) * C + c0l);
+                v[d][1] = *reinterpret_cast<const R4*>(feat + ((size_t)syl * W + sxh) * C + c0l);
+                v[d][2] = *reinterpret_cast<const R4*>(feat + ((size_t)syh * W + sxl) * C + c0l);
+                v[d][3] = *reinterpret_cast<const R4*>(feat + ((size_t)syh * W + sxh) * C + c0l);
+                if (++i_ix == gw) {
+                    i_ix = 0;
+                    if (++i_iy == gh) {
+                        i_iy = 0;
+                        i_bin += gstride;
+                        i_ph = i_bin / pooled;
+                        i_pw = i_bin - i_ph * pooled;
+                    }
+                }
+            };
+            auto consume = [&](int d) {
+                if (ok[d]) {
+                    const float w1 = wgt[d][0], w2 = wgt[d][1], w3 = wgt[d][2], w4 = wgt[d][3];
+                    const float4 v1 = widen4(v[d][0]), v2 = widen4(v[d][1]), v3 = widen4(v[d][2]), v4 = widen4(v[d][3]);
+                    TD_RA(x); TD_RA(y); TD_RA(z); TD_RA(w);
+                }
+                if (++c_n == ghw) {
+                    if (act) {
+                        acc.x = __fdiv_rn(acc.x, count);
+                        acc.y = __fdiv_rn(acc.y, count);
+                        acc.z = __fdiv_rn(acc.z, count);
+                        acc.w = __fdiv_rn(acc.w, count);
+                        store4(out + (row * nbins + c_bin) * C + c0, acc);
+                    }
+                    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    c_n = 0;
+                    c_bin += gstride;
+                }
+            };
+            if (total > 0) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) issue(d);
+                for (int s0 = 0; s0 < total; s0 += D) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        if (s0 + d < total) consume(d);
+                        issue(d);
+                    }
+                }
+            }
+        }
+#undef TD_RA
+        return;
+    }
+    // degenerate RoIs (no samples: every bin is 0) and sampling grids too large for the table: one sample at a time
+    for (int bin = g0; bin < nbins; bin += gstride) {
         const int ph = bin / pooled, pw = bin - ph * pooled;
         for (int c0 = lane * 4; c0 < C; c0 += 256) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int iy = 0; iy < gh; ++iy) {
                 int yl, yh;
                 float ly, hy;
-                if (tab) {
-                    yl = t_lo[0][ph * gh + iy];
-                    if (yl < 0) continue;
-                    yh = t_hi[0][ph * gh + iy];
-                    ly = t_l[0][ph * gh + iy];
-                    hy = t_h[0][ph * gh + iy];
-                } else if (!sample(sh, bh, ph, iy, gh, H, yl, yh, ly, hy)) continue;
+                if (!sample(sh, bh, ph, iy, gh, H, yl, yh, ly, hy)) continue;
                 for (int ix = 0; ix < gw; ++ix) {
                     int xl, xh;
                     float lx, hx;
-                    if (tab) {
-                        xl = t_lo[1][pw * gw + ix];
-                        if (xl < 0) continue;
-                        xh = t_hi[1][pw * gw + ix];
-                        lx = t_l[1][pw * gw + ix];
-                        hx = t_h[1][pw * gw + ix];
-                    } else if (!sample(sw, bw, pw, ix, gw, W, xl, xh, lx, hx)) continue;
+                    if (!sample(sw, bw, pw, ix, gw, W, xl, xh, lx, hx)) continue;
                     const float w1 = __fmul_rn(hy, hx), w2 = __fmul_rn(hy, lx), w3 = __fmul_rn(ly, hx), w4 = __fmul_rn(ly, lx);
                     const float4 v1 = load4(feat + ((size_t)yl * W + xl) * C + c0);
                     const float4 v2 = load4(feat + ((size_t)yl * W + xh) * C + c0);
@@ -141,6 +230,194 @@ __global__ __launch_bounds__(256) void roi_align_kernel(FeatLevels fl, const flo
             acc.z = __fdiv_rn(acc.z, count);
             acc.w = __fdiv_rn(acc.w, count);
             store4(out + (row * nbins + bin) * C + c0, acc);
+        }
+    }
+}
+
+// fp16 features with C <= 256: a channel row is 512 B, so with 4 channels (8 B) per lane a wave-load moves half of what
+// the texture path handles per instruction (PMC, box head: 8.4 M loads = 140 M TCP accesses, TA busy 0.53, 137
+// instructions per sample of which 65 scalar). Here a lane owns 8 channels (16-B loads) and the two halves of a wave work
+// on two NEIGHBOURING BINS of the RoI at once (bin b on lanes 0-31, bin b + 1 on lanes 32-63): both bins have the same
+// gh x gw sample grid, so the halves run in lockstep through (iy, ix) and differ only in their table entries — half the
+// load instructions, half the per-sample bookkeeping. Tables are packed {lo, hi, l, h} (one ds_read_b128 per axis);
+// addresses are 32-bit element offsets from the level's base. Per channel the arithmetic and its order are those of
+// roi_align_kernel → bit-identical outputs.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+template <int D>
+__global__ __launch_bounds__(256) void roi_align_h8_kernel(FeatLevels fl, const float* __restrict__ rois,
+                                                           const int* __restrict__ counts, int items, int roi_stride,
+                                                           int pooled, int compact, _Float16* __restrict__ out,
+                                                           int* __restrict__ total_rows, int single_level, int parts) {
+    const int item = blockIdx.y, r = blockIdx.x / parts, part = blockIdx.x - r * parts;
+    const int cnt = counts ? counts[item] : roi_stride;
+    int prefix = 0;
+    if (compact) {
+        for (int i = 0; i < item; ++i) prefix += counts[i];
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && total_rows) {
+            int t = 0;
+            for (int i = 0; i < items; ++i) t += counts[i];
+            *total_rows = t;
+        }
+    }
+    if (r >= cnt) return;
+    const size_t row = compact ? (size_t)(prefix + r) : (size_t)item * roi_stride + r;
+    const float4 bx = *reinterpret_cast<const float4*>(rois + ((size_t)item * roi_stride + r) * 4);
+    const int lvl = single_level ? 0 : fpn_level(bx.x, bx.y, bx.z, bx.w);
+    const int H = fl.h[lvl], W = fl.w[lvl], C = fl.C;
+    const float sc = fl.scale[lvl];
+    const _Float16* __restrict__ feat = static_cast<const _Float16*>(fl.feat[lvl]) + (single_level ? 0 : (size_t)item * H * W * C);
+
+    const float sw = __fsub_rn(__fmul_rn(bx.x, sc), 0.5f), sh = __fsub_rn(__fmul_rn(bx.y, sc), 0.5f);
+    const float ew = __fsub_rn(__fmul_rn(bx.z, sc), 0.5f), eh = __fsub_rn(__fmul_rn(bx.w, sc), 0.5f);
+    const float rw = __fsub_rn(ew, sw), rh = __fsub_rn(eh, sh);
+    const float bh = __fdiv_rn(rh, (float)pooled), bw = __fdiv_rn(rw, (float)pooled);
+    int gh = (int)ceilf(__fdiv_rn(rh, (float)pooled)), gw = (int)ceilf(__fdiv_rn(rw, (float)pooled));
+    gh = gh > 0 ? gh : 0;
+    gw = gw > 0 ? gw : 0;
+    const int ghw = gh * gw;
+    const float count = (float)(ghw > 1 ? ghw : 1);
+    const int nbins = pooled * pooled;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hl = lane >> 5, c0 = (lane & 31) * 8;
+    const bool act = c0 < C;
+
+    constexpr int TAB = 14 * 24;
+    __shared__ int4 tq[2][TAB];      // {lo (-1: sample outside), hi, bits(l), bits(h)} per y-sample / x-sample
+    const bool tab = pooled * gh <= TAB && pooled * gw <= TAB;
+    auto sample = [&](float start, float bin, int p, int i, int g, int size, int& lo, int& hi, float& l, float& h) -> bool {
+        const float c = __fadd_rn(__fadd_rn(start, __fmul_rn((float)p, bin)),
+                                  __fdiv_rn(__fmul_rn(__fadd_rn((float)i, 0.5f), bin), (float)g));
+        if (c < -1.f || c > (float)size) return false;
+        float cc = c <= 0.f ? 0.f : c;
+        lo = (int)cc;
+        if (lo >= size - 1) { hi = lo = size - 1; cc = (float)lo; } else hi = lo + 1;
+        l = __fsub_rn(cc, (float)lo);
+        h = __fsub_rn(1.f, l);
+        return true;
+    };
+    if (!tab || ghw == 0) {
+        // no samples (every bin is 0) or a sampling grid too large for the table: one sample at a time, 8 channels per lane,
+        // the two halves of a wave on two bins
+        for (int bin = (part * 4 + wave) * 2 + hl; bin < nbins; bin += 8 * parts) {
+            const int ph = bin / pooled, pw = bin - ph * pooled;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            for (int iy = 0; iy < gh; ++iy) {
+                int yl, yh;
+                float ly, hy;
+                if (!sample(sh, bh, ph, iy, gh, H, yl, yh, ly, hy)) continue;
+                for (int ix = 0; ix < gw; ++ix) {
+                    int xl, xh;
+                    float lx, hx;
+                    if (!sample(sw, bw, pw, ix, gw, W, xl, xh, lx, hx)) continue;
+                    if (!act) continue;
+                    const float w1 = __fmul_rn(hy, hx), w2 = __fmul_rn(hy, lx), w3 = __fmul_rn(ly, hx), w4 = __fmul_rn(ly, lx);
+                    const h8 v1 = *reinterpret_cast<const h8*>(feat + ((size_t)yl * W + xl) * C + c0);
+                    const h8 v2 = *reinterpret_cast<const h8*>(feat + ((size_t)yl * W + xh) * C + c0);
+                    const h8 v3 = *reinterpret_cast<const h8*>(feat + ((size_t)yh * W + xl) * C + c0);
+                    const h8 v4 = *reinterpret_cast<const h8*>(feat + ((size_t)yh * W + xh) * C + c0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        acc[e] = __fadd_rn(acc[e], __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w1, (float)v1[e]), __fmul_rn(w2, (float)v2[e])),
+                                                                         __fmul_rn(w3, (float)v3[e])), __fmul_rn(w4, (float)v4[e])));
+                }
+            }
+            if (act) {
+                h8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (_Float16)__fdiv_rn(acc[e], count);
+                *reinterpret_cast<h8*>(out + (row * nbins + bin) * C + c0) = o;
+            }
+        }
+        return;
+    }
+    for (int t = threadIdx.x; t < pooled * gh + pooled * gw; t += blockDim.x) {
+        const int ax = t < pooled * gh ? 0 : 1;
+        const int u = ax ? t - pooled * gh : t;
+        const int g = ax ? gw : gh;
+        const int p = u / g, i = u - p * g;
+        int lo = 0, hi = 0;
+        float l = 0.f, h = 0.f;
+        const bool ok = ax ? sample(sw, bw, p, i, g, W, lo, hi, l, h) : sample(sh, bh, p, i, g, H, lo, hi, l, h);
+        tq[ax][u] = make_int4(ok ? lo : -1, hi, __float_as_int(l), __float_as_int(h));
+    }
+    __syncthreads();
+
+    // bins of the two halves: b0 + hl, b0 = 2 (4 part + wave), advancing by 8 parts; a half past the last bin idles
+    const int b_first = (part * 4 + wave) * 2, bstride = 8 * parts;
+    const int nb0 = b_first < nbins ? (nbins - 1 - b_first) / bstride + 1 : 0;     // rounds of this wave (half 0 has the most)
+    const int total = nb0 * ghw;
+    int i_b0 = b_first, i_iy = 0, i_ix = 0;         // issue cursor (uniform; the bin of a lane is i_b0 + hl)
+    int c_b0 = b_first, c_n = 0;                    // consume cursor
+    h8 v[D][4];
+    float wgt[D][4];
+    bool okl[D];
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const unsigned uW = (unsigned)W, uC = (unsigned)C;
+    const unsigned c0l = act ? (unsigned)c0 : 0u;     // idle lanes (C < 256) load a valid address and drop the value
+    auto issue = [&](int d) {
+        // past the wave's last sample the cursor keeps walking (at most D - 1 dummy samples: clamped bin, never consumed)
+        const int bin = i_b0 + hl;
+        const bool live = bin < nbins && act;
+        const int binc = bin < nbins ? bin : nbins - 1;
+        const int ph = binc / pooled, pw = binc - ph * pooled;
+        const int4 ey = tq[0][ph * gh + i_iy], ex = tq[1][pw * gw + i_ix];
+        okl[d] = live && ey.x >= 0 && ex.x >= 0;
+        const float ly = __int_as_float(ey.z), hy = __int_as_float(ey.w), lx = __int_as_float(ex.z), hx = __int_as_float(ex.w);
+        wgt[d][0] = __fmul_rn(hy, hx);
+        wgt[d][1] = __fmul_rn(hy, lx);
+        wgt[d][2] = __fmul_rn(ly, hx);
+        wgt[d][3] = __fmul_rn(ly, lx);
+        // UNCONDITIONAL loads (a sample outside the map reads pixel (0, 0) and is dropped at the add): with a branch around
+        // them the compiler cannot count what is in flight and drains vmcnt to 0 at every add
+        const bool in = ey.x >= 0 && ex.x >= 0;
+        const unsigned yl = in ? (unsigned)ey.x : 0u, yh = in ? (unsigned)ey.y : 0u, xl = in ? (unsigned)ex.x : 0u, xh = in ? (unsigned)ex.y : 0u;
+        v[d][0] = *reinterpret_cast<const h8*>(feat + ((yl * uW + xl) * uC + c0l));
+        v[d][1] = *reinterpret_cast<const h8*>(feat + ((yl * uW + xh) * uC + c0l));
+        v[d][2] = *reinterpret_cast<const h8*>(feat + ((yh * uW + xl) * uC + c0l));
+        v[d][3] = *reinterpret_cast<const h8*>(feat + ((yh * uW + xh) * uC + c0l));
+        if (++i_ix == gw) {
+            i_ix = 0;
+            if (++i_iy == gh) {
+                i_iy = 0;
+                i_b0 += bstride;
+            }
+        }
+    };
+    auto consume = [&](int d) {
+        if (okl[d]) {
+            const float w1 = wgt[d][0], w2 = wgt[d][1], w3 = wgt[d][2], w4 = wgt[d][3];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                acc[e] = __fadd_rn(acc[e], __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w1, (float)v[d][0][e]), __fmul_rn(w2, (float)v[d][1][e])),
+                                                                 __fmul_rn(w3, (float)v[d][2][e])), __fmul_rn(w4, (float)v[d][3][e])));
+        }
+        if (++c_n == ghw) {
+            const int bin = c_b0 + hl;
+            if (act && bin < nbins) {
+                h8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (_Float16)__fdiv_rn(acc[e], count);
+                *reinterpret_cast<h8*>(out + (row * nbins + bin) * C + c0) = o;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            c_n = 0;
+            c_b0 += bstride;
+        }
+    };
+    if (total > 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) issue(d);
+        for (int s0 = 0; s0 < total; s0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (s0 + d < total) consume(d);
+                issue(d);
+            }
         }
     }
 }
@@ -345,15 +622,67 @@ __global__ __launch_bounds__(256) void paste_fill_kernel(const float* __restrict
 
 }  // namespace
 
+// ring depth of roi_align_kernel (samples in flight per wave); TD_ROI_DEPTH overrides it for diagnostics (tools/roi_bench.py)
+static bool roi_h8_ok(int C) {
+    static const char* env = getenv("TD_ROI_H8");      // diagnostics: 0 = the 4-channel-per-lane kernel for fp16 too
+    if (env && atoi(env) == 0) return false;
+    return C <= 256 && C % 8 == 0;
+}
+
+template <typename T>
+static void roi_align_dispatch(dim3 grid, hipStream_t stream, int depth, const FeatLevels& fl, const float* rois, const int* counts,
+                               int items, int roi_stride, int pooled, int compact, T* out, int* total_rows, int single_level, int parts) {
+    if constexpr (std::is_same<T, _Float16>::value) {
+        if (roi_h8_ok(fl.C)) {
+#define TD_ROI_LAUNCH8(DD) hipLaunchKernelGGL((roi_align_h8_kernel<DD>), grid, dim3(256), 0, stream, fl, rois, counts, items, \
+                                              roi_stride, pooled, compact, out, total_rows, single_level, parts)
+            switch (depth) {
+                case 1: TD_ROI_LAUNCH8(1); break;
+                case 3: TD_ROI_LAUNCH8(3); break;
+                case 4: TD_ROI_LAUNCH8(4); break;
+                default: TD_ROI_LAUNCH8(2); break;
+            }
+#undef TD_ROI_LAUNCH8
+            return;
+        }
+    }
+#define TD_ROI_LAUNCH(DD) hipLaunchKernelGGL((roi_align_kernel<T, DD>), grid, dim3(256), 0, stream, fl, rois, counts, items, \
+                                             roi_stride, pooled, compact, out, total_rows, single_level, parts)
+    switch (depth) {
+        case 1: TD_ROI_LAUNCH(1); break;
+        case 2: TD_ROI_LAUNCH(2); break;
+        case 3: TD_ROI_LAUNCH(3); break;
+        case 6: TD_ROI_LAUNCH(6); break;
+        case 8: TD_ROI_LAUNCH(8); break;
+        default: TD_ROI_LAUNCH(4); break;
+    }
+#undef TD_ROI_LAUNCH
+}
+
+static int roi_depth(int precision) {
+    static const char* env = getenv("TD_ROI_DEPTH");
+    if (env) return atoi(env);
+    return precision == TD_PRECISION_FP16 ? 2 : 4;        // measured (tools/roi_sweep.sh): fp16 0.417 / 0.351 / 0.353 / 0.362 ms at depth 1 / 2 / 3 / 4, fp32 0.659 / 0.581 / 0.575 / 0.545 / 0.550 at 1 / 2 / 3 / 4 / 6
+}
+
+// blocks per RoI: the 14 x 14 mask-head launch has few RoIs (the detections) of 196 bins each
+static int roi_parts(int pooled, long long rois) {
+    static const char* env = getenv("TD_ROI_PARTS");
+    if (env) return atoi(env) > 0 ? atoi(env) : 1;
+    return pooled * pooled >= 128 ? 4 : 1;
+}
+
 td_status roi_align_launch(const FeatLevels& fl, const float* rois, const int* counts, int items, int roi_stride,
                            int pooled, int compact, void* out, int* total_rows, int precision, hipStream_t stream) {
     TD_REQUIRE(fl.C % 4 == 0, "roi_align: C must be a multiple of 4");
+    const int parts = roi_parts(pooled, (long long)items * roi_stride);
+    const dim3 grid(roi_stride * parts, items);
     if (precision == TD_PRECISION_FP16)
-        hipLaunchKernelGGL((roi_align_kernel<_Float16>), dim3(roi_stride, items), dim3(256), 0, stream, fl, rois, counts,
-                           items, roi_stride, pooled, compact, static_cast<_Float16*>(out), total_rows, 0);
+        roi_align_dispatch<_Float16>(grid, stream, roi_depth(precision), fl, rois, counts, items, roi_stride, pooled, compact,
+                                     static_cast<_Float16*>(out), total_rows, 0, parts);
     else
-        hipLaunchKernelGGL((roi_align_kernel<float>), dim3(roi_stride, items), dim3(256), 0, stream, fl, rois, counts,
-                           items, roi_stride, pooled, compact, static_cast<float*>(out), total_rows, 0);
+        roi_align_dispatch<float>(grid, stream, roi_depth(precision), fl, rois, counts, items, roi_stride, pooled, compact,
+                                  static_cast<float*>(out), total_rows, 0, parts);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
@@ -363,12 +692,14 @@ td_status roi_align_single_launch(const void* feat, int H, int W, int C, const f
     TD_REQUIRE(C % 4 == 0 && R >= 1, "roi_align: bad shape");
     FeatLevels fl{};
     fl.feat[0] = feat; fl.h[0] = H; fl.w[0] = W; fl.scale[0] = scale; fl.C = C;
+    const int parts = roi_parts(pooled, R);
+    const dim3 grid(R * parts, 1);
     if (precision == TD_PRECISION_FP16)
-        hipLaunchKernelGGL((roi_align_kernel<_Float16>), dim3(R, 1), dim3(256), 0, stream, fl, rois, (const int*)nullptr,
-                           1, R, pooled, 0, static_cast<_Float16*>(out), (int*)nullptr, 1);
+        roi_align_dispatch<_Float16>(grid, stream, roi_depth(precision), fl, rois, nullptr, 1, R, pooled, 0,
+                                     static_cast<_Float16*>(out), nullptr, 1, parts);
     else
-        hipLaunchKernelGGL((roi_align_kernel<float>), dim3(R, 1), dim3(256), 0, stream, fl, rois, (const int*)nullptr, 1,
-                           R, pooled, 0, static_cast<float*>(out), (int*)nullptr, 1);
+        roi_align_dispatch<float>(grid, stream, roi_depth(precision), fl, rois, nullptr, 1, R, pooled, 0,
+                                  static_cast<float*>(out), nullptr, 1, parts);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
