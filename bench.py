@@ -24,6 +24,17 @@ import os
 import sys
 import time
 
+# HIP streams and hardware queues (measured, round 2; tools/timeline.py on a rocprofv3 kernel trace, Queue_Id column): the
+# software pipeline runs 1 main + 3 selection + 3 pre-stage streams, and ROCm maps streams round-robin onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4), where two streams of one queue serialise. With 4 queues the main stream
+# shares its queue with one selection stream and idles ~0.5 ms per fp16 step behind that stream's RoIAlign / NMS; with 8
+# every stream has its own queue, the gaps vanish (24 us per step) — and the fp16 step gets SLOWER (5.3 -> 7.2 ms when all
+# seven streams really run concurrently: the selection kernels' waves fragment the CUs' register files and the 256-register
+# contraction blocks wait for whole SIMDs; 4.87 ms only when the host enqueues tick by tick). fp32 is indifferent
+# (487 tiles/s either way). The default of 4 is kept; TD_BENCH_HW_QUEUES overrides it for experiments.
+if "TD_BENCH_HW_QUEUES" in os.environ:
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ["TD_BENCH_HW_QUEUES"]
+
 import numpy as np
 import torch
 
@@ -234,7 +245,7 @@ def main():
         log(f"creating 3 engines ({precision}, software pipeline: one main stream, one side stream per engine)")
         engs = [Engine(sd, device=local_rank, precision=precision) for _ in range(3)]
         outs = [e.alloc_outputs(B, S, S, paste=True) for e in engs]
-        main = torch.cuda.Stream()
+        main = torch.cuda.Stream()      # (a high-priority main stream was measured: fp32 -1.5 %, fp16 +-0)
         sides = [torch.cuda.Stream() for _ in range(3)]   # one per engine: a batch's selection phases only wait on that batch
         pres = [torch.cuda.Stream() for _ in range(3)]    # one per engine: resize + stem + pool of its NEXT batch (fp16 schedule)
         gl = None
