@@ -248,6 +248,13 @@ def main():
         main = torch.cuda.Stream()      # (a high-priority main stream was measured: fp32 -1.5 %, fp16 +-0)
         sides = [torch.cuda.Stream() for _ in range(3)]   # one per engine: a batch's selection phases only wait on that batch
         pres = [torch.cuda.Stream() for _ in range(3)]    # one per engine: resize + stem + pool of its NEXT batch (fp16 schedule)
+        layout = os.environ.get("TD_BENCH_STREAMS", "")
+        if layout == "3":        # experiment: ONE selection stream and ONE pre-stage stream for all three engines
+            sides = [sides[0]] * 3
+            pres = [pres[0]] * 3
+        elif layout == "2":      # experiment: selection and pre-stage work of all engines on one stream
+            sides = [sides[0]] * 3
+            pres = [sides[0]] * 3
         gl = None
         if world > 1 and rank == 0:
             gl = {k: [torch.empty_like(outs[0][k]) for _ in range(world)] for k in gather_keys}

@@ -3,6 +3,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -88,3 +89,99 @@ def test_merge_and_crop_images(tmp_path):
     cfg["overlapping_tiles_width"] = 40
     merge_and_crop_images(cfg, images2, sorted(ndsm.values()))
     assert len(images2) == n_img + 2 and any("exceeds" in m for lvl, m in cfg["logger"].msgs if lvl == "error")
+
+
+# ---- against the oracle (oracle/merging_ref.py: rasterio.merge "first" + the reference's centre crop, restated) -------------
+from oracle.merging_ref import crop_center_ref, merge_images_ref, neighbours_ref, seam_strips_ref  # noqa: E402
+
+
+def _rand_raster(rng, bands, h, w, dtype, zero_frac=0.0):
+    if np.issubdtype(np.dtype(dtype), np.integer):
+        a = rng.integers(1, 250, (bands, h, w)).astype(dtype)
+    else:
+        a = rng.uniform(0.5, 40.0, (bands, h, w)).astype(dtype)
+    if zero_frac:
+        a[:, rng.random((h, w)) < zero_frac] = 0
+    return a
+
+
+def test_merge_images_matches_the_oracle_adjacent_and_overlapping(tmp_path):
+    """Adjacent neighbours (what the reference merges) and OVERLAPPING rasters with nodata-valued pixels in the first one
+    (rasterio's "first" is a value rule: a later image shows through where the mosaic still holds the nodata value)."""
+    rng = np.random.default_rng(7)
+    gsd = 0.2
+    cases = [
+        # dtype, bands, (h1, w1), (h2, w2), offset of raster 2 in pixels (dx, dy), nodata tag of raster 1, zero fraction
+        (np.uint8, 4, (40, 50), (40, 50), (50, 0), None, 0.0),        # right neighbour
+        (np.uint8, 4, (40, 50), (40, 50), (0, 40), None, 0.0),        # bottom neighbour
+        (np.float32, 1, (30, 30), (30, 30), (30, 0), None, 0.0),
+        (np.uint8, 3, (40, 50), (40, 50), (35, 0), None, 0.3),        # 15-px overlap, zeros in both: second shows through
+        (np.uint8, 3, (40, 50), (30, 60), (-20, 25), None, 0.3),      # partial overlap, second starts left of the first
+        (np.float32, 1, (32, 32), (32, 32), (16, 16), -9999.0, 0.2),  # nodata tag on the first raster: -9999 is the hole value
+        (np.float32, 1, (32, 32), (32, 32), (16, 0), 3.4e38, 0.2),    # absurd nodata → 0.0 (helpers.py:1037)
+        (np.uint16, 2, (20, 25), (20, 25), (10, 5), None, 0.5),
+    ]
+    for k, (dtype, bands, s1, s2, (dx, dy), nd, zf) in enumerate(cases):
+        a1 = _rand_raster(rng, bands, s1[0], s1[1], dtype, zf)
+        a2 = _rand_raster(rng, bands, s2[0], s2[1], dtype, zf)
+        if nd is not None and abs(nd) < 1e10:
+            a1[:, rng.random(s1) < 0.2] = nd
+        t1 = (gsd, 0.0, 412000.0, 0.0, -gsd, 5318000.0)
+        t2 = (gsd, 0.0, 412000.0 + dx * gsd, 0.0, -gsd, 5318000.0 - dy * gsd)
+        p1, p2 = str(tmp_path / f"a{k}.tif"), str(tmp_path / f"b{k}.tif")
+        write_geotiff(p1, a1, t1, 25832, nodata=nd)
+        write_geotiff(p2, a2, t2, 25832)
+        g1 = GeoTiff(p1)
+        assert g1.nodata == nd
+        got, gt = merge_images(g1, GeoTiff(p2))
+        ref, rt = merge_images_ref(a1, t1, a2, t2, nd)
+        assert got.shape == ref.shape and got.dtype == ref.dtype, (k, got.shape, ref.shape)
+        assert np.array_equal(got, ref), k
+        assert np.allclose(gt, rt, rtol=0, atol=1e-9), (k, gt, rt)
+        for (cw, ch) in ((ref.shape[2], 12), (14, ref.shape[1]), (ref.shape[2] + 2, 4)):
+            want = crop_center_ref(ref, rt, cw, ch)
+            if want is None:
+                with pytest.raises(ValueError):
+                    crop_image(got, gt, cw, ch)
+            else:
+                c, ct = crop_image(got, gt, cw, ch)
+                assert np.array_equal(c, want[0]) and np.allclose(ct, want[1], rtol=0, atol=1e-9)
+
+
+def test_seam_strips_match_the_oracle_on_a_3x3_mosaic(tmp_path):
+    """merge_and_crop_images end to end (files, names, order, georeferencing) vs the oracle's in-memory restatement."""
+    rng = np.random.default_rng(11)
+    gsd, W, H = 0.25, 64, 48
+    for sub, bands, dtype, rgbi in (("rgb", 4, np.uint8, True), ("ndsm", 1, np.float32, False)):
+        d = tmp_path / sub
+        os.makedirs(d)
+        names, rasters = [], []
+        for iy in range(3):
+            for ix in range(3):
+                if (ix, iy) == (1, 1) and not rgbi:
+                    continue                                  # a hole in the height mosaic: fewer neighbours there
+                arr = _rand_raster(rng, bands, H, W, dtype, 0.1)
+                t = (gsd, 0.0, 500000.0 + ix * W * gsd, 0.0, -gsd, 5400000.0 - iy * H * gsd)
+                name = str(d / f"{7000 + iy * 3 + ix}_x.tif")
+                write_geotiff(name, arr, t, 25832)
+                names.append(name)
+                rasters.append((arr, t))
+        cfg = {"logger": Log(), "merged_path": "merged", "tile_width": 6, "tile_height": 5, "buffer": 1,
+               "overlapping_tiles_width": 2, "overlapping_tiles_height": 3}
+        imgs, hts = (list(names), []) if rgbi else ([], list(names))
+        merge_and_crop_images(cfg, imgs, hts)
+        new = (imgs if rgbi else hts)[len(names):]
+        want = seam_strips_ref([os.path.basename(n) for n in names], rasters, cfg, rgbi)
+        assert [os.path.basename(n) for n in new] == [w[0] for w in want]
+        assert len(want) == (12 if rgbi else 8)
+        for path, (fn, data, t) in zip(new, want):
+            g = GeoTiff(path)
+            assert np.array_equal(g.read(), data), fn
+            assert np.allclose(g.transform, t, rtol=0, atol=1e-9), fn
+        metas = [(t, a.shape[2], a.shape[1]) for a, t in rasters]
+        meta_info = {n: m[0] for n, m in zip(names, metas)}
+        for i, n in enumerate(names):
+            got = retrieve_neighboring_image_filenames(n, names, meta_info)
+            ref = neighbours_ref(i, metas)
+            assert got == tuple(None if j is None else names[j] for j in ref)
+        assert not [m for lvl, m in cfg["logger"].msgs if lvl == "error"]

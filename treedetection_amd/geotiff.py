@@ -70,6 +70,13 @@ class GeoTiff:
             self.transform = (m[0], m[1], m[3], m[4], m[5], m[7])
         else:
             self.transform = (1.0, 0.0, 0.0, 0.0, -1.0, float(self.height))
+        # GDAL_NODATA (tag 42113, ASCII): what rasterio reports as ``src.nodata`` (helpers.merge_images reads it)
+        self.nodata: Optional[float] = None
+        if 42113 in t:
+            try:
+                self.nodata = float(str(t[42113][0]).strip())
+            except (ValueError, IndexError):
+                self.nodata = None
         self.epsg = None
         if 34735 in t:
             keys = [int(v) for v in t[34735]]
@@ -350,7 +357,8 @@ class GeoTiff:
 
 def write_geotiff(path: str, data: np.ndarray, transform: Sequence[float], epsg: int = 25832, *,
                   tile: Optional[Tuple[int, int]] = None, rows_per_strip: Optional[int] = None,
-                  compression: Optional[str] = None, predictor: int = 1, planar: bool = False) -> None:
+                  compression: Optional[str] = None, predictor: int = 1, planar: bool = False,
+                  nodata: Optional[float] = None) -> None:
     """Classic little-endian TIFF with the GeoTIFF tags the reader understands. data: [bands, rows, cols] or
     [rows, cols]; uint8 / uint16 / float32. Defaults: one uncompressed pixel-interleaved strip (what the tile reader
     maps without copying). Options: ``tile=(tile_rows, tile_cols)`` (multiples of 16) or ``rows_per_strip``,
@@ -390,6 +398,10 @@ def write_geotiff(path: str, data: np.ndarray, transform: Sequence[float], epsg:
     entries = []   # (tag, type, count, payload bytes)
 
     def add(tag, typ, values):
+        if typ == 2:                           # ASCII, NUL-terminated
+            raw = values.encode("latin1") + b"\0"
+            entries.append((tag, typ, len(raw), raw))
+            return
         code = {3: "H", 4: "I", 12: "d"}[typ]
         entries.append((tag, typ, len(values), struct.pack("<" + str(len(values)) + code, *values)))
 
@@ -417,6 +429,8 @@ def write_geotiff(path: str, data: np.ndarray, transform: Sequence[float], epsg:
     add(33550, 12, [a, -e, 0.0])
     add(33922, 12, [0.0, 0.0, 0.0, c, f, 0.0])
     add(34735, 3, [1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, int(epsg)])
+    if nodata is not None:
+        add(42113, 2, repr(float(nodata)))
     entries.sort(key=lambda t: t[0])
     n = len(entries)
     ifd_off = 8

@@ -5,7 +5,7 @@ With ``use_overlap`` the reference mosaics every image with its right and its bo
 a strip ``(tile + 2*buffer) * overlapping_tiles`` pixels wide out of the middle of the mosaic — the seam — writes it to
 ``<dir>/<merged_path>/`` and appends it to the work list, so crowns cut by an image border are predicted whole once.
 Same steps here on :class:`treedetection_amd.geotiff.GeoTiff` (no rasterio): neighbours by origin arithmetic,
-mosaic = paste both rasters into the union extent at the first image's resolution (first image wins, nodata 0),
+mosaic = rasterio.merge's "first" rule on the union extent at the first image's resolution (oracle/merging_ref.py),
 centre crop, uncompressed GeoTIFF out; same file names, same ordering of the appended paths.
 """
 from __future__ import annotations
@@ -49,27 +49,36 @@ def retrieve_neighboring_image_filenames(filename, other_filenames, meta_info: O
 
 
 def merge_images(src1: GeoTiff, src2: GeoTiff):
-    """rasterio.merge.merge([src1, src2], nodata=0): union extent on src1's grid, src1's pixels first, then src2's
-    where nothing was written yet. → (data [bands, rows, cols], transform)."""
+    """rasterio.merge.merge([src1, src2], nodata=v), method "first", v = src1's nodata unless it is missing or absurd
+    (then 0.0): union extent on src1's grid, filled with v; each image in turn is copied where the mosaic STILL HOLDS v
+    (a value rule, as rasterio's: where the first image holds v itself a later overlapping image shows through — for the
+    exactly adjacent neighbours the reference merges the footprints never overlap). → (data [bands, rows, cols], transform)."""
     if src1.epsg != src2.epsg:
         raise ValueError("CRS of the two images do not match.")
+    nodata = getattr(src1, "nodata", None)
+    if nodata is None or abs(nodata) > 1e10:
+        nodata = 0.0
     a, _, c1, _, e, f1 = src1.transform
     _, _, c2, _, _, f2 = src2.transform
     left, top = min(c1, c2), max(f1, f2)
     right = max(c1 + a * src1.width, c2 + src2.transform[0] * src2.width)
     bottom = min(f1 + e * src1.height, f2 + src2.transform[4] * src2.height)
     W, H = int(round((right - left) / a)), int(round((bottom - top) / e))
-    out = np.zeros((src1.count, H, W), dtype=src1.dtype.newbyteorder("="))
-    filled = np.zeros((H, W), dtype=bool)
+    dt = src1.dtype.newbyteorder("=")
+    out = np.full((src1.count, H, W), nodata, dtype=dt)
     for src in (src1, src2):
         col0, row0 = int(round((src.transform[2] - left) / a)), int(round((src.transform[5] - top) / e))
         data = src.read()
         h, w = min(src.height, H - row0), min(src.width, W - col0)
         bands = min(src.count, out.shape[0])
-        free = ~filled[row0:row0 + h, col0:col0 + w]
         view = out[:bands, row0:row0 + h, col0:col0 + w]
-        view[:, free] = data[:bands, :h, :w][:, free]
-        filled[row0:row0 + h, col0:col0 + w] = True
+        if np.issubdtype(dt, np.integer):
+            free = view == dt.type(nodata)
+        elif np.isnan(nodata):
+            free = np.isnan(view)
+        else:
+            free = np.isclose(view, nodata)
+        np.copyto(view, data[:bands, :h, :w], where=free, casting="unsafe")
     return out, (a, 0.0, left, 0.0, e, top)
 
 
