@@ -248,6 +248,8 @@ def main():
         main = torch.cuda.Stream()      # (a high-priority main stream was measured: fp32 -1.5 %, fp16 +-0)
         sides = [torch.cuda.Stream() for _ in range(3)]   # one per engine: a batch's selection phases only wait on that batch
         pres = [torch.cuda.Stream() for _ in range(3)]    # one per engine: resize + stem + pool of its NEXT batch (fp16 schedule)
+        # (confining the selection / pre-stage streams to 32-128 CUs with hipExtStreamCreateWithCUMask was measured: fp16 1477 ->
+        # 826-1036 tiles/s, fp32 487 -> 392 — the masked queues slow the unmasked main stream's contractions as well)
         layout = os.environ.get("TD_BENCH_STREAMS", "")
         if layout == "3":        # experiment: ONE selection stream and ONE pre-stage stream for all three engines
             sides = [sides[0]] * 3

@@ -136,37 +136,6 @@ def test_conv_pp8_equals_the_reference_tile_bit_for_bit(case):
     assert np.abs(ref).max() > 0.5
 
 
-STREAM_CASES = [
-    # B, Cin, H, W, Cout, scale, bias, res, relu   (1x1 stride 1; persistent streaming kernel = cfg 18 / 19)
-    (1, 64, 16, 16, 256, True, True, True, True),           # 2 row tiles, one channel block
-    (2, 64, 33, 17, 256, True, True, True, True),           # M tail (1122 rows)
-    (1, 64, 50, 50, 512, True, True, False, True),          # two channel blocks, no residual
-    (1, 128, 20, 20, 512, True, True, True, True),          # K = 128 variant, four channel blocks
-    (3, 128, 31, 29, 128, False, True, True, False),        # M tail, no scale, no ReLU
-    (2, 64, 200, 200, 256, True, True, True, True),         # more row tiles than block slots: every slot loops
-    (2, 128, 100, 100, 512, True, True, True, True),
-]
-
-
-@pytest.mark.parametrize("prec", [0, 1])
-@pytest.mark.parametrize("case", STREAM_CASES)
-def test_conv_stream_kernel_equals_the_reference_tile_bit_for_bit(case, prec):
-    """conv1x1_stream_kernel (cfg 18) keeps conv_igemm_kernel's k order and epilogue op order: identical bits."""
-    B, Cin, H, W, Cout, use_scale, use_bias, res, relu = case
-    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
-    x = rng.standard_normal((B, Cin, H, W), dtype=np.float32)
-    w = rng.standard_normal((Cout, Cin, 1, 1), dtype=np.float32) / np.float32(np.sqrt(Cin))
-    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32) if use_scale else None
-    bias = rng.standard_normal(Cout).astype(np.float32) if use_bias else None
-    r = rng.standard_normal((B, Cout, H, W), dtype=np.float32) if res else None
-    kw = dict(scale=scale, bias=bias, residual_nchw=r, stride=1, pad=0, relu=relu, precision=prec)
-    ref = conv2d_hip(x, w, tile_cfg=0, **kw)
-    for _ in range(3):                                  # a racy schedule would not repeat
-        got = conv2d_hip(x, w, tile_cfg=18, **kw)
-        assert got.shape == ref.shape and np.array_equal(got, ref)
-    assert np.abs(ref).max() > 0.5
-
-
 @pytest.mark.parametrize("cfg", [4, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
 def test_conv_every_block_tile_variant(cfg):
     """The engine picks a block tile per layer by measurement; every variant must compute the same convolution.

@@ -524,156 +524,6 @@ void conv_igemm_kernel(const ConvArgs a_in) {
     conv_epilogue<T, TO, MT, NT, WM, WN, RWM, WIDE_OK>(a, acc, lds, M, m0, n0, tid, lane, wm, wn);
 }
 
-// ---- conv1x1_stream_kernel: the thin fp32 1x1 layers (K = 64 / 128: res2 conv3 / shortcut, res3 conv3) as a STREAM ----------
-// These layers move 295 KB of HBM per 128-row tile for 4-8 us of MFMA work; in conv_igemm_kernel a block's phases run
-// in sequence (load A → MFMA → residual loads → stores) and only co-resident blocks overlap them: 3.9 TB/s. Here one
-// persistent block per CU and channel block keeps the weight panel [BN][K] in LDS for its whole life and walks its tiles
-// with every transfer in flight under the next tile's MFMAs:
-//   loop:  wait A(i) (counted vmcnt: the previous tile's stores stay in flight) | barrier | issue residual loads(i)
-//          (64 dwords per lane, accumulator layout: 32 consecutive floats of a row per half-wave = whole 128-B lines) |
-//          MFMAs over the K / 32 chunks | barrier (A buffer free) | LDS-DMA of A(i+1) | epilogue in registers
-//          (scale, bias, + residual, ReLU — the same IEEE ops in the same order) | stores straight from registers.
-// Same k order and epilogue order as conv_igemm_kernel → bit-identical (tests/test_conv_gpu.py); the engine's tuner
-// takes it (tile id 18) where it measures faster.
-template <int KC, int WM, int WN, int MT, int NT>      // KC k-chunks (K = 32 KC); block tile 128 x (32 NT WN), 8 waves
-__global__ __launch_bounds__(512) void conv1x1_stream_kernel(const ConvArgs a) {
-    typedef float T;
-    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, THREADS = 512;
-    static_assert(BM == 128 && WM * WN == 8, "128-row tiles, 8 waves");
-    constexpr int LDROWS = THREADS / 8;               // 64 rows per DMA pass
-    constexpr int AROWS = BM / LDROWS, BROWS = BN / LDROWS;
-    __shared__ __attribute__((aligned(16))) char lds[KC * (BN + BM) * CHUNK_BYTES];
-    char* Ws = lds;                                   // [KC][BN][128 B]
-    char* As = lds + KC * BN * CHUNK_BYTES;           // [KC][BM][128 B]
-
-    const int M = a.M;
-    const int nblocks_n = a.Cout / BN;
-    const int nb = blockIdx.x % nblocks_n, slot = blockIdx.x / nblocks_n, nslots = gridDim.x / nblocks_n;
-    const int n0 = nb * BN;
-    const int tiles_m = (M + BM - 1) / BM;
-    if (slot >= tiles_m) return;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int ld_c = tid & 7, ld_r = tid >> 3;
-    const unsigned pix_bytes = (unsigned)a.Cin * 4;
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(a.x), 0, (int)((size_t)M * pix_bytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(a.w), 0, (int)((size_t)a.Cout * pix_bytes), 0x00020000);
-    constexpr unsigned OOB = 0xfffffff0u;
-    const unsigned src_piece = (unsigned)(ld_c ^ ((ld_r >> 1) & 7)) * 16;
-    typedef __attribute__((address_space(3))) void lds_void;
-    const unsigned wave_rows = (unsigned)__builtin_amdgcn_readfirstlane(wave) * 8u;
-
-    // weights: once per block
-#pragma unroll
-    for (int c = 0; c < KC; ++c)
-#pragma unroll
-        for (int i = 0; i < BROWS; ++i) {
-            const unsigned off = (unsigned)(n0 + ld_r + LDROWS * i) * pix_bytes + (unsigned)c * CHUNK_BYTES + src_piece;
-            char* dst = Ws + ((unsigned)c * BN + (unsigned)LDROWS * i + wave_rows) * CHUNK_BYTES;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)dst, 16, off, 0, 0, 0);
-        }
-    auto stage_a = [&](int tm) {                       // AROWS * KC DMA instructions per thread
-        const int m0 = tm * BM;
-#pragma unroll
-        for (int i = 0; i < AROWS; ++i) {
-            const int m = m0 + ld_r + LDROWS * i;
-            const unsigned base = m < M ? (unsigned)m * pix_bytes + src_piece : OOB;
-#pragma unroll
-            for (int c = 0; c < KC; ++c) {
-                const unsigned off = base == OOB ? OOB : base + (unsigned)c * CHUNK_BYTES;
-                char* dst = As + ((unsigned)c * BM + (unsigned)LDROWS * i + wave_rows) * CHUNK_BYTES;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)dst, 16, off, 0, 0, 0);
-            }
-        }
-    };
-    stage_a(slot);
-
-    // per-lane columns of the accumulator layout: scale / bias once per block
-    float sc[NT], bi[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = n0 + wn * 32 * NT + j * 32 + (lane & 31);
-        sc[j] = a.scale ? a.scale[n] : 1.f;
-        bi[j] = a.bias ? a.bias[n] : 0.f;
-    }
-    const unsigned swz = (lane >> 1) & 7, hi = lane >> 5;
-    unsigned frag_off[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) frag_off[kk] = (unsigned)(lane & 31) * CHUNK_BYTES + (((unsigned)(2 * kk) + hi) ^ swz) * 16;
-    const float* __restrict__ Rs = static_cast<const float*>(a.res);
-    float* __restrict__ Y = static_cast<float*>(a.y);
-    const int row_l = wm * 32 * MT + 4 * (lane >> 5);          // + i * 32 + (r & 3) + 8 * (r >> 2)
-    const int col_l = n0 + wn * 32 * NT + (lane & 31);         // + j * 32
-
-    bool first = true;
-    for (int tm = slot; tm < tiles_m; tm += nslots) {
-        const int m0 = tm * BM;
-        // A(tm) (and on the first pass the weights) are the OLDEST requests in flight: everything younger than them is
-        // the previous tile's stores (16 MT NT per lane) — let all but one of those stay in flight
-        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-        first = false;
-        __builtin_amdgcn_s_barrier();
-        float rs[MT][NT][16];
-        if (Rs) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + row_l + i * 32 + (r & 3) + 8 * (r >> 2);
-                        rs[i][j][r] = m < M ? Rs[(size_t)m * a.Cout + col_l + j * 32] : 0.f;
-                    }
-        }
-        f32x16 acc[MT][NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#pragma unroll
-        for (int c = 0; c < KC; ++c) {
-            const char* Ab = As + ((unsigned)c * BM + wm * 32 * MT) * CHUNK_BYTES;
-            const char* Bb = Ws + ((unsigned)c * BN + wn * 32 * NT) * CHUNK_BYTES;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                f32x4 fa[MT], fb[NT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * CHUNK_BYTES + frag_off[kk]);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * CHUNK_BYTES + frag_off[kk]);
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) Elem<T>::mma(fa[i], fb[j], acc[i][j]);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                  // every wave has read its A fragments: the buffer may be refilled
-        if (tm + nslots < tiles_m) stage_a(tm + nslots);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + row_l + i * 32 + (r & 3) + 8 * (r >> 2);
-                    float t = acc[i][j][r];
-                    if (a.scale) t = __fmul_rn(t, sc[j]);
-                    if (a.bias) t = __fadd_rn(t, bi[j]);
-                    if (Rs) t = __fadd_rn(t, rs[i][j][r]);
-                    if (a.relu) t = t > 0.f ? t : 0.f;
-                    if (m < M) Y[(size_t)m * a.Cout + col_l + j * 32] = t;
-                }
-    }
-}
-
 // ---- wino_gemm_kernel: the 16 plane contractions of Winograd F(2x2,3x3) with the INPUT TRANSFORM FUSED into the A
 // staging (fp32 engine; winograd.hip holds the algebra and the output transform) ------------------------------------------
 //   M_xi[t][n] = sum_c V_xi[t][c] * U_xi[n][c],   V_xi[t][c] = (B^T d B)[xi] of tile t's 4x4 input patch
@@ -1222,26 +1072,6 @@ td_status dispatch(const ConvArgs& a, int cfg, hipStream_t stream) {
                 td_set_error("conv2d: tile_cfg 17 is an fp16 kernel");
                 return TD_ERR_INVALID;
             }
-        case 18:                                                     // persistent streaming kernel for the thin fp32 1x1 layers
-            if constexpr (std::is_same<T, float>::value && std::is_same<TO, float>::value) {
-                int ncu = 256;
-                const int tiles_m = td_cdiv(a.M, 128);
-                if (a.Cin == 64 && a.Cout % 256 == 0) {
-                    const int nbn = a.Cout / 256, slots = tiles_m < ncu / nbn ? tiles_m : (ncu / nbn > 0 ? ncu / nbn : 1);
-                    hipLaunchKernelGGL((conv1x1_stream_kernel<2, 2, 4, 2, 2>), dim3(slots * nbn), dim3(512), 0, stream, a);
-                } else if (a.Cin == 128 && a.Cout % 128 == 0) {
-                    const int nbn = a.Cout / 128, slots = tiles_m < ncu / nbn ? tiles_m : (ncu / nbn > 0 ? ncu / nbn : 1);
-                    hipLaunchKernelGGL((conv1x1_stream_kernel<4, 4, 2, 1, 2>), dim3(slots * nbn), dim3(512), 0, stream, a);
-                } else {
-                    td_set_error("conv2d: tile_cfg 18 takes Cin 64 (Cout %% 256 == 0) or Cin 128 (Cout %% 128 == 0)");
-                    return TD_ERR_INVALID;
-                }
-                TD_KERNEL_CHECK();
-                return TD_OK;
-            } else {
-                td_set_error("conv2d: tile_cfg 18 is an fp32 kernel");
-                return TD_ERR_INVALID;
-            }
         default: td_set_error("conv2d: bad tile_cfg %d", cfg); return TD_ERR_INVALID;
     }
 }
@@ -1260,13 +1090,6 @@ td_status wino_gemm_launch(const ConvArgs& a, hipStream_t stream) {
     return TD_OK;
 }
 
-bool conv_stream_ok(const ConvArgs& a, int precision) {
-    return precision == TD_PRECISION_FP32 && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.out_mode == 0 && !a.m_dyn &&
-           a.batch_count <= 1 && a.res_shift == 0 && !a.out_f32 &&
-           ((a.Cin == 64 && a.Cout % 256 == 0) || (a.Cin == 128 && a.Cout % 128 == 0)) &&
-           (size_t)a.M * a.Cin * 4 < 0xfffffff0ull - (1u << 20);
-}
-
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream) {
     const int ke = precision == TD_PRECISION_FP16 ? 64 : 32;
     TD_REQUIRE(precision == TD_PRECISION_FP32 || precision == TD_PRECISION_FP16, "conv2d: bad precision %d", precision);
@@ -1283,7 +1106,6 @@ td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream) {
         if (forced) cfg = atoi(forced);
     }
     if (cfg == 17 && (precision != TD_PRECISION_FP16 || a.out_mode != 0 || a.batch_count > 1)) cfg = -1;      // fp16-only variant
-    if (cfg == 18 && !conv_stream_ok(a, precision)) cfg = -1;                                                   // thin fp32 1x1 layers only
     TD_REQUIRE(a.batch_count <= 1 || (a.KH == 1 && a.KW == 1 && !a.res), "conv2d: batched launches are 1x1 contractions");
     if (cfg < 0) {
         // heuristic (the engine replaces it by a measured choice per layer shape): wide N for wide layers, 64-row

@@ -725,7 +725,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         return TD_OK;
     };
     // measured block tile of one launch shape (cached per engine, shared through the TD_TUNE_CACHE file)
-    auto tuned_cfg = [&](const std::tuple<int, int, int, int, int>& key, int prec_, int ksteps, bool pp8_ok, bool stream_ok, hipStream_t s_,
+    auto tuned_cfg = [&](const std::tuple<int, int, int, int, int>& key, int prec_, int ksteps, bool pp8_ok, hipStream_t s_,
                          auto&& launch_cfg, int* cfg_out, float* best_ms) -> td_status {
         auto it = e->tuned.find(key);
         if (it == e->tuned.end()) {
@@ -745,7 +745,6 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
             if (it != e->tuned.end() && c != it->second) continue;       // known choice: only its time is wanted
             if (c >= 14 && c <= 16 && ksteps > 4) continue;      // single-stage tiles only pay on the thin 1x1 layers
             if (c == 17 && !pp8_ok) continue;                    // fp16 256x256 ping-pong tile
-            if (c == 18 && !stream_ok) continue;                 // persistent streaming kernel (thin fp32 1x1 layers)
             float ms = 1e30f;
             td_status st2 = time_launch(s_, ea, eb, [&]() { return launch_cfg(c); }, &ms);
             if (st2 < 0) return st2;
@@ -812,8 +811,6 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
             const auto key = std::make_tuple(L.cout, L.cin, L.kh * 16 + L.kw, B_ * Ho * Wo, stride * 4 + out_mode * 2 + (res_ ? 1 : 0));
             const int ksteps = L.kh * L.kw * L.cin / (prec_ == TD_PRECISION_FP16 ? 64 : 32);
             const bool pp8_ok = prec_ == TD_PRECISION_FP16 && out_mode == 0 && L.cout >= 128;
-            const bool stream_ok = prec_ == TD_PRECISION_FP32 && L.kh == 1 && L.kw == 1 && stride == 1 && pad == 0 && out_mode == 0 && !m_dyn &&
-                                   res_shift == 0 && !L.out_f32 && ((L.cin == 64 && L.cout % 256 == 0) || (L.cin == 128 && L.cout % 128 == 0));
             auto direct = [&](int c) { return run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, c); };
             const bool wino_ok = prec_ == TD_PRECISION_FP32 && L.wino_u && e->wino_v && stride == 1 && pad == 1 && !res_ && out_mode == 0 &&
                                  (!m_dyn || ((H_ | W_) & 1) == 0) &&
@@ -830,9 +827,9 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                 // 128 channels on both sides is faster through Winograd at every map size from 13x13 to 200x200
                 // (1.3-1.9x); 64 -> 64 (res2) is HBM-bound on the transforms and stays direct.
                 use_wino = L.cin >= 128 && L.cout >= 128;
-                if (use_wino && !e->wino_fused && (st2 = tuned_cfg(wkey, prec_, L.cin / 32, false, false, s_, wino, &wino_cfg, nullptr)) < 0) return st2;
+                if (use_wino && !e->wino_fused && (st2 = tuned_cfg(wkey, prec_, L.cin / 32, false, s_, wino, &wino_cfg, nullptr)) < 0) return st2;
             }
-            if (!use_wino && (st2 = tuned_cfg(key, prec_, ksteps, pp8_ok, stream_ok, s_, direct, &cfg, nullptr)) < 0) return st2;
+            if (!use_wino && (st2 = tuned_cfg(key, prec_, ksteps, pp8_ok, s_, direct, &cfg, nullptr)) < 0) return st2;
         }
         ProfScope ps(e, s_, m_dyn ? 7 : 0, m_dyn ? 0.0 : flops, m_dyn ? 0.0 : bytes);
         if (e->prof && !m_dyn) {          // category 8: FLOPs the MFMA pipe really executes
