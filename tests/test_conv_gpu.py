@@ -210,3 +210,56 @@ def test_winograd_conv_matches_torch(case):
     finally:
         del os.environ["TD_WINO_FUSED"]
     assert torch.equal(y, y2)
+
+
+WINO43_CASES = WINO_CASES + [
+    (1, 128, 100, 100, 128, True, True, True),        # res3 conv2 (whole tiles)
+    (2, 256, 50, 50, 256, False, True, True),         # 50 = 12 whole tiles + a half one per row / column
+    (1, 256, 200, 200, 256, False, True, False),      # FPN output 2 / RPN conv p2
+    (1, 128, 47, 61, 160, True, False, True),         # 3 and 1 pixels into the last tile
+]
+
+
+@pytest.mark.parametrize("case", WINO43_CASES)
+def test_winograd_f4x4_conv_matches_torch(case):
+    """Winograd F(4x4,3x3) (the fp32 engine's path on the large maps) vs torch CPU F.conv2d. Stated tolerance: the same
+    |err| <= 5e-5 * max|ref| as the direct kernel — measured about 1e-5 at 256 channels (the larger transform constants
+    cost a decimal digit against F(2x2)); partial tiles at the right / bottom border included."""
+    import os
+    from treedetection_amd import _lib
+    from tests.gpu_util import dev
+    B, Cin, H, W, Cout, use_scale, use_bias, relu = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = np.maximum(rng.standard_normal((B, Cin, H, W), dtype=np.float32), -0.5)      # mostly positive, as post-ReLU maps are
+    w = rng.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) / np.float32(np.sqrt(Cin * 9))
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32) if use_scale else None
+    bias = rng.standard_normal(Cout).astype(np.float32) if use_bias else None
+    ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), None, stride=1, padding=1)
+    if use_scale:
+        ref = ref * torch.from_numpy(scale).double().reshape(1, -1, 1, 1)
+    if use_bias:
+        ref = ref + torch.from_numpy(bias).double().reshape(1, -1, 1, 1)
+    if relu:
+        ref = F.relu(ref)
+    ref = ref.numpy()
+    lib = _lib.load()
+    xd, wd = dev(x.transpose(0, 2, 3, 1)), dev(w.transpose(0, 2, 3, 1))
+    sd = dev(scale) if use_scale else None
+    bd = dev(bias) if use_bias else None
+    p = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
+    os.environ["TD_WINO_TILE"] = "4"
+    try:
+        ys = []
+        for _ in range(2):
+            y = torch.full((B, H, W, Cout), float("nan"), dtype=torch.float32, device="cuda")
+            _lib.check(lib.td_conv2d_winograd_nhwc(p(xd), p(wd), p(sd), p(bd), y.data_ptr(), B, H, W, Cin, Cout, int(relu), _lib.stream_ptr()),
+                       "td_conv2d_winograd_nhwc")
+            ys.append(y)
+    finally:
+        del os.environ["TD_WINO_TILE"]
+    assert torch.equal(ys[0], ys[1])                            # deterministic
+    got = ys[0].cpu().numpy().transpose(0, 3, 1, 2)
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref).max()
+    print(f"\n[F(4x4)] {case}: max abs err {err:.3e} = {err / max(1.0, np.abs(ref).max()):.2e} of max|ref|")
+    assert err <= 5e-5 * max(1.0, np.abs(ref).max()), f"max abs err {err}"

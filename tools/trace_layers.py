@@ -38,31 +38,44 @@ def schedule(depth=50, B=8, Hp=800, Wp=800, P=1000):
     return L
 
 
-def is_wino(name, N, K, fp32):
-    """fp32 engine: 3x3 stride-1 layers with >= 128 channels on both sides take the Winograd path (engine.cpp run_conv):
-    two launches (wino_gemm_kernel + wino_output_kernel) instead of one."""
+def launches_of(name, M, N, K, fp32, B=8, min43=40):
+    """fp32 engine (engine.cpp run_conv): 3x3 stride-1 layers with >= 128 channels on both sides take a Winograd path —
+    F(4x4,3x3) on maps of at least `min43` pixels a side: three launches (wino43_input_kernel, the batched conv_igemm launch,
+    wino43_output_kernel); F(2x2,3x3) otherwise: two (wino_gemm_kernel + wino_output_kernel). → (launch count, label)"""
     three = ("conv2" in name or "fpn_output" in name or "rpn_conv" in name or "mask_fcn" in name)
-    return fp32 and three and N >= 128 and K // 9 >= 128
+    if not (fp32 and three and N >= 128 and K // 9 >= 128):
+        return 1, None
+    side = int(round((M / B) ** 0.5)) if M else 0
+    if M and min43 > 0 and side >= min43:
+        return 3, "winograd F(4x4)"
+    return 2, "winograd F(2x2)"
 
 
 def main(path, depth=50, fp32=False):
-    fam = ("conv_igemm", "conv_pp8", "wino_gemm", "wino_output", "wino_input")
+    import os
+    min43 = int(os.environ.get("TD_WINO43_MIN", "40"))
+    fam = ("conv_igemm", "conv_pp8", "wino_gemm", "wino_output", "wino_input", "wino43_input", "wino43_output")
     rows = [r for r in csv.DictReader(open(path)) if any(f in r["Kernel_Name"] for f in fam)]
     L = schedule(depth)
-    need = sum(2 if is_wino(n, N, K, fp32) else 1 for n, M, N, K in L)
+    need = sum(launches_of(n, M, N, K, fp32, 8, min43)[0] for n, M, N, K in L)
     last = rows[-need:]
     tot_f = tot_t = 0.0
     i = 0
     for name, M, N, K in L:
-        k = 2 if is_wino(name, N, K, fp32) else 1
+        k, label = launches_of(name, M, N, K, fp32, 8, min43)
         rs = last[i:i + k]
         i += k
-        us = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rs)
+        ts = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rs]
+        us = sum(ts)
         gf = 2.0 * M * N * K / 1e9
         kn = rs[0]["Kernel_Name"]
-        kern = "winograd" if k == 2 else ("pp8" if "conv_pp8" in kn else kn.split("conv_igemm_")[1].split("(")[0][:28])
-        assert (k == 2) == ("wino_gemm" in kn), (name, kn)
-        print(f"{name:24s} M={M:7d} N={N:5d} K={K:6d} {kern:30s} {us:9.1f} us {gf:8.2f} GF {gf/us*1e3 if us else 0:7.1f} TF/s")
+        kern = label if label else ("pp8" if "conv_pp8" in kn else kn.split("conv_igemm_")[1].split("(")[0][:28])
+        if k == 3:
+            assert "wino43_input" in kn and "wino43_output" in rs[2]["Kernel_Name"], (name, kn)
+            kern += f" [{ts[0]:.0f}+{ts[1]:.0f}+{ts[2]:.0f}]"
+        elif k == 2:
+            assert "wino_gemm" in kn, (name, kn)
+        print(f"{name:24s} M={M:7d} N={N:5d} K={K:6d} {kern:34s} {us:9.1f} us {gf:8.2f} GF {gf/us*1e3 if us else 0:7.1f} TF/s")
         if M:
             tot_f += gf
             tot_t += us

@@ -55,19 +55,23 @@ td_status td_conv2d_winograd_nhwc(const float* x, const float* w, const float* s
     TD_REQUIRE(x && w && y && B >= 1 && H >= 1 && W >= 1, "td_conv2d_winograd_nhwc: bad arguments");
     TD_REQUIRE(Cin % 32 == 0 && Cout % 4 == 0, "td_conv2d_winograd_nhwc: Cin must be a multiple of 32, Cout of 4");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t T = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
-    std::vector<float> wh((size_t)Cout * 9 * Cin), uh((size_t)16 * Cout * Cin);
+    const char* tenv = getenv("TD_WINO_TILE");            // tests: 4 = the F(4x4,3x3) form the engine uses on the large maps
+    const bool f43 = tenv && atoi(tenv) == 4;
+    const int P = f43 ? 36 : 16;                          // transform planes
+    const size_t T = f43 ? (size_t)B * ((H + 3) / 4) * ((W + 3) / 4) : (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+    std::vector<float> wh((size_t)Cout * 9 * Cin), uh((size_t)P * Cout * Cin);
     TD_HIP_CHECK(hipMemcpy(wh.data(), w, wh.size() * sizeof(float), hipMemcpyDeviceToHost));
-    wino_filter_transform(wh.data(), Cout, Cin, uh.data());
+    if (f43) wino43_filter_transform(wh.data(), Cout, Cin, uh.data());
+    else wino_filter_transform(wh.data(), Cout, Cin, uh.data());
     void *U = nullptr, *V = nullptr, *Mb = nullptr;
     td_status st;
-    if ((st = scratch(&U, uh.size() * 4)) < 0 || (st = scratch(&V, 16 * T * Cin * 4)) < 0 || (st = scratch(&Mb, 16 * T * Cout * 4)) < 0) {
+    if ((st = scratch(&U, uh.size() * 4)) < 0 || (st = scratch(&V, P * T * Cin * 4)) < 0 || (st = scratch(&Mb, P * T * Cout * 4)) < 0) {
         (void)hipFree(U); (void)hipFree(V); (void)hipFree(Mb);
         return st;
     }
     TD_HIP_CHECK(hipMemcpy(U, uh.data(), uh.size() * 4, hipMemcpyHostToDevice));
     const char* fenv = getenv("TD_WINO_FUSED");           // tests compare the two forms of the contraction (bit-identical)
-    const bool fused = !fenv || atoi(fenv) != 0;
+    const bool fused = !f43 && (!fenv || atoi(fenv) != 0);
     ConvArgs a{};
     a.w = U; a.y = Mb;
     a.Cin = Cin; a.Cout = Cout; a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
@@ -77,14 +81,17 @@ td_status td_conv2d_winograd_nhwc(const float* x, const float* w, const float* s
         a.x = x; a.B = B; a.H = H; a.W = W;
         st = wino_gemm_launch(a, s);
     } else {
-        st = wino_input_launch(x, B, H, W, Cin, static_cast<float*>(V), nullptr, 1, 0, (int)T, s);
+        st = f43 ? wino43_input_launch(x, B, H, W, Cin, static_cast<float*>(V), nullptr, s)
+                 : wino_input_launch(x, B, H, W, Cin, static_cast<float*>(V), nullptr, 1, 0, (int)T, s);
         if (st == TD_OK) {
             a.x = V; a.B = 1; a.H = 1; a.W = (int)T; a.Ho = 1; a.Wo = (int)T;
-            a.batch_count = 16; a.x_bs = (long long)T * Cin;
+            a.batch_count = P; a.x_bs = (long long)T * Cin;
             st = conv2d_launch(a, TD_PRECISION_FP32, s);
         }
     }
-    if (st == TD_OK) st = wino_output_launch(static_cast<float*>(Mb), B, H, W, Cout, scale, bias, relu, y, nullptr, 1, 0, (int)T, s);
+    if (st == TD_OK)
+        st = f43 ? wino43_output_launch(static_cast<float*>(Mb), B, H, W, Cout, scale, bias, relu, y, nullptr, s)
+                 : wino_output_launch(static_cast<float*>(Mb), B, H, W, Cout, scale, bias, relu, y, nullptr, 1, 0, (int)T, s);
     hipError_t herr = hipStreamSynchronize(s);
     (void)hipFree(U); (void)hipFree(V); (void)hipFree(Mb);
     if (st < 0) return st;

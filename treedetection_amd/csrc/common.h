@@ -69,6 +69,12 @@ td_status wino_input_launch(const float* x, int B, int H, int W, int C, float* V
 td_status wino_output_launch(const float* Mb, int B, int H, int W, int N, const float* scale, const float* bias, int relu,
                              float* y, const int* m_dyn, int m_mul, long long t0, int Ts, hipStream_t s);
 void wino_filter_transform(const float* w_ohwi, int N, int C, float* U);     // host: U [16][N][C]
+// F(4x4,3x3): whole layers only; V / Mb hold 36 planes of [T][C], T = B * ceil(H/4) * ceil(W/4)
+// (m_dyn: optional device-side image count <= B, the mask head's live RoIs)
+td_status wino43_input_launch(const float* x, int B, int H, int W, int C, float* V, const int* m_dyn, hipStream_t s);
+td_status wino43_output_launch(const float* Mb, int B, int H, int W, int N, const float* scale, const float* bias, int relu,
+                               float* y, const int* m_dyn, hipStream_t s);
+void wino43_filter_transform(const float* w_ohwi, int N, int C, float* U);   // host: U [36][N][C]
 
 // ---- stem / pooling / resize (stem.hip) ---------------------------------------------------------
 struct ImgSizes {           // per-image valid sizes, passed by value (B <= TD_MAX_BATCH)

@@ -38,6 +38,7 @@ struct ConvLayer {
     float* bias = nullptr;    // [cout] or null
     bool out_f32 = false;     // fp16 engine: this layer still writes float32 (feeds the fp32 selection kernels)
     float* wino_u = nullptr;  // fp32 engine, 3x3 layers: Winograd-transformed filters U [16][cout][cin] (winograd.hip)
+    float* wino_u43 = nullptr;  // the same for F(4x4,3x3): U [36][cout][cin] (layers with >= 128 channels on both sides)
 };
 
 struct Block {
@@ -116,6 +117,7 @@ struct td_engine {
     size_t wino_elems = 0;
     bool wino_fused = true;       // TD_WINO_FUSED=0: separate input-transform kernel + batched conv_igemm launch (diagnostics)
     int wino_slab = 0;            // TD_WINO_SLAB: tiles per slab (diagnostics); 0 = sized for the Infinity Cache
+    int wino43_min = 12;          // maps at least this large on both sides take F(4x4,3x3) (TD_WINO43_MIN; 0 = never)
     std::string tune_cache;       // TD_TUNE_CACHE: load / append measured choices (keeps profiled runs free of tuning launches)
 
     // forward context (kept between the phases of td_engine_forward_phase) and the per-phase completion events
@@ -245,7 +247,11 @@ td_status upload_wino(td_engine* e, const std::vector<float>& w_ohwi, ConvLayer&
         return TD_OK;
     std::vector<float> u((size_t)16 * L.cout * L.cin);
     wino_filter_transform(w_ohwi.data(), L.cout, L.cin, u.data());
-    return upload(e, u, &L.wino_u);
+    td_status st = upload(e, u, &L.wino_u);
+    if (st < 0 || e->wino43_min <= 0 || L.cin < 128 || L.cout < 128) return st;
+    std::vector<float> u43((size_t)36 * L.cout * L.cin);
+    wino43_filter_transform(w_ohwi.data(), L.cout, L.cin, u43.data());
+    return upload(e, u43, &L.wino_u43);
 }
 
 td_status load_conv_bn(td_engine* e, const TensorMap& tm, const std::string& p, ConvLayer& L) {
@@ -391,6 +397,7 @@ td_status td_engine_create(const td_model_desc* desc, int device, td_engine** ou
     if (const char* wg = getenv("TD_WINOGRAD")) e->winograd = atoi(wg) != 0;
     if (const char* ws = getenv("TD_WINO_SLAB")) e->wino_slab = atoi(ws);
     if (const char* wf = getenv("TD_WINO_FUSED")) e->wino_fused = atoi(wf) != 0;
+    if (const char* w4 = getenv("TD_WINO43_MIN")) e->wino43_min = atoi(w4);
     e->desc = d;
     load_tune_cache(e);
     e->device = device;
@@ -796,6 +803,24 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         }
         return TD_OK;
     };
+    // Winograd F(4x4,3x3) of a whole layer: x → V [36][T][cin] → 36 batched plane contractions → M → y. m_dyn = device-side
+    // image count (the mask head's live RoIs): the planes keep the stride of the full batch, only the live tiles are computed.
+    auto run_wino43 = [&](const ConvLayer& L, const void* x_, int B_, int H_, int W_, bool relu, void* y_, hipStream_t s_,
+                          const int* m_dyn, int gemm_cfg) -> td_status {
+        const int tiles_img = ((H_ + 3) / 4) * ((W_ + 3) / 4);
+        const long long T = (long long)B_ * tiles_img;
+        td_status st2;
+        if ((st2 = wino43_input_launch(static_cast<const float*>(x_), B_, H_, W_, L.cin, e->wino_v, m_dyn, s_)) < 0) return st2;
+        ConvArgs a{};
+        a.x = e->wino_v; a.w = L.wino_u43; a.y = e->wino_m;
+        a.Cin = L.cin; a.Cout = L.cout; a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
+        a.B = 1; a.H = 1; a.W = (int)T; a.Ho = 1; a.Wo = (int)T;
+        a.M = (int)T; a.m_dyn = m_dyn; a.m_mul = m_dyn ? tiles_img : 1;
+        a.batch_count = 36; a.x_bs = T * L.cin; a.w_bs = (long long)L.cout * L.cin; a.y_bs = T * L.cout;
+        a.tile_cfg = gemm_cfg;
+        if ((st2 = conv2d_launch(a, TD_PRECISION_FP32, s_)) < 0) return st2;
+        return wino43_output_launch(e->wino_m, B_, H_, W_, L.cout, L.scale, L.bias, relu ? 1 : 0, static_cast<float*>(y_), m_dyn, s_);
+    };
     auto run_conv = [&](const ConvLayer& L, const void* x_, int B_, int H_, int W_, int stride, int pad, bool relu,
                         void* y_, const void* res_, int res_shift, hipStream_t s_, int prec_,
                         const int* m_dyn = nullptr, int m_mul = 1, int out_mode = 0) -> td_status {
@@ -805,7 +830,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         const double es = prec_ == TD_PRECISION_FP16 ? 2.0 : 4.0;
         const double bytes = es * ((double)B_ * H_ * W_ * L.cin / (stride * stride) + M * L.cout * (res_ ? 2.0 : 1.0) + L.cout * K);
         int cfg = -1, wino_cfg = -1;
-        bool use_wino = false;
+        bool use_wino = false, use_43 = false;
         td_status st2;
         if (e->autotune) {
             const auto key = std::make_tuple(L.cout, L.cin, L.kh * 16 + L.kw, B_ * Ho * Wo, stride * 4 + out_mode * 2 + (res_ ? 1 : 0));
@@ -827,15 +852,27 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                 // 128 channels on both sides is faster through Winograd at every map size from 13x13 to 200x200
                 // (1.3-1.9x); 64 -> 64 (res2) is HBM-bound on the transforms and stays direct.
                 use_wino = L.cin >= 128 && L.cout >= 128;
-                if (use_wino && !e->wino_fused && (st2 = tuned_cfg(wkey, prec_, L.cin / 32, false, s_, wino, &wino_cfg, nullptr)) < 0) return st2;
+                // F(4x4,3x3) on the large maps (another fixed rule: map size and channels only): 2.25 multiplies per output
+                // instead of 4; the 36 plane contractions are one batched launch whose block tile is measured (flag 64)
+                const long long T43 = (long long)B_ * ((H_ + 3) / 4) * ((W_ + 3) / 4);
+                use_43 = use_wino && L.wino_u43 && e->wino43_min > 0 && H_ >= e->wino43_min && W_ >= e->wino43_min &&
+                         (size_t)36 * T43 * (size_t)std::max(L.cin, L.cout) <= e->wino_elems && T43 * std::max(L.cin, L.cout) < (1ll << 31);
+                if (use_43) {
+                    const auto key43 = std::make_tuple(L.cout, L.cin, 1 * 16 + 1, (int)T43, 4 + 64);
+                    auto w43 = [&](int c) { return run_wino43(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, c); };
+                    if ((st2 = tuned_cfg(key43, prec_, L.cin / 32, false, s_, w43, &wino_cfg, nullptr)) < 0) return st2;
+                }
+                if (use_wino && !use_43 && !e->wino_fused && (st2 = tuned_cfg(wkey, prec_, L.cin / 32, false, s_, wino, &wino_cfg, nullptr)) < 0) return st2;
             }
             if (!use_wino && (st2 = tuned_cfg(key, prec_, ksteps, pp8_ok, s_, direct, &cfg, nullptr)) < 0) return st2;
         }
         ProfScope ps(e, s_, m_dyn ? 7 : 0, m_dyn ? 0.0 : flops, m_dyn ? 0.0 : bytes);
         if (e->prof && !m_dyn) {          // category 8: FLOPs the MFMA pipe really executes
-            e->prof_flops[8] += use_wino ? flops * 4.0 / 9.0 : flops;
+            const double padded = use_43 ? (double)(((H_ + 3) / 4) * 4) * (((W_ + 3) / 4) * 4) / ((double)H_ * W_) : 1.0;
+            e->prof_flops[8] += use_43 ? flops * padded * 0.25 : (use_wino ? flops * 4.0 / 9.0 : flops);
             e->prof_launches[8] += use_wino ? 1 : 0;
         }
+        if (use_43) return run_wino43(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, wino_cfg);
         if (use_wino) return run_wino(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, m_mul, wino_cfg);
         return run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, cfg);
     };

@@ -132,6 +132,152 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 #undef TD_ADD
 }
 
+
+// ---- F(4x4, 3x3): 6x6 input patches, 36 planes, 4x4 outputs per tile ----------------------------------------------------
+// 36 / 16 = 2.25 multiplies per output instead of F(2x2)'s 4 and the direct kernel's 9: on the big maps, where the
+// contraction is the cost, the fp32 MFMA work drops another 1.78x. Matrices (Lavin & Gray, points 0, +-1, +-2, inf):
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// A V element combines up to 16 pixels, so the input transform cannot ride in the contraction's A staging as F(2x2)'s does
+// (wino_gemm_kernel): three launches — x → V [36][T][C] (2.25x the input), 36 batched plane contractions through
+// conv_igemm_kernel, M [36][T][N] → y. Numerics: the larger transform constants cost about one decimal digit
+// (|error| ~ 1e-5 of max|y| at 256 channels against 6e-7 for F(2x2), measured against float64) — inside the fp32 parity
+// tolerances; which layers take it is a fixed rule in engine.cpp (never a timing decision).
+#define TD_SUB(a, b) make_float4(__fsub_rn(a.x, b.x), __fsub_rn(a.y, b.y), __fsub_rn(a.z, b.z), __fsub_rn(a.w, b.w))
+#define TD_ADD(a, b) make_float4(__fadd_rn(a.x, b.x), __fadd_rn(a.y, b.y), __fadd_rn(a.z, b.z), __fadd_rn(a.w, b.w))
+#define TD_MUL(k, a) make_float4(__fmul_rn(k, a.x), __fmul_rn(k, a.y), __fmul_rn(k, a.z), __fmul_rn(k, a.w))
+
+// 1-D input transform t = B^T d of six values (fixed association: part of the layer's defined rounding)
+__device__ __forceinline__ void wino43_bt(const float4 (&d)[6], float4 (&t)[6]) {
+    const float4 a = TD_SUB(d[4], TD_MUL(4.f, d[2]));       // d4 - 4 d2
+    const float4 b = TD_SUB(d[3], TD_MUL(4.f, d[1]));       // d3 - 4 d1
+    const float4 c = TD_SUB(d[4], d[2]);                    // d4 - d2
+    const float4 e = TD_MUL(2.f, TD_SUB(d[3], d[1]));       // 2 (d3 - d1)
+    t[0] = TD_ADD(TD_SUB(TD_MUL(4.f, d[0]), TD_MUL(5.f, d[2])), d[4]);
+    t[1] = TD_ADD(a, b);
+    t[2] = TD_SUB(a, b);
+    t[3] = TD_ADD(c, e);
+    t[4] = TD_SUB(c, e);
+    t[5] = TD_ADD(TD_SUB(TD_MUL(4.f, d[1]), TD_MUL(5.f, d[3])), d[5]);
+}
+
+// one thread = one tile x 4 channels: x [B,H,W,C] → V [36][T][C], T = B * ceil(H/4) * ceil(W/4)
+// (m_dyn: device-side image count — the mask head's live RoIs; planes keep the stride T of the full batch)
+__global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restrict__ x, int B, int H, int W, int C,
+                                                           float* __restrict__ V, long long T, const int* __restrict__ m_dyn) {
+    const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;
+    const int c4n = C >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long t = idx / c4n;
+    const int c = (int)(idx - t * c4n) * 4;
+    long long live = T;
+    if (m_dyn) {
+        const long long n = (long long)*m_dyn * TH * TW;
+        live = n < T ? n : T;
+    }
+    if (t >= live) return;
+    const int tx = (int)(t % TW);
+    const int ty = (int)((t / TW) % TH);
+    const int b = (int)(t / ((long long)TW * TH));
+    const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+    float4 d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int yy = y0 + i;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int xx = x0 + j;
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                d[i][j] = *reinterpret_cast<const float4*>(x + (((size_t)b * H + yy) * W + xx) * C + c);
+            else
+                d[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {            // B^T d: combine rows, column by column (in place)
+        float4 col[6], r[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) col[i] = d[i][j];
+        wino43_bt(col, r);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i][j] = r[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {            // (B^T d) B: combine columns; plane xi = 6 i + j
+        float4 v[6];
+        wino43_bt(d[i], v);
+        float* p = V + ((size_t)(6 * i) * T + t) * C + c;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(p + (size_t)j * T * C) = v[j];
+    }
+}
+
+// 1-D output transform s = A^T m of six values
+__device__ __forceinline__ void wino43_at(const float4 (&m)[6], float4 (&s)[4]) {
+    const float4 p12 = TD_ADD(m[1], m[2]), m12 = TD_SUB(m[1], m[2]);
+    const float4 p34 = TD_ADD(m[3], m[4]), m34 = TD_SUB(m[3], m[4]);
+    s[0] = TD_ADD(TD_ADD(m[0], p12), p34);
+    s[1] = TD_ADD(m12, TD_MUL(2.f, m34));
+    s[2] = TD_ADD(p12, TD_MUL(4.f, p34));
+    s[3] = TD_ADD(TD_ADD(m12, TD_MUL(8.f, m34)), m[5]);
+}
+
+// one thread = one tile x 4 channels: M [36][T][N] → y [B,H,W,N] = act((A^T M A) * scale + bias); partial tiles at the
+// bottom / right border store only the pixels inside the map
+__global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restrict__ Mb, int B, int H, int W, int N,
+                                                            const float* __restrict__ scale, const float* __restrict__ bias,
+                                                            int relu, float* __restrict__ y, long long T,
+                                                            const int* __restrict__ m_dyn) {
+    const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;
+    const int c4n = N >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long t = idx / c4n;
+    const int c = (int)(idx - t * c4n) * 4;
+    long long live = T;
+    if (m_dyn) {
+        const long long n = (long long)*m_dyn * TH * TW;
+        live = n < T ? n : T;
+    }
+    if (t >= live) return;
+    const int tx = (int)(t % TW);
+    const int ty = (int)((t / TW) % TH);
+    const int b = (int)(t / ((long long)TW * TH));
+    float4 s[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {            // A^T M, column by column
+        float4 col[6], r[4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) col[i] = *reinterpret_cast<const float4*>(Mb + ((size_t)(6 * i + j) * T + t) * N + c);
+        wino43_at(col, r);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i][j] = r[i];
+    }
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale) sc = *reinterpret_cast<const float4*>(scale + c);
+    if (bias) bi = *reinterpret_cast<const float4*>(bias + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int yy = 4 * ty + i;
+        float4 o[4];
+        wino43_at(s[i], o);                  // (A^T M) A
+        if (yy >= H) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xx = 4 * tx + j;
+            if (xx >= W) continue;
+            float4 v = o[j];
+            if (scale) v = make_float4(__fmul_rn(v.x, sc.x), __fmul_rn(v.y, sc.y), __fmul_rn(v.z, sc.z), __fmul_rn(v.w, sc.w));
+            if (bias) v = TD_ADD(v, bi);
+            if (relu) v = make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f, v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
+            *reinterpret_cast<float4*>(y + (((size_t)b * H + yy) * W + xx) * N + c) = v;
+        }
+    }
+}
+#undef TD_SUB
+#undef TD_ADD
+#undef TD_MUL
+
 }  // namespace
 
 td_status wino_input_launch(const float* x, int B, int H, int W, int C, float* V, const int* m_dyn, int m_mul, long long t0,
@@ -166,5 +312,45 @@ void wino_filter_transform(const float* w, int N, int C, float* U) {
             for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 4; ++j)
                     U[((size_t)(4 * i + j) * N + n) * C + c] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+        }
+}
+
+// ---- F(4x4, 3x3) ---------------------------------------------------------------------------------------------------------
+td_status wino43_input_launch(const float* x, int B, int H, int W, int C, float* V, const int* m_dyn, hipStream_t s) {
+    TD_REQUIRE(x && V && B >= 1 && H >= 1 && W >= 1 && C >= 4 && (C & 3) == 0, "winograd F(4x4) input transform: bad arguments");
+    const long long T = (long long)B * ((H + 3) / 4) * ((W + 3) / 4);
+    const long long threads = T * (C / 4);
+    TD_REQUIRE((threads + 255) / 256 < (1ll << 31), "winograd F(4x4) input transform: grid too large");
+    hipLaunchKernelGGL(wino43_input_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, B, H, W, C, V, T, m_dyn);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
+td_status wino43_output_launch(const float* Mb, int B, int H, int W, int N, const float* scale, const float* bias, int relu,
+                               float* y, const int* m_dyn, hipStream_t s) {
+    TD_REQUIRE(Mb && y && B >= 1 && H >= 1 && W >= 1 && N >= 4 && (N & 3) == 0, "winograd F(4x4) output transform: bad arguments");
+    const long long T = (long long)B * ((H + 3) / 4) * ((W + 3) / 4);
+    const long long threads = T * (N / 4);
+    TD_REQUIRE((threads + 255) / 256 < (1ll << 31), "winograd F(4x4) output transform: grid too large");
+    hipLaunchKernelGGL(wino43_output_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, Mb, B, H, W, N, scale, bias,
+                       relu, y, T, m_dyn);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
+// U[xi][n][c] = (G g G^T)[xi], xi = 6 i + j, of the OHWI filter bank w [N][3][3][C] (float64 arithmetic, rounded once)
+void wino43_filter_transform(const float* w, int N, int C, float* U) {
+    static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    for (int n = 0; n < N; ++n)
+        for (int c = 0; c < C; ++c) {
+            double g[3][3], t[6][3];
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) g[a][b] = w[(((size_t)n * 3 + a) * 3 + b) * C + c];
+            for (int i = 0; i < 6; ++i)
+                for (int b = 0; b < 3; ++b) t[i][b] = G[i][0] * g[0][b] + G[i][1] * g[1][b] + G[i][2] * g[2][b];
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j)
+                    U[((size_t)(6 * i + j) * N + n) * C + c] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
         }
 }
