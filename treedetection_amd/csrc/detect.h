@@ -57,6 +57,8 @@ __device__ __forceinline__ bool iou_gt(const float4& a, float area_a, const floa
 }
 
 // ---- launchers (rpn.hip) ------------------------------------------------------------------------------
+// key_ws: rpn_topk_ws_elems(B, total_anchors) uint32 (dense keys + the per-(image, level) coarse histograms)
+size_t rpn_topk_ws_elems(int B, int total_anchors);
 td_status rpn_topk_decode_launch(const RpnLevels& lv, const ImgSizes& valid, int B, int topk, uint32_t* key_ws,
                                  float* cand_boxes, float* cand_scores, int* cand_valid, int* cand_idx,
                                  hipStream_t stream);

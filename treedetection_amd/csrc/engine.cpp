@@ -630,7 +630,7 @@ td_status td_engine_reserve(td_engine* e, int B, int Hp, int Wp) {
         total_anchors += (size_t)hs[l] * wsz[l] * RPN_A;
     }
     if ((st = AA(&e->rpn_t, b * hs[0] * wsz[0] * e->fpn_c)) < 0) return st;
-    if ((st = A(&e->key_ws, b * total_anchors)) < 0) return st;
+    if ((st = A(&e->key_ws, rpn_topk_ws_elems((int)b, (int)total_anchors))) < 0) return st;
     const size_t nc = b * RPN_LEVELS * RPN_CAND;
     if ((st = A(&e->cand_boxes, nc * 4)) < 0) return st;
     if ((st = A(&e->cand_scores, nc)) < 0) return st;

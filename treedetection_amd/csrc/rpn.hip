@@ -40,14 +40,69 @@ __device__ void bitonic_sort_desc(unsigned long long* s, int n) {
     }
 }
 
+// ---- dense keys + coarse histogram (all images, all levels, every CU) -----------------------------------------------
+// The fused head tensor interleaves 3 logits with 12 deltas per position (60-B rows): gathering the logits is a strided
+// read of the whole tensor, and p2 alone holds 120 000 anchors per image — as the first pass of the one-block-per-
+// (image, level) top-k kernel it was a third of that kernel's 0.3-0.5 ms. Here every CU takes part: key = order-
+// preserving integer image of the logit, written densely, and a 4096-bin histogram of the keys' top 12 bits per
+// (image, level) that lets the top-k kernel cut each level down to a few thousand candidates in ONE pass.
+constexpr int HIST_BITS = 12, HIST_BINS = 1 << HIST_BITS;
+constexpr int KEYS_PER_BLOCK = 4096;       // 256 threads x 16 anchors
+__global__ __launch_bounds__(256) void rpn_keys_hist_kernel(RpnLevels lv, uint32_t* __restrict__ key_ws,
+                                                            unsigned int* __restrict__ hist) {
+    // the logits of a level crowd into a few dozen of the 4096 bins: counted in an LDS histogram per block and level first
+    // (a block's anchors span at most two levels), only the non-empty bins reach the global one (one atomic per bin and
+    // block — per-key global atomics on the same few addresses took 0.4 ms)
+    __shared__ unsigned int lh[2][HIST_BINS];
+    const int b = blockIdx.y;
+    const int i0 = blockIdx.x * KEYS_PER_BLOCK;
+    int level0 = 0;
+#pragma unroll
+    for (int l = 1; l < RPN_LEVELS; ++l) level0 += i0 >= lv.anchor_off[l] ? 1 : 0;
+    for (int t = threadIdx.x; t < 2 * HIST_BINS; t += blockDim.x) (&lh[0][0])[t] = 0u;
+    __syncthreads();
+    bool second = false;
+    for (int i = i0 + threadIdx.x; i < i0 + KEYS_PER_BLOCK && i < lv.total_anchors; i += blockDim.x) {
+        int level = 0;
+#pragma unroll
+        for (int l = 1; l < RPN_LEVELS; ++l) level += i >= lv.anchor_off[l] ? 1 : 0;
+        const int j = i - lv.anchor_off[level];
+        const int pos = j / RPN_A, a = j - pos * RPN_A;
+        const float* __restrict__ head = lv.head[level] + (size_t)b * lv.h[level] * lv.w[level] * RPN_HEAD_C;
+        const uint32_t key = float_to_key(head[(size_t)pos * RPN_HEAD_C + a]);
+        key_ws[(size_t)b * lv.total_anchors + i] = key;
+        const int slot = level - level0;                       // 0, or 1.. when the block crosses into the next level(s)
+        if (slot <= 1) {
+            atomicAdd(&lh[slot][key >> (32 - HIST_BITS)], 1u);
+            second |= slot == 1;
+        } else {                                               // a third level inside one block (tiny top levels): straight to global
+            atomicAdd(&hist[((size_t)b * RPN_LEVELS + level) * HIST_BINS + (key >> (32 - HIST_BITS))], 1u);
+        }
+    }
+    const bool any_second = __syncthreads_or(second);
+    for (int t = threadIdx.x; t < HIST_BINS; t += blockDim.x) {
+        const unsigned int c0 = lh[0][t];
+        if (c0) atomicAdd(&hist[((size_t)b * RPN_LEVELS + level0) * HIST_BINS + t], c0);
+        if (any_second) {
+            const unsigned int c1 = lh[1][t];
+            if (c1) atomicAdd(&hist[((size_t)b * RPN_LEVELS + level0 + 1) * HIST_BINS + t], c1);
+        }
+    }
+}
+
 // ---- per (image, level) top-k + decode ---------------------------------------------------------------
-// One block (1024 threads) per (image, level). Radix-select the k-th largest key (4 x 8-bit passes, LDS
-// histogram), gather the winners (ties at the threshold: lowest indices first), bitonic-sort them by
-// (key desc, index asc), then decode / clip their boxes.
+// One block (1024 threads) per (image, level), after rpn_keys_hist_kernel. Fast path: the coarse histogram names the bin
+// that holds the k-th largest key; the keys of that bin and above (<= TOPK_FAST of them) are gathered in one pass over
+// the dense keys and sorted in LDS as (key, ~index) pairs — the first k are the top-k in (key desc, index asc) order, ties
+// at the cut included. Otherwise (a bin so crowded that the candidates do not fit: near-constant logits) the general
+// path: radix-select the k-th largest key (4 x 8-bit passes, LDS histogram), gather the winners (ties at the threshold:
+// lowest indices first), bitonic-sort them by (key desc, index asc). Then decode / clip the boxes. Same result either way.
 constexpr int TOPK_THREADS = 1024;
+constexpr int TOPK_FAST = 4096;
 
 __global__ __launch_bounds__(TOPK_THREADS) void rpn_topk_decode_kernel(RpnLevels lv, ImgSizes valid, int B, int topk,
-                                                                       uint32_t* __restrict__ key_ws,
+                                                                       const uint32_t* __restrict__ key_ws,
+                                                                       const unsigned int* __restrict__ hist12,
                                                                        float* __restrict__ cand_boxes,
                                                                        float* __restrict__ cand_scores,
                                                                        int* __restrict__ cand_valid,
@@ -57,19 +112,69 @@ __global__ __launch_bounds__(TOPK_THREADS) void rpn_topk_decode_kernel(RpnLevels
     const int n = H * W * RPN_A;
     const int k = topk < n ? topk : n;
     const float* __restrict__ head = lv.head[level] + (size_t)b * H * W * RPN_HEAD_C;
-    uint32_t* __restrict__ keys = key_ws + ((size_t)b * lv.total_anchors + lv.anchor_off[level]);
+    const uint32_t* __restrict__ keys = key_ws + ((size_t)b * lv.total_anchors + lv.anchor_off[level]);
 
     __shared__ unsigned int hist[256];
-    __shared__ unsigned long long sel[1024];
+    __shared__ unsigned long long sel[TOPK_FAST];
     __shared__ unsigned int s_prefix, s_need, s_cnt_gt, s_cnt_eq, s_eq_total;
     __shared__ unsigned int wave_cnt[2][TOPK_THREADS / 64];
+    __shared__ unsigned int scan[TOPK_THREADS];
+    __shared__ int s_tbin;
+    __shared__ unsigned int s_cand;
 
     const int tid = threadIdx.x;
-    // dense keys (the head tensor interleaves 3 logits + 12 deltas per position)
-    for (int i = tid; i < n; i += TOPK_THREADS) {
-        const int pos = i / RPN_A, a = i - pos * RPN_A;
-        keys[i] = float_to_key(head[(size_t)pos * RPN_HEAD_C + a]);
+    // ---- fast path: threshold bin of the coarse histogram ----
+    {
+        const unsigned int* __restrict__ h = hist12 + ((size_t)b * RPN_LEVELS + level) * HIST_BINS;
+        constexpr int PER = HIST_BINS / TOPK_THREADS;          // bins per thread; thread 0 owns the HIGHEST bins
+        unsigned int c[PER], mine = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            c[q] = h[HIST_BINS - 1 - (tid * PER + q)];
+            mine += c[q];
+        }
+        scan[tid] = mine;
+        if (tid == 0) {
+            s_tbin = -1;
+            s_cand = 0;
+        }
+        __syncthreads();
+        for (int off = 1; off < TOPK_THREADS; off <<= 1) {     // inclusive scan over the threads (highest bins first)
+            const unsigned int v = tid >= off ? scan[tid - off] : 0u;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        unsigned int above = scan[tid] - mine;                 // keys in bins above this thread's
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            if (above < (unsigned)k && above + c[q] >= (unsigned)k) {      // the k-th largest key lies in this bin (one bin only)
+                s_tbin = HIST_BINS - 1 - (tid * PER + q);
+                s_cand = above + c[q];
+            }
+            above += c[q];
+        }
+        __syncthreads();
     }
+    if (k > 0 && s_tbin >= 0 && s_cand <= (unsigned)TOPK_FAST) {
+        const uint32_t tb = (uint32_t)s_tbin;
+        const unsigned int ncand = s_cand;
+        __syncthreads();
+        if (tid == 0) s_cnt_gt = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += TOPK_THREADS) {
+            const uint32_t key = keys[i];
+            if ((key >> (32 - HIST_BITS)) >= tb) {
+                const unsigned int pos = atomicAdd(&s_cnt_gt, 1u);
+                sel[pos] = ((unsigned long long)key << 32) | (0xffffffffu - (uint32_t)i);
+            }
+        }
+        int P = 1024;
+        while (P < (int)ncand) P <<= 1;
+        for (int i = (int)ncand + tid; i < P; i += TOPK_THREADS) sel[i] = 0ull;      // padding sorts last
+        __syncthreads();
+        bitonic_sort_desc(sel, P);
+    } else {
     if (tid == 0) {
         s_prefix = 0;
         s_need = k;
@@ -165,6 +270,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void rpn_topk_decode_kernel(RpnLevels
     for (int i = k + tid; i < 1024; i += TOPK_THREADS) sel[i] = 0ull;   // padding sorts last
     __syncthreads();
     bitonic_sort_desc(sel, 1024);
+    }   // general path
 
     // decode + clip (apply_deltas, weights 1,1,1,1; Boxes.clip; nonempty(0); isfinite)
     const size_t obase = ((size_t)b * RPN_LEVELS + level) * RPN_CAND;
@@ -400,12 +506,19 @@ __global__ void gather_keep_kernel(const int* __restrict__ sidx, const int* __re
 
 }  // namespace
 
+size_t rpn_topk_ws_elems(int B, int total_anchors) { return (size_t)B * ((size_t)total_anchors + (size_t)RPN_LEVELS * HIST_BINS); }
+
 td_status rpn_topk_decode_launch(const RpnLevels& lv, const ImgSizes& valid, int B, int topk, uint32_t* key_ws,
                                  float* cand_boxes, float* cand_scores, int* cand_valid, int* cand_idx,
                                  hipStream_t stream) {
     TD_REQUIRE(topk >= 1 && topk <= RPN_CAND, "rpn: pre_nms_topk=%d must be in [1, %d]", topk, RPN_CAND);
+    // key_ws holds B * total_anchors keys followed by the B * RPN_LEVELS coarse histograms (rpn_topk_ws_elems)
+    unsigned int* hist = key_ws + (size_t)B * lv.total_anchors;
+    TD_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)B * RPN_LEVELS * HIST_BINS * sizeof(unsigned int), stream));
+    hipLaunchKernelGGL(rpn_keys_hist_kernel, dim3(td_cdiv(lv.total_anchors, KEYS_PER_BLOCK), B), dim3(256), 0, stream, lv, key_ws, hist);
+    TD_KERNEL_CHECK();
     hipLaunchKernelGGL(rpn_topk_decode_kernel, dim3(RPN_LEVELS, B), dim3(TOPK_THREADS), 0, stream, lv, valid, B, topk,
-                       key_ws, cand_boxes, cand_scores, cand_valid, cand_idx);
+                       key_ws, hist, cand_boxes, cand_scores, cand_valid, cand_idx);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
