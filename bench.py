@@ -44,6 +44,11 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MATRIX_TFLOPS = 2500.0
 MASK_HEAD_GFLOP_PER_DET = 1.028
+SCHED = {"streams": "{n} engines, each a whole forward on its own HIP stream, batches round-robin (HBM-bound kernels and kernel tails of one "
+                    "forward run under the MFMA-bound contractions of the others)",
+         "phases": "3 batches in flight per GPU: contraction phases on a main HIP stream, selection phases (top-k/NMS/RoIAlign/paste) on one "
+                   "side stream per batch in flight",
+         "plain": "plain loop: one batch at a time ({n} stream(s))"}
 
 
 def parse():
@@ -61,13 +66,23 @@ def parse():
     ap.add_argument("--cpu-tiles", type=int, default=16)   # ≈ 13 s of CPU work on 16 threads
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-fp16", action="store_true", help="skip the second timed region with the fp16 engine")
-    ap.add_argument("--no-pipeline", action="store_true", help="plain loop: one batch at a time on one stream")
+    ap.add_argument("--schedule", default="streams", choices=("streams", "phases", "plain"),
+                    help="streams (default): --streams engines, each a whole forward on its own HIP stream, batches round-robin; "
+                         "phases: the round-1/2 software pipeline (contraction phases on a main stream, selection phases on side "
+                         "streams); plain: one batch at a time on one stream")
+    ap.add_argument("--no-pipeline", action="store_true", help="same as --schedule plain (kept for the tools/ scripts)")
     ap.add_argument("--no-serial", action="store_true", help="skip the extra informational single-stream region")
     ap.add_argument("--no-r101", action="store_true", help="skip the extra timed region with the reference's own depth (R101-FPN)")
     ap.add_argument("--no-fp16-b32", action="store_true", help="skip the fp16 region at BASELINE configs[4]'s batch (32 per GPU)")
-    ap.add_argument("--streams", type=int, default=1, help="engines / HIP streams the batches alternate over (the "
-                    "low-occupancy selection tail of one batch overlaps the next batch's convolutions)")
-    return ap.parse_args()
+    ap.add_argument("--streams", type=int, default=0, help="engines / HIP streams the batches alternate over (default 3 for "
+                    "--schedule streams, 1 for plain): the HBM-bound kernels and the kernel tails of one forward run under the "
+                    "MFMA-bound contractions of the others")
+    a = ap.parse_args()
+    if a.no_pipeline:
+        a.schedule = "plain"
+    if a.streams <= 0:
+        a.streams = 3 if a.schedule == "streams" else 1
+    return a
 
 
 T_START = time.perf_counter()
@@ -173,7 +188,7 @@ def main():
         log(f"creating engine ({precision}, {ns} stream(s))")
         engs = [Engine(sd, device=local_rank, precision=precision) for _ in range(ns)]
         outs = [e.alloc_outputs(B, S, S, paste=True) for e in engs]
-        streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(ns - 1)]
+        streams = [torch.cuda.Stream() for _ in range(ns)] if ns > 1 else [torch.cuda.current_stream()]
         eng, out = engs[0], outs[0]
         gl = None
         if world > 1 and rank == 0:
@@ -360,34 +375,40 @@ def main():
     if "TD_TUNE_CACHE" not in os.environ:     # engines of one run share their measured block-tile choices
         import tempfile
         os.environ["TD_TUNE_CACHE"] = os.path.join(tempfile.mkdtemp(prefix="td_tune_"), f"tiles_rank{rank}.txt")
-    if args.no_pipeline:
-        dt, prof, ndet = run(args.precision, max(1, args.streams), not args.no_profile)
-    else:
-        dt, prof, ndet = run_pipelined(args.precision, not args.no_profile)
+    def go(precision, profile):
+        if args.schedule == "phases":
+            return run_pipelined(precision, profile)
+        return run(precision, args.streams, profile)
+
+    dt, prof, ndet = go(args.precision, not args.no_profile)
     extra = piped = None
     if args.precision == "fp32" and not args.no_fp16:
-        extra = run("fp16", 1, not args.no_profile) if args.no_pipeline else run_pipelined("fp16", not args.no_profile)
-    if not args.no_pipeline and not args.no_serial:
-        piped = run(args.precision, 1, False)      # informational: the plain one-batch-at-a-time loop
+        extra = go("fp16", not args.no_profile)
+    if args.schedule != "plain" and not args.no_serial:
+        # one forward at a time on one stream: the same kernels with nothing overlapping — the per-launch spans of THIS region
+        # are the kernels' own durations (the `exclusive` roofline object)
+        piped = run(args.precision, 1, not args.no_profile)
     r101 = b32 = None
-    if args.precision == "fp32" and args.depth == 50 and not args.no_pipeline and world == 1:
+    if args.precision == "fp32" and args.depth == 50 and args.schedule != "plain" and world == 1:
         if not args.no_r101:
             # the reference's own depth (TreeDetection/config.py:25 hard-codes R101-FPN): same stream, same schedule
             log("generating R101 weights")
             sd = make_synthetic_state_dict(101, seed=0)
             nsteps = max(4, args.steps // 2)
-            r101 = {"fp32": run_pipelined("fp32", not args.no_profile) + (nsteps,)}
+            r101 = {"fp32": go("fp32", not args.no_profile) + (nsteps,)}
             if not args.no_fp16:
-                r101["fp16"] = run_pipelined("fp16", not args.no_profile) + (nsteps,)
+                r101["fp16"] = go("fp16", not args.no_profile) + (nsteps,)
             sd = make_synthetic_state_dict(args.depth, seed=0)
         if not args.no_fp16 and not args.no_fp16_b32:
             # BASELINE configs[4]: the fp16 MFMA path at batch 32 per GPU (same tiles, four times the rows per launch)
             B, nsteps = 32, max(4, args.steps // 4)
-            b32 = run_pipelined("fp16", not args.no_profile) + (nsteps,)
+            b32 = go("fp16", not args.no_profile) + (nsteps,)
             B, nsteps = args.batch, args.steps
 
     if rank == 0:
         tiles_total = args.steps * B * world
+        # forwards whose contractions overlap (the phase pipeline keeps them back to back on one main stream: spans are the kernels' own)
+        conc = 1 if args.schedule == "phases" else args.streams
         line = {
             "metric": "tiles/sec (1000x1000 RGB+nDSM) predict_tiles model stage",
             "value": tiles_total / dt,
@@ -406,74 +427,76 @@ def main():
                                    f"resize 800x800 + forward + paste on device, inputs resident in HBM",
                        "depth": args.depth, "batch_per_gpu": B, "tile": S, "net_input": "3x800x800",
                        "parallelism": f"tile-shard x{world} (replicated weights, RCCL gather of detections to rank 0)",
-                       "schedule": "plain loop" if args.no_pipeline else "3 batches in flight per GPU: contraction phases on a main "
-                                   "HIP stream, selection phases (top-k/NMS/RoIAlign/paste) on one side stream per batch in flight",
-                       "detections_last_batch": ndet},
+                       "schedule": SCHED[args.schedule].format(n=args.streams),
+                       "concurrent_forwards": conc, "detections_last_batch": ndet},
         }
-        if prof is not None:
-            conv = prof["conv_igemm"]
-            peak = PEAK_F32_MATRIX_TFLOPS if args.precision == "fp32" else PEAK_F16_MATRIX_TFLOPS
-            ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+
+        def roofline(profx, dtx, k, peak, pmc_name=None):
+            """`roofline` object of one timed region of k steps. With several forwards in flight the per-launch event spans
+            of different streams overlap (their sum exceeds the wall time), so `achieved` is the family's algorithmic FLOPs per
+            step over the WALL time per step — a lower bound of its rate, since that wall time also holds every other
+            kernel; `span` keeps the literal figure (FLOPs over the summed spans, what rocprofv3's per-kernel averages
+            show). With one forward at a time both coincide and `achieved` is the literal one."""
+            cx = profx["conv_igemm"]
+            span_ms = cx["ms"] / k
+            gflop = cx["flops"] / k / 1e9
+            literal = cx["flops"] / (cx["ms"] * 1e-3) / 1e12 if cx["ms"] > 0 else 0.0
+            wall = gflop / (1000.0 * dtx / k) if dtx > 0 else 0.0
+            ach = wall if conc > 1 else literal
             traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "r02_pmc_conv_fp32.json")
-            if args.precision == "fp32" and args.depth == 50 and B == 8 and os.path.exists(pmc):
-                # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE x2
-                # gfx950 correction + WRITE_SIZE; tools/pmc_summary.py) — counters cannot be read from inside bench.py
-                with open(pmc) as f:
+            if pmc_name and os.path.exists(os.path.join(ROOT, "profiles", pmc_name)):
+                # HBM bytes per launch from the committed rocprofv3 --pmc passes of the plain-loop form of this command
+                # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_summary2.py) — counters cannot be read in here
+                with open(os.path.join(ROOT, "profiles", pmc_name)) as f:
                     pj = json.load(f)
                 traffic = pj["hbm_traffic_gb_per_step"] * 1e9 / pj["launches"]
-                traffic_src = "profiles/r02_pmc_conv_fp32.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; conv family)"
-            line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                                "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
-                                "algorithmic_bytes_per_launch": conv["bytes"] / max(conv["launches"], 1),
-                                "algorithmic_flops_per_launch": conv["flops"] / max(conv["launches"], 1),
-                                "kernel": "conv_igemm_kernel (all trunk/FPN/RPN/box-head contractions)",
-                                "launches_per_step": conv["launches"] / args.steps,
-                                "avg_launch_us": 1e3 * conv["ms"] / max(conv["launches"], 1),
-                                "gflop_per_step": conv["flops"] / args.steps / 1e9,
-                                "algorithmic_gbytes_per_step": conv["bytes"] / args.steps / 1e9}
-            ex = prof.get("executed", {"flops": conv["flops"], "launches": 0})
-            line["roofline"]["note"] = ("achieved = ALGORITHMIC FLOPs (2 x MACs of the direct convolution, SURVEY.md §8d) / time of the conv family "
-                                        "(conv_igemm_kernel + the two Winograd transform kernels of the layers that take that path); "
-                                        "executed_tflops = FLOPs the MFMA pipe really issued (Winograd F(2x2,3x3) layers run 4/9 of theirs) / the same time")
-            line["roofline"]["executed_tflops"] = ex["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
-            line["roofline"]["executed_frac"] = line["roofline"]["executed_tflops"] / peak
-            line["roofline"]["winograd_layers_per_step"] = ex["launches"] / args.steps
+                traffic_src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; conv family)"
+            o = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                 "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
+                 "algorithmic_bytes_per_launch": cx["bytes"] / max(cx["launches"], 1),
+                 "algorithmic_flops_per_launch": cx["flops"] / max(cx["launches"], 1),
+                 "kernel": "conv family: conv_igemm_kernel / conv_pp8_kernel (all trunk / FPN / RPN / box-head contractions) + the "
+                           "Winograd transform kernels of the layers that take that path",
+                 "launches_per_step": cx["launches"] / k, "gflop_per_step": gflop,
+                 "algorithmic_gbytes_per_step": cx["bytes"] / k / 1e9,
+                 "method": ("wall: algorithmic FLOPs per step / wall time per step (%d forwards overlap on %d HIP streams)" % (conc, conc))
+                           if conc > 1 else "span: algorithmic FLOPs / summed HIP-event spans of the family (nothing overlaps)",
+                 "span": {"achieved": literal, "frac": literal / peak, "span_ms_per_step": span_ms,
+                          "avg_launch_us": 1e3 * cx["ms"] / max(cx["launches"], 1), "concurrent_forwards": conc,
+                          "note": "literal: FLOPs / summed HIP-event spans on each forward's own stream; spans of concurrent forwards "
+                                  "overlap, so span_ms_per_step / concurrent_forwards (not span_ms_per_step) is what fits in ms_per_step"}}
+            ex = profx.get("executed", {"flops": cx["flops"], "launches": 0})
+            o["note"] = ("algorithmic FLOPs = 2 x MACs of the direct convolution (SURVEY.md §8d); executed_tflops = FLOPs the MFMA pipe "
+                         "really issued (Winograd F(4x4,3x3) layers run 1/4 of theirs, F(2x2,3x3) layers 4/9) over the same time")
+            o["executed_tflops"] = ach * ex["flops"] / cx["flops"] if cx["flops"] > 0 else 0.0
+            o["executed_frac"] = o["executed_tflops"] / peak
+            o["winograd_layers_per_step"] = ex["launches"] / k
+            return o
+
+        peak_main = PEAK_F32_MATRIX_TFLOPS if args.precision == "fp32" else PEAK_F16_MATRIX_TFLOPS
+        std = args.depth == 50 and B == 8
+        if prof is not None:
+            line["roofline"] = roofline(prof, dt, args.steps, peak_main,
+                                        ("r02_pmc_conv_fp32.json" if args.precision == "fp32" else "r02_pmc_conv_fp16.json") if std else None)
             line["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items() if k != "executed"}
         if extra is not None:
             dt16, prof16, ndet16 = extra
             o = {"value": tiles_total / dt16, "unit": "tiles/s", "ms_per_step": 1000.0 * dt16 / args.steps, "dtype": "f16",
-                 "note": "same workload through the fp16 engine (fp16 storage, v_mfma_f32_32x32x16_f16, fp32 accumulate "
+                 "note": "same workload and schedule through the fp16 engine (fp16 storage, v_mfma_f32_32x32x16_f16, fp32 accumulate "
                          "and selection); parity tolerances in tests/test_engine_fp16_gpu.py",
                  "detections_last_batch": ndet16}
             if prof16 is not None:
-                c16 = prof16["conv_igemm"]
-                a16 = c16["flops"] / (c16["ms"] * 1e-3) / 1e12 if c16["ms"] > 0 else 0.0
-                t16, src16 = None, None
-                pmc16 = os.path.join(ROOT, "profiles", "r02_pmc_conv_fp16.json")
-                if args.depth == 50 and B == 8 and os.path.exists(pmc16):
-                    with open(pmc16) as f:
-                        pj = json.load(f)
-                    t16 = pj["hbm_traffic_gb_per_step"] * 1e9 / pj["launches"]
-                    src16 = "profiles/r02_pmc_conv_fp16.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; conv family)"
-                o["roofline"] = {"bound": "mfma", "achieved": a16, "peak": PEAK_F16_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": a16 / PEAK_F16_MATRIX_TFLOPS, "traffic": t16, "traffic_unit": "bytes per launch (HBM, PMC)",
-                                 "traffic_source": src16,
-                                 "algorithmic_bytes_per_launch": c16["bytes"] / max(c16["launches"], 1)}
+                o["roofline"] = roofline(prof16, dt16, args.steps, PEAK_F16_MATRIX_TFLOPS, "r02_pmc_conv_fp16.json" if std else None)
                 o["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof16.items() if k != "executed"}
             line["fp16"] = o
+
         def sub(res, batch, peak, depth):
             dtx, profx, ndetx, k = res
             o = {"value": k * batch * world / dtx, "unit": "tiles/s", "ms_per_step": 1000.0 * dtx / k, "steps": k,
                  "batch_per_gpu": batch, "depth": depth, "detections_last_batch": ndetx}
             if profx is not None:
-                cx = profx["conv_igemm"]
-                ax = cx["flops"] / (cx["ms"] * 1e-3) / 1e12 if cx["ms"] > 0 else 0.0
-                o["roofline"] = {"bound": "mfma", "achieved": ax, "peak": peak, "unit": "TFLOP/s", "frac": ax / peak,
-                                 "traffic": None, "gflop_per_step": cx["flops"] / k / 1e9}
+                o["roofline"] = roofline(profx, dtx, k, peak)
                 o["breakdown_ms_per_step"] = {kk: v["ms"] / k for kk, v in profx.items() if kk != "executed"}
-                if "executed" in profx:
-                    o["roofline"]["executed_tflops"] = profx["executed"]["flops"] / (cx["ms"] * 1e-3) / 1e12 if cx["ms"] > 0 else 0.0
             return o
         if r101 is not None:
             line["r101"] = {"note": "the reference's own depth (config.py:25: mask_rcnn_R_101_FPN_3x), same stream and schedule",
@@ -485,7 +508,17 @@ def main():
             line["fp16_batch32"]["note"] = "BASELINE configs[4]: fp16 MFMA conv path at batch 32 per GPU, R50-FPN, same tile stream"
         if piped is not None:
             line["single_stream"] = {"value": tiles_total / piped[0], "unit": "tiles/s", "ms_per_step": 1000.0 * piped[0] / args.steps,
-                                     "note": "same K steps as a plain loop, one batch at a time on one stream (informational)"}
+                                     "note": "the same K steps, one forward at a time on one stream: nothing overlaps, so the event spans "
+                                             "are the kernels' own durations"}
+            if piped[1] is not None and prof is not None:
+                cs = piped[1]["conv_igemm"]
+                lit = cs["flops"] / (cs["ms"] * 1e-3) / 1e12 if cs["ms"] > 0 else 0.0
+                line["single_stream"]["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in piped[1].items() if k != "executed"}
+                # the kernel's own roofline (no other forward on the GPU): what the per-kernel rocprofv3 averages of the
+                # plain-loop profile in profiles/ agree with
+                line["roofline"]["exclusive"] = {"achieved": lit, "frac": lit / peak_main, "avg_launch_us": 1e3 * cs["ms"] / max(cs["launches"], 1),
+                                                 "span_ms_per_step": cs["ms"] / args.steps,
+                                                 "note": "the conv family with one forward at a time (the `single_stream` region of this run)"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, rgb_np, args.cpu_tiles)
         print(json.dumps(line), flush=True)

@@ -8,7 +8,10 @@ j = json.loads(sys.stdin.read().strip().splitlines()[-1])
 def show(tag, o):
     r = o.get("roofline") or {}
     b = {k: round(v, 2) for k, v in (o.get("breakdown_ms_per_step") or {}).items()}
-    print(f" {tag:14s} {o['value']:8.1f} tiles/s  {o['ms_per_step']:7.2f} ms/step  conv {r.get('achieved', 0):7.1f} TF/s (frac {r.get('frac', 0):.3f})  {b}")
+    sp = r.get("span") or {}
+    ex = r.get("exclusive") or {}
+    extra = f" span {sp.get('frac', 0):.3f}" + (f" exclusive {ex['frac']:.3f}" if ex else "")
+    print(f" {tag:14s} {o['value']:8.1f} tiles/s  {o['ms_per_step']:7.2f} ms/step  conv {r.get('achieved', 0):7.1f} TF/s (frac {r.get('frac', 0):.3f}{extra})  {b}")
 
 
 show("fp32", j)
