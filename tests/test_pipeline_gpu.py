@@ -229,22 +229,27 @@ def test_compressed_tiled_raster_gives_the_same_predictions(tmp_path):
     rgbi = np.ascontiguousarray(np.concatenate([rgb, rgb[..., 1:2]], axis=2).transpose(2, 0, 1))
     t = (0.2, 0.0, 412000.0, 0.0, -0.2, 5318100.0)
     outs = {}
+    # pipe: True = three engines in flight on their own HIP streams (the default schedule), "phases" = the phase pipeline,
+    # False = one forward at a time
     for tag, kw, pipe, devc in (("raw", {}, True, False), ("deflate", {"tile": (64, 64), "compression": "deflate", "predictor": 2}, True, False),
                                 ("deflate_plain", {"tile": (64, 64), "compression": "deflate", "predictor": 2}, False, False),
-                                ("gpu_contours", {}, True, True), ("gpu_contours_plain", {}, False, True)):
+                                ("raw_phases", {}, "phases", False),
+                                ("gpu_contours", {}, True, True), ("gpu_contours_phases", {}, "phases", True),
+                                ("gpu_contours_plain", {}, False, True)):
         d = tmp_path / tag
         (d / "rgb").mkdir(parents=True)
         tif = str(d / "rgb" / "9.tif")
         write_geotiff(tif, rgbi, t, 25832, **kw)
         tile_single_file(tif, str(d / "tiles"), buffer=10, tile_width=40, tile_height=40)
         cfg = T.setup_model_cfg(update_model="x", device="0")
-        with T.Predictor(cfg, device_type="0", max_batch_size=3, output_dir=str(d / "out"), state_dict=sd, pipeline=pipe,
-                         device_contours=devc) as pred:
+        with T.Predictor(cfg, device_type="0", max_batch_size=3, output_dir=str(d / "out"), state_dict=sd, pipeline=bool(pipe),
+                         schedule="phases" if pipe == "phases" else "streams", device_contours=devc) as pred:
             res = pred(tif, str(d / "tiles" / "9.json"))
         files = sorted(os.listdir(d / "out" / "9"))
         outs[tag] = {f: open(d / "out" / "9" / f, "rb").read().replace(tif.encode(), b"IMG") for f in files}
         assert len(files) == 9 and sum(len(json.loads(v)) for v in outs[tag].values()) == len(res) > 5
-    assert outs["raw"] == outs["deflate"] == outs["deflate_plain"] == outs["gpu_contours"] == outs["gpu_contours_plain"]
+    assert (outs["raw"] == outs["deflate"] == outs["deflate_plain"] == outs["raw_phases"] == outs["gpu_contours"]
+            == outs["gpu_contours_phases"] == outs["gpu_contours_plain"])
 
 
 def test_predictor_fp16_engine_end_to_end(tmp_path):

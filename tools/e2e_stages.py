@@ -9,7 +9,7 @@ from treedetection_amd.preprocessing import tile_data
 from treedetection_amd.synth import make_tile
 from treedetection_amd.weights import make_synthetic_state_dict
 
-def main(size=5000, depth=50, batch=16, precision="fp32", device_contours=False):
+def main(size=5000, depth=50, batch=16, precision="fp32", device_contours=False, schedule="streams"):
     root = tempfile.mkdtemp(prefix="e2e_")
     os.makedirs(f"{root}/rgb")
     base, _ = make_tile(0, 1000)
@@ -22,7 +22,7 @@ def main(size=5000, depth=50, batch=16, precision="fp32", device_contours=False)
     cfg = T.setup_model_cfg(update_model="x", device="0")
     pred = T.Predictor(cfg, device_type="0", max_batch_size=batch, output_dir=f"{root}/out", precision=precision,
                        state_dict=make_synthetic_state_dict(depth, seed=0), return_predictions=False,
-                       device_contours=device_contours)
+                       device_contours=device_contours, schedule=schedule)
     for rep in range(3):
         t0 = time.time()
         pred(tif, f"{root}/tiles/324125317.json")
@@ -34,4 +34,5 @@ def main(size=5000, depth=50, batch=16, precision="fp32", device_contours=False)
     pred.close()
 
 if __name__ == "__main__":
-    main(precision=sys.argv[1] if len(sys.argv) > 1 else "fp32", device_contours=len(sys.argv) > 2 and sys.argv[2] == "gpu_contours")
+    main(precision=sys.argv[1] if len(sys.argv) > 1 else "fp32", device_contours="gpu_contours" in sys.argv[2:],
+         schedule="phases" if "phases" in sys.argv[2:] else "streams")
