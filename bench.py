@@ -190,12 +190,13 @@ def main():
         outs = [e.alloc_outputs(B, S, S, paste=True) for e in engs]
         streams = [torch.cuda.Stream() for _ in range(ns)] if ns > 1 else [torch.cuda.current_stream()]
         eng, out = engs[0], outs[0]
-        gl = None
-        if world > 1 and rank == 0:
-            gl = {k: [torch.empty_like(out[k]) for _ in range(world)] for k in gather_keys}
+        gls = None
+        if world > 1 and rank == 0:      # one set of receive buffers per engine: their gathers run on different streams
+            gls = [{k: [torch.empty_like(out[k]) for _ in range(world)] for k in gather_keys} for _ in range(ns)]
 
         def step(i):
             e, o = engs[i % ns], outs[i % ns]
+            gl = gls[i % ns] if gls is not None else None
             with torch.cuda.stream(streams[i % ns]):
                 tiles = [rgb[(i * B + j) % n_local] for j in range(B)]
                 batch, hw_valid, hw_out = e.preprocess_tiles_u8(tiles)
@@ -449,8 +450,10 @@ def main():
                 # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_summary2.py) — counters cannot be read in here
                 with open(os.path.join(ROOT, "profiles", pmc_name)) as f:
                     pj = json.load(f)
-                traffic = pj["hbm_traffic_gb_per_step"] * 1e9 / pj["launches"]
-                traffic_src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; conv family)"
+                # per launch of THIS object's launch count (one per layer; a Winograd layer's transform kernels belong to it)
+                traffic = pj["hbm_traffic_gb_per_step"] * 1e9 / max(cx["launches"] / k, 1.0)
+                traffic_src = (f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; conv family: "
+                               f"{pj['hbm_traffic_gb_per_step']:.2f} GB per step)")
             o = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                  "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
                  "algorithmic_bytes_per_launch": cx["bytes"] / max(cx["launches"], 1),

@@ -7,8 +7,12 @@ rm -rf $O && mkdir -p $O
 export TD_TUNE_CACHE=$O/tune.txt
 python3 $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-serial --no-r101 --no-fp16-b32 > $O/warm.json 2> $O/warm.err || exit 1      # fills the tile-choice cache
 python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-serial --no-r101 --no-fp16-b32 --no-pipeline > $O/warm2.json 2> $O/warm2.err || exit 1
+# (1) the default command's schedule: three forwards overlap on three streams — per-kernel durations here are the spans under that concurrency
 rocprofv3 --kernel-trace --stats -d $O/stats -o s --output-format csv -- python3 $R/bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-serial --no-r101 --no-fp16-b32 > $O/bench_profiled.json 2> $O/bench_profiled.err || exit 1
 echo stats done
+# (2) the same steps one forward at a time (what roofline.exclusive and the single_stream region of the default command measure)
+rocprofv3 --kernel-trace --stats -d $O/stats_plain -o s --output-format csv -- python3 $R/bench.py --schedule plain --steps 16 --warmup 3 --no-cpu-baseline --no-r101 --no-fp16-b32 > $O/bench_plain_profiled.json 2> $O/bench_plain_profiled.err || exit 1
+echo plain stats done
 for prec in fp32 fp16; do
   for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
     tag=$(echo $set | cut -d' ' -f1)
@@ -24,5 +28,7 @@ python3 tools/pmc_summary2.py $O/pmc_fp16_SQ_VALU_MFMA_BUSY_CYCLES/p_counter_col
 cp $O/tune.txt $O/${TAG}_tile_choices.txt
 cp $O/stats/s_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv 2>/dev/null || cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_kernel_stats.csv
 cp $O/bench_profiled.json $O/${TAG}_bench_profiled_run.json
+cp $(find $O/stats_plain -name "*kernel_stats.csv" | head -1) $O/${TAG}_plain_kernel_stats.csv
+cp $O/bench_plain_profiled.json $O/${TAG}_plain_profiled_run.json
 python3 -c "import json;d=json.load(open('$O/${TAG}_pmc_conv_fp32.json'));print('fp32 conv family', d['conv_family'])"
 python3 -c "import json;d=json.load(open('$O/${TAG}_pmc_conv_fp16.json'));print('fp16 conv family', d['conv_family'])"
