@@ -734,6 +734,11 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
     // measured block tile of one launch shape (cached per engine, shared through the TD_TUNE_CACHE file)
     auto tuned_cfg = [&](const std::tuple<int, int, int, int, int>& key, int prec_, int ksteps, bool pp8_ok, hipStream_t s_,
                          auto&& launch_cfg, int* cfg_out, float* best_ms) -> td_status {
+        static const int forced = getenv("TD_FORCE_CFG") ? atoi(getenv("TD_FORCE_CFG")) : -1;      // diagnostics: one block tile everywhere it applies
+        if (forced >= 0 && forced <= TD_CONV_TILE_CFG_MAX && !best_ms && !(forced >= 14 && forced <= 16 && ksteps > 4) && !(forced == 17 && !pp8_ok)) {
+            *cfg_out = forced;
+            return TD_OK;
+        }
         auto it = e->tuned.find(key);
         if (it == e->tuned.end()) {
             load_tune_cache(e);                   // another engine of this process may have measured it meanwhile
