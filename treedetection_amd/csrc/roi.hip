@@ -39,6 +39,67 @@ template <> struct Raw4<_Float16> { typedef h4 type; };
 __device__ __forceinline__ float4 widen4(const float4& v) { return v; }
 __device__ __forceinline__ float4 widen4(const h4& v) { return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]); }
 
+// ---- RoI geometry shared by the two RoIAlign kernels ---------------------------------------------------------------
+// Everything a block needs about its RoI: output row, FPN level, sampling grid and the float32 quantities of the
+// oracle's coordinate arithmetic (oracle/ops_ref.py roi_align: aligned = True, sampling_ratio = 0), in its operation order.
+struct RoiGeo {
+    size_t row;                 // output row of this RoI
+    int H, W;                   // map of its FPN level
+    int gh, gw, ghw;            // sampling grid per bin
+    float sh, sw, bh, bw;       // start and bin size in map pixels
+    float count;                // divisor of a bin's sum
+    size_t feat_off;            // element offset of the image's map inside the level tensor
+    int lvl;
+};
+
+// → false when this block has no RoI (r beyond the item's count). Also block (0, 0)'s thread 0 publishes the compact row total.
+__device__ __forceinline__ bool roi_setup(const FeatLevels& fl, const float* __restrict__ rois, const int* __restrict__ counts,
+                                          int items, int roi_stride, int pooled, int compact, int* __restrict__ total_rows,
+                                          int single_level, int item, int r, RoiGeo& g) {
+    const int cnt = counts ? counts[item] : roi_stride;
+    int prefix = 0;
+    if (compact) {
+        for (int i = 0; i < item; ++i) prefix += counts[i];
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && total_rows) {
+            int t = 0;
+            for (int i = 0; i < items; ++i) t += counts[i];
+            *total_rows = t;
+        }
+    }
+    if (r >= cnt) return false;
+    g.row = compact ? (size_t)(prefix + r) : (size_t)item * roi_stride + r;
+    const float4 bx = *reinterpret_cast<const float4*>(rois + ((size_t)item * roi_stride + r) * 4);
+    g.lvl = single_level ? 0 : fpn_level(bx.x, bx.y, bx.z, bx.w);
+    g.H = fl.h[g.lvl];
+    g.W = fl.w[g.lvl];
+    const float sc = fl.scale[g.lvl];
+    g.feat_off = single_level ? 0 : (size_t)item * g.H * g.W * fl.C;
+    g.sw = __fsub_rn(__fmul_rn(bx.x, sc), 0.5f);
+    g.sh = __fsub_rn(__fmul_rn(bx.y, sc), 0.5f);
+    const float ew = __fsub_rn(__fmul_rn(bx.z, sc), 0.5f), eh = __fsub_rn(__fmul_rn(bx.w, sc), 0.5f);
+    const float rw = __fsub_rn(ew, g.sw), rh = __fsub_rn(eh, g.sh);
+    g.bh = __fdiv_rn(rh, (float)pooled);
+    g.bw = __fdiv_rn(rw, (float)pooled);
+    int gh = (int)ceilf(__fdiv_rn(rh, (float)pooled)), gw = (int)ceilf(__fdiv_rn(rw, (float)pooled));
+    g.gh = gh > 0 ? gh : 0;
+    g.gw = gw > 0 ? gw : 0;
+    g.ghw = g.gh * g.gw;
+    g.count = (float)(g.ghw > 1 ? g.ghw : 1);
+    return true;
+}
+
+// sample i of bin p along one axis: → false when it lies outside the map; else the two taps and their weights
+__device__ __forceinline__ bool roi_sample(float start, float bin, int p, int i, int g, int size, int& lo, int& hi, float& l, float& h) {
+    const float c = __fadd_rn(__fadd_rn(start, __fmul_rn((float)p, bin)), __fdiv_rn(__fmul_rn(__fadd_rn((float)i, 0.5f), bin), (float)g));
+    if (c < -1.f || c > (float)size) return false;
+    float cc = c <= 0.f ? 0.f : c;
+    lo = (int)cc;
+    if (lo >= size - 1) { hi = lo = size - 1; cc = (float)lo; } else hi = lo + 1;
+    l = __fsub_rn(cc, (float)lo);
+    h = __fsub_rn(1.f, l);
+    return true;
+}
+
 // One block (256 threads = 4 waves) per (RoI, part); wave g = part * 4 + wave walks bins g, g + 4 * parts, ...; lane =
 // channel quad. A bin is the mean of gh x gw bilinear samples = 4 corner loads each; summed one sample after the other
 // (the oracle's order: iy outer, ix inner, ((w1 v1 + w2 v2) + w3 v3) + w4 v4 per sample) the loop is a chain of
@@ -54,33 +115,12 @@ __global__ __launch_bounds__(256) void roi_align_kernel(FeatLevels fl, const flo
                                                         int pooled, int compact, T* __restrict__ out,
                                                         int* __restrict__ total_rows, int single_level, int parts) {
     const int item = blockIdx.y, r = blockIdx.x / parts, part = blockIdx.x - r * parts;
-    const int cnt = counts ? counts[item] : roi_stride;
-    int prefix = 0;
-    if (compact) {
-        for (int i = 0; i < item; ++i) prefix += counts[i];
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && total_rows) {
-            int t = 0;
-            for (int i = 0; i < items; ++i) t += counts[i];
-            *total_rows = t;
-        }
-    }
-    if (r >= cnt) return;
-    const size_t row = compact ? (size_t)(prefix + r) : (size_t)item * roi_stride + r;
-    const float4 bx = *reinterpret_cast<const float4*>(rois + ((size_t)item * roi_stride + r) * 4);
-    const int lvl = single_level ? 0 : fpn_level(bx.x, bx.y, bx.z, bx.w);
-    const int H = fl.h[lvl], W = fl.w[lvl], C = fl.C;
-    const float sc = fl.scale[lvl];
-    const T* __restrict__ feat = static_cast<const T*>(fl.feat[lvl]) + (single_level ? 0 : (size_t)item * H * W * C);
-
-    const float sw = __fsub_rn(__fmul_rn(bx.x, sc), 0.5f), sh = __fsub_rn(__fmul_rn(bx.y, sc), 0.5f);
-    const float ew = __fsub_rn(__fmul_rn(bx.z, sc), 0.5f), eh = __fsub_rn(__fmul_rn(bx.w, sc), 0.5f);
-    const float rw = __fsub_rn(ew, sw), rh = __fsub_rn(eh, sh);
-    const float bh = __fdiv_rn(rh, (float)pooled), bw = __fdiv_rn(rw, (float)pooled);
-    int gh = (int)ceilf(__fdiv_rn(rh, (float)pooled)), gw = (int)ceilf(__fdiv_rn(rw, (float)pooled));
-    gh = gh > 0 ? gh : 0;
-    gw = gw > 0 ? gw : 0;
-    const int ghw = gh * gw;
-    const float count = (float)(ghw > 1 ? ghw : 1);
+    RoiGeo geo;
+    if (!roi_setup(fl, rois, counts, items, roi_stride, pooled, compact, total_rows, single_level, item, r, geo)) return;
+    const size_t row = geo.row;
+    const int H = geo.H, W = geo.W, C = fl.C, gh = geo.gh, gw = geo.gw, ghw = geo.ghw;
+    const float sh = geo.sh, sw = geo.sw, bh = geo.bh, bw = geo.bw, count = geo.count;
+    const T* __restrict__ feat = static_cast<const T*>(fl.feat[geo.lvl]) + geo.feat_off;
 
     // Sample coordinates are the same for every channel lane: tabulate the (lo, hi, weights, in-range) tuple of every
     // y-sample and x-sample of this RoI ONCE in LDS (same float32 operation order as the oracle), so the bin loop
@@ -89,17 +129,6 @@ __global__ __launch_bounds__(256) void roi_align_kernel(FeatLevels fl, const flo
     __shared__ int t_lo[2][TAB], t_hi[2][TAB];
     __shared__ float t_l[2][TAB], t_h[2][TAB];
     const bool tab = pooled * gh <= TAB && pooled * gw <= TAB;
-    auto sample = [&](float start, float bin, int p, int i, int g, int size, int& lo, int& hi, float& l, float& h) -> bool {
-        const float c = __fadd_rn(__fadd_rn(start, __fmul_rn((float)p, bin)),
-                                  __fdiv_rn(__fmul_rn(__fadd_rn((float)i, 0.5f), bin), (float)g));
-        if (c < -1.f || c > (float)size) return false;
-        float cc = c <= 0.f ? 0.f : c;
-        lo = (int)cc;
-        if (lo >= size - 1) { hi = lo = size - 1; cc = (float)lo; } else hi = lo + 1;
-        l = __fsub_rn(cc, (float)lo);
-        h = __fsub_rn(1.f, l);
-        return true;
-    };
     if (tab) {
         for (int t = threadIdx.x; t < pooled * gh + pooled * gw; t += blockDim.x) {
             const int ax = t < pooled * gh ? 0 : 1;
@@ -108,7 +137,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(FeatLevels fl, const flo
             const int p = u / g, i = u - p * g;
             int lo = 0, hi = 0;
             float l = 0.f, h = 0.f;
-            const bool ok = ax ? sample(sw, bw, p, i, g, W, lo, hi, l, h) : sample(sh, bh, p, i, g, H, lo, hi, l, h);
+            const bool ok = ax ? roi_sample(sw, bw, p, i, g, W, lo, hi, l, h) : roi_sample(sh, bh, p, i, g, H, lo, hi, l, h);
             t_lo[ax][u] = ok ? lo : -1;
             t_hi[ax][u] = hi;
             t_l[ax][u] = l;
@@ -210,11 +239,11 @@ __global__ __launch_bounds__(256) void roi_align_kernel(FeatLevels fl, const flo
             for (int iy = 0; iy < gh; ++iy) {
                 int yl, yh;
                 float ly, hy;
-                if (!sample(sh, bh, ph, iy, gh, H, yl, yh, ly, hy)) continue;
+                if (!roi_sample(sh, bh, ph, iy, gh, H, yl, yh, ly, hy)) continue;
                 for (int ix = 0; ix < gw; ++ix) {
                     int xl, xh;
                     float lx, hx;
-                    if (!sample(sw, bw, pw, ix, gw, W, xl, xh, lx, hx)) continue;
+                    if (!roi_sample(sw, bw, pw, ix, gw, W, xl, xh, lx, hx)) continue;
                     const float w1 = __fmul_rn(hy, hx), w2 = __fmul_rn(hy, lx), w3 = __fmul_rn(ly, hx), w4 = __fmul_rn(ly, lx);
                     const float4 v1 = load4(feat + ((size_t)yl * W + xl) * C + c0);
                     const float4 v2 = load4(feat + ((size_t)yl * W + xh) * C + c0);
@@ -249,33 +278,12 @@ __global__ __launch_bounds__(256) void roi_align_h8_kernel(FeatLevels fl, const 
                                                            int pooled, int compact, _Float16* __restrict__ out,
                                                            int* __restrict__ total_rows, int single_level, int parts) {
     const int item = blockIdx.y, r = blockIdx.x / parts, part = blockIdx.x - r * parts;
-    const int cnt = counts ? counts[item] : roi_stride;
-    int prefix = 0;
-    if (compact) {
-        for (int i = 0; i < item; ++i) prefix += counts[i];
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && total_rows) {
-            int t = 0;
-            for (int i = 0; i < items; ++i) t += counts[i];
-            *total_rows = t;
-        }
-    }
-    if (r >= cnt) return;
-    const size_t row = compact ? (size_t)(prefix + r) : (size_t)item * roi_stride + r;
-    const float4 bx = *reinterpret_cast<const float4*>(rois + ((size_t)item * roi_stride + r) * 4);
-    const int lvl = single_level ? 0 : fpn_level(bx.x, bx.y, bx.z, bx.w);
-    const int H = fl.h[lvl], W = fl.w[lvl], C = fl.C;
-    const float sc = fl.scale[lvl];
-    const _Float16* __restrict__ feat = static_cast<const _Float16*>(fl.feat[lvl]) + (single_level ? 0 : (size_t)item * H * W * C);
-
-    const float sw = __fsub_rn(__fmul_rn(bx.x, sc), 0.5f), sh = __fsub_rn(__fmul_rn(bx.y, sc), 0.5f);
-    const float ew = __fsub_rn(__fmul_rn(bx.z, sc), 0.5f), eh = __fsub_rn(__fmul_rn(bx.w, sc), 0.5f);
-    const float rw = __fsub_rn(ew, sw), rh = __fsub_rn(eh, sh);
-    const float bh = __fdiv_rn(rh, (float)pooled), bw = __fdiv_rn(rw, (float)pooled);
-    int gh = (int)ceilf(__fdiv_rn(rh, (float)pooled)), gw = (int)ceilf(__fdiv_rn(rw, (float)pooled));
-    gh = gh > 0 ? gh : 0;
-    gw = gw > 0 ? gw : 0;
-    const int ghw = gh * gw;
-    const float count = (float)(ghw > 1 ? ghw : 1);
+    RoiGeo geo;
+    if (!roi_setup(fl, rois, counts, items, roi_stride, pooled, compact, total_rows, single_level, item, r, geo)) return;
+    const size_t row = geo.row;
+    const int H = geo.H, W = geo.W, C = fl.C, gh = geo.gh, gw = geo.gw, ghw = geo.ghw;
+    const float sh = geo.sh, sw = geo.sw, bh = geo.bh, bw = geo.bw, count = geo.count;
+    const _Float16* __restrict__ feat = static_cast<const _Float16*>(fl.feat[geo.lvl]) + geo.feat_off;
     const int nbins = pooled * pooled;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hl = lane >> 5, c0 = (lane & 31) * 8;
@@ -284,17 +292,6 @@ __global__ __launch_bounds__(256) void roi_align_h8_kernel(FeatLevels fl, const 
     constexpr int TAB = 14 * 24;
     __shared__ int4 tq[2][TAB];      // {lo (-1: sample outside), hi, bits(l), bits(h)} per y-sample / x-sample
     const bool tab = pooled * gh <= TAB && pooled * gw <= TAB;
-    auto sample = [&](float start, float bin, int p, int i, int g, int size, int& lo, int& hi, float& l, float& h) -> bool {
-        const float c = __fadd_rn(__fadd_rn(start, __fmul_rn((float)p, bin)),
-                                  __fdiv_rn(__fmul_rn(__fadd_rn((float)i, 0.5f), bin), (float)g));
-        if (c < -1.f || c > (float)size) return false;
-        float cc = c <= 0.f ? 0.f : c;
-        lo = (int)cc;
-        if (lo >= size - 1) { hi = lo = size - 1; cc = (float)lo; } else hi = lo + 1;
-        l = __fsub_rn(cc, (float)lo);
-        h = __fsub_rn(1.f, l);
-        return true;
-    };
     if (!tab || ghw == 0) {
         // no samples (every bin is 0) or a sampling grid too large for the table: one sample at a time, 8 channels per lane,
         // the two halves of a wave on two bins
@@ -306,11 +303,11 @@ __global__ __launch_bounds__(256) void roi_align_h8_kernel(FeatLevels fl, const 
             for (int iy = 0; iy < gh; ++iy) {
                 int yl, yh;
                 float ly, hy;
-                if (!sample(sh, bh, ph, iy, gh, H, yl, yh, ly, hy)) continue;
+                if (!roi_sample(sh, bh, ph, iy, gh, H, yl, yh, ly, hy)) continue;
                 for (int ix = 0; ix < gw; ++ix) {
                     int xl, xh;
                     float lx, hx;
-                    if (!sample(sw, bw, pw, ix, gw, W, xl, xh, lx, hx)) continue;
+                    if (!roi_sample(sw, bw, pw, ix, gw, W, xl, xh, lx, hx)) continue;
                     if (!act) continue;
                     const float w1 = __fmul_rn(hy, hx), w2 = __fmul_rn(hy, lx), w3 = __fmul_rn(ly, hx), w4 = __fmul_rn(ly, lx);
                     const h8 v1 = *reinterpret_cast<const h8*>(feat + ((size_t)yl * W + xl) * C + c0);
@@ -339,7 +336,7 @@ __global__ __launch_bounds__(256) void roi_align_h8_kernel(FeatLevels fl, const 
         const int p = u / g, i = u - p * g;
         int lo = 0, hi = 0;
         float l = 0.f, h = 0.f;
-        const bool ok = ax ? sample(sw, bw, p, i, g, W, lo, hi, l, h) : sample(sh, bh, p, i, g, H, lo, hi, l, h);
+        const bool ok = ax ? roi_sample(sw, bw, p, i, g, W, lo, hi, l, h) : roi_sample(sh, bh, p, i, g, H, lo, hi, l, h);
         tq[ax][u] = make_int4(ok ? lo : -1, hi, __float_as_int(l), __float_as_int(h));
     }
     __syncthreads();
