@@ -379,12 +379,19 @@ void conv_igemm_kernel(const ConvArgs a_in) {
     const unsigned src_piece = (unsigned)(ld_c ^ ((ld_r >> 1) & 7)) * 16;
 
     unsigned a_off[AROWS], a_ok[AROWS];      // byte offset of tap (0,0); bit t set = tap t reads a real pixel
+    // plain contractions (1x1, stride 1, no padding: most launches, and every Winograd plane) address row m directly — the
+    // (image, y, x) decomposition costs two integer divisions per staged row, a visible part of a block that runs only a
+    // handful of k-steps
+    const bool plain_rows = ntaps == 1 && a.stride == 1 && a.pad == 0;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
         const int m = m0 + ld_r + LDROWS * i;
         a_off[i] = 0;
         a_ok[i] = 0;
-        if (m < M) {
+        if (m < M && plain_rows) {
+            a_off[i] = (unsigned)m * pix_bytes + src_piece;
+            a_ok[i] = 1u;
+        } else if (m < M) {
             const int hw = a.Ho * a.Wo;
             const int b = m / hw;
             const int rem = m - b * hw;
