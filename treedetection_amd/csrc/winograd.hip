@@ -168,18 +168,20 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
                                                            float* __restrict__ V, long long T, const int* __restrict__ m_dyn) {
     const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;
     const int c4n = C >> 2;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long t = idx / c4n;
-    const int c = (int)(idx - t * c4n) * 4;
+    // 32-bit index arithmetic (the launcher checks T * C / 4 < 2^31): 64-bit divisions are ~5x the instructions
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned t = idx / (unsigned)c4n;
+    const int c = (int)(idx - t * (unsigned)c4n) * 4;
     long long live = T;
     if (m_dyn) {
         const long long n = (long long)*m_dyn * TH * TW;
         live = n < T ? n : T;
     }
-    if (t >= live) return;
-    const int tx = (int)(t % TW);
-    const int ty = (int)((t / TW) % TH);
-    const int b = (int)(t / ((long long)TW * TH));
+    if ((long long)t >= live) return;
+    const unsigned tyx = t % (unsigned)(TW * TH);
+    const int b = (int)(t / (unsigned)(TW * TH));
+    const int ty = (int)(tyx / (unsigned)TW);
+    const int tx = (int)(tyx - (unsigned)ty * (unsigned)TW);
     const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
     float4 d[6][6];
 #pragma unroll
@@ -231,18 +233,20 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
                                                             const int* __restrict__ m_dyn) {
     const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;
     const int c4n = N >> 2;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long t = idx / c4n;
-    const int c = (int)(idx - t * c4n) * 4;
+    // 32-bit index arithmetic (the launcher checks T * C / 4 < 2^31): 64-bit divisions are ~5x the instructions
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned t = idx / (unsigned)c4n;
+    const int c = (int)(idx - t * (unsigned)c4n) * 4;
     long long live = T;
     if (m_dyn) {
         const long long n = (long long)*m_dyn * TH * TW;
         live = n < T ? n : T;
     }
-    if (t >= live) return;
-    const int tx = (int)(t % TW);
-    const int ty = (int)((t / TW) % TH);
-    const int b = (int)(t / ((long long)TW * TH));
+    if ((long long)t >= live) return;
+    const unsigned tyx = t % (unsigned)(TW * TH);
+    const int b = (int)(t / (unsigned)(TW * TH));
+    const int ty = (int)(tyx / (unsigned)TW);
+    const int tx = (int)(tyx - (unsigned)ty * (unsigned)TW);
     float4 s[4][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {            // A^T M, column by column
@@ -320,7 +324,7 @@ td_status wino43_input_launch(const float* x, int B, int H, int W, int C, float*
     TD_REQUIRE(x && V && B >= 1 && H >= 1 && W >= 1 && C >= 4 && (C & 3) == 0, "winograd F(4x4) input transform: bad arguments");
     const long long T = (long long)B * ((H + 3) / 4) * ((W + 3) / 4);
     const long long threads = T * (C / 4);
-    TD_REQUIRE((threads + 255) / 256 < (1ll << 31), "winograd F(4x4) input transform: grid too large");
+    TD_REQUIRE(threads < (1ll << 31), "winograd F(4x4) input transform: grid too large");
     hipLaunchKernelGGL(wino43_input_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, B, H, W, C, V, T, m_dyn);
     TD_KERNEL_CHECK();
     return TD_OK;
@@ -331,7 +335,7 @@ td_status wino43_output_launch(const float* Mb, int B, int H, int W, int N, cons
     TD_REQUIRE(Mb && y && B >= 1 && H >= 1 && W >= 1 && N >= 4 && (N & 3) == 0, "winograd F(4x4) output transform: bad arguments");
     const long long T = (long long)B * ((H + 3) / 4) * ((W + 3) / 4);
     const long long threads = T * (N / 4);
-    TD_REQUIRE((threads + 255) / 256 < (1ll << 31), "winograd F(4x4) output transform: grid too large");
+    TD_REQUIRE(threads < (1ll << 31), "winograd F(4x4) output transform: grid too large");
     hipLaunchKernelGGL(wino43_output_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, Mb, B, H, W, N, scale, bias,
                        relu, y, T, m_dyn);
     TD_KERNEL_CHECK();
