@@ -38,22 +38,22 @@ def schedule(depth=50, B=8, Hp=800, Wp=800, P=1000):
     return L
 
 
-def launches_of(name, M, N, K, fp32, B=8, min43=40):
+def launches_of(name, M, N, K, fp32, B=8, min43=12):
     """fp32 engine (engine.cpp run_conv): 3x3 stride-1 layers with >= 128 channels on both sides take a Winograd path —
     F(4x4,3x3) on maps of at least `min43` pixels a side: three launches (wino43_input_kernel, the batched conv_igemm launch,
     wino43_output_kernel); F(2x2,3x3) otherwise: two (wino_gemm_kernel + wino_output_kernel). → (launch count, label)"""
     three = ("conv2" in name or "fpn_output" in name or "rpn_conv" in name or "mask_fcn" in name)
     if not (fp32 and three and N >= 128 and K // 9 >= 128):
         return 1, None
-    side = int(round((M / B) ** 0.5)) if M else 0
-    if M and min43 > 0 and side >= min43:
+    side = int(round((M / B) ** 0.5)) if M else 14          # M = 0: the mask head's 14 x 14 RoIs (device-side row count)
+    if min43 > 0 and side >= min43:
         return 3, "winograd F(4x4)"
     return 2, "winograd F(2x2)"
 
 
 def main(path, depth=50, fp32=False):
     import os
-    min43 = int(os.environ.get("TD_WINO43_MIN", "40"))
+    min43 = int(os.environ.get("TD_WINO43_MIN", "12"))
     fam = ("conv_igemm", "conv_pp8", "wino_gemm", "wino_output", "wino_input", "wino43_input", "wino43_output")
     rows = [r for r in csv.DictReader(open(path)) if any(f in r["Kernel_Name"] for f in fam)]
     L = schedule(depth)
