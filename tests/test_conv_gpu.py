@@ -258,6 +258,16 @@ def test_winograd_f4x4_conv_matches_torch(case):
     finally:
         del os.environ["TD_WINO_TILE"]
     assert torch.equal(ys[0], ys[1])                            # deterministic
+    # the persistent plane-contraction kernels (tile ids 18-20, plane_gemm_kernel) keep the k order: same bits
+    for cfg in ("18", "19", "20", "0", "3"):
+        os.environ["TD_WINO_TILE"], os.environ["TD_CONV_CFG"] = "4", cfg
+        try:
+            y = torch.full((B, H, W, Cout), float("nan"), dtype=torch.float32, device="cuda")
+            _lib.check(lib.td_conv2d_winograd_nhwc(p(xd), p(wd), p(sd), p(bd), y.data_ptr(), B, H, W, Cin, Cout, int(relu), _lib.stream_ptr()),
+                       "td_conv2d_winograd_nhwc")
+        finally:
+            del os.environ["TD_WINO_TILE"], os.environ["TD_CONV_CFG"]
+        assert torch.equal(y, ys[0]), f"tile_cfg {cfg} differs"
     got = ys[0].cpu().numpy().transpose(0, 3, 1, 2)
     assert np.isfinite(got).all()
     err = np.abs(got - ref).max()

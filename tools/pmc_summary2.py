@@ -18,6 +18,8 @@ def family(name):
         return "conv_pp8_kernel"
     if "conv_igemm" in name:
         return "conv_igemm_kernel"
+    if "plane_gemm" in name:
+        return "plane_gemm_kernel"
     for k in ("wino_gemm", "wino43_input", "wino43_output", "wino_input", "wino_output", "stem_conv", "maxpool", "roi_align", "rpn_topk",
               "rpn_keys", "nms_", "paste", "resize_"):
         if k in name:
@@ -71,13 +73,13 @@ def main():
                "mfma_util": f["SQ_VALU_MFMA_BUSY_CYCLES"] / simd if simd else 0.0,
                "hbm_tb_per_s": hbm / (f["us"] * 1e-6) / 1e12 if f["us"] else 0.0}
         out["families"][name] = rec
-        if name in ("conv_igemm_kernel", "conv_pp8_kernel", "wino_gemm_kernel", "wino_input_kernel", "wino_output_kernel",
+        if name in ("conv_igemm_kernel", "conv_pp8_kernel", "plane_gemm_kernel", "wino_gemm_kernel", "wino_input_kernel", "wino_output_kernel",
                     "wino43_input_kernel", "wino43_output_kernel"):
             for k in ("launches", "us", "SQ_VALU_MFMA_BUSY_CYCLES"):
                 conv[k] += f[k]
             conv["hbm"] += hbm
             conv["simd"] += simd
-    out["conv_family"] = {"members": "conv_igemm_kernel + conv_pp8_kernel + wino_gemm_kernel + wino_input_kernel + wino_output_kernel + "
+    out["conv_family"] = {"members": "conv_igemm_kernel + conv_pp8_kernel + plane_gemm_kernel + wino_gemm_kernel + wino_input_kernel + wino_output_kernel + "
                                      "wino43_input_kernel + wino43_output_kernel",
                           "launches": conv["launches"] / steps, "ms_per_step": conv["us"] / steps / 1e3,
                           "hbm_traffic_gb_per_step": conv["hbm"] / steps / 1e9,

@@ -9,7 +9,7 @@ import sys
 
 
 def short(n):
-    for k in ("conv_pp8", "conv_igemm", "wino_gemm", "wino_output", "stem_conv", "maxpool", "roi_align", "rpn_topk", "nms_scan", "nms_mask",
+    for k in ("conv_pp8", "conv_igemm", "plane_gemm", "wino_gemm", "wino_output", "stem_conv", "maxpool", "roi_align", "rpn_topk", "nms_scan", "nms_mask",
               "paste_fill", "paste_plan", "mask_predict", "resize_v", "resize_h", "rpn_merge", "sort_boxes", "det_", "mask_scatter", "subsample", "copyBuffer"):
         if k in n:
             return k

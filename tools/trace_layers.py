@@ -54,7 +54,7 @@ def launches_of(name, M, N, K, fp32, B=8, min43=12):
 def main(path, depth=50, fp32=False):
     import os
     min43 = int(os.environ.get("TD_WINO43_MIN", "12"))
-    fam = ("conv_igemm", "conv_pp8", "wino_gemm", "wino_output", "wino_input", "wino43_input", "wino43_output")
+    fam = ("conv_igemm", "conv_pp8", "plane_gemm", "wino_gemm", "wino_output", "wino_input", "wino43_input", "wino43_output")
     rows = [r for r in csv.DictReader(open(path)) if any(f in r["Kernel_Name"] for f in fam)]
     L = schedule(depth)
     need = sum(launches_of(n, M, N, K, fp32, 8, min43)[0] for n, M, N, K in L)

@@ -56,10 +56,12 @@ struct ConvArgs {
 // tile_cfg ids (conv_igemm.hip:dispatch): 0..3 4-wave tiles 128x128 / 128x64 / 64x128 / 64x64 (2 LDS stages), 4..7 the same
 // with 3 stages (measured no better: not tuned over), 8 = 256x128 / 9 = 128x256 (8 waves), 10 = 256x256 (16 waves),
 // 11..13 = 256x256 with larger per-wave tiles, 14..16 = single-LDS-stage 256x256 / 128x128 / 128x256 (thin 1x1 layers),
-// 17 = conv_pp8_kernel: 256x256, 8 waves, ping-pong phases, DMA 1.5 k-chunks ahead (fp16 only)
-#define TD_CONV_TILE_CFG_MAX 17
-static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16
+// 17 = conv_pp8_kernel: 256x256, 8 waves, ping-pong phases, DMA 1.5 k-chunks ahead (fp16 only),
+// 18..20 = plane_gemm_kernel: persistent 64x128 / 128x128 / 64x64 tile walk for the fp32 Winograd plane contractions
+#define TD_CONV_TILE_CFG_MAX 20
+static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17, 18, 19, 20};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16, 18-20 only for plane contractions
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
+bool conv_plane_ok(const ConvArgs& a, int precision);       // tile ids 18-20 apply to this launch
 td_status wino_gemm_launch(const ConvArgs& a, hipStream_t stream);     // Winograd plane contractions, input transform fused (fp32)
 
 // ---- Winograd F(2x2,3x3) transforms (winograd.hip; fp32 engine) ---------------------------------

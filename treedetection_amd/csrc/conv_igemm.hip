@@ -531,6 +531,163 @@ void conv_igemm_kernel(const ConvArgs a_in) {
     conv_epilogue<T, TO, MT, NT, WM, WN, RWM, WIDE_OK>(a, acc, lds, M, m0, n0, tid, lane, wm, wn);
 }
 
+// ---- plane_gemm_kernel: PERSISTENT tile walk for the Winograd plane contractions (fp32) -------------------------------------
+// A plane contraction M_xi[t][n] = sum_c V_xi[t][c] U_xi[n][c] has K = Cin = 128 .. 512: four to sixteen k-steps per
+// block tile. In conv_igemm_kernel such a block lives ≈ 28 us of which ≈ 7 are not MFMA work — block launch, address
+// set-up, the first loads' HBM latency (V is streamed once, never cached), the LDS-staged epilogue — and with three
+// blocks per CU the matrix pipe ends at 0.73 (FPN output 2: 94 executed GFLOP in 824 us). Here a block stays resident
+// and walks tiles t = i G + b (G = grid, XCD-remapped so that one XCD's blocks take neighbouring tiles); its k-steps
+// form ONE continuous stream across tile boundaries — the DMA of the next tile's first k-step is issued under the
+// last MFMAs of the current tile, exactly like any other k-step — and a finished tile leaves straight from the
+// accumulator registers (a register of a 32 x 32 MFMA tile is 32 consecutive floats of one row per half-wave: whole
+// 128-B lines; planes carry no scale / bias / residual), so the staging LDS is never borrowed by an epilogue. Same k
+// order → bit-identical to every other block tile (tests/test_conv_gpu.py).
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void plane_gemm_kernel(const ConvArgs a) {
+    typedef float T;
+    constexpr int WN = 2, THREADS = 256;
+    constexpr int BM = 64 * MT, BN = 64 * NT;
+    constexpr int LDROWS = THREADS / 8;               // 32 rows per DMA pass
+    constexpr int AROWS = BM / LDROWS, BROWS = BN / LDROWS;
+    __shared__ __attribute__((aligned(16))) char lds[2 * (BM + BN) * CHUNK_BYTES];
+    char* As = lds;                                   // [2][BM][128 B], XOR-swizzled pieces as in conv_igemm_kernel
+    char* Bs = lds + 2 * BM * CHUNK_BYTES;            // [2][BN][128 B]
+
+    int M = a.M;
+    if (a.m_dyn) {
+        int md = *a.m_dyn * a.m_mul - a.m_off;
+        md = md < 0 ? 0 : md;
+        M = md < M ? md : M;
+    }
+    const int planes = a.batch_count > 1 ? a.batch_count : 1;
+    const int tiles_n = (a.Cout + BN - 1) / BN;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int per_plane = tiles_m * tiles_n;
+    const int total = per_plane * planes;
+    const int G = gridDim.x;
+    const int me = xcd_remap(blockIdx.x, G);
+    if (me >= total) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ld_c = tid & 7, ld_r = tid >> 3;
+    const int cchunks = a.Cin / 32;
+    const unsigned pix_bytes = (unsigned)a.Cin * 4;
+    const unsigned src_piece = (unsigned)(ld_c ^ ((ld_r >> 1) & 7)) * 16;
+    const unsigned x_records = (unsigned)((size_t)a.M * pix_bytes), w_records = (unsigned)((size_t)a.Cout * pix_bytes);
+    constexpr unsigned OOB = 0xfffffff0u;
+    typedef __attribute__((address_space(3))) void lds_void;
+    const unsigned wave_rows = (unsigned)__builtin_amdgcn_readfirstlane(wave) * 8u;
+
+    // ---- loader cursor: runs one k-step ahead of the MFMAs, across tile boundaries ----
+    int l_t = me, l_cc = 0;
+    bool l_more = true;
+    unsigned a_off[AROWS], b_off[BROWS];
+    __amdgpu_buffer_rsrc_t xrsrc, wrsrc;
+    auto load_setup = [&](int t) {
+        const int plane = t / per_plane, r = t - plane * per_plane;
+        const int tm = r / tiles_n, tn = r - tm * tiles_n;
+        xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(static_cast<const T*>(a.x) + (long long)plane * a.x_bs), 0, (int)x_records, 0x00020000);
+        wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(static_cast<const T*>(a.w) + (long long)plane * a.w_bs), 0, (int)w_records, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            const int m = tm * BM + ld_r + LDROWS * i;
+            a_off[i] = m < M ? (unsigned)m * pix_bytes + src_piece : OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            const int n = tn * BN + ld_r + LDROWS * i;
+            b_off[i] = n < a.Cout ? (unsigned)n * pix_bytes + src_piece : OOB;
+        }
+    };
+    auto stage = [&](int buf) {
+        const unsigned cs = (unsigned)l_cc * CHUNK_BYTES;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            const unsigned off = a_off[i] == OOB ? OOB : a_off[i] + cs;
+            char* dst = As + ((unsigned)buf * BM + (unsigned)LDROWS * i + wave_rows) * CHUNK_BYTES;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)dst, 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            const unsigned off = b_off[i] == OOB ? OOB : b_off[i] + cs;
+            char* dst = Bs + ((unsigned)buf * BN + (unsigned)LDROWS * i + wave_rows) * CHUNK_BYTES;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)dst, 16, off, 0, 0, 0);
+        }
+        if (++l_cc == cchunks) {                      // the next k-step belongs to the next tile of this block
+            l_cc = 0;
+            l_t += G;
+            if (l_t < total) load_setup(l_t);
+            else l_more = false;
+        }
+    };
+
+    const unsigned swz = (lane >> 1) & 7, hi = lane >> 5;
+    unsigned frag_off[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) frag_off[kk] = (unsigned)(lane & 31) * CHUNK_BYTES + (((unsigned)(2 * kk) + hi) ^ swz) * 16;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto compute = [&](int buf) {
+        const char* Ab = &As[(buf * BM + wm * 32 * MT) * CHUNK_BYTES];
+        const char* Bb = &Bs[(buf * BN + wn * 32 * NT) * CHUNK_BYTES];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * CHUNK_BYTES + frag_off[kk]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * CHUNK_BYTES + frag_off[kk]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) Elem<T>::mma(fa[i], fb[j], acc[i][j]);
+        }
+    };
+
+    // ---- compute cursor ----
+    int c_t = me, c_cc = 0, cur = 0;
+    load_setup(l_t);
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    while (true) {
+        if (l_more) stage(cur ^ 1);
+        compute(cur);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next k-step has landed (and the previous tile's stores are out)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+        if (++c_cc == cchunks) {
+            // tile c_t is complete: store it from the accumulator layout and start the next one
+            const int plane = c_t / per_plane, r = c_t - plane * per_plane;
+            const int tm = r / tiles_n, tn = r - tm * tiles_n;
+            float* __restrict__ Y = static_cast<float*>(a.y) + (long long)plane * a.y_bs;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int n = tn * BN + wn * 32 * NT + j * 32 + (lane & 31);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int m = tm * BM + wm * 32 * MT + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                        if (m < M && n < a.Cout) Y[(size_t)m * a.Cout + n] = acc[i][j][q];
+                        acc[i][j][q] = 0.f;
+                    }
+                }
+            c_cc = 0;
+            c_t += G;
+            if (c_t >= total) break;
+        }
+    }
+}
+
 // ---- wino_gemm_kernel: the 16 plane contractions of Winograd F(2x2,3x3) with the INPUT TRANSFORM FUSED into the A
 // staging (fp32 engine; winograd.hip holds the algebra and the output transform) ------------------------------------------
 //   M_xi[t][n] = sum_c V_xi[t][c] * U_xi[n][c],   V_xi[t][c] = (B^T d B)[xi] of tile t's 4x4 input patch
@@ -1079,6 +1236,25 @@ td_status dispatch(const ConvArgs& a, int cfg, hipStream_t stream) {
                 td_set_error("conv2d: tile_cfg 17 is an fp16 kernel");
                 return TD_ERR_INVALID;
             }
+        case 18:                                                     // persistent plane contractions (fp32 Winograd planes)
+        case 19:
+        case 20:
+            if constexpr (std::is_same<T, float>::value && std::is_same<TO, float>::value) {
+                const int planes = a.batch_count > 1 ? a.batch_count : 1;
+                const int bm = cfg == 19 ? 128 : 64, bn = cfg == 20 ? 64 : 128;
+                const long long total = (long long)td_cdiv(a.M, bm) * td_cdiv(a.Cout, bn) * planes;
+                const int per_cu = (160 * 1024) / (2 * (bm + bn) * CHUNK_BYTES);       // resident blocks per CU by LDS
+                const long long cap = 256ll * (per_cu > 0 ? per_cu : 1);
+                const unsigned grid = (unsigned)(total < cap ? total : cap);
+                if (cfg == 18) hipLaunchKernelGGL((plane_gemm_kernel<1, 2>), dim3(grid), dim3(256), 0, stream, a);
+                else if (cfg == 19) hipLaunchKernelGGL((plane_gemm_kernel<2, 2>), dim3(grid), dim3(256), 0, stream, a);
+                else hipLaunchKernelGGL((plane_gemm_kernel<1, 1>), dim3(grid), dim3(256), 0, stream, a);
+                TD_KERNEL_CHECK();
+                return TD_OK;
+            } else {
+                td_set_error("conv2d: tile_cfg 18-20 are fp32 kernels");
+                return TD_ERR_INVALID;
+            }
         default: td_set_error("conv2d: bad tile_cfg %d", cfg); return TD_ERR_INVALID;
     }
 }
@@ -1097,6 +1273,13 @@ td_status wino_gemm_launch(const ConvArgs& a, hipStream_t stream) {
     return TD_OK;
 }
 
+// tile ids 18-20 (plane_gemm_kernel) take exactly the Winograd plane contractions: fp32, plain rows, raw accumulator output
+bool conv_plane_ok(const ConvArgs& a, int precision) {
+    return precision == TD_PRECISION_FP32 && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.out_mode == 0 && !a.scale &&
+           !a.bias && !a.res && !a.relu && !a.out_f32 && a.m_off == 0 && a.Cin >= 32 && a.Cin % 32 == 0 && a.M > 0 && a.Cout > 0 &&
+           (size_t)a.M * a.Cin * 4 < 0xfffffff0ull - (1u << 20);
+}
+
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream) {
     const int ke = precision == TD_PRECISION_FP16 ? 64 : 32;
     TD_REQUIRE(precision == TD_PRECISION_FP32 || precision == TD_PRECISION_FP16, "conv2d: bad precision %d", precision);
@@ -1109,10 +1292,11 @@ td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream) {
     TD_REQUIRE(a.out_mode == 0 || (a.Cout % 32 == 0 && !a.res), "conv2d: bad deconv configuration");
     int cfg = a.tile_cfg;
     if (cfg < 0) {
-        static const char* forced = getenv("TD_CONV_CFG");     // diagnostics only (tools/conv_diag.py)
+        const char* forced = getenv("TD_CONV_CFG");            // diagnostics / tests only (read per call: tests switch it)
         if (forced) cfg = atoi(forced);
     }
     if (cfg == 17 && (precision != TD_PRECISION_FP16 || a.out_mode != 0 || a.batch_count > 1)) cfg = -1;      // fp16-only variant
+    if (cfg >= 18 && cfg <= 20 && !conv_plane_ok(a, precision)) cfg = -1;                                       // plane contractions only
     TD_REQUIRE(a.batch_count <= 1 || (a.KH == 1 && a.KW == 1 && !a.res), "conv2d: batched launches are 1x1 contractions");
     if (cfg < 0) {
         // heuristic (the engine replaces it by a measured choice per layer shape): wide N for wide layers, 64-row

@@ -732,10 +732,11 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         return TD_OK;
     };
     // measured block tile of one launch shape (cached per engine, shared through the TD_TUNE_CACHE file)
-    auto tuned_cfg = [&](const std::tuple<int, int, int, int, int>& key, int prec_, int ksteps, bool pp8_ok, hipStream_t s_,
+    auto tuned_cfg = [&](const std::tuple<int, int, int, int, int>& key, int prec_, int ksteps, bool pp8_ok, bool plane_ok, hipStream_t s_,
                          auto&& launch_cfg, int* cfg_out, float* best_ms) -> td_status {
         static const int forced = getenv("TD_FORCE_CFG") ? atoi(getenv("TD_FORCE_CFG")) : -1;      // diagnostics: one block tile everywhere it applies
-        if (forced >= 0 && forced <= TD_CONV_TILE_CFG_MAX && !best_ms && !(forced >= 14 && forced <= 16 && ksteps > 4) && !(forced == 17 && !pp8_ok)) {
+        if (forced >= 0 && forced <= TD_CONV_TILE_CFG_MAX && !best_ms && !(forced >= 14 && forced <= 16 && ksteps > 4) && !(forced == 17 && !pp8_ok) &&
+            !(forced >= 18 && !plane_ok)) {
             *cfg_out = forced;
             return TD_OK;
         }
@@ -757,6 +758,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
             if (it != e->tuned.end() && c != it->second) continue;       // known choice: only its time is wanted
             if (c >= 14 && c <= 16 && ksteps > 4) continue;      // single-stage tiles only pay on the thin 1x1 layers
             if (c == 17 && !pp8_ok) continue;                    // fp16 256x256 ping-pong tile
+            if (c >= 18 && c <= 20 && !plane_ok) continue;       // persistent tile walk: Winograd plane contractions only
             float ms = 1e30f;
             td_status st2 = time_launch(s_, ea, eb, [&]() { return launch_cfg(c); }, &ms);
             if (st2 < 0) return st2;
@@ -865,11 +867,11 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                 if (use_43) {
                     const auto key43 = std::make_tuple(L.cout, L.cin, 1 * 16 + 1, (int)T43, 4 + 64);
                     auto w43 = [&](int c) { return run_wino43(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, c); };
-                    if ((st2 = tuned_cfg(key43, prec_, L.cin / 32, false, s_, w43, &wino_cfg, nullptr)) < 0) return st2;
+                    if ((st2 = tuned_cfg(key43, prec_, L.cin / 32, false, true, s_, w43, &wino_cfg, nullptr)) < 0) return st2;
                 }
-                if (use_wino && !use_43 && !e->wino_fused && (st2 = tuned_cfg(wkey, prec_, L.cin / 32, false, s_, wino, &wino_cfg, nullptr)) < 0) return st2;
+                if (use_wino && !use_43 && !e->wino_fused && (st2 = tuned_cfg(wkey, prec_, L.cin / 32, false, true, s_, wino, &wino_cfg, nullptr)) < 0) return st2;
             }
-            if (!use_wino && (st2 = tuned_cfg(key, prec_, ksteps, pp8_ok, s_, direct, &cfg, nullptr)) < 0) return st2;
+            if (!use_wino && (st2 = tuned_cfg(key, prec_, ksteps, pp8_ok, false, s_, direct, &cfg, nullptr)) < 0) return st2;
         }
         ProfScope ps(e, s_, m_dyn ? 7 : 0, m_dyn ? 0.0 : flops, m_dyn ? 0.0 : bytes);
         if (e->prof && !m_dyn) {          // category 8: FLOPs the MFMA pipe really executes
