@@ -531,7 +531,7 @@ void conv_igemm_kernel(const ConvArgs a_in) {
     conv_epilogue<T, TO, MT, NT, WM, WN, RWM, WIDE_OK>(a, acc, lds, M, m0, n0, tid, lane, wm, wn);
 }
 
-// ---- plane_gemm_kernel: PERSISTENT tile walk for the Winograd plane contractions (fp32) -------------------------------------
+// ---- plane_gemm_kernel: PERSISTENT tile walk for the fp32 contractions with plain rows (Winograd planes, 1x1 / stride-1 layers) ----
 // A plane contraction M_xi[t][n] = sum_c V_xi[t][c] U_xi[n][c] has K = Cin = 128 .. 512: four to sixteen k-steps per
 // block tile. In conv_igemm_kernel such a block lives ≈ 28 us of which ≈ 7 are not MFMA work — block launch, address
 // set-up, the first loads' HBM latency (V is streamed once, never cached), the LDS-staged epilogue — and with three
@@ -669,18 +669,38 @@ __global__ __launch_bounds__(256) void plane_gemm_kernel(const ConvArgs a) {
             const int plane = c_t / per_plane, r = c_t - plane * per_plane;
             const int tm = r / tiles_n, tn = r - tm * tiles_n;
             float* __restrict__ Y = static_cast<float*>(a.y) + (long long)plane * a.y_bs;
+            const float* __restrict__ Rs = static_cast<const float*>(a.res);
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int j = 0; j < NT; ++j) {
+                const int n = tn * BN + wn * 32 * NT + j * 32 + (lane & 31);
+                const bool n_ok = n < a.Cout;
+                // y = act(acc * scale + bias (+ residual)): the ops and their order of conv_epilogue, applied in the accumulator
+                // layout (a lane owns one output channel: its scale / bias are two scalars per 32-column tile)
+                const float sc = a.scale && n_ok ? a.scale[n] : 1.f;
+                const float bi = a.bias && n_ok ? a.bias[n] : 0.f;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int n = tn * BN + wn * 32 * NT + j * 32 + (lane & 31);
+                for (int i = 0; i < MT; ++i) {
+                    float rs[16];
+                    if (Rs) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const int m = tm * BM + wm * 32 * MT + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                            rs[q] = m < M && n_ok ? Rs[(size_t)m * a.Cout + n] : 0.f;
+                        }
+                    }
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const int m = tm * BM + wm * 32 * MT + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-                        if (m < M && n < a.Cout) Y[(size_t)m * a.Cout + n] = acc[i][j][q];
+                        float t = acc[i][j][q];
+                        if (a.scale) t = __fmul_rn(t, sc);
+                        if (a.bias) t = __fadd_rn(t, bi);
+                        if (Rs) t = __fadd_rn(t, rs[q]);
+                        if (a.relu) t = t > 0.f ? t : 0.f;
+                        if (m < M && n_ok) Y[(size_t)m * a.Cout + n] = t;
                         acc[i][j][q] = 0.f;
                     }
                 }
+            }
             c_cc = 0;
             c_t += G;
             if (c_t >= total) break;
@@ -1273,10 +1293,12 @@ td_status wino_gemm_launch(const ConvArgs& a, hipStream_t stream) {
     return TD_OK;
 }
 
-// tile ids 18-20 (plane_gemm_kernel) take exactly the Winograd plane contractions: fp32, plain rows, raw accumulator output
+// tile ids 18-20 (plane_gemm_kernel) take the fp32 contractions with plain rows: the Winograd planes and the 1x1 / stride-1
+// layers (scale, bias, same-size residual and ReLU are applied in the accumulator layout)
 bool conv_plane_ok(const ConvArgs& a, int precision) {
-    return precision == TD_PRECISION_FP32 && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.out_mode == 0 && !a.scale &&
-           !a.bias && !a.res && !a.relu && !a.out_f32 && a.m_off == 0 && a.Cin >= 32 && a.Cin % 32 == 0 && a.M > 0 && a.Cout > 0 &&
+    return precision == TD_PRECISION_FP32 && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.out_mode == 0 &&
+           a.res_shift == 0 && !a.out_f32 && a.m_off == 0 && a.Cin >= 32 && a.Cin % 32 == 0 && a.M > 0 && a.Cout > 0 &&
+           (a.batch_count <= 1 || !a.res) &&
            (size_t)a.M * a.Cin * 4 < 0xfffffff0ull - (1u << 20);
 }
 

@@ -843,6 +843,9 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
             const auto key = std::make_tuple(L.cout, L.cin, L.kh * 16 + L.kw, B_ * Ho * Wo, stride * 4 + out_mode * 2 + (res_ ? 1 : 0));
             const int ksteps = L.kh * L.kw * L.cin / (prec_ == TD_PRECISION_FP16 ? 64 : 32);
             const bool pp8_ok = prec_ == TD_PRECISION_FP16 && out_mode == 0 && L.cout >= 128;
+            // persistent tile walk (tile ids 18-20): fp32 1x1 / stride-1 layers, same-size residual at most
+            const bool plane_ok = prec_ == TD_PRECISION_FP32 && L.kh == 1 && L.kw == 1 && stride == 1 && pad == 0 && out_mode == 0 && res_shift == 0 &&
+                                  !L.out_f32 && L.cin >= 32 && L.cin % 32 == 0;
             auto direct = [&](int c) { return run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, c); };
             const bool wino_ok = prec_ == TD_PRECISION_FP32 && L.wino_u && e->wino_v && stride == 1 && pad == 1 && !res_ && out_mode == 0 &&
                                  (!m_dyn || ((H_ | W_) & 1) == 0) &&
@@ -871,7 +874,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                 }
                 if (use_wino && !use_43 && !e->wino_fused && (st2 = tuned_cfg(wkey, prec_, L.cin / 32, false, true, s_, wino, &wino_cfg, nullptr)) < 0) return st2;
             }
-            if (!use_wino && (st2 = tuned_cfg(key, prec_, ksteps, pp8_ok, false, s_, direct, &cfg, nullptr)) < 0) return st2;
+            if (!use_wino && (st2 = tuned_cfg(key, prec_, ksteps, pp8_ok, plane_ok, s_, direct, &cfg, nullptr)) < 0) return st2;
         }
         ProfScope ps(e, s_, m_dyn ? 7 : 0, m_dyn ? 0.0 : flops, m_dyn ? 0.0 : bytes);
         if (e->prof && !m_dyn) {          // category 8: FLOPs the MFMA pipe really executes
