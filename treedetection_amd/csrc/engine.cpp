@@ -117,6 +117,7 @@ struct td_engine {
     size_t wino_elems = 0;
     bool wino_fused = true;       // TD_WINO_FUSED=0: separate input-transform kernel + batched conv_igemm launch (diagnostics)
     int wino_slab = 0;            // TD_WINO_SLAB: tiles per slab (diagnostics); 0 = sized for the Infinity Cache
+    int wino_minc = 128;          // fewest channels (both sides) of a 3x3 layer on the Winograd path (TD_WINO_MINC: experiments)
     int wino43_min = 12;          // maps at least this large on both sides take F(4x4,3x3) (TD_WINO43_MIN; 0 = never)
     std::string tune_cache;       // TD_TUNE_CACHE: load / append measured choices (keeps profiled runs free of tuning launches)
 
@@ -248,7 +249,7 @@ td_status upload_wino(td_engine* e, const std::vector<float>& w_ohwi, ConvLayer&
     std::vector<float> u((size_t)16 * L.cout * L.cin);
     wino_filter_transform(w_ohwi.data(), L.cout, L.cin, u.data());
     td_status st = upload(e, u, &L.wino_u);
-    if (st < 0 || e->wino43_min <= 0 || L.cin < 128 || L.cout < 128) return st;
+    if (st < 0 || e->wino43_min <= 0 || L.cin < e->wino_minc || L.cout < e->wino_minc) return st;
     std::vector<float> u43((size_t)36 * L.cout * L.cin);
     wino43_filter_transform(w_ohwi.data(), L.cout, L.cin, u43.data());
     return upload(e, u43, &L.wino_u43);
@@ -398,6 +399,7 @@ td_status td_engine_create(const td_model_desc* desc, int device, td_engine** ou
     if (const char* ws = getenv("TD_WINO_SLAB")) e->wino_slab = atoi(ws);
     if (const char* wf = getenv("TD_WINO_FUSED")) e->wino_fused = atoi(wf) != 0;
     if (const char* w4 = getenv("TD_WINO43_MIN")) e->wino43_min = atoi(w4);
+    if (const char* wc = getenv("TD_WINO_MINC")) e->wino_minc = atoi(wc);
     e->desc = d;
     load_tune_cache(e);
     e->device = device;
@@ -861,7 +863,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                 // measured outcome on the R50/R101 layer set (profiles/r02_tile_choices.txt): every 3x3 layer with at least
                 // 128 channels on both sides is faster through Winograd at every map size from 13x13 to 200x200
                 // (1.3-1.9x); 64 -> 64 (res2) is HBM-bound on the transforms and stays direct.
-                use_wino = L.cin >= 128 && L.cout >= 128;
+                use_wino = L.cin >= e->wino_minc && L.cout >= e->wino_minc;
                 // F(4x4,3x3) on the large maps (another fixed rule: map size and channels only): 2.25 multiplies per output
                 // instead of 4; the 36 plane contractions are one batched launch whose block tile is measured (flag 64)
                 const long long T43 = (long long)B_ * ((H_ + 3) / 4) * ((W_ + 3) / 4);
