@@ -102,3 +102,45 @@ def check_fp16_detections(got, ref, label=""):
 
 def test_fp16_detections_within_tolerance(setup16):
     check_fp16_detections(setup16["got"], setup16["ref"], "fixture 256x320")
+
+
+def test_fp16_mfma_stem_on_uint8_input():
+    """fp16 engine, uint8 HWC input (the production path): the stem runs on the matrix cores (stem_mfma_kernel: raw pixels x
+    fp16-rounded filters, mean folded into the bias, fp16(mean) in the zero padding). Against the fp32 engine's stem on the
+    same bytes: within the trunk bound of test_fp16_trunk_close_to_fp32 (8e-3 of max; measured ~1e-3, the VALU fp16 stem
+    3.5e-4), border ring and a partially valid image included; and the network's detections stay those of the VALU stem up
+    to the usual fp16 noise."""
+    import os
+    from treedetection_amd.engine import Engine, INPUT_U8_HWC
+    sd = make_synthetic_state_dict(50, seed=5)
+    rng = np.random.default_rng(33)
+    B, Hp, Wp = 2, 256, 320
+    img = np.stack([np.clip(np.rint(smooth_image(rng, Hp, Wp)), 0, 255).astype(np.uint8).transpose(1, 2, 0) for _ in range(B)])
+    batch = torch.from_numpy(np.ascontiguousarray(img)).cuda()
+    hw_valid = [(Hp, Wp), (201, 263)]                      # the second image is smaller than the padded frame
+    hw_out = [(Hp, Wp), (201, 263)]
+    stems, counts = {}, {}
+    for tag, prec, env in (("fp32", "fp32", None), ("mfma", "fp16", None), ("valu", "fp16", "0")):
+        if env is not None:
+            os.environ["TD_STEM_MFMA"] = env
+        try:
+            eng = Engine(sd, precision=prec)
+        finally:
+            os.environ.pop("TD_STEM_MFMA", None)
+        out = eng.alloc_outputs(B, Hp, Wp, paste=False)
+        eng.forward_raw(batch, INPUT_U8_HWC, hw_valid, hw_out, out)
+        torch.cuda.synchronize()
+        stems[tag] = eng.tensor("stem").float().cpu().numpy()
+        counts[tag] = out["count"].cpu().numpy().copy()
+        eng.close()
+    ref = stems["fp32"]
+    scale = np.abs(ref).max()
+    e_mfma = np.abs(stems["mfma"] - ref).max() / scale
+    e_valu = np.abs(stems["valu"] - ref).max() / scale
+    border = np.abs(stems["mfma"] - ref)[:, :2].max() / scale
+    print(f"\n[fp16 stem, uint8 input] max |err| / max|ref|: MFMA {e_mfma:.2e} (first two rows {border:.2e}), VALU {e_valu:.2e}")
+    assert stems["mfma"].shape == ref.shape and np.isfinite(stems["mfma"]).all()
+    assert e_mfma < 8e-3 and e_valu < 8e-3
+    # rows that only see the invalid area: relu(bias) in the VALU form, relu(bias + scale * sum w (fp16(mean) - mean)) here
+    assert np.abs(stems["mfma"][1, 104:] - stems["valu"][1, 104:]).max() <= 2e-3 * scale
+    assert np.abs(counts["mfma"].astype(int) - counts["valu"].astype(int)).max() <= 2

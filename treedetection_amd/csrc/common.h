@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstddef>
 #include "../../include/treedet.h"
+#include <vector>
 
 void td_set_error(const char* fmt, ...);
 
@@ -84,9 +85,12 @@ struct ImgSizes {           // per-image valid sizes, passed by value (B <= TD_M
     int w[64];
 };
 #define TD_MAX_BATCH 64
+// w16 / bias16 (optional, from stem_mfma_prepare): the fp16 engine's uint8 inputs with 64 channels take the MFMA stem
 td_status stem_launch(const void* images, int input_format, const ImgSizes& valid, int B, int Hp, int Wp,
                       const float* w_kc /*[147][cout]*/, const float* scale, const float* bias, void* y,
-                      int cout, int precision, hipStream_t stream);
+                      int cout, int precision, hipStream_t stream, const void* w16 = nullptr, const float* bias16 = nullptr);
+void stem_mfma_prepare(const float* w_kc, const float* scale, const float* bias, int cout, std::vector<unsigned short>& w16_bits,
+                       std::vector<float>& bias16);       // w16_bits: IEEE half bit patterns (this header is also compiled by g++)
 td_status maxpool3x3s2_launch(const void* x, void* y, int B, int H, int W, int C, int precision, hipStream_t stream);
 td_status subsample2_launch(const void* x, void* y, int B, int H, int W, int C, int precision, hipStream_t stream);
 td_status resize_batch_u8_launch(const uint8_t* const* srcs, int n, int h, int w, int c, uint8_t* dst, int out_h,

@@ -66,6 +66,8 @@ struct td_engine {
     float* stem_w = nullptr;  // [147][stem_c]
     float* stem_scale = nullptr;
     float* stem_bias = nullptr;
+    unsigned short* stem_w16 = nullptr;   // fp16 engine: filter image (half bit patterns) of the MFMA stem [64][192] (stem.hip stem_mfma_kernel)
+    float* stem_bias16 = nullptr;   //              bias with the mean subtraction folded in
     int stem_c = 64;
     std::vector<Block> stages[4];
     ConvLayer lateral[4], fpn_out[4];
@@ -453,6 +455,14 @@ td_status td_engine_load_weights(td_engine* e, const td_tensor_desc* tensors, si
         if ((st = bn_fold(tm, "backbone.bottom_up.stem.conv1", e->stem_c, s, b)) < 0) return st;
         if ((st = upload(e, s, &e->stem_scale)) < 0) return st;
         if ((st = upload(e, b, &e->stem_bias)) < 0) return st;
+        const char* mfma_stem = getenv("TD_STEM_MFMA");              // 0 = the VALU stem for uint8 inputs too (diagnostics, tests)
+        if (e->desc.precision == TD_PRECISION_FP16 && e->stem_c == 64 && !(mfma_stem && atoi(mfma_stem) == 0)) {
+            std::vector<unsigned short> w16;
+            std::vector<float> b16;
+            stem_mfma_prepare(p.data(), s.data(), b.data(), e->stem_c, w16, b16);
+            if ((st = upload(e, w16, &e->stem_w16)) < 0) return st;
+            if ((st = upload(e, b16, &e->stem_bias16)) < 0) return st;
+        }
     }
     for (int si = 0; si < 4; ++si) {
         e->stages[si].clear();
@@ -922,7 +932,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         if (do_stem) {
             { ProfScope ps(e, s, 1);
             if ((st = stem_launch(img_sub, input_format, vsub, nb_img, Hp, Wp, e->stem_w, e->stem_scale, e->stem_bias, stem_sub,
-                                  e->stem_c, prec, s)) < 0) return st; }
+                                  e->stem_c, prec, s, e->stem_w16, e->stem_bias16)) < 0) return st; }
             { ProfScope ps(e, s, 2);
             if ((st = maxpool3x3s2_launch(stem_sub, pool_sub, nb_img, Hp / 2, Wp / 2, e->stem_c, prec, s)) < 0) return st; }
         }

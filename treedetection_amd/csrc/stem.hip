@@ -210,6 +210,145 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const void* __restrict__
     }
 }
 
+// ---- fp16 engine, uint8 input: the stem on the matrix cores ---------------------------------------------------------
+// The VALU kernel above spends 0.27 ms per 8-tile batch on 24 GFLOP (5-6 % of the fp16 step). Here the taps are the k
+// axis of a contraction with A = the RAW pixels (0..255 are exact in fp16) and Wt = the fp16-rounded filters; the mean
+// subtraction moves into the bias (conv(x - mean) = conv(x) - sum_k w_k mean_c(k), folded on the host with the SAME
+// rounded filters), and a tap in the zero padding — (x - mean) = 0 — becomes the value mean_c in fp16 (103.5 / 116.25 /
+// 123.6875 for 103.53 / 116.28 / 123.675: an error of <= 0.03 |w| on the 3-pixel border ring only).
+// k is laid out so that NO im2col image is needed: k' = ky * 32 + kx * 4 + c with kx in 0..7 and c in 0..3 (kx = 7, c = 3
+// and ky = 7 are dummies with zero filters): 256 = four 128-B chunks of halves. The input patch sits in LDS as fp16 BGR0
+// pixels (8 B each), so the 16-B MFMA fragment of output pixel (ty, tx) for (ky, two neighbouring kx) is simply the two
+// patch pixels (2 ty + ky, 2 tx + kx), (.., + 1): one ds_read_b128 straight from the patch — the first version of this
+// kernel built a 48-KB A image per 128 pixels and lost to the VALU kernel (0.34 vs 0.27 ms).
+// A block is resident and walks 8 x 16-pixel tiles (the 32-KB filter image is loaded once per block); 4 waves as 2 x 2
+// run 2 x 1 MFMA tiles (v_mfma_f32_32x32x16_f16) over the 16 k-steps; scale / bias' / ReLU / the fp16 rounding finish in
+// registers and the tile leaves through LDS as whole 128-B pixel rows.
+typedef float sf32x16 __attribute__((ext_vector_type(16)));
+typedef float sf32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 sh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sh4 __attribute__((ext_vector_type(4)));
+constexpr int SM_TY = 8, SM_TX = 16;                       // output tile
+constexpr int SM_PH = 2 * SM_TY + 6, SM_PW = 2 * SM_TX + 6;   // 22 x 38 patch pixels (one dummy row / column for ky = 7 / kx = 7)
+constexpr int SM_K = 256, SM_CH = 4;                       // padded k, chunks of 64 halves
+
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const uint8_t* __restrict__ images, ImgSizes valid, int B, int Hp, int Wp,
+                                                        const _Float16* __restrict__ w16 /*[64][256]*/,
+                                                        const float* __restrict__ scale, const float* __restrict__ bias16,
+                                                        _Float16* __restrict__ y) {
+    constexpr int W_BYTES = SM_CH * 64 * 128, P_BYTES = SM_PH * SM_PW * 8, O_STRIDE = 72;
+    __shared__ __attribute__((aligned(16))) char lds[W_BYTES + P_BYTES + 128 * O_STRIDE * 2];
+    char* Ws = lds;                                        // [4][64 rows][128 B], XOR-swizzled pieces
+    char* Ps = lds + W_BYTES;                              // [22][38] pixels x {B, G, R, 0} halves
+    _Float16* Os = reinterpret_cast<_Float16*>(lds + W_BYTES + P_BYTES);   // [128 pixels][64 + 8] halves
+    const int Ho = Hp >> 1, Wo = Wp >> 1;
+    const int tiles_x = (Wo + SM_TX - 1) / SM_TX, tiles_y = (Ho + SM_TY - 1) / SM_TY;
+    const int total = tiles_x * tiles_y * B;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;               // 2 x 2 waves: pixels 64 wm .., channels 32 wn ..
+
+    // filter image, once per block: 4 chunks x 64 rows x 8 pieces of 16 B, swizzled like the conv kernels' B rows
+    {
+        constexpr int W_IT = SM_CH * 64 * 8 / 256;
+        sf32x4 wv[W_IT];
+#pragma unroll
+        for (int j = 0; j < W_IT; ++j) {
+            const int i = tid + 256 * j;
+            wv[j] = *reinterpret_cast<const sf32x4*>(w16 + (size_t)((i >> 3) & 63) * SM_K + (i >> 9) * 64 + (i & 7) * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < W_IT; ++j) {
+            const int i = tid + 256 * j;
+            const int pc = i & 7, n = (i >> 3) & 63, c = i >> 9;
+            *reinterpret_cast<sf32x4*>(Ws + (c * 64 + n) * 128 + ((pc ^ ((n >> 1) & 7)) * 16)) = wv[j];
+        }
+    }
+    const int n_col = wn * 32 + (lane & 31);
+    const float sc = scale[n_col], bi = bias16[n_col];
+    const unsigned swz = (lane >> 1) & 7, hi = lane >> 5;
+    const _Float16 m0 = (_Float16)103.530f, m1 = (_Float16)116.280f, m2 = (_Float16)123.675f;
+    // this lane's two output pixels (MFMA rows lane & 31 of the wave's two 32-row tiles) inside the tile
+    int pix_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = wm * 64 + i * 32 + (lane & 31);
+        pix_off[i] = ((2 * (m >> 4)) * SM_PW + 2 * (m & 15)) * 8;
+    }
+
+    // patch of tile t: 22 x 38 pixels, 3 bytes each → fp16 BGR0 in registers; outside the image: fp16(mean)
+    constexpr int P_IT = (SM_PH * SM_PW + 255) / 256;
+    sh4 pv[P_IT];
+    auto load_patch = [&](int t) {
+        const int b = t / (tiles_x * tiles_y), r0 = t - b * (tiles_x * tiles_y);
+        const int iy_base = 2 * (r0 / tiles_x) * SM_TY - 3, ix_base = 2 * (r0 - (r0 / tiles_x) * tiles_x) * SM_TX - 3;
+        const int vh = valid.h[b], vw = valid.w[b];
+#pragma unroll
+        for (int j = 0; j < P_IT; ++j) {
+            const int i = tid + 256 * j;
+            const int py = i / SM_PW, px = i - py * SM_PW;
+            const int iy = iy_base + py, ix = ix_base + px;
+            sh4 v = {m0, m1, m2, (_Float16)0.f};
+            if (i < SM_PH * SM_PW && iy >= 0 && iy < vh && ix >= 0 && ix < vw) {
+                const uint8_t* q = images + ((size_t)(b * Hp + iy) * Wp + ix) * 3;
+                v[0] = (_Float16)(float)q[0];
+                v[1] = (_Float16)(float)q[1];
+                v[2] = (_Float16)(float)q[2];
+            }
+            pv[j] = v;
+        }
+    };
+    load_patch(blockIdx.x);
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const int b = t / (tiles_x * tiles_y), r0 = t - b * (tiles_x * tiles_y);
+        const int oy0 = (r0 / tiles_x) * SM_TY, ox0 = (r0 - (r0 / tiles_x) * tiles_x) * SM_TX;
+        __syncthreads();                                   // the previous tile's fragment reads and output copies are done
+#pragma unroll
+        for (int j = 0; j < P_IT; ++j) {
+            const int i = tid + 256 * j;
+            if (i < SM_PH * SM_PW) *reinterpret_cast<sh4*>(Ps + i * 8) = pv[j];
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < total) load_patch(t + gridDim.x);      // the next tile's bytes travel under this tile's MFMAs and stores
+
+        sf32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+#pragma unroll
+        for (int c = 0; c < SM_CH; ++c)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                // k' = 64 c + 16 kk + 8 hi .. + 8  =  filter row ky = 2 c + (kk >> 1), pixels kx = 2 (2 (kk & 1) + hi), + 1
+                const sf32x4 fb = *reinterpret_cast<const sf32x4*>(Ws + (c * 64 + wn * 32 + (lane & 31)) * 128 + ((((unsigned)(2 * kk) + hi) ^ swz) * 16));
+                const int tap = ((2 * c + (kk >> 1)) * SM_PW + 2 * (2 * (kk & 1) + (int)hi)) * 8;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const sf32x4 fa = *reinterpret_cast<const sf32x4*>(Ps + pix_off[i] + tap);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sh8, fa), __builtin_bit_cast(sh8, fb), acc[i], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                const float u = __fadd_rn(__fmul_rn(acc[i][q], sc), bi);
+                Os[row * O_STRIDE + n_col] = (_Float16)(u > 0.f ? u : 0.f);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 256 * j;
+            const int m = i >> 3, pc = i & 7;
+            const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
+            if (oy < Ho && ox < Wo)
+                *reinterpret_cast<sf32x4*>(y + ((size_t)(b * Ho + oy) * Wo + ox) * 64 + pc * 8) = *reinterpret_cast<const sf32x4*>(Os + m * O_STRIDE + pc * 8);
+        }
+    }
+}
+
 // ---- max-pool 3x3 / s2 / p1 over NHWC (16 bytes of channels per thread: 4 floats or 8 halves) -------------------------
 template <typename T>
 struct Vec16;
@@ -307,10 +446,38 @@ td_status resize_tile_u8_launch(const uint8_t* src, int h, int w, int c, uint8_t
     return resize_batch_u8_launch(&src, 1, h, w, c, dst, out_h, out_w, dst_pitch_px, 0, tmp, stream);
 }
 
+// host: the fp16 filter image [cout][192] (k = (ky, kx, c), zero-padded) of stem_mfma_kernel and the bias with the mean
+// subtraction folded in: bias' = bias - scale * sum_k w16[n][k] * mean_c(k), from the ROUNDED filters (float64, rounded once)
+void stem_mfma_prepare(const float* w_kc /*[147][cout]*/, const float* scale, const float* bias, int cout,
+                       std::vector<unsigned short>& w16, std::vector<float>& bias16) {
+    static const double mean[3] = {103.530, 116.280, 123.675};
+    w16.assign((size_t)cout * SM_K, (unsigned short)0);      // k' = ky * 32 + kx * 4 + c; kx = 7, c = 3, ky = 7 stay zero
+    bias16.assign(cout, 0.f);
+    for (int n = 0; n < cout; ++n) {
+        double corr = 0.0;
+        for (int ky = 0; ky < 7; ++ky)
+            for (int kx = 0; kx < 7; ++kx)
+                for (int c = 0; c < 3; ++c) {
+                    const _Float16 h = (_Float16)w_kc[(size_t)((ky * 7 + kx) * 3 + c) * cout + n];
+                    w16[(size_t)n * SM_K + ky * 32 + kx * 4 + c] = __builtin_bit_cast(unsigned short, h);
+                    corr += (double)(float)h * mean[c];
+                }
+        bias16[n] = (float)((double)bias[n] - (double)scale[n] * corr);
+    }
+}
+
 td_status stem_launch(const void* images, int input_format, const ImgSizes& valid, int B, int Hp, int Wp,
                       const float* w_kc, const float* scale, const float* bias, void* y, int cout, int precision,
-                      hipStream_t stream) {
+                      hipStream_t stream, const void* w16, const float* bias16) {
     TD_REQUIRE(Hp % 2 == 0 && Wp % 2 == 0 && B <= TD_MAX_BATCH, "stem: bad geometry");
+    if (w16 && bias16 && precision == TD_PRECISION_FP16 && input_format == TD_INPUT_U8_HWC && cout == 64) {
+        const int total = td_cdiv(Wp / 2, SM_TX) * td_cdiv(Hp / 2, SM_TY) * B;
+        const int cap = 256 * 3;                               // resident blocks (57 KB of LDS each)
+        hipLaunchKernelGGL(stem_mfma_kernel, dim3(total < cap ? total : cap), dim3(256), 0, stream, static_cast<const uint8_t*>(images),
+                           valid, B, Hp, Wp, static_cast<const _Float16*>(w16), scale, bias16, static_cast<_Float16*>(y));
+        TD_KERNEL_CHECK();
+        return TD_OK;
+    }
     const dim3 grid(td_cdiv(Wp / 2, ST), td_cdiv(Hp / 2, ST), B);
     const bool u8 = input_format == TD_INPUT_U8_HWC, h = precision == TD_PRECISION_FP16;
 #define TD_STEM_CASE(F, C, TO)                                                                                       \
