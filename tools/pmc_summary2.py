@@ -20,7 +20,7 @@ def family(name):
         return "conv_igemm_kernel"
     if "plane_gemm" in name:
         return "plane_gemm_kernel"
-    for k in ("wino_gemm", "wino43_input", "wino43_output", "wino_input", "wino_output", "stem_conv", "maxpool", "roi_align", "rpn_topk",
+    for k in ("wino_gemm", "wino43_input", "wino43_output", "wino_input", "wino_output", "stem_conv", "stem_mfma", "maxpool", "roi_align", "rpn_topk",
               "rpn_keys", "nms_", "paste", "resize_"):
         if k in name:
             return k.rstrip("_") + "_kernel" if not k.endswith("kernel") else k
@@ -38,7 +38,7 @@ def load(path):
 
 def last_steps(rows, steps):
     """Dispatches of the last `steps` forwards: a forward starts at its stem_conv launch."""
-    starts = [i for i, r in enumerate(rows) if "stem_conv" in r["name"]]
+    starts = [i for i, r in enumerate(rows) if "stem_conv" in r["name"] or "stem_mfma" in r["name"]]
     return rows[starts[-steps]:] if len(starts) >= steps else rows
 
 
