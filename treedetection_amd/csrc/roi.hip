@@ -663,7 +663,7 @@ static int roi_depth(int precision) {
 }
 
 // blocks per RoI: the 14 x 14 mask-head launch has few RoIs (the detections) of 196 bins each
-static int roi_parts(int pooled, long long rois) {
+static int roi_parts(int pooled) {
     static const char* env = getenv("TD_ROI_PARTS");
     if (env) return atoi(env) > 0 ? atoi(env) : 1;
     return pooled * pooled >= 128 ? 4 : 1;
@@ -672,7 +672,7 @@ static int roi_parts(int pooled, long long rois) {
 td_status roi_align_launch(const FeatLevels& fl, const float* rois, const int* counts, int items, int roi_stride,
                            int pooled, int compact, void* out, int* total_rows, int precision, hipStream_t stream) {
     TD_REQUIRE(fl.C % 4 == 0, "roi_align: C must be a multiple of 4");
-    const int parts = roi_parts(pooled, (long long)items * roi_stride);
+    const int parts = roi_parts(pooled);
     const dim3 grid(roi_stride * parts, items);
     if (precision == TD_PRECISION_FP16)
         roi_align_dispatch<_Float16>(grid, stream, roi_depth(precision), fl, rois, counts, items, roi_stride, pooled, compact,
@@ -689,7 +689,7 @@ td_status roi_align_single_launch(const void* feat, int H, int W, int C, const f
     TD_REQUIRE(C % 4 == 0 && R >= 1, "roi_align: bad shape");
     FeatLevels fl{};
     fl.feat[0] = feat; fl.h[0] = H; fl.w[0] = W; fl.scale[0] = scale; fl.C = C;
-    const int parts = roi_parts(pooled, R);
+    const int parts = roi_parts(pooled);
     const dim3 grid(R * parts, 1);
     if (precision == TD_PRECISION_FP16)
         roi_align_dispatch<_Float16>(grid, stream, roi_depth(precision), fl, rois, nullptr, 1, R, pooled, 0,
