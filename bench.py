@@ -395,14 +395,14 @@ def main():
             # the reference's own depth (TreeDetection/config.py:25 hard-codes R101-FPN): same stream, same schedule
             log("generating R101 weights")
             sd = make_synthetic_state_dict(101, seed=0)
-            nsteps = max(4, args.steps // 2)
+            nsteps = -(-max(4, args.steps // 2) // args.streams) * args.streams      # whole rounds of the engines (these regions choose their own K)
             r101 = {"fp32": go("fp32", not args.no_profile) + (nsteps,)}
             if not args.no_fp16:
                 r101["fp16"] = go("fp16", not args.no_profile) + (nsteps,)
             sd = make_synthetic_state_dict(args.depth, seed=0)
         if not args.no_fp16 and not args.no_fp16_b32:
             # BASELINE configs[4]: the fp16 MFMA path at batch 32 per GPU (same tiles, four times the rows per launch)
-            B, nsteps = 32, max(4, args.steps // 4)
+            B, nsteps = 32, -(-max(4, args.steps // 4) // args.streams) * args.streams
             b32 = go("fp16", not args.no_profile) + (nsteps,)
             B, nsteps = args.batch, args.steps
 
