@@ -389,6 +389,11 @@ def main():
         # one forward at a time on one stream: the same kernels with nothing overlapping — the per-launch spans of THIS region
         # are the kernels' own durations (the `exclusive` roofline object)
         piped = run(args.precision, 1, not args.no_profile)
+    phased = None
+    if args.schedule == "streams" and not args.no_serial and world == 1:
+        # informational: the phase pipeline — three batches in flight whose CONTRACTION kernels never overlap each other, so its
+        # event spans are the kernels' own durations (the literal roofline of a schedule that still overlaps the selection work)
+        phased = run_pipelined(args.precision, not args.no_profile)
     r101 = b32 = None
     if args.precision == "fp32" and args.depth == 50 and args.schedule != "plain" and world == 1:
         if not args.no_r101:
@@ -522,6 +527,17 @@ def main():
                 line["roofline"]["exclusive"] = {"achieved": lit, "frac": lit / peak_main, "avg_launch_us": 1e3 * cs["ms"] / max(cs["launches"], 1),
                                                  "span_ms_per_step": cs["ms"] / args.steps,
                                                  "note": "the conv family with one forward at a time (the `single_stream` region of this run)"}
+        if phased is not None:
+            o = {"value": tiles_total / phased[0], "unit": "tiles/s", "ms_per_step": 1000.0 * phased[0] / args.steps,
+                 "note": "the same K steps through the phase pipeline (--schedule phases: contraction phases of three batches back to back on "
+                         "a main stream, selection phases on side streams); its contraction spans do not overlap: literal roofline"}
+            if phased[1] is not None:
+                cp = phased[1]["conv_igemm"]
+                lit = cp["flops"] / (cp["ms"] * 1e-3) / 1e12 if cp["ms"] > 0 else 0.0
+                o["roofline"] = {"achieved": lit, "frac": lit / peak_main, "span_ms_per_step": cp["ms"] / args.steps,
+                                 "avg_launch_us": 1e3 * cp["ms"] / max(cp["launches"], 1), "method": "span"}
+                o["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in phased[1].items() if k != "executed"}
+            line["phase_pipeline"] = o
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, rgb_np, args.cpu_tiles)
         print(json.dumps(line), flush=True)

@@ -15,7 +15,7 @@ def show(tag, o):
 
 
 show("fp32", j)
-for k, tag in (("fp16", "fp16"), ("fp16_batch32", "fp16 b32"), ("single_stream", "fp32 plain")):
+for k, tag in (("fp16", "fp16"), ("fp16_batch32", "fp16 b32"), ("single_stream", "plain loop"), ("phase_pipeline", "phase pipeline")):
     if k in j:
         show(tag, j[k])
 if "r101" in j:
