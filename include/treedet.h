@@ -102,7 +102,9 @@ td_status td_engine_forward(td_engine* e, const void* images, int input_format, 
  * batches back to back on a main stream and each batch's odd phases on its own side stream, and the selection work of
  * one batch overlaps the contractions of the next (bench.py: per tick trunk(t), mask convs(t-2), FCs(t-1)). Phase 0 takes the arguments of td_engine_forward and stores them; phases 1-5
  * ignore everything but `e`, `phase` and `stream`. Each phase waits (hipStreamWaitEvent) for the previous phase of the
- * same batch and phase 0 for the engine's previous batch, so any stream assignment is correct.
+ * same batch; phase 0 waits for phases 0-4 of the engine's previous batch (the trunk rewrites what they read, the
+ * Winograd workspace of the fp32 mask-head convolutions included) and phase 3 for the previous batch's phase 5 (whose
+ * predictor / paste read the mask buffers and row count that phases 3-4 rewrite), so any stream assignment is correct.
  * Optional pre-phase TD_PHASE_STEM (6): stem convolution + max-pool of the NEXT batch (VALU / HBM work, no matrix
  * cores) with the arguments of phase 0; the following phase 0 (images may be NULL) then starts at res2. Run it on a side
  * stream while the previous batch's contractions hold the main stream. */

@@ -31,16 +31,35 @@ def bounds_of(transform: Affine, width: int, height: int):
     return c, f + e * height, c + a * width, f          # west, south, east, north (north-up rasters: e < 0)
 
 
-def merge_first(rasters: Sequence[Tuple[np.ndarray, Affine]], nodata: float = 0.0):
-    """rasterio.merge.merge(datasets, nodata=nodata) for north-up rasters on a common pixel grid → (data, transform)."""
+def _is_value(cur, value, integer: bool) -> bool:
+    if isinstance(value, float) and np.isnan(value):
+        return bool(np.isnan(cur))
+    return bool(cur == value) if integer else bool(np.isclose(cur, value))
+
+
+def merge_first(rasters: Sequence[Tuple[np.ndarray, Affine]], nodata: float = 0.0, own_nodata: Optional[Sequence[Optional[float]]] = None):
+    """rasterio.merge.merge(datasets, nodata=nodata) for north-up rasters on a common pixel grid → (data, transform).
+    ``own_nodata[i]`` = dataset i's own nodata value (its GDAL_NODATA tag) or None: rasterio reads every dataset
+    ``masked=True``, so a source pixel that equals the SOURCE's nodata is masked and never copied; a ``nodata`` that
+    does not fit the output dtype leaves the destination at zero (rasterio warns and skips the fill)."""
     d0, t0 = rasters[0]
+    integer = np.issubdtype(d0.dtype, np.integer)
+    if integer:
+        info = np.iinfo(d0.dtype)
+        if (isinstance(nodata, float) and np.isnan(nodata)) or not (info.min <= nodata <= info.max) or float(nodata) != int(nodata):
+            nodata = 0.0
+    if own_nodata is None:
+        own_nodata = [None] * len(rasters)
     xres, yres = t0[0], -t0[4]
     bs = [bounds_of(t, d.shape[2], d.shape[1]) for d, t in rasters]
     west, south = min(b[0] for b in bs), min(b[1] for b in bs)
     east, north = max(b[2] for b in bs), max(b[3] for b in bs)
     W, H = int(round((east - west) / xres)), int(round((north - south) / yres))
     dest = np.full((d0.shape[0], H, W), nodata, dtype=d0.dtype)
-    for data, t in rasters:
+    for (data, t), own in zip(rasters, own_nodata):
+        if own is not None and np.issubdtype(data.dtype, np.integer) and not (
+                not np.isnan(own) and np.iinfo(data.dtype).min <= own <= np.iinfo(data.dtype).max):
+            own = None                       # a tag that cannot occur in the data masks nothing
         col0 = int(round((t[2] - west) / xres))
         row0 = int(round((north - t[5]) / yres))
         for r in range(data.shape[1]):
@@ -52,20 +71,20 @@ def merge_first(rasters: Sequence[Tuple[np.ndarray, Affine]], nodata: float = 0.
                 if not 0 <= cc < W:
                     continue
                 for b in range(min(data.shape[0], dest.shape[0])):
-                    cur = dest[b, rr, cc]
-                    is_nodata = np.isnan(cur) if (isinstance(nodata, float) and np.isnan(nodata)) else (
-                        cur == nodata if np.issubdtype(dest.dtype, np.integer) else bool(np.isclose(cur, nodata)))
-                    if is_nodata:
+                    if own is not None and _is_value(data[b, r, c], own, np.issubdtype(data.dtype, np.integer)):
+                        continue             # masked in the source
+                    if _is_value(dest[b, rr, cc], nodata, integer):
                         dest[b, rr, cc] = data[b, r, c]
     return dest, (xres, 0.0, west, 0.0, -yres, north)
 
 
-def merge_images_ref(data1, t1, data2, t2, nodata1: Optional[float] = None):
-    """helpers.merge_images: nodata = src1.nodata unless it is None or absurdly large, then 0.0."""
+def merge_images_ref(data1, t1, data2, t2, nodata1: Optional[float] = None, nodata2: Optional[float] = None):
+    """helpers.merge_images: nodata = src1.nodata unless it is None or absurdly large, then 0.0; each source keeps its
+    own nodata mask (``nodata1`` / ``nodata2`` = the files' GDAL_NODATA tags)."""
     nd = nodata1
     if nd is None or abs(nd) > 1e10:
         nd = 0.0
-    return merge_first([(data1, t1), (data2, t2)], nd)
+    return merge_first([(data1, t1), (data2, t2)], nd, own_nodata=[nodata1, nodata2])
 
 
 def crop_center_ref(data: np.ndarray, transform: Affine, width: int, height: int):

@@ -185,3 +185,38 @@ def test_seam_strips_match_the_oracle_on_a_3x3_mosaic(tmp_path):
             ref = neighbours_ref(i, metas)
             assert got == tuple(None if j is None else names[j] for j in ref)
         assert not [m for lvl, m in cfg["logger"].msgs if lvl == "error"]
+
+
+def test_merge_images_masks_each_source_by_its_own_nodata(tmp_path):
+    """rasterio reads every source ``masked=True``: pixels that equal the SOURCE's own GDAL_NODATA are never copied, also
+    when the mosaic's fill value is another one (first raster untagged → 0; second tagged -9999): they stay at the fill
+    value instead of showing up as -9999 in the seam strip. A tag that does not fit the dtype (-9999 on a
+    uint8 raster) warns and fills with 0, as rasterio.merge does."""
+    rng = np.random.default_rng(11)
+    gsd = 0.2
+    t1 = (gsd, 0.0, 412000.0, 0.0, -gsd, 5318000.0)
+    for k, (dx, dy) in enumerate(((32, 0), (16, 8))):
+        a1 = _rand_raster(rng, 1, 32, 32, np.float32, 0.2)          # untagged; zeros are its "holes" by the value rule
+        a2 = _rand_raster(rng, 1, 32, 32, np.float32, 0.0)
+        holes = rng.random((32, 32)) < 0.25
+        a2[:, holes] = -9999.0
+        t2 = (gsd, 0.0, 412000.0 + dx * gsd, 0.0, -gsd, 5318000.0 - dy * gsd)
+        p1, p2 = str(tmp_path / f"m{k}a.tif"), str(tmp_path / f"m{k}b.tif")
+        write_geotiff(p1, a1, t1, 25832)
+        write_geotiff(p2, a2, t2, 25832, nodata=-9999.0)
+        got, gt = merge_images(GeoTiff(p1), GeoTiff(p2))
+        ref, rt = merge_images_ref(a1, t1, a2, t2, None, -9999.0)
+        assert np.array_equal(got, ref) and np.allclose(gt, rt, rtol=0, atol=1e-9)
+        assert not np.any(got == -9999.0), "a source's nodata pixels must not be pasted into the mosaic"
+        assert np.any(got[:, dy:dy + 32, dx:dx + 32][:, holes] == 0.0)
+    # integer raster whose tag cannot be represented: fill 0 + warning, no overflow
+    b1 = _rand_raster(rng, 3, 16, 16, np.uint8, 0.0)
+    b2 = _rand_raster(rng, 3, 16, 16, np.uint8, 0.0)
+    t2 = (gsd, 0.0, 412000.0 + 16 * gsd, 0.0, -gsd, 5318000.0)
+    p1, p2 = str(tmp_path / "u8a.tif"), str(tmp_path / "u8b.tif")
+    write_geotiff(p1, b1, t1, 25832, nodata=-9999.0)
+    write_geotiff(p2, b2, t2, 25832)
+    with pytest.warns(UserWarning, match="beyond the valid range"):
+        got, _ = merge_images(GeoTiff(p1), GeoTiff(p2))
+    ref, _ = merge_images_ref(b1, t1, b2, t2, -9999.0, None)
+    assert got.dtype == np.uint8 and np.array_equal(got, ref)

@@ -68,6 +68,11 @@ def setup_model_cfg(base_model="COCO-InstanceSegmentation/mask_rcnn_R_101_FPN_3x
         gpu_id = int(device)
         if _cuda_available():
             import torch
+            from . import distributed as D
+            if D.world() > 1:
+                # one process per GPU: config.yml names ONE device for all ranks, each rank takes its own
+                # (LOCAL_RANK); selecting the configured index here would put every rank on the same GPU
+                gpu_id = D.local_device(gpu_id)
             torch.cuda.set_device(gpu_id)
             cfg.MODEL.DEVICE = "cuda"
             cfg.MODEL.DEVICE_INDEX = gpu_id

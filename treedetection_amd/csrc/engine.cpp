@@ -133,6 +133,8 @@ struct td_engine {
     } ctx;
     hipEvent_t phase_ev[7] = {};           // [6] = the optional stem pre-phase (TD_PHASE_STEM)
     bool phase_ev_recorded[7] = {};
+    hipEvent_t prev5_ev = nullptr;         // phase-5 event of the previous batch (the next batch's phase 3 waits for it)
+    bool prev5_recorded = false;
     bool stem_done = false;                // stem + pool of the current batch already ran in the pre-phase
 
     // optional per-category device timing (td_engine_profile_*)
@@ -417,6 +419,7 @@ void td_engine_destroy(td_engine* e) {
     for (auto& r : e->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto ev : e->prof_free) (void)hipEventDestroy(ev);
     for (auto ev : e->phase_ev) if (ev) (void)hipEventDestroy(ev);
+    if (e->prev5_ev) (void)hipEventDestroy(e->prev5_ev);
     delete e;
 }
 
@@ -1190,16 +1193,32 @@ td_status td_engine_forward_phase(td_engine* e, int phase, const void* images, i
         } else if ((st = set_forward_ctx(e, images, input_format, hw_valid, hw_out, B, Hp, Wp, out)) < 0) {
             return st;
         }
-        // The engine's previous batch must have left the buffers the trunk writes: the FPN levels and RPN head maps are
-        // read last by RoIAlign 14x14 in phase 3 (phases 4 and 5 — mask convs, predictor, paste — only touch the mask
-        // buffers and the caller's outputs). Waiting for phase 5 instead chained every trunk behind the previous-but-two
-        // batch's mask tail, which starts only after that batch's mask convs earlier in the same tick: 0.5-0.8 ms of idle
-        // main stream per fp16 step (rocprof trace, round 2).
-        if (e->phase_ev_recorded[3]) TD_HIP_CHECK(hipStreamWaitEvent(s, e->phase_ev[3], 0));
+        // The engine's previous batch must have left the buffers the trunk writes. The FPN levels and RPN head maps are
+        // read last by RoIAlign 14x14 in phase 3, but phase 4 (the mask-head 3x3 convs) goes through run_conv like any
+        // other layer: in the fp32 engine its Winograd transforms use e->wino_v / e->wino_m, the workspace the next
+        // trunk's Winograd layers write. So the trunk waits for the previous batch's phase 4 (which implies 0-3). Its
+        // phase 5 (predictor, scatter, paste) only reads deconv_out / total_rows / the mask buffers, which the next
+        // batch rewrites in phases 3 and 4: that dependency is kept in its own slot (prev5_ev) and taken by the next
+        // batch's phase 3 — waiting for phase 5 HERE chained every trunk behind the previous-but-two batch's mask tail
+        // (0.5-0.8 ms of idle main stream per fp16 step, rocprof trace of round 2). With the even phases on one
+        // stream, as the Predictor and bench.py enqueue them, the phase-4 wait is already satisfied by stream order.
+        for (int k = 4; k >= 0; --k)
+            if (e->phase_ev_recorded[k]) {
+                TD_HIP_CHECK(hipStreamWaitEvent(s, e->phase_ev[k], 0));
+                break;
+            }
+        if (e->phase_ev_recorded[5]) {            // hand the previous batch's phase-5 event to the slot phase 3 waits on
+            std::swap(e->phase_ev[5], e->prev5_ev);
+            e->prev5_recorded = true;
+        }
     } else {
         TD_REQUIRE(e->ctx.valid_ctx, "td_engine_forward_phase: phase %d before phase 0", phase);
         TD_REQUIRE(e->phase_ev_recorded[phase - 1], "td_engine_forward_phase: phase %d before phase %d", phase, phase - 1);
         TD_HIP_CHECK(hipStreamWaitEvent(s, e->phase_ev[phase - 1], 0));
+        if (phase == 3 && e->prev5_recorded) {    // the previous batch's predictor / paste still read what phases 3-4 rewrite
+            TD_HIP_CHECK(hipStreamWaitEvent(s, e->prev5_ev, 0));
+            e->prev5_recorded = false;
+        }
     }
     if ((st = forward_impl(e, 1u << phase, s)) < 0) return st;
     if (!e->phase_ev[phase]) TD_HIP_CHECK(hipEventCreateWithFlags(&e->phase_ev[phase], hipEventDisableTiming));

@@ -37,6 +37,7 @@ def predict_on_model(config, model_path, tiles_path, output_path, batch_size=10,
         if name == "Tiles directory" and not os.path.isdir(path):
             raise NotADirectoryError(f"{name} is not a directory: {path}")
     os.makedirs(output_path, exist_ok=True)
+    D.bind_device(config["device"])      # before the first collective of this stage (nccl picks the current device)
     cfg = setup_model_cfg(update_model=model_path, device=config["device"])
     # one process per GPU under torch.distributed: the shared config names one device, each rank takes its own
     # (LOCAL_RANK), see distributed.local_device
@@ -90,6 +91,7 @@ def predict_tiles(config):
     """Reference detection.py:134-253: two-model flow (urban + forest, exclude flags) when all three of urban_model,
     forrest_model, forrest_outline exist, else the combined model, else FileNotFoundError."""
     Config()._load_into_config(config)
+    D.bind_device(config.get("device", "cpu"))
     logger = config["logger"]
     out = config["output_directory"]
     two = all(config.get(k) and os.path.exists(config[k]) for k in ("urban_model", "forrest_model", "forrest_outline"))
@@ -130,6 +132,7 @@ def preprocess_files(config):
     """Reference detection.py:256-339: collect the rasters, seam strips between neighbours (``use_overlap``), tile
     metadata for every image."""
     Config()._load_into_config(config)
+    D.bind_device(config.get("device", "cpu"))      # the broadcast below is this stage's first collective
     logger = config["logger"]
     for key, what in (("image_directory", "Image"), ("height_data_path", "Height")):
         p = config[key]
@@ -225,6 +228,9 @@ def process_files(config):
     """Reference detection.py:342-373."""
     logger = config["logger"]
     Config()._load_into_config(config)
+    # world > 1: every rank selects ITS GPU (LOCAL_RANK) before any barrier / broadcast — under nccl those collectives
+    # run on torch.cuda.current_device(), which is cuda:0 on every rank until someone sets it
+    D.bind_device(config.get("device", "cpu"))
     t0 = time.time()
     preprocess_files(config)
     t1 = time.time()

@@ -3,7 +3,8 @@
 The reference is single-device (TreeDetection/config.py:45-53). Tiles are independent (each forward sees one tile;
 overlap is handled by the buffer + later stitching, preprocessing.py:60-65), so rank r simply takes tiles
 ``i ≡ r (mod world)`` of the ordered tile list and every rank keeps a full weight replica. The only exchange step is
-the gather of the per-tile detections (count, boxes, scores, 28x28 mask probabilities ≈ 3.2 KB per detection) to
+the gather of the per-tile detections (count, boxes, scores, 28x28 mask probabilities: FIXED-SHAPE fp32 tensors,
+[B,100,28,28] + boxes + scores + counts ≈ 2.5 MB per 8-tile batch and rank, whatever the detection count) to
 rank 0, which pastes / traces / writes the ``Prediction_*.json`` files — ``torch.distributed.gather`` over RCCL
 (backend "nccl") on GPUs, gloo in the CPU tests. No collective touches the forward itself.
 """
@@ -29,7 +30,10 @@ def barrier() -> None:
     """All ranks meet here (no-op in a single process). Used around the file-system stages of ``process_files``:
     rank 0 alone writes / deletes the shared folders, the others wait."""
     if world() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])     # never "the default GPU": every rank names its own
+        else:
+            dist.barrier()
 
 
 def all_ok(ok: bool) -> bool:
@@ -37,10 +41,7 @@ def all_ok(ok: bool) -> bool:
     stay paired if all ranks take the same decision about an image or a round)."""
     if world() == 1:
         return bool(ok)
-    dev = "cpu"
-    if dist.get_backend() == "nccl":
-        dev = torch.device("cuda", torch.cuda.current_device())
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=collective_device())
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     return bool(int(flag.item()))
 
@@ -50,16 +51,20 @@ def broadcast_object(obj, src: int = 0):
     if world() == 1:
         return obj
     box = [obj if rank() == src else None]
-    dist.broadcast_object_list(box, src=src)
+    if dist.get_backend() == "nccl":
+        dist.broadcast_object_list(box, src=src, device=collective_device())
+    else:
+        dist.broadcast_object_list(box, src=src)
     return box[0]
 
 
 def local_device(configured) -> int:
     """GPU index of THIS rank. A single process keeps ``config['device']`` (reference config.py:112-142). Under
     ``torch.distributed`` the shared config.yml cannot name one device per rank, so the index comes from LOCAL_RANK
-    (set by ``torch.distributed.run``), else ``rank % device_count``; with the nccl backend two ranks of a node on
-    one GPU abort inside RCCL ("Duplicate GPU detected"), so that case is refused here with a readable message.
-    (gloo rehearsal runs may share a GPU.)"""
+    (set by ``torch.distributed.run``); launchers that do not set it (srun / mpirun, several nodes) give the GLOBAL
+    rank only, which is out of range on every node but the first, so the fallback is ``rank % device_count``. With the
+    nccl backend two ranks of a node on one GPU abort inside RCCL ("Duplicate GPU detected"), so that case is refused
+    here with a readable message. (gloo rehearsal runs may share a GPU.)"""
     import os
     if world() == 1:
         return int(configured)
@@ -67,13 +72,41 @@ def local_device(configured) -> int:
     if n < 1:
         raise RuntimeError("no GPU visible to this rank")
     lr = os.environ.get("LOCAL_RANK")
-    idx = int(lr) if lr is not None else rank()
+    idx = int(lr) if lr is not None else rank() % n
     if dist.get_backend() == "nccl":
-        lws = int(os.environ.get("LOCAL_WORLD_SIZE", world()))
-        if lws > n:
-            raise RuntimeError(f"{lws} ranks on this node but only {n} GPUs: one process per GPU (nccl backend)")
+        lws = int(os.environ.get("LOCAL_WORLD_SIZE", min(world(), n) if lr is None else world()))
+        if lws > n or idx >= n:
+            raise RuntimeError(f"{lws} ranks on this node (local rank {idx}) but only {n} GPUs: one process per GPU (nccl backend)")
         return idx
     return idx % n
+
+
+_bound_device: Optional[int] = None
+
+
+def bind_device(configured) -> Optional[int]:
+    """Make THIS rank's GPU the current device BEFORE its first collective (world > 1 only; returns the index).
+
+    With the nccl backend ``broadcast_object_list`` / ``barrier`` / ``all_reduce`` place their tensors on
+    ``torch.cuda.current_device()``: if every rank still sits on cuda:0 when ``preprocess_files`` broadcasts, RCCL
+    aborts with "Duplicate GPU detected" (or rank > 0 opens a context on GPU 0). ``process_files`` / ``predict_tiles``
+    / ``preprocess_files`` call this first; the Engine constructor later selects the same index."""
+    global _bound_device
+    if world() == 1 or str(configured) == "cpu":
+        return None
+    idx = local_device(configured)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(idx)
+    _bound_device = idx
+    return idx
+
+
+def collective_device() -> torch.device:
+    """Device the small control collectives (flags, pickled objects) put their tensors on: the rank's own GPU under
+    nccl (RCCL moves device memory only), the host otherwise."""
+    if world() > 1 and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
 
 
 def shard_indices(n: int, r: Optional[int] = None, w: Optional[int] = None) -> List[int]:

@@ -11,6 +11,7 @@ centre crop, uncompressed GeoTIFF out; same file names, same ordering of the app
 from __future__ import annotations
 
 import os
+import warnings
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List, Optional, Tuple
 
@@ -48,11 +49,32 @@ def retrieve_neighboring_image_filenames(filename, other_filenames, meta_info: O
     return left, right, up, down
 
 
+def _fill_value(nodata: float, dt: np.dtype) -> float:
+    """The value the mosaic starts from. rasterio.merge checks the nodata value against the range of the output dtype and,
+    when it does not fit (GDAL_NODATA -9999 on a uint8 raster), warns and leaves the destination at zero."""
+    if np.issubdtype(dt, np.integer):
+        info = np.iinfo(dt)
+        if np.isnan(nodata) or not (info.min <= nodata <= info.max) or float(nodata) != int(nodata):
+            warnings.warn(f"nodata value {nodata} is beyond the valid range of {dt}: the mosaic starts from 0 (as rasterio.merge does)")
+            return 0.0
+    return float(nodata)
+
+
+def _equals(a: np.ndarray, value: float) -> np.ndarray:
+    if np.issubdtype(a.dtype, np.integer):
+        return a == a.dtype.type(value)
+    if np.isnan(value):
+        return np.isnan(a)
+    return np.isclose(a, value)
+
+
 def merge_images(src1: GeoTiff, src2: GeoTiff):
     """rasterio.merge.merge([src1, src2], nodata=v), method "first", v = src1's nodata unless it is missing or absurd
     (then 0.0): union extent on src1's grid, filled with v; each image in turn is copied where the mosaic STILL HOLDS v
-    (a value rule, as rasterio's: where the first image holds v itself a later overlapping image shows through — for the
-    exactly adjacent neighbours the reference merges the footprints never overlap). → (data [bands, rows, cols], transform)."""
+    AND the image's pixel is not one of ITS OWN nodata pixels (rasterio reads every source masked by the source's
+    nodata: ``copyto(dest, new, where=dest_is_nodata & ~new_mask)``). A value rule on the destination side: where the
+    first image holds v itself a later overlapping image shows through — for the exactly adjacent neighbours the
+    reference merges the footprints never overlap. → (data [bands, rows, cols], transform)."""
     if src1.epsg != src2.epsg:
         raise ValueError("CRS of the two images do not match.")
     nodata = getattr(src1, "nodata", None)
@@ -65,6 +87,7 @@ def merge_images(src1: GeoTiff, src2: GeoTiff):
     bottom = min(f1 + e * src1.height, f2 + src2.transform[4] * src2.height)
     W, H = int(round((right - left) / a)), int(round((bottom - top) / e))
     dt = src1.dtype.newbyteorder("=")
+    nodata = _fill_value(nodata, dt)
     out = np.full((src1.count, H, W), nodata, dtype=dt)
     for src in (src1, src2):
         col0, row0 = int(round((src.transform[2] - left) / a)), int(round((src.transform[5] - top) / e))
@@ -72,13 +95,15 @@ def merge_images(src1: GeoTiff, src2: GeoTiff):
         h, w = min(src.height, H - row0), min(src.width, W - col0)
         bands = min(src.count, out.shape[0])
         view = out[:bands, row0:row0 + h, col0:col0 + w]
-        if np.issubdtype(dt, np.integer):
-            free = view == dt.type(nodata)
-        elif np.isnan(nodata):
-            free = np.isnan(view)
-        else:
-            free = np.isclose(view, nodata)
-        np.copyto(view, data[:bands, :h, :w], where=free, casting="unsafe")
+        new = data[:bands, :h, :w]
+        free = _equals(view, nodata)
+        own = getattr(src, "nodata", None)
+        if own is not None:                      # the source's own nodata pixels stay out of the mosaic
+            sdt = new.dtype
+            fits = not np.issubdtype(sdt, np.integer) or (not np.isnan(own) and np.iinfo(sdt).min <= own <= np.iinfo(sdt).max)
+            if fits:
+                free &= ~_equals(new, own)
+        np.copyto(view, new, where=free, casting="unsafe")
     return out, (a, 0.0, left, 0.0, e, top)
 
 

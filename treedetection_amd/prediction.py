@@ -59,6 +59,7 @@ class _Slot:
         self.event = torch.cuda.Event(blocking=True)
         self.pending = 0
         self.lock = threading.Lock()
+        self.transient = False      # stand-in for a round that has no real slot (reader failure, _drain): never enters a free list
 
     def staging(self, nbytes: int, device) -> np.ndarray:
         if self.pin_in is None or self.pin_in.numel() < nbytes:
@@ -337,10 +338,10 @@ class Predictor:
         slot.copy_results(len(batch), self.device_contours)
         slot.event.record()
         slot.pending = len(batch)
-        return [self._pool.submit(self._process_and_save_single, b, i, slot, pred_subdir, tifpath)
+        return [self._pool.submit(self._process_and_save_single, b, i, slot, pred_subdir, tifpath, self._free)
                 for i, b in enumerate(batch)]
 
-    def _process_and_save_single(self, b, i, slot: _Slot, pred_subdir, tifpath):
+    def _process_and_save_single(self, b, i, slot: _Slot, pred_subdir, tifpath, free: "queue.Queue"):
         """Reference prediction.py:198-266 for one tile: polygons of its instance masks → Prediction_<tile>.json."""
         try:
             t0 = time.perf_counter()
@@ -370,7 +371,7 @@ class Predictor:
             with slot.lock:
                 slot.pending -= 1
                 if slot.pending == 0:
-                    self._free.put(slot)
+                    self._give_back(slot, free)
 
     def _finish_local(self, item, pred_subdir, tifpath, futures, stream=None) -> None:
         """A batch's last phase is enqueued: packed results → pinned memory (on ``stream``), epilogue tasks queued."""
@@ -382,7 +383,7 @@ class Predictor:
             slot.copy_results(len(batch), self.device_contours)
             slot.event.record()
         slot.pending = len(batch)
-        futures.extend(self._pool.submit(self._process_and_save_single, b, i, slot, pred_subdir, tifpath)
+        futures.extend(self._pool.submit(self._process_and_save_single, b, i, slot, pred_subdir, tifpath, self._free)
                        for i, b in enumerate(batch))
 
     def _launch_pipelined(self, ready, prepare, finish, total_rounds: Optional[int] = None) -> None:
@@ -493,6 +494,12 @@ class Predictor:
             finish(item)
             self.stats["launch"] += time.perf_counter() - t0
 
+    @staticmethod
+    def _transient_slot() -> _Slot:
+        slot = _Slot()
+        slot.transient = True
+        return slot
+
     def _drain(self, reader, ready, futures, stop) -> None:
         """Leaves no work of this call behind (every exit path of ``__call__`` runs it): the reader thread is told to
         stop and unblocked, and every epilogue task that was submitted is waited for — their slots' pinned buffers
@@ -504,9 +511,10 @@ class Predictor:
                 ready.get(timeout=0.05)
             except queue.Empty:
                 pass
-            # the reader may also be waiting for a free slot: hand it one it will not use
+            # the reader may also be waiting for a free slot: hand it one it will not use (never a real slot: those
+            # may still be in flight, and a second copy in the list would be handed out twice)
             if self._free.empty():
-                self._free.put(self._slots[0])
+                self._free.put(self._transient_slot())
         reader.join()
         for f in futures:
             try:
@@ -608,9 +616,9 @@ class Predictor:
         def round_tiles(r, k):
             return [i for i in D.shard_indices(len(tiles), r, W)[k * B:(k + 1) * B] if ok[i]]
         self.stats = dict.fromkeys(self.stats, 0.0)
-        self._free = queue.Queue()
+        free = self._free = queue.Queue()       # this image's free list: tasks capture it, never look it up later
         for s in self._slots:
-            self._free.put(s)
+            free.put(s)
         ready: "queue.Queue" = queue.Queue(maxsize=2)
         stop = threading.Event()
         errors: List[BaseException] = []
@@ -631,7 +639,9 @@ class Predictor:
                     ready.put((batch, slot))
             except BaseException as e:              # cannot get slots any more: fail the remaining rounds, keep the count
                 for _ in range(k, rounds):
-                    ready.put((e, self._slots[0]))
+                    # a stand-in slot per failed round, NOT one of self._slots: those may be in flight for other
+                    # batches, and finish() zeroes / gathers into / pastes from the slot it is given
+                    ready.put((e, self._transient_slot()))
 
         th = threading.Thread(target=reader, name="td-tile-reader", daemon=True)
         th.start()
@@ -662,7 +672,7 @@ class Predictor:
                 if me != 0:
                     # the slot (pinned staging included) may be refilled once this batch's copies and sends have run
                     slot.event.record()
-                    self._pool.submit(self._release_when_done, slot)
+                    futures.append(self._pool.submit(self._release_when_done, slot, free))
                     return
                 jobs = []
                 try:
@@ -681,10 +691,10 @@ class Predictor:
                 slot.event.record()
             slot.pending = sum(len(idx) for _, idx, _ in jobs)
             if slot.pending == 0:
-                self._pool.submit(self._release_when_done, slot)
+                futures.append(self._pool.submit(self._release_when_done, slot, free))
             for src, idx, pin in jobs:
                 for j, ti in enumerate(idx):
-                    futures.append(self._pool.submit(self._save_gathered, slot, pin, j, tiles[ti], pred_subdir, tifpath))
+                    futures.append(self._pool.submit(self._save_gathered, slot, pin, j, tiles[ti], pred_subdir, tifpath, free))
 
         try:
             if self.pipeline:
@@ -751,11 +761,19 @@ class Predictor:
             raise err if err is not None else RuntimeError(f"another rank failed while predicting {tifpath}")
         return preds
 
-    def _release_when_done(self, slot: _Slot) -> None:
-        slot.event.synchronize()
-        self._free.put(slot)
+    @staticmethod
+    def _give_back(slot: _Slot, free: "queue.Queue") -> None:
+        """Slot → the free list of the call that owns it (``free`` is captured when the task is created: a task that
+        outlives its image must not feed the NEXT call's fresh list a second copy of the slot)."""
+        if not slot.transient:
+            free.put(slot)
 
-    def _save_gathered(self, slot: _Slot, pin, j, tile, pred_subdir, tifpath):
+    def _release_when_done(self, slot: _Slot, free: "queue.Queue"):
+        slot.event.synchronize()
+        self._give_back(slot, free)
+        return []
+
+    def _save_gathered(self, slot: _Slot, pin, j, tile, pred_subdir, tifpath, free: "queue.Queue"):
         try:
             slot.event.synchronize()
             n = int(pin["count"][j])
@@ -768,7 +786,7 @@ class Predictor:
             with slot.lock:
                 slot.pending -= 1
                 if slot.pending == 0:
-                    self._free.put(slot)
+                    self._give_back(slot, free)
 
     def __call__(self, tifpath, tilepath):
         pred_subdir = os.path.join(self.output_dir, os.path.basename(tifpath).replace(".tif", "").replace(".json", ""))
