@@ -43,6 +43,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MATRIX_TFLOPS = 2500.0
+PMC_TAG = "r03" if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_conv_fp32.json")) else "r02"
+HBM_ACHIEVABLE_TBS = 6.3            # MI355X_MICROARCH.md: measured streaming rate (8.0 TB/s spec)
 MASK_HEAD_GFLOP_PER_DET = 1.028
 SCHED = {"streams": "{n} engines, each a whole forward on its own HIP stream, batches round-robin (HBM-bound kernels and kernel tails of one "
                     "forward run under the MFMA-bound contractions of the others)",
@@ -182,6 +184,25 @@ def main():
 
     nsteps = args.steps      # the extra regions below re-bind sd / B / nsteps before calling run_pipelined again
 
+    def collect_profile(engs):
+        """Sum of the engines' per-category accumulators; "_classes" = the speed-of-light accounting by kernel class."""
+        prof = None
+        for e in engs:
+            p1 = e.profile_read(reset=True)
+            p1["_classes"] = e.profile_classes(reset=True)
+            e.profile_enable(False)
+            if prof is None:
+                prof = p1
+            else:
+                for k in prof:
+                    for f in prof[k]:
+                        if isinstance(prof[k][f], dict):
+                            for g in prof[k][f]:
+                                prof[k][f][g] += p1[k][f][g]
+                        else:
+                            prof[k][f] += p1[k][f]
+        return prof
+
     def run(precision, ns, profile):
         """Warm-up + timed region for one engine precision over `ns` engines / HIP streams → (seconds max over
         ranks, profile dict or None, detections)."""
@@ -216,8 +237,9 @@ def main():
             log(f"warm-up step {i + 1} done")
         if profile:
             for e in engs:
-                e.profile_enable(True)
+                e.profile_enable(profile)            # True / 2 (detail: an event pair per contraction launch)
                 e.profile_read(reset=True)
+                e.profile_classes(reset=True)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -231,17 +253,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         log(f"timed region done ({precision}): {dt:.3f} s (host enqueue {t_enq:.3f} s)")
-        prof = None
-        if profile:
-            for e in engs:      # sum the per-engine accumulators
-                p1 = e.profile_read(reset=True)
-                e.profile_enable(False)
-                if prof is None:
-                    prof = p1
-                else:
-                    for k in prof:
-                        for f in prof[k]:
-                            prof[k][f] += p1[k][f]
+        prof = collect_profile(engs) if profile else None
         ndet = int(out["count"].sum().item())     # detections of one batch (for the mask-head FLOP estimate)
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         if world > 1:
@@ -342,6 +354,7 @@ def main():
             for e in engs:
                 e.profile_enable(True)
                 e.profile_read(reset=True)
+                e.profile_classes(reset=True)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -354,17 +367,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         log(f"timed region done ({precision}, pipelined): {dt:.3f} s (host enqueue {t_enq:.3f} s)")
-        prof = None
-        if profile:
-            for e in engs:
-                p1 = e.profile_read(reset=True)
-                e.profile_enable(False)
-                if prof is None:
-                    prof = p1
-                else:
-                    for k in prof:
-                        for f in prof[k]:
-                            prof[k][f] += p1[k][f]
+        prof = collect_profile(engs) if profile else None
         ndet = int(outs[0]["count"].sum().item())
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         if world > 1:
@@ -389,6 +392,19 @@ def main():
         # one forward at a time on one stream: the same kernels with nothing overlapping — the per-launch spans of THIS region
         # are the kernels' own durations (the `exclusive` roofline object)
         piped = run(args.precision, 1, not args.no_profile)
+    # speed-of-light class table: a short plain-loop region with one HIP-event pair per contraction launch (it perturbs the
+    # forward, so it is a region of its own and nothing else is quoted from it); fp16: its own plain loop + table
+    detail = detail16 = piped16 = None
+    detail_steps = max(1, min(4, args.steps))
+    if not args.no_serial and not args.no_profile and world == 1:
+        keep = nsteps
+        if extra is not None:
+            piped16 = run("fp16", 1, True)
+        nsteps = detail_steps
+        detail = run(args.precision, 1, 2)
+        if extra is not None:
+            detail16 = run("fp16", 1, 2)
+        nsteps = keep
     phased = None
     if args.schedule == "streams" and not args.no_serial and world == 1:
         # informational: the phase pipeline — three batches in flight whose CONTRACTION kernels never overlap each other, so its
@@ -410,6 +426,15 @@ def main():
             B, nsteps = 32, -(-max(4, args.steps // 4) // args.streams) * args.streams
             b32 = go("fp16", not args.no_profile) + (nsteps,)
             B, nsteps = args.batch, args.steps
+
+    # what the collective layer saw (for the reader of an N > 1 line: did RCCL really run N ranks on N different GPUs?)
+    props = torch.cuda.get_device_properties(local_rank)
+    me_info = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name,
+               "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", ""))}
+    ranks_info = [me_info]
+    if world > 1:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me_info)
 
     if rank == 0:
         tiles_total = args.steps * B * world
@@ -437,18 +462,62 @@ def main():
                        "concurrent_forwards": conc, "detections_last_batch": ndet},
         }
 
-        def roofline(profx, dtx, k, peak, pmc_name=None):
-            """`roofline` object of one timed region of k steps. With several forwards in flight the per-launch event spans
-            of different streams overlap (their sum exceeds the wall time), so `achieved` is the family's algorithmic FLOPs per
-            step over the WALL time per step — a lower bound of its rate, since that wall time also holds every other
-            kernel; `span` keeps the literal figure (FLOPs over the summed spans, what rocprofv3's per-kernel averages
-            show). With one forward at a time both coincide and `achieved` is the literal one."""
+        payload = B * (100 * 4 * 4 + 100 * 4 + 4 + 100 * 28 * 28 * 4)      # boxes, scores, count, mask_probs of one batch (fp32 / int32)
+        line["ranks"] = {"world": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None,
+                         "devices": [r["device"] for r in ranks_info], "distinct_gpus": len({(r["pci_bus_id"], r["uuid"], r["device"]) for r in ranks_info}),
+                         "ranks": ranks_info, "gather_bytes_per_step": payload * (world - 1),
+                         "gather": "torch.distributed.gather of count / boxes / scores / 28x28 probabilities to rank 0 after every batch, "
+                                   "enqueued on the batch's own HIP stream (fixed-shape fp32 payload per rank and step: %d bytes)" % payload}
+
+        def breakdown(profx, k):
+            return {kk: v["ms"] / k for kk, v in profx.items() if kk not in ("executed", "_classes")}
+
+        def class_table(profx, k, peak, detail=None, kd=1):
+            """Per kernel class of the contraction family, per step: launches, executed GFLOP, GB the chosen algorithm moves,
+            t_min = sum over launches of max(executed FLOPs / MFMA peak, bytes / achievable HBM rate), the resource that sets
+            it; `ms` / `frac` = measured time (HIP event pair per launch, `detail` = a plain-loop region of kd steps run for
+            this table) and t_min over it."""
+            out = {}
+            for name, c in profx["_classes"].items():
+                if c["launches"] == 0:
+                    continue
+                t_m, t_h = c["exec_flops"] / (peak * 1e12), c["bytes"] / (HBM_ACHIEVABLE_TBS * 1e12)
+                o = {"launches_per_step": c["launches"] / k, "executed_gflop": c["exec_flops"] / k / 1e9, "gbytes": c["bytes"] / k / 1e9,
+                     "t_min_ms": c["tmin_ms"] / k, "bound": "mfma" if t_m >= t_h else "hbm"}
+                if name == "mask_head":
+                    o = {"launches_per_step": c["launches"] / k, "bound": "mfma", "note": "row count lives on the device: time only"}
+                if detail is not None and detail["_classes"][name]["ms"] > 0:
+                    o["ms"] = detail["_classes"][name]["ms"] / kd
+                    if "t_min_ms" in o:
+                        o["frac"] = o["t_min_ms"] / o["ms"]
+                out[name] = o
+            return out
+
+        def roofline(profx, dtx, k, peak, pmc_name=None, detail=None, kd=1):
+            """`roofline` object of one timed region of k steps (conv family = every MFMA contraction + the Winograd transform
+            kernels of the layers on that path).
+
+            achieved / frac: FLOPs the MFMA pipe really EXECUTED (a Winograd F(4x4,3x3) layer issues 1/4 of its direct-convolution
+            multiplies, times its tile padding; F(2x2,3x3) 4/9) over the time — always <= peak. `effective_tflops` keeps the
+            ALGORITHMIC rate (2 x MACs of the direct convolution), which may exceed the peak because of Winograd.
+            With several forwards in flight the per-launch event spans of different streams overlap (their sum exceeds the wall
+            time), so the time is the WALL time per step — a lower bound of the family's rate, since that wall time also holds
+            every other kernel; `span` keeps the literal figure (FLOPs over the summed spans = what rocprofv3's per-kernel
+            averages show). With one forward at a time both coincide.
+            sol: the time-based speed of light — per launch t_min = max(executed FLOPs / MFMA peak, bytes moved by the chosen
+            algorithm / achievable HBM rate); `frac_launches` = sum of t_min over the measured family time (one forward at a time:
+            the `exclusive` object), `frac_chip` = max(sum FLOPs / peak, sum bytes / rate) over the wall time per step (under
+            concurrency an HBM-bound kernel of one forward may hide under an MFMA-bound one of another, so only the chip-level
+            bound is a bound there)."""
             cx = profx["conv_igemm"]
+            ex = profx.get("executed", {"flops": cx["flops"], "launches": 0})
+            exec_ratio = ex["flops"] / cx["flops"] if cx["flops"] > 0 else 1.0
             span_ms = cx["ms"] / k
             gflop = cx["flops"] / k / 1e9
             literal = cx["flops"] / (cx["ms"] * 1e-3) / 1e12 if cx["ms"] > 0 else 0.0
             wall = gflop / (1000.0 * dtx / k) if dtx > 0 else 0.0
-            ach = wall if conc > 1 else literal
+            eff = wall if conc > 1 else literal
+            ach = eff * exec_ratio
             traffic, traffic_src = None, None
             if pmc_name and os.path.exists(os.path.join(ROOT, "profiles", pmc_name)):
                 # HBM bytes per launch from the committed rocprofv3 --pmc passes of the plain-loop form of this command
@@ -459,34 +528,68 @@ def main():
                 traffic = pj["hbm_traffic_gb_per_step"] * 1e9 / max(cx["launches"] / k, 1.0)
                 traffic_src = (f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; conv family: "
                                f"{pj['hbm_traffic_gb_per_step']:.2f} GB per step)")
+            cls = profx["_classes"]
+            static = [c for n, c in cls.items() if n != "mask_head"]
+            sol_flops = sum(c["exec_flops"] for c in static) / k
+            sol_bytes = sum(c["bytes"] for c in static) / k
+            t_mfma, t_hbm = 1e3 * sol_flops / (peak * 1e12), 1e3 * sol_bytes / (HBM_ACHIEVABLE_TBS * 1e12)
+            t_launch = sum(c["tmin_ms"] for c in static) / k
+            wall_ms = 1000.0 * dtx / k
             o = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                 "effective_tflops": eff, "executed_over_algorithmic": exec_ratio,
                  "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
                  "algorithmic_bytes_per_launch": cx["bytes"] / max(cx["launches"], 1),
                  "algorithmic_flops_per_launch": cx["flops"] / max(cx["launches"], 1),
-                 "kernel": "conv family: conv_igemm_kernel / conv_pp8_kernel (all trunk / FPN / RPN / box-head contractions) + the "
-                           "Winograd transform kernels of the layers that take that path",
-                 "launches_per_step": cx["launches"] / k, "gflop_per_step": gflop,
+                 "executed_flops_per_launch": ex["flops"] / max(cx["launches"], 1),
+                 "kernel": "conv family: conv_igemm_kernel / conv_pp8_kernel / conv_sk_kernel / bottleneck_tail_kernel (all trunk / FPN / RPN / "
+                           "box-head contractions) + the Winograd transform kernels of the layers that take that path",
+                 "launches_per_step": cx["launches"] / k, "gflop_per_step": gflop, "executed_gflop_per_step": gflop * exec_ratio,
                  "algorithmic_gbytes_per_step": cx["bytes"] / k / 1e9,
-                 "method": ("wall: algorithmic FLOPs per step / wall time per step (%d forwards overlap on %d HIP streams)" % (conc, conc))
-                           if conc > 1 else "span: algorithmic FLOPs / summed HIP-event spans of the family (nothing overlaps)",
-                 "span": {"achieved": literal, "frac": literal / peak, "span_ms_per_step": span_ms,
+                 "method": ("wall: executed FLOPs per step / wall time per step (%d forwards overlap on %d HIP streams)" % (conc, conc))
+                           if conc > 1 else "span: executed FLOPs / summed HIP-event spans of the family (nothing overlaps)",
+                 "span": {"achieved": literal * exec_ratio, "frac": literal * exec_ratio / peak, "effective_tflops": literal,
+                          "span_ms_per_step": span_ms,
                           "avg_launch_us": 1e3 * cx["ms"] / max(cx["launches"], 1), "concurrent_forwards": conc,
                           "note": "literal: FLOPs / summed HIP-event spans on each forward's own stream; spans of concurrent forwards "
-                                  "overlap, so span_ms_per_step / concurrent_forwards (not span_ms_per_step) is what fits in ms_per_step"}}
-            ex = profx.get("executed", {"flops": cx["flops"], "launches": 0})
-            o["note"] = ("algorithmic FLOPs = 2 x MACs of the direct convolution (SURVEY.md §8d); executed_tflops = FLOPs the MFMA pipe "
-                         "really issued (Winograd F(4x4,3x3) layers run 1/4 of theirs, F(2x2,3x3) layers 4/9) over the same time")
-            o["executed_tflops"] = ach * ex["flops"] / cx["flops"] if cx["flops"] > 0 else 0.0
-            o["executed_frac"] = o["executed_tflops"] / peak
+                                  "overlap, so span_ms_per_step / concurrent_forwards (not span_ms_per_step) is what fits in ms_per_step"},
+                 "sol": {"hbm_rate_tbs": HBM_ACHIEVABLE_TBS, "executed_gflop_per_step": sol_flops / 1e9, "moved_gbytes_per_step": sol_bytes / 1e9,
+                         "t_mfma_ms": t_mfma, "t_hbm_ms": t_hbm, "t_min_launches_ms": t_launch,
+                         "frac_chip": max(t_mfma, t_hbm) / wall_ms if wall_ms > 0 else 0.0,
+                         "note": "t_min per launch = max(executed FLOPs / MFMA peak, bytes the chosen algorithm moves / achievable HBM rate); "
+                                 "frac_chip = max(sum FLOPs / peak, sum bytes / rate) / wall time per step (the whole step, every kernel)"},
+                 "classes": class_table(profx, k, peak, detail, kd)}
+            o["note"] = ("achieved = FLOPs the MFMA pipe really issued (Winograd F(4x4,3x3) layers run 1/4 of their direct-convolution FLOPs "
+                         "times the tile padding, F(2x2,3x3) layers 4/9) over the time; effective_tflops = algorithmic FLOPs (2 x MACs of "
+                         "the direct convolution, SURVEY.md §8d) over the same time")
             o["winograd_layers_per_step"] = ex["launches"] / k
+            for key in ("frac",):
+                assert o[key] <= 1.0 + 1e-9, f"roofline.{key} = {o[key]} is not a fraction"
+            assert o["sol"]["frac_chip"] <= 1.0 + 1e-9 and o["span"]["frac"] <= 1.0 + 1e-9, "speed-of-light fraction above 1"
+            return o
+
+        def exclusive(pp, k, peak):
+            """The conv family one forward at a time (nothing else on the GPU): the kernel-quality figures."""
+            cs = pp["conv_igemm"]
+            exs = pp.get("executed", {"flops": cs["flops"]})
+            r = exs["flops"] / cs["flops"] if cs["flops"] > 0 else 1.0
+            lit = cs["flops"] / (cs["ms"] * 1e-3) / 1e12 if cs["ms"] > 0 else 0.0
+            t_launch = sum(c["tmin_ms"] for n, c in pp["_classes"].items() if n != "mask_head") / k
+            o = {"achieved": lit * r, "frac": lit * r / peak, "effective_tflops": lit, "avg_launch_us": 1e3 * cs["ms"] / max(cs["launches"], 1),
+                 "span_ms_per_step": cs["ms"] / k, "t_min_launches_ms": t_launch,
+                 "sol_frac": t_launch / (cs["ms"] / k) if cs["ms"] > 0 else 0.0,
+                 "note": "the conv family with one forward at a time (the `single_stream` region of this run); sol_frac = sum over launches "
+                         "of max(executed FLOPs / peak, moved bytes / HBM rate) over the family's measured time"}
+            assert o["frac"] <= 1.0 + 1e-9 and o["sol_frac"] <= 1.0 + 1e-9, "exclusive roofline fraction above 1"
             return o
 
         peak_main = PEAK_F32_MATRIX_TFLOPS if args.precision == "fp32" else PEAK_F16_MATRIX_TFLOPS
         std = args.depth == 50 and B == 8
+        kd = detail_steps
         if prof is not None:
             line["roofline"] = roofline(prof, dt, args.steps, peak_main,
-                                        ("r02_pmc_conv_fp32.json" if args.precision == "fp32" else "r02_pmc_conv_fp16.json") if std else None)
-            line["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items() if k != "executed"}
+                                        (f"{PMC_TAG}_pmc_conv_fp32.json" if args.precision == "fp32" else f"{PMC_TAG}_pmc_conv_fp16.json") if std else None,
+                                        detail[1] if detail else None, kd)
+            line["breakdown_ms_per_step"] = breakdown(prof, args.steps)
         if extra is not None:
             dt16, prof16, ndet16 = extra
             o = {"value": tiles_total / dt16, "unit": "tiles/s", "ms_per_step": 1000.0 * dt16 / args.steps, "dtype": "f16",
@@ -494,8 +597,13 @@ def main():
                          "and selection); parity tolerances in tests/test_engine_fp16_gpu.py",
                  "detections_last_batch": ndet16}
             if prof16 is not None:
-                o["roofline"] = roofline(prof16, dt16, args.steps, PEAK_F16_MATRIX_TFLOPS, "r02_pmc_conv_fp16.json" if std else None)
-                o["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof16.items() if k != "executed"}
+                o["roofline"] = roofline(prof16, dt16, args.steps, PEAK_F16_MATRIX_TFLOPS, f"{PMC_TAG}_pmc_conv_fp16.json" if std else None,
+                                         detail16[1] if detail16 else None, kd)
+                o["breakdown_ms_per_step"] = breakdown(prof16, args.steps)
+                if piped16 is not None and piped16[1] is not None:
+                    o["roofline"]["exclusive"] = exclusive(piped16[1], args.steps, PEAK_F16_MATRIX_TFLOPS)
+                    o["single_stream"] = {"value": tiles_total / piped16[0], "unit": "tiles/s", "ms_per_step": 1000.0 * piped16[0] / args.steps,
+                                          "breakdown_ms_per_step": breakdown(piped16[1], args.steps)}
             line["fp16"] = o
 
         def sub(res, batch, peak, depth):
@@ -504,7 +612,7 @@ def main():
                  "batch_per_gpu": batch, "depth": depth, "detections_last_batch": ndetx}
             if profx is not None:
                 o["roofline"] = roofline(profx, dtx, k, peak)
-                o["breakdown_ms_per_step"] = {kk: v["ms"] / k for kk, v in profx.items() if kk != "executed"}
+                o["breakdown_ms_per_step"] = breakdown(profx, k)
             return o
         if r101 is not None:
             line["r101"] = {"note": "the reference's own depth (config.py:25: mask_rcnn_R_101_FPN_3x), same stream and schedule",
@@ -519,24 +627,19 @@ def main():
                                      "note": "the same K steps, one forward at a time on one stream: nothing overlaps, so the event spans "
                                              "are the kernels' own durations"}
             if piped[1] is not None and prof is not None:
-                cs = piped[1]["conv_igemm"]
-                lit = cs["flops"] / (cs["ms"] * 1e-3) / 1e12 if cs["ms"] > 0 else 0.0
-                line["single_stream"]["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in piped[1].items() if k != "executed"}
+                line["single_stream"]["breakdown_ms_per_step"] = breakdown(piped[1], args.steps)
                 # the kernel's own roofline (no other forward on the GPU): what the per-kernel rocprofv3 averages of the
                 # plain-loop profile in profiles/ agree with
-                line["roofline"]["exclusive"] = {"achieved": lit, "frac": lit / peak_main, "avg_launch_us": 1e3 * cs["ms"] / max(cs["launches"], 1),
-                                                 "span_ms_per_step": cs["ms"] / args.steps,
-                                                 "note": "the conv family with one forward at a time (the `single_stream` region of this run)"}
+                line["roofline"]["exclusive"] = exclusive(piped[1], args.steps, peak_main)
         if phased is not None:
             o = {"value": tiles_total / phased[0], "unit": "tiles/s", "ms_per_step": 1000.0 * phased[0] / args.steps,
                  "note": "the same K steps through the phase pipeline (--schedule phases: contraction phases of three batches back to back on "
                          "a main stream, selection phases on side streams); its contraction spans do not overlap: literal roofline"}
             if phased[1] is not None:
-                cp = phased[1]["conv_igemm"]
-                lit = cp["flops"] / (cp["ms"] * 1e-3) / 1e12 if cp["ms"] > 0 else 0.0
-                o["roofline"] = {"achieved": lit, "frac": lit / peak_main, "span_ms_per_step": cp["ms"] / args.steps,
-                                 "avg_launch_us": 1e3 * cp["ms"] / max(cp["launches"], 1), "method": "span"}
-                o["breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in phased[1].items() if k != "executed"}
+                o["roofline"] = exclusive(phased[1], args.steps, peak_main)
+                o["roofline"]["method"] = "span"
+                o["roofline"]["note"] = "contraction spans of the phase pipeline do not overlap each other (selection kernels run underneath)"
+                o["breakdown_ms_per_step"] = breakdown(phased[1], args.steps)
             line["phase_pipeline"] = o
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, rgb_np, args.cpu_tiles)

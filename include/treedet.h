@@ -128,8 +128,27 @@ td_status td_engine_read_tensor(td_engine* e, const char* name, void* dst_dev, i
  * ms[c] device milliseconds, launches[c], flops[c] algorithmic FLOPs (2*M*N*K, conv only), bytes[c] algorithmic
  * HBM bytes (inputs read once + outputs written once). Arrays hold TD_PROF_CATEGORIES entries. */
 #define TD_PROF_CATEGORIES 9
+/* enable: 0 off, 1 one event pair per category group, 2 "detail": additionally one event pair per launch of the
+ * contraction family for td_engine_profile_classes (perturbs the forward: use it on a region of its own). */
 td_status td_engine_profile_enable(td_engine* e, int enable);
 td_status td_engine_profile_read(td_engine* e, double* ms, int64_t* launches, double* flops, double* bytes, int reset);
+/* Speed-of-light accounting of the contraction family by class. Per class since the last reset: launches; the FLOPs the
+ * launches really EXECUTE (a Winograd layer's plane products, not the direct convolution's multiplies); the bytes the
+ * chosen algorithm moves through HBM when every tensor is read / written once (V / M planes of the Winograd layers
+ * included); tmin_ms = sum over launches of max(executed FLOPs / MFMA peak of the engine's precision, bytes /
+ * achievable HBM rate) with the constants below (MI355X_MICROARCH.md); ms = measured time (detail mode only, else 0).
+ * Class 5 (mask head) has a device-side row count: only its time is reported. Arrays hold TD_PROF_CLASSES entries. */
+#define TD_PROF_CLASSES 6
+#define TD_CLS_WINO_GEMM 0   /* Winograd plane contractions (fp32 engine) */
+#define TD_CLS_WINO_XFORM 1  /* Winograd input / output transform kernels */
+#define TD_CLS_CONV1X1 2     /* 1x1 convolutions: bottleneck conv1 / conv3 / shortcut, FPN laterals, RPN heads */
+#define TD_CLS_CONV3X3 3     /* direct 3x3 convolutions (fp16 engine: all of them; fp32: the 64-channel res2 layers) */
+#define TD_CLS_FC 4          /* box head: fc1, fc2, predictors */
+#define TD_CLS_MASK_HEAD 5   /* mask-head contractions and transforms (rows = live detections, known on the device only) */
+#define TD_PEAK_F32_MFMA_TFLOPS 157.3   /* v_mfma_f32_32x32x2_f32, dense */
+#define TD_PEAK_F16_MFMA_TFLOPS 2500.0  /* v_mfma_f32_32x32x16_f16, dense */
+#define TD_HBM_ACHIEVABLE_TBS 6.3       /* measured streaming rate (8.0 TB/s spec) */
+td_status td_engine_profile_classes(td_engine* e, double* ms, int64_t* launches, double* exec_flops, double* bytes, double* tmin_ms, int reset);
 const char* td_last_error(void);
 void td_engine_destroy(td_engine* e);
 
@@ -143,6 +162,14 @@ td_status td_resize_tile_u8(const uint8_t* src, int h, int w, int c, uint8_t* ds
  * written to dst + i*dst_image_stride_bytes; tmp_dev >= n*h*out_w*3 bytes. */
 td_status td_resize_batch_u8(const uint8_t* const* src_tiles, int n, int h, int w, int c, uint8_t* dst, int out_h,
                              int out_w, int dst_pitch_px, int64_t dst_image_stride_bytes, void* tmp_dev, void* stream);
+/* The float branch of the same step (prediction.py:167-169): a tile that is not uint8 (16-bit imagery rescaled by
+ * 255 * x / 65535, float rasters) goes through detectron2's ResizeTransform → torch.nn.functional.interpolate(mode="bilinear",
+ * align_corners=False) and is then cast to float32. src dev float64 [c, h, w] (planar, BGR already picked); dst dev float32,
+ * written at dst[ch * dst_plane_stride + y * dst_pitch_px + x] for y < out_h, x < out_w (the caller zero-fills the padding).
+ * Arithmetic in float64 in torch's own order (half-pixel centres, source index clamped at 0, border neighbours clamped),
+ * rounded to float32 once. */
+td_status td_resize_bilinear_f64(const double* src, int c, int h, int w, float* dst, int out_h, int out_w, int dst_pitch_px,
+                                 int64_t dst_plane_stride, void* stream);
 /* ResizeShortestEdge(800, 1333) output shape for an h x w tile (Appendix A item 2). */
 void td_resize_shape(int h, int w, int short_edge, int max_size, int* out_h, int* out_w);
 

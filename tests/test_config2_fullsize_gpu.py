@@ -1,0 +1,147 @@
+"""BASELINE configs[2] at its stated shape: the two-model (urban + forest) path over 1000x1000-px tiles of a 4-band RGBI
+raster (+ nDSM side file), two FULL-WIDTH R50-FPN weight sets, a forest outline that flags tiles both ways
+(reference TreeDetection/detection.py:154-164: urban model with exclude_vars ["only_forest"], forest model with
+["only_urban"]; prediction.py:79-93: a tile whose flag is set is skipped by that model).
+
+Checked: which tiles each model visits; for one tile that ONLY the urban model and one that ONLY the forest model
+predicts, the engine's detections against the oracle with that model's weights at the fp32 tolerances of
+tests/test_fullsize_gpu.py (boxes <= 1e-2 px, scores <= 1e-4, mask probabilities <= 1e-3, pasted-mask IoU >= 0.995,
+detections one to one) and the written Prediction_*.json against the oracle's contours (score <= 1e-4, rings <= 1 px)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import ops_ref as R
+from oracle.contours_ref import find_contours as ref_contours
+from oracle.maskrcnn_ref import MaskRCNNOracle
+from treedetection_amd.geotiff import GeoTiff, write_geotiff
+from treedetection_amd.synth import make_tile
+from treedetection_amd.weights import make_synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+
+GSD = 0.2
+COLS, ROWS = 3, 2          # 3 x 2 tiles of 200 m = 1000 px
+
+
+@pytest.fixture(scope="module")
+def two_model(tmp_path_factory):
+    import treedetection_amd as T
+    torch.set_num_threads(8)
+    root = tmp_path_factory.mktemp("cfg2")
+    (root / "rgb").mkdir()
+    (root / "ndsm").mkdir()
+    sds = {}
+    for seed, name in ((0, "urban"), (1, "forest")):
+        sds[name] = make_synthetic_state_dict(50, seed=seed)            # full width
+        np.savez(root / f"model_{name}.npz", **sds[name])
+    rgbi = np.zeros((4, ROWS * 1000, COLS * 1000), np.uint8)
+    ndsm = np.zeros((ROWS * 1000, COLS * 1000), np.float32)
+    for r in range(ROWS):
+        for c in range(COLS):
+            rgb, nd = make_tile(300 + r * COLS + c, 1000)
+            rgbi[:3, r * 1000:(r + 1) * 1000, c * 1000:(c + 1) * 1000] = rgb.transpose(2, 0, 1)
+            rgbi[3, r * 1000:(r + 1) * 1000, c * 1000:(c + 1) * 1000] = rgb[..., 1] // 2 + 60      # NIR band (unused by the model)
+            ndsm[r * 1000:(r + 1) * 1000, c * 1000:(c + 1) * 1000] = nd
+    x0, y_top = 412000.0, 5318000.0 + ROWS * 200.0
+    t = (GSD, 0.0, x0, 0.0, -GSD, y_top)
+    write_geotiff(str(root / "rgb" / "1.tif"), rgbi, t, 25832)
+    write_geotiff(str(root / "ndsm" / "1.tif"), ndsm[::5, ::5].copy(), (1.0, 0.0, x0, 0.0, -1.0, y_top), 25832)
+    # forest = everything left of x0 + 300 m: column 0 lies within it (only_forest), column 1 straddles its border
+    # (both models), column 2 is outside (only_urban)
+    outline = {"type": "FeatureCollection", "features": [{"type": "Feature", "properties": {}, "geometry": {
+        "type": "Polygon", "coordinates": [[[x0 - 100, y_top - 600], [x0 + 300, y_top - 600], [x0 + 300, y_top + 100],
+                                            [x0 - 100, y_top + 100], [x0 - 100, y_top - 600]]]}}]}
+    (root / "forest.geojson").write_text(json.dumps(outline))
+    cfg = {"image_directory": str(root / "rgb"), "height_data_path": str(root / "ndsm"),
+           "urban_model": str(root / "model_urban.npz"), "forrest_model": str(root / "model_forest.npz"),
+           "forrest_outline": str(root / "forest.geojson"), "output_directory": str(root / "output"),
+           "tiles_path": str(root / "tiles"), "use_overlap": False, "tile_width": 200, "tile_height": 200, "buffer": 0,
+           "batch_size": 4, "parallel": False, "num_workers": 2, "keep_intermediate": True, "device": "0"}
+    (root / "config.yml").write_text(yaml.safe_dump(cfg))
+    config, _ = T.get_config(str(root / "config.yml"))
+    T.preprocess_files(config)
+    T.predict_tiles(config)
+    meta = json.load(open(root / "tiles" / "1.json"))
+    return root, config, sds, meta
+
+
+def test_each_model_visits_the_tiles_its_flags_leave(two_model):
+    root, config, sds, meta = two_model
+    assert len(meta) == COLS * ROWS
+    only_forest = {k for k, v in meta.items() if v["only_forest"]}
+    only_urban = {k for k, v in meta.items() if v["only_urban"]}
+    assert len(only_forest) == ROWS and len(only_urban) == ROWS and not (only_forest & only_urban)
+    for v in meta.values():         # 1000 x 1000-px windows
+        b = v["bounds"]
+        assert round((b[2] - b[0]) / GSD) == 1000 and round((b[3] - b[1]) / GSD) == 1000
+    urban = {f[len("Prediction_"):-5] for f in os.listdir(root / "output" / "urban_predictions" / "1")}
+    forest = {f[len("Prediction_"):-5] for f in os.listdir(root / "output" / "forrest_predictions" / "1")}
+    assert urban == set(meta) - only_forest and forest == set(meta) - only_urban
+    assert len(urban) + len(forest) == 2 * COLS * ROWS - 2 * ROWS          # tiles VISITED by the two models
+    for d in ("urban_geojson", "forrest_geojson", "geojson_predictions"):
+        assert os.path.exists(root / "output" / d / "1.gpkg")
+
+
+@pytest.mark.parametrize("model,flag,folder", [("urban", "only_urban", "urban_predictions"), ("forest", "only_forest", "forrest_predictions")])
+def test_one_tile_per_model_matches_the_oracle(two_model, model, flag, folder):
+    from treedetection_amd.engine import Engine, INPUT_U8_HWC, unpack_outputs
+    root, config, sds, meta = two_model
+    tile_id = sorted(k for k, v in meta.items() if v[flag])[0]       # a tile only THIS model predicts
+    td = meta[tile_id]
+    tif = str(root / "rgb" / "1.tif")
+    bands = GeoTiff(tif).read_bounds(td["bounds"])                   # [4, 1000, 1000] uint8, file band order
+    assert bands.shape == (4, 1000, 1000)
+    x, h, w = R.preprocess_tile_u8(bands)
+    ref = MaskRCNNOracle(sds[model]).forward([{"image": x, "height": h, "width": w}])[0]
+    assert len(ref["scores"]) >= 5
+    # (1) the engine with this model's weights on the tile's bytes (the Predictor's device path: band pick + resize + forward + paste)
+    eng = Engine(sds[model])
+    tile = torch.from_numpy(np.ascontiguousarray(bands[:3].transpose(1, 2, 0))).cuda()
+    batch, hv, ho = eng.preprocess_tiles_u8([tile])
+    out = eng.alloc_outputs(1, 1000, 1000, paste=True)
+    eng.forward_raw(batch, INPUT_U8_HWC, hv, ho, out)
+    torch.cuda.synchronize()
+    g = unpack_outputs(out, ho, True)[0]
+    eng.close()
+    assert abs(len(g["scores"]) - len(ref["scores"])) <= 1
+    matched = 0
+    for j in range(len(ref["scores"])):
+        d = np.abs(g["pred_boxes"] - ref["pred_boxes"][j]).max(axis=1)
+        k = int(np.argmin(d))
+        if d[k] <= 1e-2 and abs(g["scores"][k] - ref["scores"][j]) <= 1e-4:
+            a, b = g["pred_masks"][k], ref["pred_masks"][j]
+            u = (a | b).sum()
+            assert u == 0 or (a & b).sum() / u >= 0.995
+            assert np.abs(g["mask_probs"][k] - ref["mask_probs"][j]).max() <= 1e-3
+            matched += 1
+    assert matched >= len(ref["scores"]) - 1, (matched, len(ref["scores"]))
+    # (2) the file predict_tiles wrote for this tile with this model
+    got = json.load(open(root / "output" / folder / "1" / f"Prediction_{tile_id}.json"))
+    exp = []
+    t = td["transform"]
+    for d in range(len(ref["scores"])):
+        for c in ref_contours(ref["pred_masks"][d]):
+            if c.size < 8:
+                continue
+            cx, cy = c[:, 0].tolist(), c[:, 1].tolist()
+            if (cx[0], cy[0]) != (cx[-1], cy[-1]):
+                cx.append(cx[0]); cy.append(cy[0])
+            exp.append((float(ref["scores"][d]), [[t[0] * a + t[1] * b + t[2], t[3] * a + t[4] * b + t[5]] for a, b in zip(cx, cy)]))
+    assert abs(len(got) - len(exp)) <= max(2, 0.02 * len(exp)), (len(got), len(exp))
+    same = 0
+    for e in got:
+        assert e["image_id"] == tif and e["category_id"] == 0
+        for s, ring in exp:
+            if abs(e["score"] - s) <= 1e-4 and len(ring) == len(e["polygon_coords"][0]):
+                if np.abs(np.asarray(ring) - np.asarray(e["polygon_coords"][0])).max() <= GSD + 1e-9:      # <= 1 px
+                    same += 1
+                    break
+    assert same >= 0.9 * len(exp), (same, len(exp))
+    # the OTHER model never wrote this tile
+    other = "forrest_predictions" if folder == "urban_predictions" else "urban_predictions"
+    assert not os.path.exists(root / "output" / other / "1" / f"Prediction_{tile_id}.json")

@@ -15,7 +15,9 @@ a saturated score. The synthetic classifier puts most detections in the steep pa
     the oracle's probability is within that 3e-2 of the 0.5 cut — this holds for every pixel of every detection;
   * pasted-mask IoU >= 0.97 for masks with < 3 % of their pixels that close to the cut (what a trained mask head
     produces), else >= 1 - 1.5 x that fraction: the seeded random mask head leaves ~10 % of the pixels within 3e-2 of
-    0.5 (median; up to 19 %), where IoU measures the fixture, not the engine (measured min 0.86, median 0.98).
+    0.5 (median; up to 19 %), where IoU measures the fixture, not the engine (measured min 0.86, median 0.98);
+  * on a mask head whose output is a compact blob (tests/blob_head.py) IoU >= 0.97 is asserted OUTRIGHT for every
+    matched detection (test_fp16_stated_tolerances_on_heads_with_trained_like_margins).
 The measured distribution is printed by the test (pytest -s)."""
 import numpy as np
 import pytest
@@ -147,26 +149,27 @@ def test_fp16_mfma_stem_on_uint8_input():
 
 
 def test_fp16_stated_tolerances_on_heads_with_trained_like_margins():
-    """'fix the fixture, don't move the bar'. The seeded heads put most class scores in the steep part
-    of the sigmoid and produce noise-like masks (boundary pixels ~ 2 x area). With the classifier gain a trained model has
-    (x3 on this fixture: scores saturate) BASELINE.md's proposals hold OUTRIGHT: |score error| <= 5e-3 for EVERY matched
-    detection (measured max 9e-4), boxes <= 0.5 px. For the masks the shape-independent statement is about boundary pixels:
-    the pasted masks differ from the oracle's in at most 15 % of the oracle mask's boundary pixels (measured max 10-13 %,
-    median 2.3 %, whatever the predictor gain) — for a compact crown (a disc of 2 000 px has ~320 boundary pixels by this
-    count) that is IoU >= 0.979 in the worst case and 0.996 at the median, i.e. the proposed 0.97; the fixture's ragged
-    masks (666 boundary pixels on 345 px of area) turn the same flip rate into IoU 0.88-0.90, which measures the fixture."""
+    """'fix the fixture, don't move the bar'. The seeded heads put most class scores in
+    the steep part of the sigmoid and produce noise-like masks (boundary pixels ~ 2 x area), on which IoU measures the
+    fixture. Here the classifier has the gain of a trained model (x3: scores saturate) and the mask head is
+    tests/blob_head.py: its OUTPUT is a compact blob — the level set of a smooth function of the real RoI features
+    (every kernel of the mask branch runs: RoIAlign 14x14, four 3x3 convs, deconv, predictor, paste). On that fixture
+    BASELINE.md's proposals are asserted OUTRIGHT on the engine's own outputs: |score error| <= 5e-3 and boxes <= 0.5 px
+    for every matched detection, pasted-mask IoU >= 0.97 for EVERY matched detection. The fixture itself is checked too:
+    the ORACLE's masks are compact (boundary / area <= 0.2 for at least 95 % of them, median <= 0.12)."""
+    from tests.blob_head import blob_mask_head, boundary_over_area
     from treedetection_amd.engine import Engine
     torch.set_num_threads(8)
     sd = make_synthetic_state_dict(50, seed=5)
     sd["roi_heads.box_predictor.cls_score.weight"] = sd["roi_heads.box_predictor.cls_score.weight"] * np.float32(3.0)
-    sd["roi_heads.mask_head.predictor.weight"] = sd["roi_heads.mask_head.predictor.weight"] * np.float32(4.0)
+    sd = blob_mask_head(sd)
     rng = np.random.default_rng(21)
     inputs = [{"image": smooth_image(rng, 256, 320), "height": 320, "width": 400},
-              {"image": smooth_image(rng, 224, 256), "height": 224, "width": 256}]
+              {"image": smooth_image(rng, 224, 256), "height": 560, "width": 640}]
     ref = MaskRCNNOracle(sd).forward(inputs)
     eng = Engine(sd, precision="fp16")
     got = eng(inputs)
-    es, flips, ious = [], [], []
+    es, ious, compact, flips = [], [], [], []
     for g, r in zip(got, ref):
         assert len(r["scores"]) > 20 and abs(len(g["scores"]) - len(r["scores"])) <= 2
         matched = 0
@@ -180,22 +183,19 @@ def test_fp16_stated_tolerances_on_heads_with_trained_like_margins():
             assert e <= 5e-3, (i, float(r["scores"][i]), e)
             assert np.abs(g["pred_boxes"][bj] - r["pred_boxes"][i]).max() <= 0.5
             a, b = g["pred_masks"][bj], r["pred_masks"][i]
-            boundary = int((b ^ np.roll(b, 1, 0)).sum() + (b ^ np.roll(b, 1, 1)).sum())
-            diff = int((a ^ b).sum())
-            assert diff <= max(4, 0.15 * boundary), (i, diff, boundary)
+            assert b.sum() > 0
             u = (a | b).sum()
+            m_iou = (a & b).sum() / u
+            assert m_iou >= 0.97, (i, m_iou, int(b.sum()), boundary_over_area(b))
+            assert np.abs(g["mask_probs"][bj] - r["mask_probs"][i]).max() <= 3e-2
             es.append(e)
-            flips.append(diff / max(boundary, 1))
-            ious.append((a & b).sum() / u if u else 1.0)
+            ious.append(m_iou)
+            compact.append(boundary_over_area(b))
+            flips.append(int((a ^ b).sum()))
         assert matched >= len(r["scores"]) - 2
-    flips = np.array(flips)
-    print(f"\n[fp16, trained-like margins] {len(es)} matched detections: score err max {max(es):.4f}; differing / boundary pixels max "
-          f"{flips.max():.3f} median {np.median(flips):.3f}; mask IoU on the fixture's ragged masks min {min(ious):.3f} median {np.median(ious):.3f}")
-    assert np.median(flips) <= 0.04
-    # what the flip rate means for a compact crown: disc of 2 000 px, boundary counted the same way
-    yy, xx = np.mgrid[0:80, 0:80]
-    disc = (yy - 40) ** 2 + (xx - 40) ** 2 <= 2000 / np.pi
-    bd = int((disc ^ np.roll(disc, 1, 0)).sum() + (disc ^ np.roll(disc, 1, 1)).sum())
-    worst = flips.max() * bd
-    assert (disc.sum() - worst / 2) / (disc.sum() + worst / 2) >= 0.97
+    compact = np.array(compact)
+    print(f"\n[fp16, trained-like heads] {len(es)} matched detections: score err max {max(es):.4f}; pasted-mask IoU min {min(ious):.4f} "
+          f"median {np.median(ious):.4f}; differing pixels max {max(flips)}; oracle masks boundary/area median {np.median(compact):.3f} "
+          f"p95 {np.quantile(compact, 0.95):.3f} max {compact.max():.3f}")
+    assert np.median(compact) <= 0.12 and (compact <= 0.2).mean() >= 0.95       # the fixture's masks ARE compact
     eng.close()

@@ -330,7 +330,8 @@ def test_config4_fp16_batch32_full_size():
 def test_full_width_r101_tile_matches_oracle():
     """The reference's only depth (TreeDetection/config.py:25: mask_rcnn_R_101_FPN_3x, blocks [3,4,23,3]) at full width on
     one 1000x1000 tile through the bench's device path (resize → forward → paste), against the oracle: same detections
-    one-to-one, boxes <= 1e-2 px, scores <= 1e-4, mask probabilities <= 1e-3, pasted masks IoU >= 0.995."""
+    one-to-one, boxes <= 1e-2 px, scores <= 1e-4, mask probabilities <= 1e-3, pasted masks IoU >= 0.995; and at the batch the
+    bench runs (8): batch-8 == batch-1 forwards bit for bit."""
     from treedetection_amd.engine import Engine, INPUT_U8_HWC, unpack_outputs
     torch.set_num_threads(8)
     sd = make_synthetic_state_dict(101, seed=0)
@@ -358,4 +359,21 @@ def test_full_width_r101_tile_matches_oracle():
             assert np.abs(g["mask_probs"][k] - ref["mask_probs"][j]).max() <= 1e-3
             matched += 1
     assert matched >= len(ref["scores"]) - 1, (matched, len(ref["scores"]))
+    # the bench's R101 regions run batch 8: the batched forward equals eight batch-1 forwards bit for bit (tile 0 = the tile
+    # checked against the oracle above), so the benched configuration is the tested one
+    tiles8 = tiles + [torch.from_numpy(make_tile(60 + i, 1000)[0]).cuda() for i in range(7)]
+    x8, hv8, ho8 = eng.preprocess_tiles_u8(tiles8)
+    o8 = eng.alloc_outputs(8, 1000, 1000, paste=True)
+    eng.forward_raw(x8.clone(), INPUT_U8_HWC, hv8, ho8, o8)
+    torch.cuda.synchronize()
+    for k in ("count", "boxes", "scores", "mask_probs", "mask_region"):
+        assert torch.equal(o8[k][0], out[k][0]), k
+    for i in (3, 7):
+        x1, hv1, ho1 = eng.preprocess_tiles_u8(tiles8[i:i + 1])
+        o1 = eng.alloc_outputs(1, 1000, 1000, paste=True)
+        eng.forward_raw(x1.clone(), INPUT_U8_HWC, hv1, ho1, o1)
+        torch.cuda.synchronize()
+        for k in ("count", "boxes", "scores", "mask_probs", "mask_region"):
+            assert torch.equal(o1[k][0], o8[k][i]), (i, k)
+        assert _same_bits(o1, {k: v[i:i + 1] for k, v in o8.items()}), i
     eng.close()

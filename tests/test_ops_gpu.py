@@ -181,6 +181,32 @@ def test_resize_tile_pillow_exact(h, w, c):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("h,w,oh,ow", [(450, 450, 800, 800), (1000, 1000, 800, 800), (350, 450, 800, 1029), (97, 211, 613, 1333), (800, 800, 800, 800)])
+def test_resize_bilinear_f64_matches_torch_interpolate(h, w, oh, ow):
+    """td_resize_bilinear_f64 (the float branch of the reference's resize, prediction.py:167-169) against what the reference
+    itself calls for non-uint8 tiles: torch.nn.functional.interpolate(bilinear, align_corners=False) on the CPU in float64,
+    then .astype(float32). Same operations in the same order in float64; the only freedom is a fused multiply-add inside
+    torch's vectorised loop, i.e. one float64 ulp before the final rounding: equal to 1 float32 ulp at most, bit-equal
+    almost everywhere. Up- and down-scaling, 16-bit value range, padded destination."""
+    import torch.nn.functional as F
+    lib = _lib.load()
+    rng = np.random.default_rng(h * 13 + w)
+    src = (255.0 * rng.integers(0, 65536, (3, h, w)).astype(np.float64) / 65535.0)          # prediction.py:167
+    ref = F.interpolate(torch.from_numpy(src)[None], size=(oh, ow), mode="bilinear", align_corners=False)[0].float().numpy()
+    pitch, rows = (ow + 31) // 32 * 32, (oh + 31) // 32 * 32
+    dst = torch.full((3, rows, pitch), -1.0, dtype=torch.float32, device="cuda")
+    d = dev(src)
+    _lib.check(lib.td_resize_bilinear_f64(d.data_ptr(), 3, h, w, dst.data_ptr(), oh, ow, pitch, rows * pitch, _lib.stream_ptr()),
+               "td_resize_bilinear_f64")
+    torch.cuda.synchronize()
+    out = dst.cpu().numpy()
+    got = out[:, :oh, :ow]
+    assert (out[:, oh:, :] == -1.0).all() and (out[:, :, ow:] == -1.0).all()        # nothing written outside the image
+    ulp = np.spacing(np.abs(ref).astype(np.float32))
+    assert (np.abs(got - ref) <= ulp).all()
+    assert (got == ref).mean() >= 0.9999
+
+
 def test_paste_masks_batch_equals_per_image_paste():
     """td_paste_masks_batch (rank 0's paste of gathered detections: ragged image sizes, device-side counts, one
     asynchronous launch pair) against td_paste_masks image by image."""

@@ -55,12 +55,15 @@ SIGNATURES = {
     "td_engine_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "td_engine_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                          C.POINTER(C.c_double), C.c_int]),
+    "td_engine_profile_classes": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                            C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "td_last_error": (C.c_char_p, []),
     "td_engine_destroy": (None, [C.c_void_p]),
     "td_resize_tile_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p]),
     "td_resize_batch_u8": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                      C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "td_resize_bilinear_f64": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "td_resize_shape": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "td_conv2d_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
                        + [C.c_int] * 11 + [C.c_void_p]),

@@ -110,6 +110,11 @@ td_status td_resize_batch_u8(const uint8_t* const* src_tiles, int n, int h, int 
                                   tmp_dev, static_cast<hipStream_t>(stream));
 }
 
+td_status td_resize_bilinear_f64(const double* src, int c, int h, int w, float* dst, int out_h, int out_w, int dst_pitch_px,
+                                 int64_t dst_plane_stride, void* stream) {
+    return resize_bilinear_f64_launch(src, c, h, w, dst, out_h, out_w, dst_pitch_px, (long long)dst_plane_stride, static_cast<hipStream_t>(stream));
+}
+
 void td_resize_shape(int h, int w, int short_edge, int max_size, int* out_h, int* out_w) {
     // detectron2 ResizeShortestEdge.get_output_shape (python doubles; int(x + 0.5)) — Appendix A item 2
     const double scale = (double)short_edge / (double)(h < w ? h : w);

@@ -95,5 +95,7 @@ td_status maxpool3x3s2_launch(const void* x, void* y, int B, int H, int W, int C
 td_status subsample2_launch(const void* x, void* y, int B, int H, int W, int C, int precision, hipStream_t stream);
 td_status resize_batch_u8_launch(const uint8_t* const* srcs, int n, int h, int w, int c, uint8_t* dst, int out_h,
                                  int out_w, int dst_pitch_px, size_t dst_img_bytes, void* tmp, hipStream_t stream);
+td_status resize_bilinear_f64_launch(const double* src, int c, int h, int w, float* dst, int out_h, int out_w, int dst_pitch,
+                                     long long dst_plane, hipStream_t stream);
 td_status resize_tile_u8_launch(const uint8_t* src, int h, int w, int c, uint8_t* dst, int out_h, int out_w,
                                 int dst_pitch_px, void* tmp, hipStream_t stream);

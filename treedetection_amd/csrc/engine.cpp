@@ -147,6 +147,18 @@ struct td_engine {
     int64_t prof_launches[TD_PROF_CATEGORIES] = {};
     double prof_flops[TD_PROF_CATEGORIES] = {};
     double prof_bytes[TD_PROF_CATEGORIES] = {};
+    // per-class speed-of-light accounting of the contraction family (td_engine_profile_classes): what each launch EXECUTES
+    // (Winograd planes: the plane products, not the direct convolution's multiplies) and the bytes its algorithm moves
+    // (V / M planes included), with t_min = max(executed FLOPs / MFMA peak, bytes / achievable HBM rate) per launch;
+    // measured time per class only in detail mode (td_engine_profile_enable(e, 2): an event pair per launch)
+    bool prof_detail = false;
+    double cls_ms[TD_PROF_CLASSES] = {};
+    int64_t cls_launches[TD_PROF_CLASSES] = {};
+    double cls_flops[TD_PROF_CLASSES] = {};
+    double cls_bytes[TD_PROF_CLASSES] = {};
+    double cls_tmin_ms[TD_PROF_CLASSES] = {};
+    struct ClsRec { hipEvent_t a, b; int cls; };
+    std::vector<ClsRec> cls_recs;
 };
 
 namespace {
@@ -361,6 +373,32 @@ struct ProfScope {
     }
 };
 
+// One launch of the contraction family under its speed-of-light class: always adds the model side (executed FLOPs,
+// bytes the chosen algorithm moves, t_min) while profiling is on; in detail mode also an event pair of its own.
+struct ClassScope {
+    td_engine* e;
+    hipStream_t s;
+    hipEvent_t a = nullptr;
+    int cls;
+    ClassScope(td_engine* e_, hipStream_t s_, int cls_, double exec_flops, double bytes) : e(e_), s(s_), cls(cls_) {
+        if (!e->prof) return;
+        const double peak = (e->desc.precision == TD_PRECISION_FP16 ? TD_PEAK_F16_MFMA_TFLOPS : TD_PEAK_F32_MFMA_TFLOPS) * 1e12;
+        e->cls_launches[cls] += 1;
+        e->cls_flops[cls] += exec_flops;
+        e->cls_bytes[cls] += bytes;
+        e->cls_tmin_ms[cls] += 1e3 * std::max(exec_flops / peak, bytes / (TD_HBM_ACHIEVABLE_TBS * 1e12));
+        if (!e->prof_detail) return;
+        a = prof_event(e);
+        (void)hipEventRecord(a, s);
+    }
+    ~ClassScope() {
+        if (!a) return;
+        hipEvent_t b = prof_event(e);
+        (void)hipEventRecord(b, s);
+        e->cls_recs.push_back({a, b, cls});
+    }
+};
+
 // Measured block-tile choices shared between engines (and runs) through the TD_TUNE_CACHE file: read at creation and
 // again whenever a layer shape is missing, so engines created together pick up what the first one measured.
 void load_tune_cache(td_engine* e) {
@@ -417,6 +455,7 @@ void td_engine_destroy(td_engine* e) {
     free_pool(e->weight_allocs);
     free_pool(e->ws_allocs);
     for (auto& r : e->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto& r : e->cls_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto ev : e->prof_free) (void)hipEventDestroy(ev);
     for (auto ev : e->phase_ev) if (ev) (void)hipEventDestroy(ev);
     if (e->prev5_ev) (void)hipEventDestroy(e->prev5_ev);
@@ -809,17 +848,26 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
             a.M = n; a.m_dyn = m_dyn; a.m_mul = m_dyn ? m_mul / 4 : 1;    // even H, W with a device row count: tiles = rows / 4
             a.m_off = (int)t0;
             a.w_bs = (long long)L.cout * L.cin; a.y_bs = (long long)n * L.cout;
+            // speed-of-light model (static row counts only): 16 plane products of [n x cin] x [cin x cout]; V = 4x the input,
+            // M = 4x the output, each crossing HBM once per direction
+            const double xb = 4.0 * B_ * H_ * W_ * L.cin, yb = 4.0 * B_ * H_ * W_ * L.cout, ub = 4.0 * 16 * L.cout * L.cin;
+            const double vb = 4.0 * 16 * n * L.cin, mb = 4.0 * 16 * n * L.cout, pf = 2.0 * 16 * n * (double)L.cin * L.cout;
+            const bool dyn = m_dyn != nullptr;
             if (e->wino_fused) {
                 // input transform fused into the contraction's A staging (wino_gemm_kernel): V never exists in memory
+                ClassScope cs(e, s_, dyn ? TD_CLS_MASK_HEAD : TD_CLS_WINO_GEMM, dyn ? 0.0 : pf, dyn ? 0.0 : xb + ub + mb);
                 a.x = x_; a.B = B_; a.H = H_; a.W = W_;
                 if ((st2 = wino_gemm_launch(a, s_)) < 0) return st2;
             } else {
-                if ((st2 = wino_input_launch(static_cast<const float*>(x_), B_, H_, W_, L.cin, e->wino_v, m_dyn, m_mul, t0, n, s_)) < 0) return st2;
+                { ClassScope cs(e, s_, dyn ? TD_CLS_MASK_HEAD : TD_CLS_WINO_XFORM, 0.0, dyn ? 0.0 : xb + vb);
+                if ((st2 = wino_input_launch(static_cast<const float*>(x_), B_, H_, W_, L.cin, e->wino_v, m_dyn, m_mul, t0, n, s_)) < 0) return st2; }
                 a.x = e->wino_v; a.B = 1; a.H = 1; a.W = n; a.Ho = 1; a.Wo = n;
                 a.batch_count = 16; a.x_bs = (long long)n * L.cin;
                 a.tile_cfg = gemm_cfg;
+                ClassScope cs(e, s_, dyn ? TD_CLS_MASK_HEAD : TD_CLS_WINO_GEMM, dyn ? 0.0 : pf, dyn ? 0.0 : vb + ub + mb);
                 if ((st2 = conv2d_launch(a, TD_PRECISION_FP32, s_)) < 0) return st2;
             }
+            ClassScope cs(e, s_, dyn ? TD_CLS_MASK_HEAD : TD_CLS_WINO_XFORM, 0.0, dyn ? 0.0 : mb + yb);
             if ((st2 = wino_output_launch(e->wino_m, B_, H_, W_, L.cout, L.scale, L.bias, relu ? 1 : 0, static_cast<float*>(y_), m_dyn,
                                           m_mul, t0, n, s_)) < 0) return st2;
         }
@@ -832,7 +880,12 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         const int tiles_img = ((H_ + 3) / 4) * ((W_ + 3) / 4);
         const long long T = (long long)B_ * tiles_img;
         td_status st2;
-        if ((st2 = wino43_input_launch(static_cast<const float*>(x_), B_, H_, W_, L.cin, e->wino_v, m_dyn, s_)) < 0) return st2;
+        // speed-of-light model: 36 plane products of [T x cin] x [cin x cout]; V / M = 36 T rows (2.25x the padded input / output)
+        const bool dyn = m_dyn != nullptr;
+        const double xb = 4.0 * B_ * H_ * W_ * L.cin, yb = 4.0 * B_ * H_ * W_ * L.cout, ub = 4.0 * 36 * L.cout * L.cin;
+        const double vb = 4.0 * 36 * T * L.cin, mb = 4.0 * 36 * T * L.cout, pf = 2.0 * 36 * T * (double)L.cin * L.cout;
+        { ClassScope cs(e, s_, dyn ? TD_CLS_MASK_HEAD : TD_CLS_WINO_XFORM, 0.0, dyn ? 0.0 : xb + vb);
+        if ((st2 = wino43_input_launch(static_cast<const float*>(x_), B_, H_, W_, L.cin, e->wino_v, m_dyn, s_)) < 0) return st2; }
         ConvArgs a{};
         a.x = e->wino_v; a.w = L.wino_u43; a.y = e->wino_m;
         a.Cin = L.cin; a.Cout = L.cout; a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
@@ -840,7 +893,9 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         a.M = (int)T; a.m_dyn = m_dyn; a.m_mul = m_dyn ? tiles_img : 1;
         a.batch_count = 36; a.x_bs = T * L.cin; a.w_bs = (long long)L.cout * L.cin; a.y_bs = T * L.cout;
         a.tile_cfg = gemm_cfg;
-        if ((st2 = conv2d_launch(a, TD_PRECISION_FP32, s_)) < 0) return st2;
+        { ClassScope cs(e, s_, dyn ? TD_CLS_MASK_HEAD : TD_CLS_WINO_GEMM, dyn ? 0.0 : pf, dyn ? 0.0 : vb + ub + mb);
+        if ((st2 = conv2d_launch(a, TD_PRECISION_FP32, s_)) < 0) return st2; }
+        ClassScope cs(e, s_, dyn ? TD_CLS_MASK_HEAD : TD_CLS_WINO_XFORM, 0.0, dyn ? 0.0 : mb + yb);
         return wino43_output_launch(e->wino_m, B_, H_, W_, L.cout, L.scale, L.bias, relu ? 1 : 0, static_cast<float*>(y_), m_dyn, s_);
     };
     auto run_conv = [&](const ConvLayer& L, const void* x_, int B_, int H_, int W_, int stride, int pad, bool relu,
@@ -899,6 +954,8 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         }
         if (use_43) return run_wino43(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, wino_cfg);
         if (use_wino) return run_wino(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, m_mul, wino_cfg);
+        const int cls = m_dyn ? TD_CLS_MASK_HEAD : (H_ == 1 && W_ == 1 ? TD_CLS_FC : (L.kh == 1 && L.kw == 1 ? TD_CLS_CONV1X1 : TD_CLS_CONV3X3));
+        ClassScope cs(e, s_, cls, m_dyn ? 0.0 : flops, m_dyn ? 0.0 : bytes);
         return run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, cfg);
     };
     // ---- backbone ------------------------------------------------------------------------------------------
@@ -1248,6 +1305,33 @@ td_status td_engine_tensor(td_engine* e, const char* name, void** dev_ptr, int64
 td_status td_engine_profile_enable(td_engine* e, int enable) {
     TD_REQUIRE(e, "td_engine_profile_enable: null engine");
     e->prof = enable != 0;
+    e->prof_detail = enable == 2;
+    return TD_OK;
+}
+
+td_status td_engine_profile_classes(td_engine* e, double* ms, int64_t* launches, double* exec_flops, double* bytes, double* tmin_ms, int reset) {
+    TD_REQUIRE(e, "td_engine_profile_classes: null engine");
+    for (auto& r : e->cls_recs) {
+        TD_HIP_CHECK(hipEventSynchronize(r.b));
+        float t = 0.f;
+        TD_HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
+        e->cls_ms[r.cls] += t;
+        e->prof_free.push_back(r.a);
+        e->prof_free.push_back(r.b);
+    }
+    e->cls_recs.clear();
+    for (int c = 0; c < TD_PROF_CLASSES; ++c) {
+        if (ms) ms[c] = e->cls_ms[c];
+        if (launches) launches[c] = e->cls_launches[c];
+        if (exec_flops) exec_flops[c] = e->cls_flops[c];
+        if (bytes) bytes[c] = e->cls_bytes[c];
+        if (tmin_ms) tmin_ms[c] = e->cls_tmin_ms[c];
+        if (reset) {
+            e->cls_ms[c] = 0.0;
+            e->cls_launches[c] = 0;
+            e->cls_flops[c] = e->cls_bytes[c] = e->cls_tmin_ms[c] = 0.0;
+        }
+    }
     return TD_OK;
 }
 

@@ -495,6 +495,46 @@ td_status resize_tile_u8_launch(const uint8_t* src, int h, int w, int c, uint8_t
     return resize_batch_u8_launch(&src, 1, h, w, c, dst, out_h, out_w, dst_pitch_px, 0, tmp, stream);
 }
 
+// ---- float resize of the non-uint8 rasters (reference prediction.py:167-169) -----------------------------------------
+// 16-bit / float tiles do not take Pillow's 8-bit filter: detectron2's ResizeTransform.apply_image hands every other dtype to
+// torch.nn.functional.interpolate(mode="bilinear", align_corners=False). Restated here operation for operation in the
+// input's precision (float64: the reference's 255 * x / 65535 makes the tile a float64 array): scale = in / out,
+// src = max(scale * (dst + 0.5) - 0.5, 0), i1 = (int)src, lambda1 = src - i1, lambda0 = 1 - lambda1, neighbour index
+// clamped at the border, value = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11) — one IEEE operation per step
+// (-ffp-contract=off), then ONE rounding to float32 (the reference's .astype("float32")). HBM-bound: 8 B in, 4 B out.
+__global__ __launch_bounds__(256) void resize_bilinear_f64_kernel(const double* __restrict__ src, int C, int h, int w, float* __restrict__ dst,
+                                                                   int out_h, int out_w, int dst_pitch, long long dst_plane) {
+    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+    const int oy = blockIdx.y;
+    if (ox >= out_w || oy >= out_h) return;
+    const double sh = (double)h / (double)out_h, sw = (double)w / (double)out_w;
+    double fy = sh * ((double)oy + 0.5) - 0.5;
+    double fx = sw * ((double)ox + 0.5) - 0.5;
+    fy = fy < 0.0 ? 0.0 : fy;
+    fx = fx < 0.0 ? 0.0 : fx;
+    const int y1 = (int)fy, x1 = (int)fx;
+    const int yp = y1 < h - 1 ? 1 : 0, xp = x1 < w - 1 ? 1 : 0;
+    const double h1 = fy - (double)y1, h0 = 1.0 - h1;
+    const double w1 = fx - (double)x1, w0 = 1.0 - w1;
+    for (int c = 0; c < C; ++c) {
+        const double* p = src + ((size_t)c * h + y1) * w + x1;
+        const double v00 = p[0], v01 = p[xp], v10 = p[(size_t)yp * w], v11 = p[(size_t)yp * w + xp];
+        const double top = __dadd_rn(__dmul_rn(w0, v00), __dmul_rn(w1, v01));
+        const double bot = __dadd_rn(__dmul_rn(w0, v10), __dmul_rn(w1, v11));
+        dst[(size_t)c * dst_plane + (size_t)oy * dst_pitch + ox] = (float)__dadd_rn(__dmul_rn(h0, top), __dmul_rn(h1, bot));
+    }
+}
+
+td_status resize_bilinear_f64_launch(const double* src, int c, int h, int w, float* dst, int out_h, int out_w, int dst_pitch,
+                                     long long dst_plane, hipStream_t stream) {
+    TD_REQUIRE(src && dst && c >= 1 && h >= 1 && w >= 1 && out_h >= 1 && out_w >= 1 && dst_pitch >= out_w && dst_plane >= (long long)out_h * dst_pitch,
+               "resize_bilinear_f64: bad geometry (%d x %d x %d -> %d x %d, pitch %d)", c, h, w, out_h, out_w, dst_pitch);
+    hipLaunchKernelGGL(resize_bilinear_f64_kernel, dim3(td_cdiv(out_w, 256), out_h), dim3(256), 0, stream, src, c, h, w, dst, out_h, out_w,
+                       dst_pitch, dst_plane);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
 // host: the fp16 filter image [cout][192] (k = (ky, kx, c), zero-padded) of stem_mfma_kernel and the bias with the mean
 // subtraction folded in: bias' = bias - scale * sum_k w16[n][k] * mean_c(k), from the ROUNDED filters (float64, rounded once)
 void stem_mfma_prepare(const float* w_kc /*[147][cout]*/, const float* scale, const float* bias, int cout,

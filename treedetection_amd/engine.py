@@ -220,6 +220,22 @@ class Engine:
         hw_out = [(int(t.shape[0]), int(t.shape[1])) for t in tiles]
         return batch, shapes, hw_out
 
+    def preprocess_tiles_f64(self, planes: Sequence[torch.Tensor]):
+        """float64 CUDA tiles [3,h,w] (BGR already picked, 16-bit imagery already rescaled: reference prediction.py:166-167)
+        → (float32 [B,3,Hp,Wp] batch, hw_valid): the reference's float resize branch — detectron2 hands non-uint8 images
+        to F.interpolate(bilinear, align_corners=False) — on the device (td_resize_bilinear_f64), zero padding included."""
+        shapes = [self.resize_shape(t.shape[1], t.shape[2]) for t in planes]
+        Hp = _round_up(max(s[0] for s in shapes), 32)
+        Wp = _round_up(max(s[1] for s in shapes), 32)
+        dev = torch.device("cuda", self.device)
+        x = torch.zeros((len(planes), 3, Hp, Wp), dtype=torch.float32, device=dev)
+        st = _lib.stream_ptr()
+        for i, (t, (oh, ow)) in enumerate(zip(planes, shapes)):
+            assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.shape[0] == 3
+            _lib.check(self.lib.td_resize_bilinear_f64(t.data_ptr(), 3, t.shape[1], t.shape[2], x[i].data_ptr(), oh, ow, Wp, Hp * Wp, st),
+                       "td_resize_bilinear_f64")
+        return x, shapes
+
     CONTOUR_MAX = 256         # TD_CONTOUR_MAX
 
     def alloc_contours(self, B: int, points_cap: int = 65536) -> Dict[str, torch.Tensor]:
@@ -281,8 +297,20 @@ class Engine:
     # -- device timing ------------------------------------------------------------------------------------
     PROF_NAMES = ("conv_igemm", "stem", "pool", "rpn_select", "roi_align", "detect", "mask_tail", "mask_convs", "executed")
 
-    def profile_enable(self, on: bool = True) -> None:
+    CLASS_NAMES = ("wino_contraction", "wino_transform", "conv1x1", "conv3x3_direct", "fc", "mask_head")
+
+    def profile_enable(self, on=True) -> None:
+        """on: False / True, or 2 = detail (an event pair per contraction launch for :meth:`profile_classes`)."""
         _lib.check(self.lib.td_engine_profile_enable(self._h, int(on)), "td_engine_profile_enable")
+
+    def profile_classes(self, reset: bool = True) -> Dict[str, dict]:
+        """Speed-of-light accounting of the contraction family by class (include/treedet.h td_engine_profile_classes)."""
+        n = len(self.CLASS_NAMES)
+        ms, fl, by, tm = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+        la = (C.c_int64 * n)()
+        _lib.check(self.lib.td_engine_profile_classes(self._h, ms, la, fl, by, tm, int(reset)), "td_engine_profile_classes")
+        return {k: {"ms": ms[i], "launches": int(la[i]), "exec_flops": fl[i], "bytes": by[i], "tmin_ms": tm[i]}
+                for i, k in enumerate(self.CLASS_NAMES)}
 
     def profile_read(self, reset: bool = True) -> Dict[str, dict]:
         n = len(self.PROF_NAMES)

@@ -279,20 +279,15 @@ class Predictor:
             tiles = [b["data"]["u8"].to(self.device, non_blocking=True) for b in batch]
             images, hw_valid, hw_out = eng.preprocess_tiles_u8(tiles)
             return images, INPUT_U8_HWC, hw_valid, hw_out
-        shapes, planes = [], []
+        planes = []
         for b in batch:
             if "u8" in b["data"]:
                 t = b["data"]["u8"].to(self.device).permute(2, 0, 1)[[2, 1, 0]].double()
             else:
                 t = b["data"]["f"].to(self.device)
-            oh, ow = eng.resize_shape(t.shape[1], t.shape[2])
-            planes.append(torch.nn.functional.interpolate(t[None], size=(oh, ow), mode="bilinear", align_corners=False)[0].float())
-            shapes.append((oh, ow))
-        Hp = (max(s[0] for s in shapes) + 31) // 32 * 32
-        Wp = (max(s[1] for s in shapes) + 31) // 32 * 32
-        x = torch.zeros((len(batch), 3, Hp, Wp), dtype=torch.float32, device=self.device)
-        for i, p in enumerate(planes):
-            x[i, :, : p.shape[1], : p.shape[2]] = p
+            planes.append(t.contiguous())
+        # the reference's float resize branch (prediction.py:167-169) as a HIP kernel: td_resize_bilinear_f64
+        x, shapes = eng.preprocess_tiles_f64(planes)
         return x, INPUT_F32_CHW, shapes, [(b["orig_height"], b["orig_width"]) for b in batch]
 
     # -- single process: reader thread → launcher (this thread) → epilogue workers --------------------------------
