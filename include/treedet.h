@@ -138,13 +138,14 @@ td_status td_engine_profile_read(td_engine* e, double* ms, int64_t* launches, do
  * included); tmin_ms = sum over launches of max(executed FLOPs / MFMA peak of the engine's precision, bytes /
  * achievable HBM rate) with the constants below (MI355X_MICROARCH.md); ms = measured time (detail mode only, else 0).
  * Class 5 (mask head) has a device-side row count: only its time is reported. Arrays hold TD_PROF_CLASSES entries. */
-#define TD_PROF_CLASSES 6
+#define TD_PROF_CLASSES 7
 #define TD_CLS_WINO_GEMM 0   /* Winograd plane contractions (fp32 engine) */
 #define TD_CLS_WINO_XFORM 1  /* Winograd input / output transform kernels */
 #define TD_CLS_CONV1X1 2     /* 1x1 convolutions: bottleneck conv1 / conv3 / shortcut, FPN laterals, RPN heads */
 #define TD_CLS_CONV3X3 3     /* direct 3x3 convolutions (fp16 engine: all of them; fp32: the 64-channel res2 layers) */
 #define TD_CLS_FC 4          /* box head: fc1, fc2, predictors */
 #define TD_CLS_MASK_HEAD 5   /* mask-head contractions and transforms (rows = live detections, known on the device only) */
+#define TD_CLS_TAIL 6        /* fused bottleneck tail: 3x3 (mid -> mid) + 1x1 (mid -> 4 mid) + shortcut in one launch (res2; fp16: res3 too) */
 #define TD_PEAK_F32_MFMA_TFLOPS 157.3   /* v_mfma_f32_32x32x2_f32, dense */
 #define TD_PEAK_F16_MFMA_TFLOPS 2500.0  /* v_mfma_f32_32x32x16_f16, dense */
 #define TD_HBM_ACHIEVABLE_TBS 6.3       /* measured streaming rate (8.0 TB/s spec) */
@@ -174,6 +175,13 @@ td_status td_resize_bilinear_f64(const double* src, int c, int h, int w, float* 
 void td_resize_shape(int h, int w, int short_edge, int max_size, int* out_h, int* out_w);
 
 /* ---- op-level entry points (parity tests; each is the kernel the engine itself launches) ---- */
+/* Fused tail of a bottleneck block (detectron2 BottleneckBlock: conv2 3x3 + FrozenBN + ReLU, conv3 1x1 + FrozenBN, + shortcut,
+ * ReLU) in one launch: x [B,H,W,mid], w2 [mid,3,3,mid], w3 [cout,mid], scale / bias per layer (NULL = 1 / 0),
+ * shortcut and y [B,H,W,cout]; cout = 4 mid; mid = 64 (fp32, fp16) or 128 (fp16). precision: TD_PRECISION_*.
+ * Bit-identical to td_conv2d_nhwc(3x3, relu) followed by td_conv2d_nhwc(1x1, residual, relu). */
+td_status td_bottleneck_tail_nhwc(const void* x, const void* w2, const float* scale2, const float* bias2, const void* w3,
+                                  const float* scale3, const float* bias3, const void* shortcut, void* y, int B, int H, int W,
+                                  int mid, int cout, int precision, void* stream);
 /* NHWC convolution: y = act(conv(x, w) * scale + bias [+ residual]).
  * x [B,H,W,Cin], w [Cout,KH,KW,Cin], scale/bias [Cout] (NULL = 1 / 0), residual [B,Ho>>rs,Wo>>rs,Cout]
  * (rs = res_shift: 1 = nearest-2x upsampled add, the FPN top-down path), y [B,Ho,Wo,Cout].

@@ -273,3 +273,94 @@ def test_winograd_f4x4_conv_matches_torch(case):
     err = np.abs(got - ref).max()
     print(f"\n[F(4x4)] {case}: max abs err {err:.3e} = {err / max(1.0, np.abs(ref).max()):.2e} of max|ref|")
     assert err <= 5e-5 * max(1.0, np.abs(ref).max()), f"max abs err {err}"
+
+
+# ---- fused bottleneck tail (bottleneck.hip): conv2 3x3 + BN + ReLU → conv3 1x1 + BN + shortcut + ReLU in one launch ----
+TAIL_CASES = [  # (precision, B, H, W, mid)
+    (0, 2, 37, 41, 64),       # fp32 res2 shape class; M = 3034 is not a multiple of the 128-row tile
+    (0, 1, 200, 200, 64),     # one res2 image at BASELINE size
+    (1, 2, 37, 41, 64),
+    (1, 1, 100, 100, 128),    # fp16 res3 shape class
+    (1, 3, 13, 9, 128),       # fewer rows than one tile per image, padding everywhere
+]
+
+
+@pytest.mark.parametrize("case", TAIL_CASES)
+def test_bottleneck_tail_equals_the_two_launches_bit_for_bit(case):
+    """td_bottleneck_tail_nhwc == td_conv2d_nhwc(3x3, BN, ReLU) followed by td_conv2d_nhwc(1x1, BN, + shortcut, ReLU), BIT FOR BIT
+    (same k order in both contractions, the same single IEEE operations in both epilogues, the same fp16 rounding of the mid
+    tensor in the fp16 engine) — and therefore within the conv tolerances of this file against torch (checked in fp64 below)."""
+    import torch.nn.functional as F
+    from treedetection_amd import _lib
+    prec, B, H, W, mid = case
+    cout = 4 * mid
+    rng = np.random.default_rng(B * 1000 + H * 10 + mid + prec)
+    x = rng.normal(0, 1, (B, mid, H, W)).astype(np.float32)
+    x = np.maximum(x, 0)                                               # the block's first 1x1 ends in a ReLU
+    w2 = (rng.normal(0, 1, (mid, mid, 3, 3)) * np.sqrt(2.0 / (9 * mid))).astype(np.float32)
+    w3 = (rng.normal(0, 1, (cout, mid, 1, 1)) * np.sqrt(1.0 / mid)).astype(np.float32)
+    s2, b2 = rng.uniform(0.8, 1.2, mid).astype(np.float32), rng.normal(0, 0.2, mid).astype(np.float32)
+    s3, b3 = rng.uniform(0.8, 1.2, cout).astype(np.float32), rng.normal(0, 0.2, cout).astype(np.float32)
+    sc = rng.normal(0, 1, (B, cout, H, W)).astype(np.float32)
+    # two launches through the op-level entry (what the engine ran before the fused kernel)
+    t2 = conv2d_hip(x, w2, scale=s2, bias=b2, pad=1, relu=True, precision=prec)
+    two = conv2d_hip(t2, w3, scale=s3, bias=b3, residual_nchw=sc, relu=True, precision=prec)
+    # fused
+    lib = _lib.load()
+    dt = torch.float32 if prec == 0 else torch.float16
+    from tests.gpu_util import dev
+    dx = dev(np.transpose(x, (0, 2, 3, 1)), dt)
+    dw2 = dev(np.transpose(w2, (0, 2, 3, 1)), dt)
+    dw3 = dev(w3.reshape(cout, mid), dt)
+    dsc = dev(np.transpose(sc, (0, 2, 3, 1)), dt)
+    ds2, db2, ds3, db3 = (dev(v, torch.float32) for v in (s2, b2, s3, b3))
+    y = torch.full((B, H, W, cout), float("nan"), dtype=dt, device="cuda")
+    _lib.check(lib.td_bottleneck_tail_nhwc(dx.data_ptr(), dw2.data_ptr(), ds2.data_ptr(), db2.data_ptr(), dw3.data_ptr(), ds3.data_ptr(),
+                                           db3.data_ptr(), dsc.data_ptr(), y.data_ptr(), B, H, W, mid, cout, prec, _lib.stream_ptr()),
+               "td_bottleneck_tail_nhwc")
+    torch.cuda.synchronize()
+    got = y.float().cpu().numpy().transpose(0, 3, 1, 2)
+    assert np.isfinite(got).all()
+    assert np.array_equal(got, two), float(np.abs(got - two).max())
+    # and against torch in float64 (fp16: inputs rounded as the kernel sees them)
+    rd = (lambda a: a.astype(np.float16).astype(np.float64)) if prec == 1 else (lambda a: a.astype(np.float64))
+    t = F.conv2d(torch.from_numpy(rd(x)), torch.from_numpy(rd(w2)), padding=1) * torch.from_numpy(s2.astype(np.float64))[None, :, None, None] \
+        + torch.from_numpy(b2.astype(np.float64))[None, :, None, None]
+    t = torch.relu(t)
+    if prec == 1:
+        t = t.to(torch.float16).to(torch.float64)
+    r = F.conv2d(t, torch.from_numpy(rd(w3))) * torch.from_numpy(s3.astype(np.float64))[None, :, None, None] \
+        + torch.from_numpy(b3.astype(np.float64))[None, :, None, None] + torch.from_numpy(rd(sc))
+    ref = torch.relu(r).numpy()
+    tol = 5e-5 if prec == 0 else 4e-3
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max(), float(np.abs(got - ref).max() / np.abs(ref).max())
+
+
+def test_engine_with_fused_tail_equals_engine_without_it():
+    """The engine's default (res2 — fp16: res2 + res3 — tails fused) against TD_FUSE_TAIL=0 on the same inputs: every output bit for
+    bit, both precisions."""
+    import os
+    from tests.test_engine_gpu import smooth_image
+    from treedetection_amd.engine import Engine
+    from treedetection_amd.weights import make_synthetic_state_dict
+    sd = make_synthetic_state_dict(50, seed=5)
+    rng = np.random.default_rng(2)
+    inputs = [{"image": smooth_image(rng, 256, 320), "height": 320, "width": 400},
+              {"image": smooth_image(rng, 224, 256), "height": 224, "width": 256}]
+    for prec in ("fp32", "fp16"):
+        outs = []
+        for env in (None, "0"):
+            if env is not None:
+                os.environ["TD_FUSE_TAIL"] = env
+            try:
+                eng = Engine(sd, precision=prec)
+            finally:
+                os.environ.pop("TD_FUSE_TAIL", None)
+            got = eng(inputs)
+            res3 = eng.tensor("res3").float().cpu().numpy()
+            outs.append((got, res3))
+            eng.close()
+        assert np.array_equal(outs[0][1], outs[1][1]), prec
+        for a, b in zip(outs[0][0], outs[1][0]):
+            for k in ("pred_boxes", "scores", "mask_probs", "pred_masks"):
+                assert np.array_equal(a[k], b[k]), (prec, k)

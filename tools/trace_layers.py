@@ -4,7 +4,7 @@ import csv
 import sys
 
 
-def schedule(depth=50, B=8, Hp=800, Wp=800, P=1000):
+def schedule(depth=50, B=8, Hp=800, Wp=800, P=1000, fp32=False, fuse_tail=True):
     blocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}[depth]
     mids, outs = (64, 128, 256, 512), (256, 512, 1024, 2048)
     L = []
@@ -16,8 +16,12 @@ def schedule(depth=50, B=8, Hp=800, Wp=800, P=1000):
             if bi == 0:
                 L.append((f"res{si+2}.{bi}.shortcut", B * ho * wo, outs[si], cin))
             L.append((f"res{si+2}.{bi}.conv1", B * ho * wo, mids[si], cin))
-            L.append((f"res{si+2}.{bi}.conv2", B * ho * wo, mids[si], mids[si] * 9))
-            L.append((f"res{si+2}.{bi}.conv3", B * ho * wo, outs[si], mids[si]))
+            if fuse_tail and (si == 0 or (si == 1 and not fp32)):
+                # bottleneck_tail_kernel: conv2 + conv3 in one launch (N, K of the 3x3; the 1x1's FLOPs ride in the 5th field)
+                L.append((f"res{si+2}.{bi}.conv2+3", B * ho * wo, mids[si], mids[si] * 9, 2.0 * B * ho * wo * outs[si] * mids[si] / 1e9))
+            else:
+                L.append((f"res{si+2}.{bi}.conv2", B * ho * wo, mids[si], mids[si] * 9))
+                L.append((f"res{si+2}.{bi}.conv3", B * ho * wo, outs[si], mids[si]))
             cin, h, w = outs[si], ho, wo
     hs = [Hp >> (l + 2) for l in range(4)]
     ws = [Wp >> (l + 2) for l in range(4)]
@@ -54,22 +58,26 @@ def launches_of(name, M, N, K, fp32, B=8, min43=12):
 def main(path, depth=50, fp32=False):
     import os
     min43 = int(os.environ.get("TD_WINO43_MIN", "12"))
-    fam = ("conv_igemm", "conv_pp8", "plane_gemm", "wino_gemm", "wino_output", "wino_input", "wino43_input", "wino43_output")
+    fam = ("conv_igemm", "conv_pp8", "plane_gemm", "wino_gemm", "wino_output", "wino_input", "wino43_input", "wino43_output", "bottleneck_tail", "conv_sk")
     rows = [r for r in csv.DictReader(open(path)) if any(f in r["Kernel_Name"] for f in fam)]
-    L = schedule(depth)
-    need = sum(launches_of(n, M, N, K, fp32, 8, min43)[0] for n, M, N, K in L)
+    L = schedule(depth, fp32=fp32, fuse_tail=os.environ.get("TD_FUSE_TAIL", "1") != "0")
+    need = sum(launches_of(e[0], e[1], e[2], e[3], fp32, 8, min43)[0] for e in L)
     last = rows[-need:]
     tot_f = tot_t = 0.0
     i = 0
-    for name, M, N, K in L:
+    for ent in L:
+        name, M, N, K = ent[:4]
         k, label = launches_of(name, M, N, K, fp32, 8, min43)
         rs = last[i:i + k]
         i += k
         ts = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rs]
         us = sum(ts)
-        gf = 2.0 * M * N * K / 1e9
+        gf = 2.0 * M * N * K / 1e9 + (ent[4] if len(ent) > 4 else 0.0)
         kn = rs[0]["Kernel_Name"]
-        kern = label if label else ("pp8" if "conv_pp8" in kn else kn.split("conv_igemm_")[1].split("(")[0][:28])
+        if "conv2+3" in name:
+            assert "bottleneck_tail" in kn, (name, kn)
+        kern = label if label else ("pp8" if "conv_pp8" in kn else "bottleneck_tail" if "bottleneck_tail" in kn else
+                                    "conv_sk" if "conv_sk" in kn else kn.split("conv_igemm_")[1].split("(")[0][:28])
         if k == 3:
             assert "wino43_input" in kn and "wino43_output" in rs[2]["Kernel_Name"], (name, kn)
             kern += f" [{ts[0]:.0f}+{ts[1]:.0f}+{ts[2]:.0f}]"

@@ -110,6 +110,16 @@ td_status td_resize_batch_u8(const uint8_t* const* src_tiles, int n, int h, int 
                                   tmp_dev, static_cast<hipStream_t>(stream));
 }
 
+td_status td_bottleneck_tail_nhwc(const void* x, const void* w2, const float* scale2, const float* bias2, const void* w3,
+                                  const float* scale3, const float* bias3, const void* shortcut, void* y, int B, int H, int W,
+                                  int mid, int cout, int precision, void* stream) {
+    TD_REQUIRE(x && w2 && w3 && shortcut && y && B > 0 && H > 0 && W > 0, "td_bottleneck_tail_nhwc: null argument or empty tensor");
+    TailArgs a{};
+    a.x = x; a.w2 = w2; a.scale2 = scale2; a.bias2 = bias2; a.w3 = w3; a.scale3 = scale3; a.bias3 = bias3; a.res = shortcut; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.MID = mid; a.COUT = cout; a.M = B * H * W;
+    return bottleneck_tail_launch(a, precision, static_cast<hipStream_t>(stream));
+}
+
 td_status td_resize_bilinear_f64(const double* src, int c, int h, int w, float* dst, int out_h, int out_w, int dst_pitch_px,
                                  int64_t dst_plane_stride, void* stream) {
     return resize_bilinear_f64_launch(src, c, h, w, dst, out_h, out_w, dst_pitch_px, (long long)dst_plane_stride, static_cast<hipStream_t>(stream));

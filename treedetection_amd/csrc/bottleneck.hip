@@ -1,0 +1,311 @@
+// bottleneck_tail_kernel: conv2 (3x3, mid -> mid) + FrozenBN + ReLU and conv3 (1x1, mid -> 4 mid) + FrozenBN + shortcut add +
+// ReLU of a ResNet bottleneck block in ONE launch (detectron2 BottleneckBlock behind TreeDetection/prediction.py:183; SURVEY.md
+// Appendix A item 3). The mid tensor between the two convolutions never exists in HBM.
+//
+// Why: in res2 / res3 the 1x1 "expand" layer is HBM-bound on its own (K = 64 / 128: one to four k-steps of MFMA work per
+// tile against a residual read and an output write of 4x the input) and the 3x3 before it writes a tensor that is read back
+// once. Fused, a block of 128 output pixels
+//   1. runs the 3x3 as conv_igemm_kernel does (LDS-DMA staging of 128-B k-chunks into the XOR-swizzled image, channel chunk
+//      outer / filter tap inner, two LDS stages, raw s_barrier + counted vmcnt) into 128 x mid accumulators,
+//   2. applies scale / bias / ReLU (and the fp16 rounding of the fp16 engine) in registers and writes the tile into LDS in
+//      exactly the image the DMA would have produced from a [row][mid] tensor — it is the A operand of the 1x1,
+//   3. streams the 1x1 filters through LDS 128 output channels at a time and contracts (k = mid), then finishes each
+//      128 x 128 piece with conv_epilogue (scale, bias, + shortcut, ReLU; whole coalesced row segments).
+// Every sum keeps the k order of the two separate launches and every epilogue operation is the same single IEEE operation,
+// so the result is BIT-IDENTICAL to conv2d_launch(3x3) followed by conv2d_launch(1x1 + residual) (tests/test_conv_gpu.py) —
+// all engine-level parity statements carry over unchanged.
+// HBM traffic per block of a stage: t1 (read, halo through L2) + shortcut (read) + y (write) instead of those plus one write
+// and one read of the mid tensor; one launch instead of two.
+#include "common.h"
+#include "conv_tiles.h"
+
+namespace {
+
+constexpr int cmax(int x, int y) { return x > y ? x : y; }
+
+template <typename T, int MID, bool OVERLAP>
+struct TailGeom {
+    static constexpr int ES = sizeof(T);
+    static constexpr int KE = Elem<T>::PER_CHUNK;            // elements per 128-B k-chunk
+    static constexpr int KC = MID / KE;                      // channel chunks of the mid tensor
+    static constexpr int BM = 128, THREADS = 256, LDROWS = 32;
+    static constexpr int NT1 = MID / 64;                     // phase 1: wave tile 64 x (32 NT1), block tile 128 x MID
+    static constexpr int STAGE1 = 2 * (BM + MID) * CHUNK_BYTES;
+    static constexpr int W3_BYTES = KC * 128 * CHUNK_BYTES;  // the 1x1 filters of one 128-channel output piece: [KC][128][128 B]
+    static constexpr int EPI_BYTES = conv_epilogue_lds_bytes<T, 2, 2, 2, 2, 1, false>();
+    static constexpr int EPI_OFF = OVERLAP ? W3_BYTES : 0;   // OVERLAP: the next piece's filters arrive while this piece is finished
+    // region 0 = the phase-1 stages, later the filters of a piece and the epilogue's staging tile (side by side or aliased)
+    static constexpr int R0 = cmax(STAGE1, cmax(W3_BYTES, EPI_OFF + EPI_BYTES));
+    static constexpr int T2_BYTES = KC * BM * CHUNK_BYTES;   // the mid tile as the 1x1's A image: [KC][128][128 B]
+    static constexpr int LDS_BYTES = R0 + T2_BYTES;
+};
+
+// The body is a __device__ function (the __global__ entry below only owns the LDS array): with the staging lambdas called
+// straight from a __global__ template, hipcc (ROCm 7.2) silently dropped the kernel's HOST stub from the object file.
+template <typename T, int MID, bool OVERLAP>
+__device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* lds) {
+    typedef TailGeom<T, MID, OVERLAP> G;
+    constexpr int ES = G::ES, KE = G::KE, KC = G::KC, BM = G::BM, LDROWS = G::LDROWS, NT1 = G::NT1;
+    constexpr int AROWS = BM / LDROWS, BROWS1 = MID / LDROWS, BROWS3 = 128 / LDROWS;
+    char* As = lds;                                   // phase 1: [2][BM][128 B]
+    char* Bs = lds + 2 * BM * CHUNK_BYTES;            //          [2][MID][128 B]
+    char* W3s = lds;                                  // phase 3: [KC][128][128 B] (the phase-1 stages are dead by then)
+    char* Epi = lds + G::EPI_OFF;
+    char* T2s = lds + G::R0;                          // [KC][BM][128 B]
+
+    const int M = a.M;
+    const int nblk = (M + BM - 1) / BM;
+    if ((int)blockIdx.x >= nblk) return;
+    const int m0 = xcd_remap(blockIdx.x, nblk) * BM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ld_c = tid & 7, ld_r = tid >> 3;
+
+    // ---- phase 1: the 3x3 (stride 1, pad 1) as in conv_igemm_kernel ------------------------------------------------------
+    const int K2 = 9 * MID;
+    const int nit = 9 * KC;
+    const unsigned pix_bytes = (unsigned)MID * ES;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.x), 0, (int)((size_t)a.B * a.H * a.W * pix_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.w2), 0, (int)((size_t)MID * K2 * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.w3), 0, (int)((size_t)a.COUT * MID * ES), 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+    const unsigned src_piece = (unsigned)(ld_c ^ ((ld_r >> 1) & 7)) * 16;
+
+    unsigned a_off[AROWS], a_ok[AROWS];
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+        const int m = m0 + ld_r + LDROWS * i;
+        a_off[i] = 0;
+        a_ok[i] = 0;
+        if (m < M) {
+            const int hw = a.H * a.W;
+            const int b = m / hw;
+            const int rem = m - b * hw;
+            const int oy = rem / a.W;
+            const int ox = rem - oy * a.W;
+            const int iy0 = oy - 1, ix0 = ox - 1;
+            a_off[i] = (unsigned)((b * a.H + iy0) * a.W + ix0) * pix_bytes + src_piece;
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx)
+                    if ((unsigned)(iy0 + ky) < (unsigned)a.H && (unsigned)(ix0 + kx) < (unsigned)a.W)
+                        a_ok[i] |= 1u << (ky * 3 + kx);
+        }
+    }
+    unsigned b_off[BROWS1];
+#pragma unroll
+    for (int i = 0; i < BROWS1; ++i) b_off[i] = (unsigned)(ld_r + LDROWS * i) * (unsigned)K2 * ES + src_piece;
+
+    typedef __attribute__((address_space(3))) void lds_void;
+    const unsigned wave_rows = (unsigned)__builtin_amdgcn_readfirstlane(wave) * 8u;
+    int ld_tap = 0, ld_ky = 0, ld_kx = 0, ld_cc = 0;
+    auto stage = [&](int buf) {
+        const unsigned xs = (unsigned)(ld_ky * a.W + ld_kx) * pix_bytes + (unsigned)ld_cc * CHUNK_BYTES;
+        const unsigned ws = (unsigned)ld_tap * pix_bytes + (unsigned)ld_cc * CHUNK_BYTES;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            const unsigned off = ((a_ok[i] >> ld_tap) & 1u) ? a_off[i] + xs : OOB;
+            char* dst = As + ((unsigned)buf * BM + (unsigned)LDROWS * i + wave_rows) * CHUNK_BYTES;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)dst, 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS1; ++i) {
+            char* dst = Bs + ((unsigned)buf * MID + (unsigned)LDROWS * i + wave_rows) * CHUNK_BYTES;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w2rsrc, (lds_void*)dst, 16, b_off[i] + ws, 0, 0, 0);
+        }
+        if (++ld_kx == 3) {
+            ld_kx = 0;
+            ++ld_ky;
+        }
+        if (++ld_tap == 9) {
+            ld_tap = 0;
+            ld_ky = 0;
+            ld_kx = 0;
+            ++ld_cc;
+        }
+    };
+
+    const unsigned swz = (lane >> 1) & 7, hi = lane >> 5;
+    unsigned frag_off[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) frag_off[kk] = (unsigned)(lane & 31) * CHUNK_BYTES + (((unsigned)(2 * kk) + hi) ^ swz) * 16;
+
+    f32x16 acc2[2][NT1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT1; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int it = 0; it < nit; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nit) stage(cur ^ 1);
+        const char* Ab = &As[(cur * BM + wm * 64) * CHUNK_BYTES];
+        const char* Bb = &Bs[(cur * MID + wn * 32 * NT1) * CHUNK_BYTES];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 fa[2], fb[NT1];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * CHUNK_BYTES + frag_off[kk]);
+#pragma unroll
+            for (int j = 0; j < NT1; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * CHUNK_BYTES + frag_off[kk]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT1; ++j) Elem<T>::mma(fa[i], fb[j], acc2[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next k-step has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's fragment reads of buf[cur] are done
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- the 1x1's filters of output piece `nc` (128 channels x MID): KC pieces of [128 rows][128 B] -------------------------
+    auto stage_w3 = [&](int nc) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int i = 0; i < BROWS3; ++i) {
+                const unsigned n = (unsigned)nc * 128u + (unsigned)(ld_r + LDROWS * i);
+                const unsigned off = n < (unsigned)a.COUT ? n * pix_bytes + (unsigned)kc * CHUNK_BYTES + src_piece : OOB;
+                char* dst = W3s + ((unsigned)kc * 128 + (unsigned)LDROWS * i + wave_rows) * CHUNK_BYTES;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w3rsrc, (lds_void*)dst, 16, off, 0, 0, 0);
+            }
+    };
+    stage_w3(0);                                       // the phase-1 stages are free (barrier above); lands under phase 2
+
+    // ---- phase 2: mid tile = ReLU(acc2 * scale2 + bias2) → LDS, in the image the DMA builds from a [row][MID] tensor --------
+#pragma unroll
+    for (int j = 0; j < NT1; ++j) {
+        const int n = wn * 32 * NT1 + j * 32 + (lane & 31);            // mid channel of this lane's accumulator column
+        const float sc = a.scale2 ? a.scale2[n] : 1.f;
+        const float bi = a.bias2 ? a.bias2[n] : 0.f;
+        const unsigned c = (unsigned)n / KE, e = (unsigned)n % KE;
+        const unsigned piece = (e * ES) >> 4, inb = (e * ES) & 15;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float t = acc2[i][j][q];
+                    if (a.scale2) t = __fmul_rn(t, sc);
+                    if (a.bias2) t = __fadd_rn(t, bi);
+                    t = t > 0.f ? t : 0.f;
+                    const unsigned row = (unsigned)(wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5));
+                    *reinterpret_cast<float*>(T2s + (c * BM + row) * CHUNK_BYTES + ((piece ^ ((row >> 1) & 7)) << 4) + inb) = t;
+                }
+            } else {
+                // fp16: neighbouring lanes hold neighbouring channels of the same rows — swap one value (DPP quad_perm) so that
+                // an even lane owns rows R of the channel pair and an odd lane rows R + 1: 4-B stores of packed pairs
+                const int odd = lane & 1;
+                const unsigned inb2 = ((e & ~1u) * ES) & 15;
+#pragma unroll
+                for (int q = 0; q < 16; q += 2) {
+                    float t0 = acc2[i][j][q], t1 = acc2[i][j][q + 1];
+                    if (a.scale2) { t0 = __fmul_rn(t0, sc); t1 = __fmul_rn(t1, sc); }
+                    if (a.bias2) { t0 = __fadd_rn(t0, bi); t1 = __fadd_rn(t1, bi); }
+                    t0 = t0 > 0.f ? t0 : 0.f;
+                    t1 = t1 > 0.f ? t1 : 0.f;
+                    const float give = odd ? t0 : t1;
+                    const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                        0, __builtin_bit_cast(int, give), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false));
+                    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                    f16x2 pk;
+                    pk[0] = (_Float16)(odd ? got : t0);
+                    pk[1] = (_Float16)(odd ? t1 : got);
+                    const unsigned row = (unsigned)(wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5) + odd);
+                    *reinterpret_cast<f16x2*>(T2s + (c * BM + row) * CHUNK_BYTES + ((piece ^ ((row >> 1) & 7)) << 4) + inb2) = pk;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // mid tile visible to every wave, filters of piece 0 landed
+
+    // ---- phase 3: the 1x1, 128 output channels per piece -------------------------------------------------------------------------
+    ConvArgs e{};
+    e.y = a.y; e.res = a.res; e.scale = a.scale3; e.bias = a.bias3;
+    e.Cout = a.COUT; e.relu = 1; e.out_mode = 0; e.res_shift = 0; e.Ho = a.H; e.Wo = a.W;
+    const int npieces = (a.COUT + 127) / 128;
+    for (int nc = 0; nc < npieces; ++nc) {
+        f32x16 acc3[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc3[i][j][r] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const char* Ab = T2s + (kc * BM + wm * 64) * CHUNK_BYTES;
+            const char* Bb = W3s + (kc * 128 + wn * 64) * CHUNK_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                f32x4 fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * CHUNK_BYTES + frag_off[kk]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * CHUNK_BYTES + frag_off[kk]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) Elem<T>::mma(fa[i], fb[j], acc3[i][j]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // every wave has read this piece's filters (and the staging tile is free)
+        const bool more = nc + 1 < npieces;
+        if (OVERLAP && more) stage_w3(nc + 1);         // arrives while this piece is finished below
+        conv_epilogue<T, T, 2, 2, 2, 2, 1, false>(e, acc3, Epi, M, m0, nc * 128, tid, lane, wm, wn);
+        if (more) {
+            if (!OVERLAP) {
+                __syncthreads();                       // the staging tile (aliased with the filters) has been read
+                stage_w3(nc + 1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+}
+
+// BPC = blocks per CU the LDS footprint allows (1 or 2): __launch_bounds__' second argument is waves per SIMD = BPC for 4-wave blocks
+template <typename T, int MID, bool OVERLAP, int BPC>
+__global__ __launch_bounds__(256, BPC)
+void bottleneck_tail_kernel(const TailArgs a) {
+    static_assert(BPC * TailGeom<T, MID, OVERLAP>::LDS_BYTES <= 160 * 1024, "LDS footprint does not allow that many blocks per CU");
+    __shared__ __attribute__((aligned(16))) char lds[TailGeom<T, MID, OVERLAP>::LDS_BYTES];
+    bottleneck_tail_body<T, MID, OVERLAP>(a, lds);
+}
+
+template <typename T, int MID, bool OVERLAP>
+td_status launch_tail(const TailArgs& a, hipStream_t stream) {
+    const int tiles = td_cdiv(a.M, 128);
+    constexpr int BPC = TailGeom<T, MID, OVERLAP>::LDS_BYTES <= 80 * 1024 ? 2 : 1;
+    hipLaunchKernelGGL((bottleneck_tail_kernel<T, MID, OVERLAP, BPC>), dim3(tiles), dim3(256), 0, stream, a);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
+}  // namespace
+
+bool bottleneck_tail_ok(int precision, int mid, int cout) {
+    if (cout != 4 * mid) return false;
+    if (precision == TD_PRECISION_FP32) return mid == 64;            // larger fp32 3x3 layers take the Winograd path
+    return mid == 64 || mid == 128;
+}
+
+td_status bottleneck_tail_launch(const TailArgs& a, int precision, hipStream_t stream) {
+    TD_REQUIRE(bottleneck_tail_ok(precision, a.MID, a.COUT), "bottleneck tail: unsupported shape (precision %d, mid %d, out %d)", precision, a.MID, a.COUT);
+    TD_REQUIRE(a.M == a.B * a.H * a.W && a.M > 0, "bottleneck tail: M must be B*H*W");
+    const size_t es = precision == TD_PRECISION_FP16 ? 2 : 4;
+    TD_REQUIRE((size_t)a.M * a.MID * es < 0xfffffff0ull - (1u << 20), "bottleneck tail: input tensor must stay below 4 GB (32-bit buffer offsets)");
+    if (precision == TD_PRECISION_FP32) return launch_tail<float, 64, false>(a, stream);
+    if (a.MID == 64) return launch_tail<_Float16, 64, true>(a, stream);
+    return launch_tail<_Float16, 128, true>(a, stream);
+}

@@ -65,6 +65,22 @@ td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
 bool conv_plane_ok(const ConvArgs& a, int precision);       // tile ids 18-20 apply to this launch
 td_status wino_gemm_launch(const ConvArgs& a, hipStream_t stream);     // Winograd plane contractions, input transform fused (fp32)
 
+// ---- fused bottleneck tail (bottleneck.hip): 3x3 (mid -> mid) + BN + ReLU, then 1x1 (mid -> 4 mid) + BN + shortcut + ReLU ----
+struct TailArgs {
+    const void* x;        // NHWC [B,H,W,MID]: output of the block's first 1x1
+    const void* w2;       // [MID][3][3][MID]
+    const float* scale2;  // [MID] FrozenBN fold of conv2 (nullptr = 1 / 0)
+    const float* bias2;
+    const void* w3;       // [COUT][MID]
+    const float* scale3;  // [COUT]
+    const float* bias3;
+    const void* res;      // NHWC [B,H,W,COUT]: the block's shortcut (same size)
+    void* y;              // NHWC [B,H,W,COUT]
+    int B, H, W, MID, COUT, M;
+};
+bool bottleneck_tail_ok(int precision, int mid, int cout);          // shapes the fused kernel is built for
+td_status bottleneck_tail_launch(const TailArgs& a, int precision, hipStream_t stream);
+
 // ---- Winograd F(2x2,3x3) transforms (winograd.hip; fp32 engine) ---------------------------------
 // tiles [t0, t0 + Ts) of the layer ("slab"): V / Mb hold 16 planes of [Ts][C]
 td_status wino_input_launch(const float* x, int B, int H, int W, int C, float* V, const int* m_dyn, int m_mul, long long t0, int Ts,

@@ -117,6 +117,7 @@ struct td_engine {
     bool winograd = true;         // TD_WINOGRAD=0 disables the Winograd path (diagnostics)
     float *wino_v = nullptr, *wino_m = nullptr;
     size_t wino_elems = 0;
+    bool fuse_tail = true;        // TD_FUSE_TAIL=0: conv2 / conv3 of res2 (fp16: and res3) as two launches (diagnostics, tests)
     bool wino_fused = true;       // TD_WINO_FUSED=0: separate input-transform kernel + batched conv_igemm launch (diagnostics)
     int wino_slab = 0;            // TD_WINO_SLAB: tiles per slab (diagnostics); 0 = sized for the Infinity Cache
     int wino_minc = 128;          // fewest channels (both sides) of a 3x3 layer on the Winograd path (TD_WINO_MINC: experiments)
@@ -440,6 +441,7 @@ td_status td_engine_create(const td_model_desc* desc, int device, td_engine** ou
     if (const char* wg = getenv("TD_WINOGRAD")) e->winograd = atoi(wg) != 0;
     if (const char* ws = getenv("TD_WINO_SLAB")) e->wino_slab = atoi(ws);
     if (const char* wf = getenv("TD_WINO_FUSED")) e->wino_fused = atoi(wf) != 0;
+    if (const char* ft = getenv("TD_FUSE_TAIL")) e->fuse_tail = atoi(ft) != 0;
     if (const char* w4 = getenv("TD_WINO43_MIN")) e->wino43_min = atoi(w4);
     if (const char* wc = getenv("TD_WINO_MINC")) e->wino_minc = atoi(wc);
     e->desc = d;
@@ -958,6 +960,25 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         ClassScope cs(e, s_, cls, m_dyn ? 0.0 : flops, m_dyn ? 0.0 : bytes);
         return run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, cfg);
     };
+    // conv2 (3x3) → conv3 (1x1) + shortcut + ReLU of a bottleneck block as one launch (bottleneck_tail_kernel)
+    auto run_tail = [&](const Block& blk, const void* t1_, int B_, int H_, int W_, void* y_, const void* shortcut_, hipStream_t s_) -> td_status {
+        TailArgs a{};
+        a.x = t1_; a.w2 = blk.c2.w; a.scale2 = blk.c2.scale; a.bias2 = blk.c2.bias;
+        a.w3 = blk.c3.w; a.scale3 = blk.c3.scale; a.bias3 = blk.c3.bias; a.res = shortcut_; a.y = y_;
+        a.B = B_; a.H = H_; a.W = W_; a.MID = blk.c2.cout; a.COUT = blk.c3.cout; a.M = B_ * H_ * W_;
+        const double M = (double)a.M, mid = a.MID, co = a.COUT, es = prec == TD_PRECISION_FP16 ? 2.0 : 4.0;
+        const double flops = 2.0 * M * mid * (9.0 * mid) + 2.0 * M * co * mid;
+        const double bytes = es * (M * mid + 2.0 * M * co + 9.0 * mid * mid + co * mid);       // t1 in, shortcut in, y out, both filter banks
+        ProfScope ps(e, s_, 0, flops, bytes);
+        if (e->prof) {
+            e->prof_flops[8] += flops;
+            e->prof_launches[0] += 1;          // two layers of the reference in one launch: keep "launches" = layers
+            // the unfused pair's algorithmic bytes (what `bytes` of category 0 means: every tensor of every LAYER once)
+            e->prof_bytes[0] += es * 2.0 * M * mid;
+        }
+        ClassScope cs(e, s_, TD_CLS_TAIL, flops, bytes);
+        return bottleneck_tail_launch(a, prec, s_);
+    };
     // ---- backbone ------------------------------------------------------------------------------------------
     // Runs in sub-batches of `sb` images (stem → res5 per sub-batch): the stage-2/3 activations of a sub-batch
     // (≈ 80 MB per 256-channel tensor and image at fp32) then hand over from layer to layer through the 256 MiB
@@ -1021,8 +1042,15 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                     shortcut = scb;
                 }
                 if ((st = run_conv(blk.c1, x, nb_img, xh, xw, blk.stride, 0, true, t1, nullptr, 0, s, prec)) < 0) return st;
-                if ((st = run_conv(blk.c2, t1, nb_img, oh, ow, 1, 1, true, t2, nullptr, 0, s, prec)) < 0) return st;
-                if ((st = run_conv(blk.c3, t2, nb_img, oh, ow, 1, 0, true, y, shortcut, 0, s, prec)) < 0) return st;
+                if (e->fuse_tail && blk.c2.kh == 3 && blk.c2.kw == 3 && blk.c2.cin == blk.c2.cout && blk.c3.cin == blk.c2.cout &&
+                    bottleneck_tail_ok(prec, blk.c2.cout, blk.c3.cout)) {
+                    // res2 (both precisions) / res3 (fp16): conv2 + conv3 + shortcut add in one launch, bit-identical to the two
+                    // launches below (bottleneck.hip); the mid tensor t2 never reaches HBM
+                    if ((st = run_tail(blk, t1, nb_img, oh, ow, y, shortcut, s)) < 0) return st;
+                } else {
+                    if ((st = run_conv(blk.c2, t1, nb_img, oh, ow, 1, 1, true, t2, nullptr, 0, s, prec)) < 0) return st;
+                    if ((st = run_conv(blk.c3, t2, nb_img, oh, ow, 1, 0, true, y, shortcut, 0, s, prec)) < 0) return st;
+                }
                 x = y;
                 xh = oh;
                 xw = ow;

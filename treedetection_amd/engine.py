@@ -297,7 +297,7 @@ class Engine:
     # -- device timing ------------------------------------------------------------------------------------
     PROF_NAMES = ("conv_igemm", "stem", "pool", "rpn_select", "roi_align", "detect", "mask_tail", "mask_convs", "executed")
 
-    CLASS_NAMES = ("wino_contraction", "wino_transform", "conv1x1", "conv3x3_direct", "fc", "mask_head")
+    CLASS_NAMES = ("wino_contraction", "wino_transform", "conv1x1", "conv3x3_direct", "fc", "mask_head", "bottleneck_tail")
 
     def profile_enable(self, on=True) -> None:
         """on: False / True, or 2 = detail (an event pair per contraction launch for :meth:`profile_classes`)."""
