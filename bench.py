@@ -76,6 +76,10 @@ def parse():
     ap.add_argument("--no-serial", action="store_true", help="skip the extra informational single-stream region")
     ap.add_argument("--no-r101", action="store_true", help="skip the extra timed region with the reference's own depth (R101-FPN)")
     ap.add_argument("--no-fp16-b32", action="store_true", help="skip the fp16 region at BASELINE configs[4]'s batch (32 per GPU)")
+    ap.add_argument("--no-two-model", action="store_true", help="skip the two-model (urban + forest, exclude flags) region of BASELINE configs[2]")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end region: warm Predictor.__call__ over a synthetic GeoTIFF on tmpfs "
+                    "(window reads → device → Prediction_*.json files)")
+    ap.add_argument("--e2e-side", type=int, default=8, help="the e2e raster is side x side tiles of --tile pixels")
     ap.add_argument("--streams", type=int, default=0, help="engines / HIP streams the batches alternate over (default 3 for "
                     "--schedule streams, 1 for plain): the HBM-bound kernels and the kernel tails of one forward run under the "
                     "MFMA-bound contractions of the others")
@@ -376,6 +380,98 @@ def main():
             e.close()
         return float(tmax.item()), prof, ndet
 
+    def run_two_model(precision):
+        """BASELINE configs[2]: the two-model path (reference detection.py:154-164 — the urban model over every tile that is not
+        flagged only_forest, THEN the forest model over every tile that is not only_urban; prediction.py:79-93 drops a flagged
+        tile before batching). Stream = the K steps' tiles with the flags a forest outline over the left part of a mosaic
+        gives: of every three consecutive tiles one is forest-only, one mixed, one urban-only. Each model has its own engines
+        (weights resident, three HIP streams as in the headline region); the timed region runs model after model, fill and
+        drain included. → (seconds, tiles visited by urban, by forest)."""
+        log(f"two-model region ({precision}): creating 2 x {args.streams} engines")
+        sds = {"urban": sd, "forest": make_synthetic_state_dict(args.depth, seed=2)}
+        ns = args.streams
+        n_tiles = nsteps * B
+        flags = [("only_forest", "mixed", "only_urban")[t % 3] for t in range(n_tiles)]
+        visit = {"urban": [t for t in range(n_tiles) if flags[t] != "only_forest"],
+                 "forest": [t for t in range(n_tiles) if flags[t] != "only_urban"]}
+        engs = {m: [Engine(sds[m], device=local_rank, precision=precision) for _ in range(ns)] for m in sds}
+        outs = {m: [e.alloc_outputs(B, S, S, paste=True) for e in engs[m]] for m in sds}
+        streams = [torch.cuda.Stream() for _ in range(ns)]
+
+        def model_pass(m, tiles_idx):
+            for k in range(0, len(tiles_idx), B):
+                idx = tiles_idx[k:k + B]
+                j = (k // B) % ns
+                with torch.cuda.stream(streams[j]):
+                    tiles = [rgb[t % n_local] for t in idx]
+                    batch, hw_valid, hw_out = engs[m][j].preprocess_tiles_u8(tiles)
+                    o = outs[m][j]
+                    engs[m][j].forward_raw(batch, INPUT_U8_HWC, hw_valid, hw_out, {kk: v[:len(idx)] for kk, v in o.items()})
+
+        for m in sds:                                   # warm-up: tile choices, allocations
+            model_pass(m, visit[m][: B * max(ns, args.warmup)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for m in ("urban", "forest"):
+            model_pass(m, visit[m])
+        torch.cuda.synchronize()
+        dtm = time.perf_counter() - t0
+        dets = {m: int(outs[m][0]["count"].sum().item()) for m in sds}
+        for m in sds:
+            for e in engs[m]:
+                e.close()
+        log(f"two-model region done: {dtm:.3f} s")
+        return dtm, len(visit["urban"]), len(visit["forest"]), n_tiles, dets
+
+    def run_e2e(precision, side):
+        """predict_tiles' model stage end to end, files to files (reference prediction.py:47-77,197-265): a warm
+        Predictor.__call__ over ONE synthetic GeoTIFF on tmpfs — side x side tiles of S x S pixels, 4-band RGBI uint8, tile
+        metadata from the package's own tile producer — window reads into pinned memory, H2D, resize, forward, paste, D2H of the
+        packed masks, contours → polygons → Prediction_<tile>.json written and counted. First call = warm-up (weights, tile
+        choices, buffers), then two timed calls."""
+        import shutil
+        import tempfile
+        import treedetection_amd as T
+        from treedetection_amd.geotiff import write_geotiff
+        from treedetection_amd.preprocessing import tile_data
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        root = tempfile.mkdtemp(prefix="td_e2e_", dir=base)
+        try:
+            os.makedirs(f"{root}/rgb")
+            img = np.zeros((4, side * S, side * S), np.uint8)
+            for r in range(side):
+                for c in range(side):
+                    t = rgb_np[(r * side + c) % len(rgb_np)]
+                    img[:3, r * S:(r + 1) * S, c * S:(c + 1) * S] = t.transpose(2, 0, 1)
+                    img[3, r * S:(r + 1) * S, c * S:(c + 1) * S] = t[..., 1]
+            gsd = 0.2
+            tif = f"{root}/rgb/324125317.tif"
+            write_geotiff(tif, img, (gsd, 0.0, 412000.0, 0.0, -gsd, 5318000.0 + side * S * gsd), 25832)
+            del img
+            tile_data([tif], f"{root}/tiles", buffer=0, tile_width=int(S * gsd), tile_height=int(S * gsd))
+            tjson = f"{root}/tiles/324125317.json"
+            ntiles = len(json.load(open(tjson)))
+            cfg = T.setup_model_cfg(update_model="synthetic", device=str(local_rank))
+            pred = T.Predictor(cfg, device_type=str(local_rank), max_batch_size=B, output_dir=f"{root}/out", precision=precision,
+                               state_dict=sd, return_predictions=False)
+            pred(tif, tjson)                        # warm-up call
+            times = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                pred(tif, tjson)
+                times.append(time.perf_counter() - t0)
+            stats = dict(pred.stats)
+            pred.close()
+            files = [f for f in os.listdir(f"{root}/out/324125317") if f.startswith("Prediction_")]
+            nbytes = sum(os.path.getsize(f"{root}/out/324125317/{f}") for f in files)
+            dt_e = min(times)
+            log(f"e2e region ({precision}): {ntiles} tiles per call, calls {[round(t, 3) for t in times]} s")
+            return {"value": ntiles / dt_e, "unit": "tiles/s", "tiles_per_call": ntiles, "calls_s": times, "files_written": len(files),
+                    "prediction_bytes": nbytes, "batch": B, "raster": f"{side * S}x{side * S}x4 uint8 GeoTIFF on {'tmpfs' if base else 'disk'}",
+                    "host_stage_seconds_last_call": stats}
+        finally:
+            shutil.rmtree(root, ignore_errors=True)
+
     if "TD_TUNE_CACHE" not in os.environ:     # engines of one run share their measured block-tile choices
         import tempfile
         os.environ["TD_TUNE_CACHE"] = os.path.join(tempfile.mkdtemp(prefix="td_tune_"), f"tiles_rank{rank}.txt")
@@ -426,6 +522,16 @@ def main():
             B, nsteps = 32, -(-max(4, args.steps // 4) // args.streams) * args.streams
             b32 = go("fp16", not args.no_profile) + (nsteps,)
             B, nsteps = args.batch, args.steps
+    two = e2e = None
+    if args.depth == 50 and world == 1 and args.schedule == "streams":
+        if not args.no_two_model:
+            two = {args.precision: run_two_model(args.precision)}
+            if args.precision == "fp32" and not args.no_fp16:
+                two["fp16"] = run_two_model("fp16")
+        if not args.no_e2e:
+            e2e = {args.precision: run_e2e(args.precision, args.e2e_side)}
+            if args.precision == "fp32" and not args.no_fp16:
+                e2e["fp16"] = run_e2e("fp16", args.e2e_side)
 
     # what the collective layer saw (for the reader of an N > 1 line: did RCCL really run N ranks on N different GPUs?)
     props = torch.cuda.get_device_properties(local_rank)
@@ -641,6 +747,25 @@ def main():
                 o["roofline"]["note"] = "contraction spans of the phase pipeline do not overlap each other (selection kernels run underneath)"
                 o["breakdown_ms_per_step"] = breakdown(phased[1], args.steps)
             line["phase_pipeline"] = o
+        if two is not None:
+            o = {"note": "BASELINE configs[2]: two-model path (urban model over the tiles not flagged only_forest, then the forest model over those "
+                         "not flagged only_urban; one tile in three forest-only, one mixed, one urban-only), full-width R50-FPN x 2 weight sets, "
+                         "same 1000x1000 tile stream and schedule; value = tiles VISITED (both models) per second; parity: "
+                         "tests/test_config2_fullsize_gpu.py"}
+            for pk, (dtm, nu, nf, nt, dets) in two.items():
+                o["f32" if pk == "fp32" else "f16"] = {"value": (nu + nf) / dtm, "unit": "tile visits/s", "seconds": dtm, "stream_tiles": nt,
+                                                       "visited_by_urban": nu, "visited_by_forest": nf,
+                                                       "stream_tiles_per_s": nt / dtm, "detections_last_batch": dets}
+            line["two_model"] = o
+        if e2e is not None:
+            o = {"note": "predict_tiles' model stage files to files: warm Predictor.__call__ over a synthetic GeoTIFF (window reads, H2D, resize, "
+                         "forward, paste, D2H, contours, Prediction_*.json written); ratio = e2e rate / the model-stage rate of the same precision "
+                         "in this line (inputs resident in HBM, results left in HBM)"}
+            for pk, r in e2e.items():
+                ref_rate = line["value"] if pk == args.precision else (line.get("fp16") or {}).get("value")
+                r["ratio_to_model_stage"] = r["value"] / ref_rate if ref_rate else None
+                o["f32" if pk == "fp32" else "f16"] = r
+            line["e2e"] = o
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, rgb_np, args.cpu_tiles)
         print(json.dumps(line), flush=True)

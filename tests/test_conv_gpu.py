@@ -337,8 +337,8 @@ def test_bottleneck_tail_equals_the_two_launches_bit_for_bit(case):
 
 
 def test_engine_with_fused_tail_equals_engine_without_it():
-    """The engine's default (res2 — fp16: res2 + res3 — tails fused) against TD_FUSE_TAIL=0 on the same inputs: every output bit for
-    bit, both precisions."""
+    """The engine with the res2 (fp16: res2 + res3) tails fused (TD_FUSE_TAIL=2; the fp32 engine fuses res2 by default) against
+    TD_FUSE_TAIL=0 on the same inputs: every output bit for bit, both precisions."""
     import os
     from tests.test_engine_gpu import smooth_image
     from treedetection_amd.engine import Engine
@@ -349,13 +349,14 @@ def test_engine_with_fused_tail_equals_engine_without_it():
               {"image": smooth_image(rng, 224, 256), "height": 224, "width": 256}]
     for prec in ("fp32", "fp16"):
         outs = []
-        for env in (None, "0"):
-            if env is not None:
-                os.environ["TD_FUSE_TAIL"] = env
+        for env in ("2", "0"):
+            os.environ["TD_FUSE_TAIL"] = env
+            os.environ["TD_STREAMK"] = "0"       # at this small image size the stream-K rule would take the unfused 3x3s (another association)
             try:
                 eng = Engine(sd, precision=prec)
             finally:
                 os.environ.pop("TD_FUSE_TAIL", None)
+                os.environ.pop("TD_STREAMK", None)
             got = eng(inputs)
             res3 = eng.tensor("res3").float().cpu().numpy()
             outs.append((got, res3))
@@ -364,3 +365,50 @@ def test_engine_with_fused_tail_equals_engine_without_it():
         for a, b in zip(outs[0][0], outs[1][0]):
             for k in ("pred_boxes", "scores", "mask_probs", "pred_masks"):
                 assert np.array_equal(a[k], b[k]), (prec, k)
+
+
+# ---- stream-K form (conv_streamk.hip; the fp16 engine's small-map layers): tile_cfg 21 = 128 x 128, 22 = 256 x 128 ----
+SK_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, res, relu
+    (8, 256, 50, 50, 256, 3, 1, 1, 0, True),          # res4 conv2 at BASELINE size: 36 k-steps, every resident block gets a range
+    (8, 512, 25, 25, 512, 3, 1, 1, 0, True),          # res5 conv2: 72 k-steps, 40 - 160 tiles on 256 - 512 blocks
+    (8, 2048, 25, 25, 512, 1, 1, 0, 0, True),         # res5 conv1
+    (8, 512, 25, 25, 2048, 1, 1, 0, 1, True),         # res5 conv3: residual + ReLU in the last arriver's epilogue
+    (8, 512, 100, 100, 1024, 1, 2, 0, 0, False),      # res4 shortcut: stride 2
+    (2, 256, 13, 13, 256, 3, 1, 1, 0, True),          # p6-sized map: fewer units than resident blocks
+    (1, 1024, 8, 10, 300, 1, 1, 0, 2, False),         # M and N tails, nearest-2x residual, one or two tiles
+]
+
+
+@pytest.mark.parametrize("cfg", [21, 22])
+@pytest.mark.parametrize("case", SK_CASES)
+def test_conv_streamk_matches_the_reference_tile(case, cfg):
+    """Stream-K cuts a tile's k range into pieces that different blocks sum and the last arriver adds in segment order: same
+    products, another association than the one-chain tiles — compared with the 128 x 128 reference tile (cfg 0, checked against
+    torch above) to fp32-accumulation noise BEFORE the fp16 rounding of the output (|diff| <= 1 fp16 ulp of the value, equal
+    almost everywhere), deterministic across repeats (a racy reduction would not repeat), counters back at zero after every
+    launch (the entry point launches twice)."""
+    B, Cin, H, W, Cout, k, stride, pad, res, relu = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.standard_normal((B, Cin, H, W), dtype=np.float32)
+    w = rng.standard_normal((Cout, Cin, k, k), dtype=np.float32) / np.float32(np.sqrt(Cin * k * k))
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    r = None
+    if res == 1:
+        r = rng.standard_normal((B, Cout, Ho, Wo), dtype=np.float32)
+    elif res == 2:
+        r = rng.standard_normal((B, Cout, Ho // 2, Wo // 2), dtype=np.float32)
+    kw = dict(scale=scale, bias=bias, residual_nchw=r, res_shift=1 if res == 2 else 0, stride=stride, pad=pad, relu=relu, precision=1)
+    ref = conv2d_hip(x, w, tile_cfg=0, **kw)
+    first = conv2d_hip(x, w, tile_cfg=cfg, **kw)
+    assert first.shape == ref.shape and np.isfinite(first).all()
+    # one fp16 ulp of the larger of the two values (a sum that lands on the other side of a rounding boundary or of a power
+    # of two), 1e-4 absolute for sums that the ReLU cuts at zero
+    ulp = np.spacing(np.maximum(np.abs(ref), np.abs(first)).astype(np.float16)).astype(np.float32)
+    assert (np.abs(first - ref) <= ulp + 1e-4).all(), float(np.abs(first - ref).max())
+    assert (first == ref).mean() >= 0.98
+    for _ in range(2):
+        assert np.array_equal(conv2d_hip(x, w, tile_cfg=cfg, **kw), first)
+    assert np.abs(ref).max() > 0.5

@@ -16,7 +16,7 @@ def schedule(depth=50, B=8, Hp=800, Wp=800, P=1000, fp32=False, fuse_tail=True):
             if bi == 0:
                 L.append((f"res{si+2}.{bi}.shortcut", B * ho * wo, outs[si], cin))
             L.append((f"res{si+2}.{bi}.conv1", B * ho * wo, mids[si], cin))
-            if fuse_tail and (si == 0 or (si == 1 and not fp32)):
+            if (fuse_tail and fp32 and si == 0) or (fuse_tail == 2 and not fp32 and si <= 1):
                 # bottleneck_tail_kernel: conv2 + conv3 in one launch (N, K of the 3x3; the 1x1's FLOPs ride in the 5th field)
                 L.append((f"res{si+2}.{bi}.conv2+3", B * ho * wo, mids[si], mids[si] * 9, 2.0 * B * ho * wo * outs[si] * mids[si] / 1e9))
             else:
@@ -60,7 +60,7 @@ def main(path, depth=50, fp32=False):
     min43 = int(os.environ.get("TD_WINO43_MIN", "12"))
     fam = ("conv_igemm", "conv_pp8", "plane_gemm", "wino_gemm", "wino_output", "wino_input", "wino43_input", "wino43_output", "bottleneck_tail", "conv_sk")
     rows = [r for r in csv.DictReader(open(path)) if any(f in r["Kernel_Name"] for f in fam)]
-    L = schedule(depth, fp32=fp32, fuse_tail=os.environ.get("TD_FUSE_TAIL", "1") != "0")
+    L = schedule(depth, fp32=fp32, fuse_tail=int(os.environ.get("TD_FUSE_TAIL", "1")))
     need = sum(launches_of(e[0], e[1], e[2], e[3], fp32, 8, min43)[0] for e in L)
     last = rows[-need:]
     tot_f = tot_t = 0.0

@@ -47,6 +47,25 @@ td_status td_conv2d_nhwc(const void* x, const void* w, const float* scale, const
     a.res_shift = res_shift; a.relu = relu; a.out_mode = 0;
     a.M = B * a.Ho * a.Wo; a.m_dyn = nullptr; a.m_mul = 1; a.out_f32 = 0;
     a.tile_cfg = ((precision >> 8) & 0xff) - 1;          // tests: force one block-tile variant (0 = the library chooses)
+    if (a.tile_cfg == 21 || a.tile_cfg == 22) {
+        // tests: the stream-K form (conv_streamk.hip) with a scratch workspace of its own (the engine owns one per engine)
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        void *ws = nullptr, *cnt = nullptr;
+        td_status st = scratch(&ws, conv_sk_workspace_floats() * sizeof(float));
+        if (st < 0) return st;
+        if ((st = scratch(&cnt, (size_t)conv_sk_max_tiles() * sizeof(int))) < 0) { (void)hipFree(ws); return st; }
+        hipError_t herr = hipMemsetAsync(cnt, 0, (size_t)conv_sk_max_tiles() * sizeof(int), s);
+        a.sk_ws = static_cast<float*>(ws);
+        a.sk_cnt = static_cast<int*>(cnt);
+        if (herr == hipSuccess) st = conv_sk_launch(a, precision & 0xff, a.tile_cfg - 21, s);
+        if (herr == hipSuccess && st == TD_OK) st = conv_sk_launch(a, precision & 0xff, a.tile_cfg - 21, s);     // twice: the counters must be back at zero
+        hipError_t herr2 = hipStreamSynchronize(s);
+        (void)hipFree(ws); (void)hipFree(cnt);
+        if (st < 0) return st;
+        TD_HIP_CHECK(herr);
+        TD_HIP_CHECK(herr2);
+        return TD_OK;
+    }
     return conv2d_launch(a, precision & 0xff, static_cast<hipStream_t>(stream));
 }
 

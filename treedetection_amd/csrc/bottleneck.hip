@@ -18,33 +18,35 @@
 // and one read of the mid tensor; one launch instead of two.
 #include "common.h"
 #include "conv_tiles.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int cmax(int x, int y) { return x > y ? x : y; }
 
-template <typename T, int MID, bool OVERLAP>
+template <typename T, int MID, bool OVERLAP, int MT>
 struct TailGeom {
     static constexpr int ES = sizeof(T);
     static constexpr int KE = Elem<T>::PER_CHUNK;            // elements per 128-B k-chunk
     static constexpr int KC = MID / KE;                      // channel chunks of the mid tensor
-    static constexpr int BM = 128, THREADS = 256, LDROWS = 32;
+    static constexpr int BM = 64 * MT, THREADS = 256, LDROWS = 32;   // 2 x 2 waves, a wave owns 32 MT rows
     static constexpr int NT1 = MID / 64;                     // phase 1: wave tile 64 x (32 NT1), block tile 128 x MID
     static constexpr int STAGE1 = 2 * (BM + MID) * CHUNK_BYTES;
     static constexpr int W3_BYTES = KC * 128 * CHUNK_BYTES;  // the 1x1 filters of one 128-channel output piece: [KC][128][128 B]
-    static constexpr int EPI_BYTES = conv_epilogue_lds_bytes<T, 2, 2, 2, 2, 1, false>();
+    static constexpr int EPI_BYTES = conv_epilogue_lds_bytes<T, MT, 2, 2, 2, 1, false>();
     static constexpr int EPI_OFF = OVERLAP ? W3_BYTES : 0;   // OVERLAP: the next piece's filters arrive while this piece is finished
     // region 0 = the phase-1 stages, later the filters of a piece and the epilogue's staging tile (side by side or aliased)
     static constexpr int R0 = cmax(STAGE1, cmax(W3_BYTES, EPI_OFF + EPI_BYTES));
     static constexpr int T2_BYTES = KC * BM * CHUNK_BYTES;   // the mid tile as the 1x1's A image: [KC][128][128 B]
     static constexpr int LDS_BYTES = R0 + T2_BYTES;
+    static constexpr int BPC = 160 * 1024 / LDS_BYTES >= 4 ? 4 : 160 * 1024 / LDS_BYTES;      // blocks per CU the LDS footprint allows
 };
 
 // The body is a __device__ function (the __global__ entry below only owns the LDS array): with the staging lambdas called
 // straight from a __global__ template, hipcc (ROCm 7.2) silently dropped the kernel's HOST stub from the object file.
-template <typename T, int MID, bool OVERLAP>
+template <typename T, int MID, bool OVERLAP, int MT>
 __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* lds) {
-    typedef TailGeom<T, MID, OVERLAP> G;
+    typedef TailGeom<T, MID, OVERLAP, MT> G;
     constexpr int ES = G::ES, KE = G::KE, KC = G::KC, BM = G::BM, LDROWS = G::LDROWS, NT1 = G::NT1;
     constexpr int AROWS = BM / LDROWS, BROWS1 = MID / LDROWS, BROWS3 = 128 / LDROWS;
     char* As = lds;                                   // phase 1: [2][BM][128 B]
@@ -133,9 +135,9 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) frag_off[kk] = (unsigned)(lane & 31) * CHUNK_BYTES + (((unsigned)(2 * kk) + hi) ^ swz) * 16;
 
-    f32x16 acc2[2][NT1];
+    f32x16 acc2[MT][NT1];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT1; ++j)
 #pragma unroll
@@ -147,17 +149,17 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
     for (int it = 0; it < nit; ++it) {
         const int cur = it & 1;
         if (it + 1 < nit) stage(cur ^ 1);
-        const char* Ab = &As[(cur * BM + wm * 64) * CHUNK_BYTES];
+        const char* Ab = &As[(cur * BM + wm * 32 * MT) * CHUNK_BYTES];
         const char* Bb = &Bs[(cur * MID + wn * 32 * NT1) * CHUNK_BYTES];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            f32x4 fa[2], fb[NT1];
+            f32x4 fa[MT], fb[NT1];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * CHUNK_BYTES + frag_off[kk]);
+            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * CHUNK_BYTES + frag_off[kk]);
 #pragma unroll
             for (int j = 0; j < NT1; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * CHUNK_BYTES + frag_off[kk]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT1; ++j) Elem<T>::mma(fa[i], fb[j], acc2[i][j]);
         }
@@ -189,7 +191,7 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
         const unsigned c = (unsigned)n / KE, e = (unsigned)n % KE;
         const unsigned piece = (e * ES) >> 4, inb = (e * ES) & 15;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MT; ++i) {
             if constexpr (sizeof(T) == 4) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
@@ -197,7 +199,7 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
                     if (a.scale2) t = __fmul_rn(t, sc);
                     if (a.bias2) t = __fadd_rn(t, bi);
                     t = t > 0.f ? t : 0.f;
-                    const unsigned row = (unsigned)(wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5));
+                    const unsigned row = (unsigned)(wm * 32 * MT + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5));
                     *reinterpret_cast<float*>(T2s + (c * BM + row) * CHUNK_BYTES + ((piece ^ ((row >> 1) & 7)) << 4) + inb) = t;
                 }
             } else {
@@ -219,7 +221,7 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
                     f16x2 pk;
                     pk[0] = (_Float16)(odd ? got : t0);
                     pk[1] = (_Float16)(odd ? t1 : got);
-                    const unsigned row = (unsigned)(wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5) + odd);
+                    const unsigned row = (unsigned)(wm * 32 * MT + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5) + odd);
                     *reinterpret_cast<f16x2*>(T2s + (c * BM + row) * CHUNK_BYTES + ((piece ^ ((row >> 1) & 7)) << 4) + inb2) = pk;
                 }
             }
@@ -234,26 +236,26 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
     e.Cout = a.COUT; e.relu = 1; e.out_mode = 0; e.res_shift = 0; e.Ho = a.H; e.Wo = a.W;
     const int npieces = (a.COUT + 127) / 128;
     for (int nc = 0; nc < npieces; ++nc) {
-        f32x16 acc3[2][2];
+        f32x16 acc3[MT][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc3[i][j][r] = 0.f;
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
-            const char* Ab = T2s + (kc * BM + wm * 64) * CHUNK_BYTES;
+            const char* Ab = T2s + (kc * BM + wm * 32 * MT) * CHUNK_BYTES;
             const char* Bb = W3s + (kc * 128 + wn * 64) * CHUNK_BYTES;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                f32x4 fa[2], fb[2];
+                f32x4 fa[MT], fb[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * CHUNK_BYTES + frag_off[kk]);
+                for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * CHUNK_BYTES + frag_off[kk]);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * CHUNK_BYTES + frag_off[kk]);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) Elem<T>::mma(fa[i], fb[j], acc3[i][j]);
             }
@@ -262,7 +264,7 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
         __builtin_amdgcn_s_barrier();                  // every wave has read this piece's filters (and the staging tile is free)
         const bool more = nc + 1 < npieces;
         if (OVERLAP && more) stage_w3(nc + 1);         // arrives while this piece is finished below
-        conv_epilogue<T, T, 2, 2, 2, 2, 1, false>(e, acc3, Epi, M, m0, nc * 128, tid, lane, wm, wn);
+        conv_epilogue<T, T, MT, 2, 2, 2, 1, false>(e, acc3, Epi, M, m0, nc * 128, tid, lane, wm, wn);
         if (more) {
             if (!OVERLAP) {
                 __syncthreads();                       // the staging tile (aliased with the filters) has been read
@@ -274,20 +276,20 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
     }
 }
 
-// BPC = blocks per CU the LDS footprint allows (1 or 2): __launch_bounds__' second argument is waves per SIMD = BPC for 4-wave blocks
-template <typename T, int MID, bool OVERLAP, int BPC>
+// BPC = blocks per CU the LDS footprint allows (__launch_bounds__' second argument is waves per SIMD = BPC for 4-wave blocks)
+template <typename T, int MID, bool OVERLAP, int MT, int BPC>
 __global__ __launch_bounds__(256, BPC)
 void bottleneck_tail_kernel(const TailArgs a) {
-    static_assert(BPC * TailGeom<T, MID, OVERLAP>::LDS_BYTES <= 160 * 1024, "LDS footprint does not allow that many blocks per CU");
-    __shared__ __attribute__((aligned(16))) char lds[TailGeom<T, MID, OVERLAP>::LDS_BYTES];
-    bottleneck_tail_body<T, MID, OVERLAP>(a, lds);
+    static_assert(BPC >= 1 && BPC * TailGeom<T, MID, OVERLAP, MT>::LDS_BYTES <= 160 * 1024, "LDS footprint does not allow that many blocks per CU");
+    __shared__ __attribute__((aligned(16))) char lds[TailGeom<T, MID, OVERLAP, MT>::LDS_BYTES];
+    bottleneck_tail_body<T, MID, OVERLAP, MT>(a, lds);
 }
 
-template <typename T, int MID, bool OVERLAP>
+template <typename T, int MID, bool OVERLAP, int MT>
 td_status launch_tail(const TailArgs& a, hipStream_t stream) {
-    const int tiles = td_cdiv(a.M, 128);
-    constexpr int BPC = TailGeom<T, MID, OVERLAP>::LDS_BYTES <= 80 * 1024 ? 2 : 1;
-    hipLaunchKernelGGL((bottleneck_tail_kernel<T, MID, OVERLAP, BPC>), dim3(tiles), dim3(256), 0, stream, a);
+    typedef TailGeom<T, MID, OVERLAP, MT> G;
+    const int tiles = td_cdiv(a.M, G::BM);
+    hipLaunchKernelGGL((bottleneck_tail_kernel<T, MID, OVERLAP, MT, G::BPC>), dim3(tiles), dim3(256), 0, stream, a);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
@@ -305,7 +307,11 @@ td_status bottleneck_tail_launch(const TailArgs& a, int precision, hipStream_t s
     TD_REQUIRE(a.M == a.B * a.H * a.W && a.M > 0, "bottleneck tail: M must be B*H*W");
     const size_t es = precision == TD_PRECISION_FP16 ? 2 : 4;
     TD_REQUIRE((size_t)a.M * a.MID * es < 0xfffffff0ull - (1u << 20), "bottleneck tail: input tensor must stay below 4 GB (32-bit buffer offsets)");
-    if (precision == TD_PRECISION_FP32) return launch_tail<float, 64, false>(a, stream);
-    if (a.MID == 64) return launch_tail<_Float16, 64, true>(a, stream);
-    return launch_tail<_Float16, 128, true>(a, stream);
+    // rows per block: 64 (three or four blocks per CU: more independent latency chains in flight) or 128 (half the filter
+    // re-reads); TD_TAIL_BM picks for experiments, the default is what measured faster per shape (profiles/)
+    static const int forced = getenv("TD_TAIL_BM") ? atoi(getenv("TD_TAIL_BM")) : 0;
+    const int bm = forced == 64 || forced == 128 ? forced : 64;
+    if (precision == TD_PRECISION_FP32) return bm == 64 ? launch_tail<float, 64, false, 1>(a, stream) : launch_tail<float, 64, false, 2>(a, stream);
+    if (a.MID == 64) return bm == 64 ? launch_tail<_Float16, 64, false, 1>(a, stream) : launch_tail<_Float16, 64, true, 2>(a, stream);
+    return bm == 64 ? launch_tail<_Float16, 128, false, 1>(a, stream) : launch_tail<_Float16, 128, true, 2>(a, stream);
 }

@@ -51,6 +51,9 @@ struct ConvArgs {
     // whose 16 transform planes are 16 independent 1x1 contractions (winograd.hip). 0 / 1 = a plain launch.
     int batch_count;
     long long x_bs, w_bs, y_bs;
+    // stream-K launches (conv_streamk.hip): partial-tile slots and per-tile ticket counters (zero between launches)
+    float* sk_ws;
+    int* sk_cnt;
     int tile_cfg;         // -1 = heuristic; 0..3 = block tile 128x128, 128x64, 64x128, 64x64 with 2 LDS stages,
                           // 4..7 = the same tiles with 3 stages (engine autotunes)
 };
@@ -62,6 +65,12 @@ struct ConvArgs {
 #define TD_CONV_TILE_CFG_MAX 20
 static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17, 18, 19, 20};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16, 18-20 only for plane contractions
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
+// stream-K form for the fp16 engine's small-map layers (conv_streamk.hip): variant 0 = 128 x 128 tiles / 4 waves / 512 resident
+// blocks, 1 = 256 x 128 / 8 waves / 256 blocks. a.sk_ws: conv_sk_workspace_floats() floats; a.sk_cnt: conv_sk_max_tiles() zeroed ints.
+int conv_sk_grid(int bm, int bn);
+size_t conv_sk_workspace_floats(void);
+int conv_sk_max_tiles(void);
+td_status conv_sk_launch(const ConvArgs& a, int precision, int variant, hipStream_t stream);
 bool conv_plane_ok(const ConvArgs& a, int precision);       // tile ids 18-20 apply to this launch
 td_status wino_gemm_launch(const ConvArgs& a, hipStream_t stream);     // Winograd plane contractions, input transform fused (fp32)
 

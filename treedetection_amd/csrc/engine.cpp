@@ -117,7 +117,16 @@ struct td_engine {
     bool winograd = true;         // TD_WINOGRAD=0 disables the Winograd path (diagnostics)
     float *wino_v = nullptr, *wino_m = nullptr;
     size_t wino_elems = 0;
-    bool fuse_tail = true;        // TD_FUSE_TAIL=0: conv2 / conv3 of res2 (fp16: and res3) as two launches (diagnostics, tests)
+    int sk_variant = -1;          // TD_STREAMK_VARIANT: force 0 (128 x 128) / 1 (256 x 128) everywhere the rule applies (experiments)
+    // TD_STREAMK=1: the fp16 engine's small-map layers through conv_sk_kernel. OFF by default — measured (round 3, plain loop,
+    // batch 8, profiles/r03_streamk_layers.txt): every layer the rule takes gets SLOWER (res4 conv2 38 -> 64 us, res5 conv2 56 ->
+    // 67, res4 conv1 22 -> 52): a block's partial-tile publish (128 KB of fp32 + agent-scope release), the last arriver's acquire +
+    // slab reads and the per-segment prologue cost 20-40 us per launch, more than the 10-15 us the evener k-step distribution saves.
+    bool stream_k = false;
+    float* sk_ws = nullptr;       // stream-K partial-tile slots / per-tile ticket counters (fp16 engine; reserve())
+    int* sk_cnt = nullptr;
+    bool fuse_tail = true;        // TD_FUSE_TAIL=0: conv2 / conv3 of res2 as two launches (diagnostics, tests); 2: fuse in the fp16 engine too
+    bool fuse_tail_fp16 = false;
     bool wino_fused = true;       // TD_WINO_FUSED=0: separate input-transform kernel + batched conv_igemm launch (diagnostics)
     int wino_slab = 0;            // TD_WINO_SLAB: tiles per slab (diagnostics); 0 = sized for the Infinity Cache
     int wino_minc = 128;          // fewest channels (both sides) of a 3x3 layer on the Winograd path (TD_WINO_MINC: experiments)
@@ -441,7 +450,9 @@ td_status td_engine_create(const td_model_desc* desc, int device, td_engine** ou
     if (const char* wg = getenv("TD_WINOGRAD")) e->winograd = atoi(wg) != 0;
     if (const char* ws = getenv("TD_WINO_SLAB")) e->wino_slab = atoi(ws);
     if (const char* wf = getenv("TD_WINO_FUSED")) e->wino_fused = atoi(wf) != 0;
-    if (const char* ft = getenv("TD_FUSE_TAIL")) e->fuse_tail = atoi(ft) != 0;
+    if (const char* ft = getenv("TD_FUSE_TAIL")) { e->fuse_tail = atoi(ft) != 0; e->fuse_tail_fp16 = atoi(ft) == 2; }
+    if (const char* sk = getenv("TD_STREAMK")) e->stream_k = atoi(sk) != 0;
+    if (const char* skv = getenv("TD_STREAMK_VARIANT")) e->sk_variant = atoi(skv);
     if (const char* w4 = getenv("TD_WINO43_MIN")) e->wino43_min = atoi(w4);
     if (const char* wc = getenv("TD_WINO_MINC")) e->wino_minc = atoi(wc);
     e->desc = d;
@@ -726,6 +737,13 @@ td_status td_engine_reserve(td_engine* e, int B, int Hp, int Wp) {
     if ((st = A(&e->o_classes, b * D)) < 0) return st;
     if ((st = A(&e->o_count, b)) < 0) return st;
     if ((st = A(&e->o_mask_probs, mrows * 784)) < 0) return st;
+    e->sk_ws = nullptr;
+    e->sk_cnt = nullptr;
+    if (e->desc.precision == TD_PRECISION_FP16 && e->stream_k) {
+        if ((st = A(&e->sk_ws, conv_sk_workspace_floats())) < 0) return st;
+        if ((st = A(&e->sk_cnt, (size_t)conv_sk_max_tiles())) < 0) return st;
+        TD_HIP_CHECK(hipMemset(e->sk_cnt, 0, (size_t)conv_sk_max_tiles() * sizeof(int)));     // every launch leaves them at zero again
+    }
     e->wino_v = e->wino_m = nullptr;
     e->wino_elems = 0;
     if (e->desc.precision == TD_PRECISION_FP32 && e->winograd) {
@@ -911,6 +929,25 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         int cfg = -1, wino_cfg = -1;
         bool use_wino = false, use_43 = false;
         td_status st2;
+        // Stream-K (conv_streamk.hip) for the fp16 engine's small-map layers (opt-in, TD_STREAMK=1). A FIXED RULE on the launch shape, never a timing
+        // decision: its partial sums are associated differently from the plain block tiles, so a measured choice would make
+        // results differ between processes. Rule: rows <= 20 000 x batch-8-sized maps (M <= 24 000: res4 / res5, p4 - p6), at
+        // least 8 k-steps (K >= 512), no device-side row count; 256 x 128 tiles when the layer has the rows and channels for them.
+        const int sk_ksteps = prec_ == TD_PRECISION_FP16 ? L.kh * L.kw * L.cin / 64 : 0;
+        if (prec_ == TD_PRECISION_FP16 && e->stream_k && e->sk_ws && !m_dyn && out_mode == 0 && sk_ksteps >= 8 && (long long)B_ * Ho * Wo <= 24000 &&
+            L.cout >= 128 && L.cin % 64 == 0) {
+            ConvArgs a{};
+            a.x = x_; a.w = L.w; a.scale = L.scale; a.bias = L.bias; a.res = res_; a.y = y_;
+            a.B = B_; a.H = H_; a.W = W_; a.Cin = L.cin; a.Cout = L.cout; a.KH = L.kh; a.KW = L.kw; a.stride = stride; a.pad = pad;
+            a.Ho = Ho; a.Wo = Wo; a.res_shift = res_shift; a.relu = relu ? 1 : 0; a.out_mode = 0; a.M = B_ * Ho * Wo; a.m_mul = 1;
+            a.out_f32 = L.out_f32 ? 1 : 0; a.sk_ws = e->sk_ws; a.sk_cnt = e->sk_cnt;
+            const int variant = e->sk_variant >= 0 ? e->sk_variant : (a.M >= 2048 ? 1 : 0);
+            ProfScope ps(e, s_, 0, flops, bytes);
+            if (e->prof) e->prof_flops[8] += flops;
+            const int cls = H_ == 1 && W_ == 1 ? TD_CLS_FC : (L.kh == 1 && L.kw == 1 ? TD_CLS_CONV1X1 : TD_CLS_CONV3X3);
+            ClassScope cs(e, s_, cls, flops, bytes);
+            return conv_sk_launch(a, prec_, variant, s_);
+        }
         if (e->autotune) {
             const auto key = std::make_tuple(L.cout, L.cin, L.kh * 16 + L.kw, B_ * Ho * Wo, stride * 4 + out_mode * 2 + (res_ ? 1 : 0));
             const int ksteps = L.kh * L.kw * L.cin / (prec_ == TD_PRECISION_FP16 ? 64 : 32);
@@ -1042,10 +1079,14 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                     shortcut = scb;
                 }
                 if ((st = run_conv(blk.c1, x, nb_img, xh, xw, blk.stride, 0, true, t1, nullptr, 0, s, prec)) < 0) return st;
-                if (e->fuse_tail && blk.c2.kh == 3 && blk.c2.kw == 3 && blk.c2.cin == blk.c2.cout && blk.c3.cin == blk.c2.cout &&
-                    bottleneck_tail_ok(prec, blk.c2.cout, blk.c3.cout)) {
-                    // res2 (both precisions) / res3 (fp16): conv2 + conv3 + shortcut add in one launch, bit-identical to the two
-                    // launches below (bottleneck.hip); the mid tensor t2 never reaches HBM
+                // Measured (round 3, plain loop, batch 8): fp32 res2 365 us fused against 215 + 185 us as two launches; the fp16
+                    // engine's two launches are faster than this first fused form (res2 141 vs 146-161 us, res3 88 vs 145 us: the
+                    // fused block is a chain of short latency-bound steps at two blocks per CU), so fp16 fuses only on request
+                    // (TD_FUSE_TAIL=2). Either way the result is bit-identical, so this IS allowed to follow a measurement.
+                if (e->fuse_tail && (prec == TD_PRECISION_FP32 || e->fuse_tail_fp16) && blk.c2.kh == 3 && blk.c2.kw == 3 &&
+                    blk.c2.cin == blk.c2.cout && blk.c3.cin == blk.c2.cout && bottleneck_tail_ok(prec, blk.c2.cout, blk.c3.cout)) {
+                    // conv2 + conv3 + shortcut add in one launch, bit-identical to the two launches below (bottleneck.hip); the mid
+                    // tensor t2 never reaches HBM
                     if ((st = run_tail(blk, t1, nb_img, oh, ow, y, shortcut, s)) < 0) return st;
                 } else {
                     if ((st = run_conv(blk.c2, t1, nb_img, oh, ow, 1, 1, true, t2, nullptr, 0, s, prec)) < 0) return st;
