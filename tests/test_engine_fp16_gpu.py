@@ -155,10 +155,9 @@ def test_fp16_stated_tolerances_on_heads_with_trained_like_margins():
     tests/blob_head.py: its OUTPUT is a compact blob — the level set of a smooth function of the real RoI features
     (every kernel of the mask branch runs: RoIAlign 14x14, four 3x3 convs, deconv, predictor, paste). On that fixture
     BASELINE.md's proposals are asserted OUTRIGHT on the engine's own outputs: |score error| <= 5e-3 and boxes <= 0.5 px
-    for every matched detection; pasted-mask IoU >= 0.97 for EVERY matched detection whose crown is large enough that the
-    allowed box error cannot cost 3 % by itself (boundary / area <= 0.10), and for the smaller ones a loss explained by the
-    measured box displacement (1 - IoU <= 1.2 x boundary/area x box error + 1 %); median >= 0.985. The fixture itself is
-    checked too: the ORACLE's masks are compact (boundary / area <= 0.2 for at least 95 % of them, median <= 0.12)."""
+    for every matched detection; pasted-mask IoU >= 0.97 for EVERY matched detection whose oracle mask is compact (boundary /
+    area <= 0.2 — at least 90 % of the fixture, median 0.09), at most 16 differing pixels for the few smaller ones; median IoU
+    >= 0.99."""
     from tests.blob_head import blob_mask_head, boundary_over_area
     from treedetection_amd.engine import Engine
     torch.set_num_threads(8)
@@ -201,13 +200,12 @@ def test_fp16_stated_tolerances_on_heads_with_trained_like_margins():
     print(f"[fp16, trained-like heads] {len(es)} matched detections: score err max {max(es):.4f}; box err max {berr.max():.3f} px; pasted-mask IoU "
           f"min {ious.min():.4f} p10 {np.quantile(ious, 0.1):.4f} median {np.median(ious):.4f}; oracle masks boundary/area median "
           f"{np.median(compact):.3f} p95 {np.quantile(compact, 0.95):.3f} max {compact.max():.3f}")
-    assert np.median(compact) <= 0.12 and (compact <= 0.2).mean() >= 0.95       # the fixture's masks ARE compact
-    # IoU >= 0.97 outright wherever the ALLOWED box error (0.5 px) cannot cost 3 % by itself, i.e. on crowns of at least
-    # ~45 px across (boundary / area <= 0.10: a 0.25-px displacement of such a mask moves <= 2.5 % of its area);
-    # for smaller crowns the box tolerance and the IoU proposal contradict each other, so there the statement is that
-    # the loss is EXPLAINED by the measured box displacement: 1 - IoU <= 1.2 x boundary/area x box error + 1 %.
-    big = compact <= 0.10
-    assert big.sum() >= 30 and (ious[big] >= 0.97).all(), (int(big.sum()), float(ious[big].min()))
-    assert (1.0 - ious <= 1.2 * compact * berr + 0.01).all(), float((1.0 - ious - 1.2 * compact * berr).max())
-    assert np.median(ious) >= 0.985 and ious.min() >= 0.94
+    assert np.median(compact) <= 0.12 and (compact <= 0.2).mean() >= 0.9        # the fixture's masks ARE compact
+    # IoU >= 0.97 OUTRIGHT for every matched detection with a compact oracle mask (boundary / area <= 0.2: crowns from ~25 px
+    # across, 90+ % of the fixture); the handful of smaller ones (a 12-px crown has 4 boundary pixels per 10 of area: one
+    # flipped border pixel row is 8 % of it) may differ in at most 16 pixels.
+    big = compact <= 0.2
+    assert big.sum() >= 150 and (ious[big] >= 0.97).all(), (int(big.sum()), float(ious[big].min()))
+    assert (rows[~big, 4] <= 16).all(), rows[~big]
+    assert np.median(ious) >= 0.99
     eng.close()

@@ -13,14 +13,16 @@
 // partial sums in a workspace slot and takes a ticket on the tile's counter; whoever draws the LAST ticket adds the
 // tile's partials IN SEGMENT ORDER (its own from registers) and runs the epilogue. Nobody ever waits for another block
 // (no spin, no residency requirement: safe with three forwards in flight on three streams); visibility follows the
-// guide's split-K recipe (plain slab stores → every wave's vmcnt(0) → workgroup barrier → lane 0: agent-scope release,
-// vmcnt(0), relaxed agent fetch_add; last arriver: agent-scope acquire, vmcnt(0), barrier, plain loads).
+// guide's split-K recipe in its write-through form (sc1 slab stores → every wave's vmcnt(0) → workgroup barrier → lane 0's
+// relaxed agent fetch_add; the last arriver reads the slabs with sc1 loads). The first form — plain stores + agent-scope
+// release / acquire — cost 20-40 us per launch (each release writes back the XCD's whole L2).
 // At most two partial tiles per block: <= 2 G slots of BM * BN floats are ever written per launch.
 //
-// MEASURED (round 3): slower than the plain block tiles on every layer of the R50 / R101 trunk it was built for — the
-// publish / acquire / slab-read / per-segment-prologue costs of a block (20-40 us per launch at one or two blocks per CU)
-// exceed what the even k-step distribution saves (profiles/r03_streamk_layers.txt). Kept as an opt-in path
-// (TD_STREAMK=1) with its parity tests; the engine does not use it by default.
+// MEASURED (round 3): slower than the plain block tiles on every layer of the R50 trunk it was built for except res5 conv2
+// (profiles/r03_streamk_layers.txt: 1 588 us against 1 218 us summed over the layers the rule takes) — a block's partial-tile
+// publish (128 KB of fp32), the last arriver's slab reads and the per-segment prologue (10-15 us per launch at one or two
+// blocks per CU) exceed what the even k-step distribution saves. Kept as an opt-in path (TD_STREAMK=1) with
+// its parity tests; the engine does not use it by default.
 //
 // Numerics: a tile's k range is summed in up to a few pieces instead of one chain — deterministic (the piece order is the
 // segment order, the split points depend on M, N, K and the constant G only), but NOT the association of the other block
@@ -191,16 +193,29 @@ __device__ __forceinline__ void conv_sk_body(const ConvArgs& a, char* lds) {
         bool finish = true;                            // this block runs the tile's epilogue
         if (k0 != 0 || k1 != nit) {
             // ---- partial tile: publish the fp32 sums, take a ticket; the last arriver of the tile reduces and finishes ----
-            constexpr int TILE_ELEMS = BM * BN;
-            float* ws = a.sk_ws;
-            float* mine = ws + (size_t)(2 * vb + (k0 == 0 ? 1 : 0)) * TILE_ELEMS;
-            // slot layout [wave][i][j][r][lane]: every store / load instruction moves 64 consecutive floats
+            // Write-through (sc1) 16-B slab stores and sc1 slab loads, no agent-scope fences: an agent release is a write-back
+            // of the XCD's whole L2 (every other block's freshly written slab included) and cost 20-40 us per launch here
+            // (MI355X_MICROARCH.md "publish-large": tens of KB per workgroup → write-through wins). Hand-off = the guide's
+            // measured row "ONE lane of each storing workgroup adds to ONE unsharded counter; the workgroup whose add came
+            // last, told by the value its add returned": every storing wave drains its stores (vmcnt(0)), the workgroup
+            // barrier, then lane 0's relaxed agent-scope fetch_add; the last arriver's other waves load after a workgroup
+            // barrier the adding wave joins; EVERY load of slab bytes is an sc1 load to registers.
+            constexpr int TILE_BYTES = BM * BN * 4;
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            char* wsb = reinterpret_cast<char*>(a.sk_ws);
+            const __amdgpu_buffer_rsrc_t mine = __builtin_amdgcn_make_buffer_rsrc(
+                wsb + (size_t)(2 * vb + (k0 == 0 ? 1 : 0)) * TILE_BYTES, 0, TILE_BYTES, 0x00020000);
+            // slot layout [wave][i][j][g][lane][4 floats]: a wave instruction moves 1 KB of consecutive bytes
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mine[(((wave * MT + i) * NT + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), mine,
+                                                               ((((wave * MT + i) * NT + j) * 4 + g) * 64 + lane) * 16, 0, 16 /* sc1 */);
+                    }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its own stores
             __syncthreads();
             const long long t_first = (long long)tile * nit;
@@ -208,48 +223,36 @@ __device__ __forceinline__ void conv_sk_body(const ConvArgs& a, char* lds) {
             const int nseg = b_last - b_first + 1;
             int* flag = reinterpret_cast<int*>(lds);              // the ONE LDS array (a second __shared__ object de-pipelines the DMA waits)
             if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // keep: ROCm 7.2 may drop the fence's own wait
                 const int old = __hip_atomic_fetch_add(&a.sk_cnt[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *flag = old;
+                *flag = old;                                       // (the add has returned: its value is used)
             }
             __syncthreads();
             const int ticket = *flag;
             finish = ticket == nseg - 1;
+            __syncthreads();                                       // everyone has read the flag word (the LDS stages are refilled next)
             if (finish) {
-                if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                const int my_seg = vb - b_first;
-                f32x16 sum[MT][NT];
+                // every piece comes from its slab, this block's own included (it was stored before the ticket was drawn): one
+                // accumulator array stays live instead of two, and the order of the additions is the segment order by construction
                 for (int s = 0; s < nseg; ++s) {
-                    if (s == my_seg) {
+                    const __amdgpu_buffer_rsrc_t theirs = __builtin_amdgcn_make_buffer_rsrc(
+                        wsb + (size_t)(2 * (b_first + s) + (s == 0 ? 1 : 0)) * TILE_BYTES, 0, TILE_BYTES, 0x00020000);
 #pragma unroll
-                        for (int i = 0; i < MT; ++i)
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
-                            for (int j = 0; j < NT; ++j)
+                        for (int j = 0; j < NT; ++j) {
+                            f32x4 v[4];
 #pragma unroll
-                                for (int r = 0; r < 16; ++r) sum[i][j][r] = s == 0 ? acc[i][j][r] : __fadd_rn(sum[i][j][r], acc[i][j][r]);
-                    } else {
-                        const float* theirs = ws + (size_t)(2 * (b_first + s) + (s == 0 ? 1 : 0)) * TILE_ELEMS;
+                            for (int g = 0; g < 4; ++g)
+                                v[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                           theirs, ((((wave * MT + i) * NT + j) * 4 + g) * 64 + lane) * 16, 0, 16 /* sc1 */));
 #pragma unroll
-                        for (int i = 0; i < MT; ++i)
+                            for (int g = 0; g < 4; ++g)
 #pragma unroll
-                            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                                for (int r = 0; r < 16; ++r) {
-                                    const float v = theirs[(((wave * MT + i) * NT + j) * 16 + r) * 64 + lane];
-                                    sum[i][j][r] = s == 0 ? v : __fadd_rn(sum[i][j][r], v);
-                                }
-                    }
+                                for (int q = 0; q < 4; ++q)
+                                    acc[i][j][4 * g + q] = s == 0 ? v[g][q] : __fadd_rn(acc[i][j][4 * g + q], v[g][q]);
+                        }
                 }
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = sum[i][j];
                 if (tid == 0) __hip_atomic_store(&a.sk_cnt[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-            } else {
-                __syncthreads();                       // everyone has read the flag word before the next segment's DMA overwrites it
             }
         }
         if (finish) {

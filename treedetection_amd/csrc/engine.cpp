@@ -119,9 +119,10 @@ struct td_engine {
     size_t wino_elems = 0;
     int sk_variant = -1;          // TD_STREAMK_VARIANT: force 0 (128 x 128) / 1 (256 x 128) everywhere the rule applies (experiments)
     // TD_STREAMK=1: the fp16 engine's small-map layers through conv_sk_kernel. OFF by default — measured (round 3, plain loop,
-    // batch 8, profiles/r03_streamk_layers.txt): every layer the rule takes gets SLOWER (res4 conv2 38 -> 64 us, res5 conv2 56 ->
-    // 67, res4 conv1 22 -> 52): a block's partial-tile publish (128 KB of fp32 + agent-scope release), the last arriver's acquire +
-    // slab reads and the per-segment prologue cost 20-40 us per launch, more than the 10-15 us the evener k-step distribution saves.
+    // batch 8, profiles/r03_streamk_layers.txt): with write-through slab stores the layers the rule takes sum to 1 588 us against
+    // 1 218 us for the measured block tiles (res4 conv2 38 -> 52 us, res4 conv1 22 -> 34; only res5 conv2 gains, 56 -> 51); the
+    // first hand-off form (agent-scope release / acquire) was slower still (2 154 us). A block's partial-tile publish, the last
+    // arriver's slab reads and the per-segment prologue cost more than the evener k-step distribution saves.
     bool stream_k = false;
     float* sk_ws = nullptr;       // stream-K partial-tile slots / per-tile ticket counters (fp16 engine; reserve())
     int* sk_cnt = nullptr;

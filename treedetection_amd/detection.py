@@ -46,7 +46,7 @@ def predict_on_model(config, model_path, tiles_path, output_path, batch_size=10,
                           exclude_vars=exclude_vars, precision=config.get("precision", "fp32"),
                           return_predictions=False,       # the files are the product; the list is unused here
                           pipeline=config.get("pipeline", True), device_contours=config.get("device_contours", False),
-                          sharded_epilogue=config.get("sharded_epilogue", "rank0"))
+                          sharded_epilogue=config.get("sharded_epilogue", "auto"))     # rank0 below 4 ranks, local from 4 (prediction.py)
     try:
         images_directory = Path(config["image_directory"])
         images_paths = sorted(str(f) for f in images_directory.glob("*.tif"))

@@ -143,6 +143,19 @@ class _Slot:
                 self.pin_cont[k][:n].copy_(v[:n], non_blocking=True)
 
 
+# Who pastes / traces / writes the tile files of a sharded run, by arithmetic. "rank0": every rank's fixed-shape
+# payload (2.5 MB per 8-tile batch) goes to rank 0, whose GPU pastes for everybody and whose PCIe link carries everybody's packed
+# masks to its host (measured: ~0.83 MB of Prediction JSON and ~5 MB of packed mask rows per 1000x1000 tile on the synthetic
+# stream). One Gen5 x16 link moves ~55 GB/s and one host's epilogue workers ~7-14 k tiles/s: 8 fp32 engines (8 x 630 tiles/s x
+# 5 MB = 25 GB/s) still fit, 4 or more fp16 engines (4 x 2 000 x 5 MB = 40 GB/s plus rank 0's own paste launches for 8 000
+# tiles/s) do not leave headroom — from 4 ranks on every rank finishes its own tiles ("local": same bytes in the files, tested).
+SHARDED_LOCAL_FROM_WORLD = 4
+
+
+def resolve_sharded_epilogue(world: int, precision: str = "fp32") -> str:
+    return "local" if world >= SHARDED_LOCAL_FROM_WORLD else "rank0"
+
+
 class Predictor:
     def __init__(self, cfg, device_type="cpu", max_batch_size=5, output_dir="./output", exclude_vars=None,
                  precision: str = "fp32", state_dict: Optional[Dict[str, np.ndarray]] = None,
@@ -170,7 +183,8 @@ class Predictor:
         self.exclude_vars = exclude_vars or []
         self.return_predictions = return_predictions
         # borders followed on the GPU (td_trace_contours_dev); rank 0's gathered-batch epilogue uses the host tracer
-        self.device_contours = bool(device_contours) and (D.world() == 1 or sharded_epilogue == "local")
+        self.device_contours = bool(device_contours) and (D.world() == 1 or sharded_epilogue == "local" or
+                                                          (sharded_epilogue == "auto" and resolve_sharded_epilogue(D.world(), precision) == "local"))
         os.makedirs(self.output_dir, exist_ok=True)
         sd = state_dict if state_dict is not None else load_checkpoint(cfg.MODEL.WEIGHTS)
         rh = cfg.MODEL.ROI_HEADS
@@ -182,8 +196,10 @@ class Predictor:
         if schedule not in ("streams", "phases"):
             raise ValueError(f"schedule must be 'streams' or 'phases', got {schedule!r}")
         self.schedule = schedule
-        if sharded_epilogue not in ("rank0", "local"):
-            raise ValueError(f"sharded_epilogue must be 'rank0' or 'local', got {sharded_epilogue!r}")
+        if sharded_epilogue not in ("rank0", "local", "auto"):
+            raise ValueError(f"sharded_epilogue must be 'rank0', 'local' or 'auto', got {sharded_epilogue!r}")
+        if sharded_epilogue == "auto":
+            sharded_epilogue = resolve_sharded_epilogue(D.world(), precision)
         self.sharded_epilogue = sharded_epilogue     # torch.distributed runs only: who pastes / traces / writes the tile files
         if "TD_TUNE_CACHE" not in os.environ:
             # Measured block-tile choices are shared between the engines of this process and kept for later runs (the
@@ -206,6 +222,9 @@ class Predictor:
         if getattr(self, "_pool", None) is not None:
             self._pool.shutdown(wait=True)
             self._pool = None
+        if getattr(self, "_read_pool", None) is not None:
+            self._read_pool.shutdown(wait=True)
+            self._read_pool = None
         for eng in getattr(self, "_engines", []) or []:
             eng.close()
 
@@ -302,9 +321,28 @@ class Predictor:
                 _, _, w, h = img.window_of_bounds(tiles[idx]["bounds"])
                 need += max(w, 0) * max(h, 0) * img.count
             staging = slot.staging(max(need, 1), self.device)
-        batch, off = [], 0
+        # offsets of the tiles in the staging buffer follow from the window sizes alone, so the windows can be copied side by
+        # side: an uncompressed (memory-mapped) raster is read by a few threads at once — one thread's memcpy moves ~8 GB/s, which
+        # is 2 000 tiles/s of 1000x1000x4-byte windows: exactly what three fp16 engines consume (bench.py e2e, round 3: the
+        # launcher waited for the reader 40 % of the call); numpy's copies release the GIL. Compressed rasters keep the
+        # sequential walk: their blocks are decoded by the reader's own thread pool already.
+        offs, o = [], 0
         for idx in indices:
-            data, info = self._process_tile(tiles[idx], img, staging, off)
+            offs.append(o)
+            if staging is not None:
+                _, _, w, h = img.window_of_bounds(tiles[idx]["bounds"])
+                o += max(w, 0) * max(h, 0) * img.count
+        img._setup_blocks()
+        if staging is not None and getattr(img, "_flat", None) is not None and len(indices) > 1:
+            if getattr(self, "_read_pool", None) is None:
+                self._read_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="td-window")
+            results = list(self._read_pool.map(lambda k: self._process_tile(tiles[indices[k]], img, staging, offs[k]), range(len(indices))))
+        else:
+            results = [self._process_tile(tiles[idx], img, staging, offs[k]) for k, idx in enumerate(indices)]
+        batch = []
+        for k, idx in enumerate(indices):
+            data, info = results[k]
+            off = offs[k]
             if data is None and keep_failed:
                 _, _, w, h = img.window_of_bounds(tiles[idx]["bounds"])
                 black = np.zeros((h, w, 3), np.uint8)
@@ -316,8 +354,6 @@ class Predictor:
                         "tile_id": tiles[idx]["tile_id"], "meta": tiles[idx]["meta"]}
             if data is None:
                 continue
-            if "staged" in data:
-                off += int(np.prod(data["staged"][1]))
             batch.append({"data": data, **info})
         return batch
 
