@@ -17,8 +17,9 @@ import numpy as np
 
 NF = 8          # feature channels that shape the outline
 GAIN = 24.0     # logit slope: a trained head is confident away from the outline
-LEVEL = 0.55    # bump level of the outline (bump: 1 at the centre, ~0.3 in the corners)
-AMP = 0.025      # how much the features move the outline
+LEVEL = 0.8     # bump level of the outline (bump: 1 at the centre, ~0.3 in the corners): the blob stays clear of the RoI border, so a
+                # box edge that crosses an integer (the paste region moves by one pixel column) cannot flip a column of the mask
+AMP = 0.06      # how much the features move the outline
 
 
 def blob_mask_head(sd, seed=0):

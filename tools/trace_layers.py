@@ -16,7 +16,7 @@ def schedule(depth=50, B=8, Hp=800, Wp=800, P=1000, fp32=False, fuse_tail=True):
             if bi == 0:
                 L.append((f"res{si+2}.{bi}.shortcut", B * ho * wo, outs[si], cin))
             L.append((f"res{si+2}.{bi}.conv1", B * ho * wo, mids[si], cin))
-            if (fuse_tail and fp32 and si == 0) or (fuse_tail == 2 and not fp32 and si <= 1):
+            if (fuse_tail and si == 0) or (fuse_tail == 2 and not fp32 and si == 1):
                 # bottleneck_tail_kernel: conv2 + conv3 in one launch (N, K of the 3x3; the 1x1's FLOPs ride in the 5th field)
                 L.append((f"res{si+2}.{bi}.conv2+3", B * ho * wo, mids[si], mids[si] * 9, 2.0 * B * ho * wo * outs[si] * mids[si] / 1e9))
             else:
@@ -58,7 +58,7 @@ def launches_of(name, M, N, K, fp32, B=8, min43=12):
 def main(path, depth=50, fp32=False):
     import os
     min43 = int(os.environ.get("TD_WINO43_MIN", "12"))
-    fam = ("conv_igemm", "conv_pp8", "plane_gemm", "wino_gemm", "wino_output", "wino_input", "wino43_input", "wino43_output", "bottleneck_tail", "conv_sk")
+    fam = ("conv_igemm", "conv_pp8", "plane_gemm", "wino_gemm", "wino_output", "wino_input", "wino43_input", "wino43_output", "bottleneck_tail", "conv_sk", "conv_bd")
     rows = [r for r in csv.DictReader(open(path)) if any(f in r["Kernel_Name"] for f in fam)]
     L = schedule(depth, fp32=fp32, fuse_tail=int(os.environ.get("TD_FUSE_TAIL", "1")))
     need = sum(launches_of(e[0], e[1], e[2], e[3], fp32, 8, min43)[0] for e in L)
@@ -77,7 +77,8 @@ def main(path, depth=50, fp32=False):
         if "conv2+3" in name:
             assert "bottleneck_tail" in kn, (name, kn)
         kern = label if label else ("pp8" if "conv_pp8" in kn else "bottleneck_tail" if "bottleneck_tail" in kn else
-                                    "conv_sk" if "conv_sk" in kn else kn.split("conv_igemm_")[1].split("(")[0][:28])
+                                    "conv_sk" if "conv_sk" in kn else ("conv_bd 64x256" if "Li2ELi2ELi4" in kn or "2, 2, 4" in kn else "conv_bd 64x128") if "conv_bd" in kn else
+                                    kn.split("conv_igemm_")[1].split("(")[0][:28])
         if k == 3:
             assert "wino43_input" in kn and "wino43_output" in rs[2]["Kernel_Name"], (name, kn)
             kern += f" [{ts[0]:.0f}+{ts[1]:.0f}+{ts[2]:.0f}]"

@@ -47,6 +47,28 @@ td_status td_conv2d_nhwc(const void* x, const void* w, const float* scale, const
     a.res_shift = res_shift; a.relu = relu; a.out_mode = 0;
     a.M = B * a.Ho * a.Wo; a.m_dyn = nullptr; a.m_mul = 1; a.out_f32 = 0;
     a.tile_cfg = ((precision >> 8) & 0xff) - 1;          // tests: force one block-tile variant (0 = the library chooses)
+    if ((a.tile_cfg == 23 || a.tile_cfg == 24) && (precision & 0xff) == TD_PRECISION_FP16 && Cin % 64 == 0) {
+        // tests: the filter-direct tiles (conv_bdirect.hip) need the filters in fragment order: packed here from the caller's
+        // [Cout][KH][KW][Cin] fp16 bank (the engine packs once at load time)
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const size_t n = (size_t)Cout * KH * KW * Cin;
+        std::vector<unsigned short> bits(n), packed;
+        TD_HIP_CHECK(hipStreamSynchronize(s));
+        TD_HIP_CHECK(hipMemcpy(bits.data(), w, n * 2, hipMemcpyDeviceToHost));
+        conv_bd_pack(bits.data(), Cout, KH, KW, Cin, packed);
+        void* wf = nullptr;
+        td_status st = scratch(&wf, packed.size() * 2);
+        if (st < 0) return st;
+        hipError_t herr = hipMemcpy(wf, packed.data(), packed.size() * 2, hipMemcpyHostToDevice);
+        a.w_frag = wf;
+        if (herr == hipSuccess) st = conv2d_launch(a, precision & 0xff, s);
+        hipError_t herr2 = hipStreamSynchronize(s);
+        (void)hipFree(wf);
+        if (st < 0) return st;
+        TD_HIP_CHECK(herr);
+        TD_HIP_CHECK(herr2);
+        return TD_OK;
+    }
     if (a.tile_cfg == 21 || a.tile_cfg == 22) {
         // tests: the stream-K form (conv_streamk.hip) with a scratch workspace of its own (the engine owns one per engine)
         hipStream_t s = static_cast<hipStream_t>(stream);

@@ -1,0 +1,240 @@
+// conv_bd_kernel: fp16 implicit-GEMM convolution whose FILTER fragments bypass LDS (tile ids 23 / 24).
+//
+// Why: the fp16 engine's mid-size layers (res4 / res5, FPN and RPN at p4 - p6, the 1x1 layers of res3) are bound by the
+// LDS-DMA fill of their block tiles: a CU's `buffer_load ... lds` path moves ~60-70 GB/s (MI355X_MICROARCH.md "ldsdma-fill"),
+// a k-step of the measured 64 x 128 tile stages 24 KB of which 16 KB are filter rows, and the MFMAs of that k-step take a
+// quarter of the time the staging does. Plain vector loads from L2 run at about twice that rate per CU (L2 34.5 TB/s over
+// 256 CUs), on a path that the LDS-DMA does not fill. So here
+//   * the activations (A: BM rows x 128 B per k-step, shared by all waves of the block) keep conv_igemm_kernel's path — LDS-DMA
+//     into the XOR-swizzled image, two stages, raw s_barrier;
+//   * the filters (B) are read by each wave for ITSELF, straight into the registers the MFMA takes them from: the engine keeps
+//     a second copy of every fp16 filter bank in FRAGMENT ORDER — [32-column tile][k-step][kk][lane][8 halves], exactly the
+//     16 bytes lane `l` of a wave feeds to v_mfma_f32_32x32x16_f16 for that (tile, k-step, kk) — so one wave instruction is one
+//     fully contiguous 1-KB read (no fragment-shaped gather: that is what costs TA cycles), issued one k-step ahead;
+//   * the waves of a block tile N only (1 x WN waves, each 32 MT rows x 32 NT columns): no two waves want the same filter
+//     fragment, so nothing is fetched twice, and the A tile — the only operand in LDS — is read by every wave.
+// Per k-step a 64 x 256 block stages 8 KB through LDS-DMA and 32 KB through vector loads for 2 x 64 x 256 x 64 FLOP: half the
+// L2 bytes per FLOP of the 64 x 128 tile, a sixth of its LDS-DMA bytes.
+// Same k order (channel chunk outer, filter tap inner), same MFMA, same epilogue (conv_epilogue) as every other block tile:
+// BIT-IDENTICAL results (tests/test_conv_gpu.py), so the engine's tuner may pick it per layer shape by measurement.
+#include "common.h"
+#include "conv_tiles.h"
+
+namespace {
+
+template <typename TO, int MT, int NT, int WN>
+__device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
+    typedef _Float16 T;
+    constexpr int THREADS = 64 * WN;
+    constexpr int BM = 32 * MT, BN = 32 * NT * WN;
+    constexpr int LDROWS = THREADS / 8;
+    constexpr int AROWS = BM / LDROWS;
+    static_assert(BM % LDROWS == 0 && AROWS >= 1, "tile / thread-count mismatch");
+    constexpr int ES = 2, KE = 64;
+    char* As = lds;                                   // [2][BM][128 B]
+
+    int M = a.M;
+    if (a.m_dyn) {
+        int md = *a.m_dyn * a.m_mul - a.m_off;
+        md = md < 0 ? 0 : md;
+        M = md < M ? md : M;
+    }
+    const int tiles_n = (a.Cout + BN - 1) / BN;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int nblk = tiles_m * tiles_n;
+    if ((int)blockIdx.x >= nblk) return;
+    const int pid = xcd_remap(blockIdx.x, nblk);
+    const int tm = pid / tiles_n, tn = pid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;       // wave = wn (WM = 1)
+    const int ld_c = tid & 7, ld_r = tid >> 3;
+    const int cchunks = a.Cin / KE;
+    const int ntaps = a.KH * a.KW;
+    const int nit = ntaps * cchunks;
+    const unsigned pix_bytes = (unsigned)a.Cin * ES;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.x), 0, (int)((size_t)a.B * a.H * a.W * pix_bytes), 0x00020000);
+    const int ntiles32 = (a.Cout + 31) / 32;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.w_frag), 0, (int)((size_t)ntiles32 * nit * 4096), 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+    const unsigned src_piece = (unsigned)(ld_c ^ ((ld_r >> 1) & 7)) * 16;
+
+    unsigned a_off[AROWS], a_ok[AROWS];
+    const bool plain_rows = ntaps == 1 && a.stride == 1 && a.pad == 0;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+        const int m = m0 + ld_r + LDROWS * i;
+        a_off[i] = 0;
+        a_ok[i] = 0;
+        if (m < M && plain_rows) {
+            a_off[i] = (unsigned)m * pix_bytes + src_piece;
+            a_ok[i] = 1u;
+        } else if (m < M) {
+            const int hw = a.Ho * a.Wo;
+            const int b = m / hw;
+            const int rem = m - b * hw;
+            const int oy = rem / a.Wo;
+            const int ox = rem - oy * a.Wo;
+            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+            a_off[i] = (unsigned)((b * a.H + iy0) * a.W + ix0) * pix_bytes + src_piece;
+            for (int ky = 0; ky < a.KH; ++ky)
+                for (int kx = 0; kx < a.KW; ++kx)
+                    if ((unsigned)(iy0 + ky) < (unsigned)a.H && (unsigned)(ix0 + kx) < (unsigned)a.W)
+                        a_ok[i] |= 1u << (ky * a.KW + kx);
+        }
+    }
+    // this wave's filter fragments: 32-column tiles n0/32 + wave*NT + j; a tile past Cout reads beyond num_records → zeros
+    unsigned w_off[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int nt = n0 / 32 + wave * NT + j;
+        w_off[j] = nt < ntiles32 ? (unsigned)nt * (unsigned)nit * 4096u + (unsigned)lane * 16u : OOB;
+    }
+
+    typedef __attribute__((address_space(3))) void lds_void;
+    const unsigned wave_rows = (unsigned)__builtin_amdgcn_readfirstlane(wave) * 8u;
+    int ld_tap = 0, ld_ky = 0, ld_kx = 0, ld_cc = 0;
+    auto stage_a = [&](int buf) {
+        const unsigned xs = (unsigned)(ld_ky * a.W + ld_kx) * pix_bytes + (unsigned)ld_cc * CHUNK_BYTES;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            const unsigned off = ((a_ok[i] >> ld_tap) & 1u) ? a_off[i] + xs : OOB;
+            char* dst = As + ((unsigned)buf * BM + (unsigned)LDROWS * i + wave_rows) * CHUNK_BYTES;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)dst, 16, off, 0, 0, 0);
+        }
+        if (++ld_kx == a.KW) {
+            ld_kx = 0;
+            ++ld_ky;
+        }
+        if (++ld_tap == ntaps) {
+            ld_tap = 0;
+            ld_ky = 0;
+            ld_kx = 0;
+            ++ld_cc;
+        }
+    };
+    auto load_b = [&](f32x4 (&fb)[NT][4], int it) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const unsigned off = w_off[j] == OOB ? OOB : w_off[j] + (unsigned)it * 4096u + (unsigned)kk * 1024u;
+                fb[j][kk] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0));
+            }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const unsigned swz = (lane >> 1) & 7, hi = lane >> 5;
+    unsigned frag_off[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) frag_off[kk] = (unsigned)(lane & 31) * CHUNK_BYTES + (((unsigned)(2 * kk) + hi) ^ swz) * 16;
+    auto compute = [&](int buf, const f32x4 (&fb)[NT][4]) {
+        const char* Ab = &As[buf * BM * CHUNK_BYTES];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 fa[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * CHUNK_BYTES + frag_off[kk]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) Elem<T>::mma(fa[i], fb[j][kk], acc[i][j]);
+        }
+    };
+
+    // two register sets for the filter fragments (the loop is unrolled by two so that they never have to be copied): set P
+    // holds k-step `it`, set Q is being filled for `it + 1` while P is consumed
+    f32x4 fbP[NT][4], fbQ[NT][4];
+    stage_a(0);
+    load_b(fbP, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int it = 0; it < nit; it += 2) {
+        if (it + 1 < nit) {
+            stage_a(1);
+            load_b(fbQ, it + 1);
+        }
+        compute(0, fbP);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (it + 1 >= nit) break;
+        if (it + 2 < nit) {
+            stage_a(0);
+            load_b(fbP, it + 2);
+        }
+        compute(1, fbQ);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    conv_epilogue<T, TO, MT, NT, 1, WN, 1>(a, acc, lds, M, m0, n0, tid, lane, 0, wave);
+}
+
+template <typename TO, int MT, int NT, int WN, int BPC>
+__global__ __launch_bounds__(64 * WN, (BPC * WN + 3) / 4)
+void conv_bd_kernel(const ConvArgs a) {
+    constexpr int BM = 32 * MT;
+    constexpr int STAGE_BYTES = 2 * BM * CHUNK_BYTES;
+    constexpr int EPI_BYTES = conv_epilogue_lds_bytes<TO, MT, NT, 1, WN, 1>();
+    constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+    static_assert(BPC * LDS_BYTES <= 160 * 1024, "LDS footprint does not allow that many blocks per CU");
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    conv_bd_body<TO, MT, NT, WN>(a, lds);
+}
+
+template <typename TO, int MT, int NT, int WN, int BPC>
+td_status launch_bd(const ConvArgs& a, hipStream_t stream) {
+    const int tiles = td_cdiv(a.M, 32 * MT) * td_cdiv(a.Cout, 32 * NT * WN);
+    hipLaunchKernelGGL((conv_bd_kernel<TO, MT, NT, WN, BPC>), dim3(tiles), dim3(64 * WN), 0, stream, a);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
+}  // namespace
+
+// Filter bank [Cout][KH][KW][Cin] (fp16 bit patterns) → fragment order [ceil(Cout/32)][nit][4][64 lanes][8 halves], nit = KH*KW*(Cin/64)
+// k-steps in the kernels' order (channel chunk outer, filter tap inner). Lane l = (r = l & 31, h = l >> 5) of (tile t, step it, kk)
+// holds W[t*32 + r][tap][cc*64 + (2 kk + h)*8 .. +8]; columns past Cout are zero.
+void conv_bd_pack(const unsigned short* w_ohwi, int cout, int kh, int kw, int cin, std::vector<unsigned short>& out) {
+    const int ntaps = kh * kw, cchunks = cin / 64, nit = ntaps * cchunks, nt32 = (cout + 31) / 32;
+    out.assign((size_t)nt32 * nit * 4 * 64 * 8, (unsigned short)0);
+    for (int t = 0; t < nt32; ++t)
+        for (int cc = 0; cc < cchunks; ++cc)
+            for (int tap = 0; tap < ntaps; ++tap) {
+                const int it = cc * ntaps + tap;
+                for (int kk = 0; kk < 4; ++kk)
+                    for (int l = 0; l < 64; ++l) {
+                        const int n = t * 32 + (l & 31), h = l >> 5;
+                        if (n >= cout) continue;
+                        const unsigned short* src = w_ohwi + ((size_t)n * ntaps + tap) * cin + cc * 64 + (2 * kk + h) * 8;
+                        unsigned short* dst = out.data() + ((((size_t)t * nit + it) * 4 + kk) * 64 + l) * 8;
+                        for (int j = 0; j < 8; ++j) dst[j] = src[j];
+                    }
+            }
+}
+
+bool conv_bd_ok(const ConvArgs& a, int precision) {
+    return precision == TD_PRECISION_FP16 && a.w_frag && a.out_mode == 0 && a.batch_count <= 1 && a.Cin % 64 == 0 && a.KH * a.KW <= 32 &&
+           (size_t)((a.Cout + 31) / 32) * (size_t)(a.KH * a.KW * (a.Cin / 64)) * 4096 < 0xfffffff0ull - (1u << 20);
+}
+
+// variant 0: 64 x 256 block tile (4 waves of 64 x 64), 1: 64 x 128 (4 waves of 64 x 32: narrow layers, more blocks)
+td_status conv_bd_launch(const ConvArgs& a, int variant, hipStream_t stream) {
+    TD_REQUIRE(conv_bd_ok(a, TD_PRECISION_FP16), "filter-direct convolution: unsupported launch (fp16, packed filters, plain output only)");
+    if (variant == 1) {
+        if (a.out_f32) return launch_bd<float, 2, 1, 4, 4>(a, stream);
+        return launch_bd<_Float16, 2, 1, 4, 4>(a, stream);
+    }
+    if (a.out_f32) return launch_bd<float, 2, 2, 4, 2>(a, stream);
+    return launch_bd<_Float16, 2, 2, 4, 2>(a, stream);
+}

@@ -37,6 +37,7 @@ struct ConvLayer {
     float* scale = nullptr;   // [cout] or null
     float* bias = nullptr;    // [cout] or null
     bool out_f32 = false;     // fp16 engine: this layer still writes float32 (feeds the fp32 selection kernels)
+    void* w_frag = nullptr;   // fp16 engine: the filters in MFMA fragment order (conv_bdirect.hip), layers with cin % 64 == 0
     float* wino_u = nullptr;  // fp32 engine, 3x3 layers: Winograd-transformed filters U [16][cout][cin] (winograd.hip)
     float* wino_u43 = nullptr;  // the same for F(4x4,3x3): U [36][cout][cin] (layers with >= 128 channels on both sides)
 };
@@ -126,7 +127,7 @@ struct td_engine {
     bool stream_k = false;
     float* sk_ws = nullptr;       // stream-K partial-tile slots / per-tile ticket counters (fp16 engine; reserve())
     int* sk_cnt = nullptr;
-    bool fuse_tail = true;        // TD_FUSE_TAIL=0: conv2 / conv3 of res2 as two launches (diagnostics, tests); 2: fuse in the fp16 engine too
+    bool fuse_tail = true;        // TD_FUSE_TAIL=0: conv2 / conv3 of res2 as two launches (diagnostics, tests); 2: fuse the fp16 engine's res3 too
     bool fuse_tail_fp16 = false;
     bool wino_fused = true;       // TD_WINO_FUSED=0: separate input-transform kernel + batched conv_igemm launch (diagnostics)
     int wino_slab = 0;            // TD_WINO_SLAB: tiles per slab (diagnostics); 0 = sized for the Infinity Cache
@@ -204,6 +205,21 @@ td_status upload_w(td_engine* e, const std::vector<float>& h, void** d) {
     float* p = nullptr;
     td_status st = upload(e, h, &p);
     *d = p;
+    return st;
+}
+
+// fp16 engine: second copy of a filter bank in fragment order for conv_bd_kernel (tile ids 23 / 24)
+td_status upload_frag(td_engine* e, const std::vector<float>& h, ConvLayer& L) {
+    L.w_frag = nullptr;
+    static const bool off = getenv("TD_BDIRECT") && atoi(getenv("TD_BDIRECT")) == 0;
+    if (off || e->desc.precision != TD_PRECISION_FP16 || L.cin % 64 != 0 || L.kh * L.kw > 32 || (size_t)L.cout * L.kh * L.kw * L.cin != h.size())
+        return TD_OK;
+    std::vector<unsigned short> bits(h.size()), packed;
+    for (size_t i = 0; i < h.size(); ++i) bits[i] = __builtin_bit_cast(unsigned short, (_Float16)h[i]);
+    conv_bd_pack(bits.data(), L.cout, L.kh, L.kw, L.cin, packed);
+    unsigned short* d = nullptr;
+    td_status st = upload(e, packed, &d);
+    L.w_frag = d;
     return st;
 }
 
@@ -292,6 +308,7 @@ td_status load_conv_bn(td_engine* e, const TensorMap& tm, const std::string& p, 
     L.kw = (int)w->shape[3];
     const std::vector<float> packed = pack_ohwi(*w);
     if ((st = upload_w(e, packed, &L.w)) < 0) return st;
+    if ((st = upload_frag(e, packed, L)) < 0) return st;
     if ((st = upload_wino(e, packed, L)) < 0) return st;
     std::vector<float> s, b;
     if ((st = bn_fold(tm, p, L.cout, s, b)) < 0) return st;
@@ -314,6 +331,7 @@ td_status load_conv_bias(td_engine* e, const TensorMap& tm, const std::string& p
     }
     const std::vector<float> packed = pack_ohwi(*w);
     if ((st = upload_w(e, packed, &L.w)) < 0) return st;
+    if ((st = upload_frag(e, packed, L)) < 0) return st;
     if ((st = upload_wino(e, packed, L)) < 0) return st;
     L.scale = nullptr;
     return upload(e, std::vector<float>(b->data, b->data + L.cout), &L.bias);
@@ -323,7 +341,7 @@ td_status run_conv_raw(const ConvLayer& L, const void* x, int B, int H, int W, i
                        const void* res, int res_shift, hipStream_t s, int precision, const int* m_dyn, int m_mul,
                        int out_mode, int tile_cfg = -1) {
     ConvArgs a{};
-    a.x = x; a.w = L.w; a.scale = L.scale; a.bias = L.bias; a.res = res; a.y = y;
+    a.x = x; a.w = L.w; a.w_frag = L.w_frag; a.scale = L.scale; a.bias = L.bias; a.res = res; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = L.cin; a.Cout = L.cout; a.KH = L.kh; a.KW = L.kw;
     a.stride = stride; a.pad = pad;
     a.Ho = (H + 2 * pad - L.kh) / stride + 1;
@@ -564,6 +582,7 @@ td_status td_engine_load_weights(td_engine* e, const td_tensor_desc* tensors, si
         e->rpn_head.cout = RPN_HEAD_C; e->rpn_head.cin = c; e->rpn_head.kh = e->rpn_head.kw = 1;
         e->rpn_head.out_f32 = true;
         if ((st = upload_w(e, w, &e->rpn_head.w)) < 0) return st;
+        if ((st = upload_frag(e, w, e->rpn_head)) < 0) return st;
         if ((st = upload(e, b, &e->rpn_head.bias)) < 0) return st;
     }
     {   // fc1: input index c*49 + y*7 + x → (y*7 + x)*C + c (RoIAlign writes NHWC rows)
@@ -582,6 +601,7 @@ td_status td_engine_load_weights(td_engine* e, const td_tensor_desc* tensors, si
         e->fc1.cout = o; e->fc1.cin = c * 49; e->fc1.kh = e->fc1.kw = 1;
         e->fc_dim = o;
         if ((st = upload_w(e, p, &e->fc1.w)) < 0) return st;
+        if ((st = upload_frag(e, p, e->fc1)) < 0) return st;
         if ((st = upload(e, std::vector<float>(b->data, b->data + o), &e->fc1.bias)) < 0) return st;
     }
     {
@@ -589,7 +609,9 @@ td_status td_engine_load_weights(td_engine* e, const td_tensor_desc* tensors, si
         if ((st = need(tm, "roi_heads.box_head.fc2.weight", 2, &w)) < 0) return st;
         if ((st = need(tm, "roi_heads.box_head.fc2.bias", 1, &b)) < 0) return st;
         e->fc2.cout = (int)w->shape[0]; e->fc2.cin = (int)w->shape[1]; e->fc2.kh = e->fc2.kw = 1;
-        if ((st = upload_w(e, std::vector<float>(w->data, w->data + w->numel()), &e->fc2.w)) < 0) return st;
+        const std::vector<float> w2v(w->data, w->data + w->numel());
+        if ((st = upload_w(e, w2v, &e->fc2.w)) < 0) return st;
+        if ((st = upload_frag(e, w2v, e->fc2)) < 0) return st;
         if ((st = upload(e, std::vector<float>(b->data, b->data + e->fc2.cout), &e->fc2.bias)) < 0) return st;
     }
     {
@@ -612,6 +634,7 @@ td_status td_engine_load_weights(td_engine* e, const td_tensor_desc* tensors, si
         e->pred.cout = 6; e->pred.cin = k; e->pred.kh = e->pred.kw = 1;
         e->pred.out_f32 = true;
         if ((st = upload_w(e, w, &e->pred.w)) < 0) return st;
+        if ((st = upload_frag(e, w, e->pred)) < 0) return st;
         if ((st = upload(e, b, &e->pred.bias)) < 0) return st;
     }
     for (int i = 0; i < 4; ++i)
@@ -807,11 +830,12 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         return TD_OK;
     };
     // measured block tile of one launch shape (cached per engine, shared through the TD_TUNE_CACHE file)
+    bool bd_ok = false;        // set by run_conv for the launch being tuned (fp16 layer with packed filters, plain output)
     auto tuned_cfg = [&](const std::tuple<int, int, int, int, int>& key, int prec_, int ksteps, bool pp8_ok, bool plane_ok, hipStream_t s_,
                          auto&& launch_cfg, int* cfg_out, float* best_ms) -> td_status {
         static const int forced = getenv("TD_FORCE_CFG") ? atoi(getenv("TD_FORCE_CFG")) : -1;      // diagnostics: one block tile everywhere it applies
         if (forced >= 0 && forced <= TD_CONV_TILE_CFG_MAX && !best_ms && !(forced >= 14 && forced <= 16 && ksteps > 4) && !(forced == 17 && !pp8_ok) &&
-            !(forced >= 18 && !plane_ok)) {
+            !(forced >= 18 && forced <= 20 && !plane_ok) && !(forced >= 23 && !bd_ok)) {
             *cfg_out = forced;
             return TD_OK;
         }
@@ -834,6 +858,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
             if (c >= 14 && c <= 16 && ksteps > 4) continue;      // single-stage tiles only pay on the thin 1x1 layers
             if (c == 17 && !pp8_ok) continue;                    // fp16 256x256 ping-pong tile
             if (c >= 18 && c <= 20 && !plane_ok) continue;       // persistent tile walk: Winograd plane contractions only
+            if ((c == 23 || c == 24) && !bd_ok) continue;        // filter-direct tiles: fp16 layers with a fragment-ordered filter copy
             float ms = 1e30f;
             td_status st2 = time_launch(s_, ea, eb, [&]() { return launch_cfg(c); }, &ms);
             if (st2 < 0) return st2;
@@ -953,6 +978,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
             const auto key = std::make_tuple(L.cout, L.cin, L.kh * 16 + L.kw, B_ * Ho * Wo, stride * 4 + out_mode * 2 + (res_ ? 1 : 0));
             const int ksteps = L.kh * L.kw * L.cin / (prec_ == TD_PRECISION_FP16 ? 64 : 32);
             const bool pp8_ok = prec_ == TD_PRECISION_FP16 && out_mode == 0 && L.cout >= 128;
+            bd_ok = prec_ == TD_PRECISION_FP16 && out_mode == 0 && L.w_frag != nullptr;
             // persistent tile walk (tile ids 18-20): fp32 1x1 / stride-1 layers, same-size residual at most
             const bool plane_ok = prec_ == TD_PRECISION_FP32 && L.kh == 1 && L.kw == 1 && stride == 1 && pad == 0 && out_mode == 0 && res_shift == 0 &&
                                   !L.out_f32 && L.cin >= 32 && L.cin % 32 == 0;
@@ -1080,11 +1106,11 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                     shortcut = scb;
                 }
                 if ((st = run_conv(blk.c1, x, nb_img, xh, xw, blk.stride, 0, true, t1, nullptr, 0, s, prec)) < 0) return st;
-                // Measured (round 3, plain loop, batch 8): fp32 res2 365 us fused against 215 + 185 us as two launches; the fp16
-                    // engine's two launches are faster than this first fused form (res2 141 vs 146-161 us, res3 88 vs 145 us: the
-                    // fused block is a chain of short latency-bound steps at two blocks per CU), so fp16 fuses only on request
-                    // (TD_FUSE_TAIL=2). Either way the result is bit-identical, so this IS allowed to follow a measurement.
-                if (e->fuse_tail && (prec == TD_PRECISION_FP32 || e->fuse_tail_fp16) && blk.c2.kh == 3 && blk.c2.kw == 3 &&
+                // Measured (round 3, plain loop, batch 8, 64-row blocks): fp32 res2 345 us fused against 215 + 185 us as two launches;
+                // fp16 res2 130 us against 54 + 87; fp16 res3 111 us against 41 + 47 — slower (a fused block is a chain of short
+                // latency-bound steps, and with 128 mid channels only two blocks fit a CU), so res3 fuses only on request
+                // (TD_FUSE_TAIL=2). Either way the result is bit-identical, so this IS allowed to follow a measurement.
+                if (e->fuse_tail && (blk.c2.cout == 64 || e->fuse_tail_fp16) && blk.c2.kh == 3 && blk.c2.kw == 3 &&
                     blk.c2.cin == blk.c2.cout && blk.c3.cin == blk.c2.cout && bottleneck_tail_ok(prec, blk.c2.cout, blk.c3.cout)) {
                     // conv2 + conv3 + shortcut add in one launch, bit-identical to the two launches below (bottleneck.hip); the mid
                     // tensor t2 never reaches HBM
