@@ -1,22 +1,22 @@
 # Regenerates the judged artefacts of profiles/ on the GPU box: bash tools/profile_round.sh [round tag, default r02]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
 export TD_TUNE_CACHE=$O/tune.txt
-python3 $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-serial --no-r101 --no-fp16-b32 > $O/warm.json 2> $O/warm.err || exit 1      # fills the tile-choice cache
-python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-serial --no-r101 --no-fp16-b32 --no-pipeline > $O/warm2.json 2> $O/warm2.err || exit 1
+python3 $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-serial --no-r101 --no-fp16-b32 --no-e2e --no-two-model > $O/warm.json 2> $O/warm.err || exit 1      # fills the tile-choice cache
+python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-serial --no-r101 --no-fp16-b32 --no-e2e --no-two-model --no-pipeline > $O/warm2.json 2> $O/warm2.err || exit 1
 # (1) the default command's schedule: three forwards overlap on three streams — per-kernel durations here are the spans under that concurrency
-rocprofv3 --kernel-trace --stats -d $O/stats -o s --output-format csv -- python3 $R/bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-serial --no-r101 --no-fp16-b32 > $O/bench_profiled.json 2> $O/bench_profiled.err || exit 1
+rocprofv3 --kernel-trace --stats -d $O/stats -o s --output-format csv -- python3 $R/bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-serial --no-r101 --no-fp16-b32 --no-e2e --no-two-model > $O/bench_profiled.json 2> $O/bench_profiled.err || exit 1
 echo stats done
 # (2) the same steps one forward at a time (what roofline.exclusive and the single_stream region of the default command measure)
-rocprofv3 --kernel-trace --stats -d $O/stats_plain -o s --output-format csv -- python3 $R/bench.py --schedule plain --steps 16 --warmup 3 --no-cpu-baseline --no-r101 --no-fp16-b32 > $O/bench_plain_profiled.json 2> $O/bench_plain_profiled.err || exit 1
+rocprofv3 --kernel-trace --stats -d $O/stats_plain -o s --output-format csv -- python3 $R/bench.py --schedule plain --steps 16 --warmup 3 --no-cpu-baseline --no-r101 --no-fp16-b32 --no-e2e --no-two-model > $O/bench_plain_profiled.json 2> $O/bench_plain_profiled.err || exit 1
 echo plain stats done
 for prec in fp32 fp16; do
   for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
     tag=$(echo $set | cut -d' ' -f1)
-    rocprofv3 --kernel-trace --pmc $set -d $O/pmc_${prec}_$tag -o p --output-format csv -- python3 $R/bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-fp16 --no-pipeline --no-serial > $O/pmc_${prec}_$tag.log 2>&1 || exit 1
+    rocprofv3 --kernel-trace --pmc $set -d $O/pmc_${prec}_$tag -o p --output-format csv -- python3 $R/bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-fp16 --no-pipeline --no-serial --no-e2e --no-two-model > $O/pmc_${prec}_$tag.log 2>&1 || exit 1
     echo pmc $prec $tag done
   done
 done
