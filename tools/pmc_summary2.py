@@ -85,8 +85,8 @@ def main():
                 conv[k] += f[k]
             conv["hbm"] += hbm
             conv["simd"] += simd
-    out["conv_family"] = {"members": "conv_igemm_kernel + conv_pp8_kernel + plane_gemm_kernel + wino_gemm_kernel + wino_input_kernel + wino_output_kernel + "
-                                     "wino43_input_kernel + wino43_output_kernel",
+    out["conv_family"] = {"members": "conv_igemm_kernel + conv_pp8_kernel + conv_bd_kernel + conv_sk_kernel + bottleneck_tail_kernel + plane_gemm_kernel + "
+                                     "wino_gemm_kernel + wino_input_kernel + wino_output_kernel + wino43_input_kernel + wino43_output_kernel",
                           "launches": conv["launches"] / steps, "ms_per_step": conv["us"] / steps / 1e3,
                           "hbm_traffic_gb_per_step": conv["hbm"] / steps / 1e9,
                           "hbm_bytes_per_launch": conv["hbm"] / max(conv["launches"], 1),

@@ -78,6 +78,7 @@ def main(path, depth=50, fp32=False):
             assert "bottleneck_tail" in kn, (name, kn)
         kern = label if label else ("pp8" if "conv_pp8" in kn else "bottleneck_tail" if "bottleneck_tail" in kn else
                                     "conv_sk" if "conv_sk" in kn else ("conv_bd 64x256" if "Li2ELi2ELi4" in kn or "2, 2, 4" in kn else "conv_bd 64x128") if "conv_bd" in kn else
+                                    "plane_gemm" + kn.split("plane_gemm_kernel")[1].split("(")[0][:12] if "plane_gemm" in kn else
                                     kn.split("conv_igemm_")[1].split("(")[0][:28])
         if k == 3:
             assert "wino43_input" in kn and "wino43_output" in rs[2]["Kernel_Name"], (name, kn)
