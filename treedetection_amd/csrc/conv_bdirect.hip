@@ -22,7 +22,9 @@
 
 namespace {
 
-template <typename TO, int MT, int NT, int WN>
+// KS = k-chunks (128-B rows) per barrier interval: 1, or 2 ("super-steps": half the barriers and exposed round trips per MFMA —
+// the per-kernel PMC view shows the waves of these tiles parked at s_waitcnt / s_barrier for 50-70 % of their cycles)
+template <typename TO, int MT, int NT, int WN, int KS>
 __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
     typedef _Float16 T;
     constexpr int THREADS = 64 * WN;
@@ -31,7 +33,7 @@ __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
     constexpr int AROWS = BM / LDROWS;
     static_assert(BM % LDROWS == 0 && AROWS >= 1, "tile / thread-count mismatch");
     constexpr int ES = 2, KE = 64;
-    char* As = lds;                                   // [2][BM][128 B]
+    char* As = lds;                                   // [2 stages][KS chunks][BM][128 B]
 
     int M = a.M;
     if (a.m_dyn) {
@@ -97,7 +99,7 @@ __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
     typedef __attribute__((address_space(3))) void lds_void;
     const unsigned wave_rows = (unsigned)__builtin_amdgcn_readfirstlane(wave) * 8u;
     int ld_tap = 0, ld_ky = 0, ld_kx = 0, ld_cc = 0;
-    auto stage_a = [&](int buf) {
+    auto stage_a = [&](int buf) {                     // buf = stage * KS + chunk
         const unsigned xs = (unsigned)(ld_ky * a.W + ld_kx) * pix_bytes + (unsigned)ld_cc * CHUNK_BYTES;
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
@@ -152,27 +154,34 @@ __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
     };
 
     // two register sets for the filter fragments (the loop is unrolled by two so that they never have to be copied): set P
-    // holds k-step `it`, set Q is being filled for `it + 1` while P is consumed
-    f32x4 fbP[NT][4], fbQ[NT][4];
-    stage_a(0);
-    load_b(fbP, 0);
+    // holds super-step `s`, set Q is being filled for `s + 1` while P is consumed
+    f32x4 fbP[KS][NT][4], fbQ[KS][NT][4];
+    const int nsuper = (nit + KS - 1) / KS;
+    auto fill = [&](int stage, f32x4 (&fb)[KS][NT][4], int s) {       // DMA + filter loads of super-step s
+#pragma unroll
+        for (int c = 0; c < KS; ++c)
+            if (s * KS + c < nit) {
+                stage_a(stage * KS + c);
+                load_b(fb[c], s * KS + c);
+            }
+    };
+    auto run = [&](int stage, const f32x4 (&fb)[KS][NT][4], int s) {
+#pragma unroll
+        for (int c = 0; c < KS; ++c)
+            if (s * KS + c < nit) compute(stage * KS + c, fb[c]);
+    };
+    fill(0, fbP, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int it = 0; it < nit; it += 2) {
-        if (it + 1 < nit) {
-            stage_a(1);
-            load_b(fbQ, it + 1);
-        }
-        compute(0, fbP);
+    for (int s = 0; s < nsuper; s += 2) {
+        if (s + 1 < nsuper) fill(1, fbQ, s + 1);
+        run(0, fbP, s);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (it + 1 >= nit) break;
-        if (it + 2 < nit) {
-            stage_a(0);
-            load_b(fbP, it + 2);
-        }
-        compute(1, fbQ);
+        if (s + 1 >= nsuper) break;
+        if (s + 2 < nsuper) fill(0, fbP, s + 2);
+        run(1, fbQ, s + 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -180,22 +189,22 @@ __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
     conv_epilogue<T, TO, MT, NT, 1, WN, 1>(a, acc, lds, M, m0, n0, tid, lane, 0, wave);
 }
 
-template <typename TO, int MT, int NT, int WN, int BPC>
+template <typename TO, int MT, int NT, int WN, int BPC, int KS>
 __global__ __launch_bounds__(64 * WN, (BPC * WN + 3) / 4)
 void conv_bd_kernel(const ConvArgs a) {
     constexpr int BM = 32 * MT;
-    constexpr int STAGE_BYTES = 2 * BM * CHUNK_BYTES;
+    constexpr int STAGE_BYTES = 2 * KS * BM * CHUNK_BYTES;
     constexpr int EPI_BYTES = conv_epilogue_lds_bytes<TO, MT, NT, 1, WN, 1>();
     constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
     static_assert(BPC * LDS_BYTES <= 160 * 1024, "LDS footprint does not allow that many blocks per CU");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-    conv_bd_body<TO, MT, NT, WN>(a, lds);
+    conv_bd_body<TO, MT, NT, WN, KS>(a, lds);
 }
 
-template <typename TO, int MT, int NT, int WN, int BPC>
+template <typename TO, int MT, int NT, int WN, int BPC, int KS>
 td_status launch_bd(const ConvArgs& a, hipStream_t stream) {
     const int tiles = td_cdiv(a.M, 32 * MT) * td_cdiv(a.Cout, 32 * NT * WN);
-    hipLaunchKernelGGL((conv_bd_kernel<TO, MT, NT, WN, BPC>), dim3(tiles), dim3(64 * WN), 0, stream, a);
+    hipLaunchKernelGGL((conv_bd_kernel<TO, MT, NT, WN, BPC, KS>), dim3(tiles), dim3(64 * WN), 0, stream, a);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
@@ -228,13 +237,18 @@ bool conv_bd_ok(const ConvArgs& a, int precision) {
            (size_t)((a.Cout + 31) / 32) * (size_t)(a.KH * a.KW * (a.Cin / 64)) * 4096 < 0xfffffff0ull - (1u << 20);
 }
 
-// variant 0: 64 x 256 block tile (4 waves of 64 x 64), 1: 64 x 128 (4 waves of 64 x 32: narrow layers, more blocks)
+// variant 0: 64 x 256 block tile (4 waves of 64 x 64), 1: 64 x 128 (4 waves of 64 x 32: narrow layers, more blocks), 2: 64 x 128 with
+// two k-chunks per barrier interval
 td_status conv_bd_launch(const ConvArgs& a, int variant, hipStream_t stream) {
     TD_REQUIRE(conv_bd_ok(a, TD_PRECISION_FP16), "filter-direct convolution: unsupported launch (fp16, packed filters, plain output only)");
-    if (variant == 1) {
-        if (a.out_f32) return launch_bd<float, 2, 1, 4, 4>(a, stream);
-        return launch_bd<_Float16, 2, 1, 4, 4>(a, stream);
+    if (variant == 2) {
+        if (a.out_f32) return launch_bd<float, 2, 1, 4, 3, 2>(a, stream);
+        return launch_bd<_Float16, 2, 1, 4, 3, 2>(a, stream);
     }
-    if (a.out_f32) return launch_bd<float, 2, 2, 4, 2>(a, stream);
-    return launch_bd<_Float16, 2, 2, 4, 2>(a, stream);
+    if (variant == 1) {
+        if (a.out_f32) return launch_bd<float, 2, 1, 4, 4, 1>(a, stream);
+        return launch_bd<_Float16, 2, 1, 4, 4, 1>(a, stream);
+    }
+    if (a.out_f32) return launch_bd<float, 2, 2, 4, 2, 1>(a, stream);
+    return launch_bd<_Float16, 2, 2, 4, 2, 1>(a, stream);
 }
