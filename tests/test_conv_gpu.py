@@ -416,7 +416,7 @@ def test_conv_streamk_matches_the_reference_tile(case, cfg):
 
 # ---- filter-direct tiles (conv_bdirect.hip): tile_cfg 23 = 64 x 256, 24 = 64 x 128; A through LDS-DMA, filter fragments from a
 # fragment-ordered copy of the bank straight into registers ----
-@pytest.mark.parametrize("cfg", [23, 24, 25])
+@pytest.mark.parametrize("cfg", [23, 24, 25, 26, 27])
 @pytest.mark.parametrize("case", PP8_CASES + [(8, 256, 50, 50, 256, 3, 1, 1, 0, True), (8, 2048, 25, 25, 512, 1, 1, 0, 0, True),
                                               (2, 256, 13, 13, 15, 1, 1, 0, 0, False)])
 def test_conv_filter_direct_equals_the_reference_tile_bit_for_bit(case, cfg):

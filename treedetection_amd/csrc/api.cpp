@@ -47,7 +47,7 @@ td_status td_conv2d_nhwc(const void* x, const void* w, const float* scale, const
     a.res_shift = res_shift; a.relu = relu; a.out_mode = 0;
     a.M = B * a.Ho * a.Wo; a.m_dyn = nullptr; a.m_mul = 1; a.out_f32 = 0;
     a.tile_cfg = ((precision >> 8) & 0xff) - 1;          // tests: force one block-tile variant (0 = the library chooses)
-    if (a.tile_cfg >= 23 && a.tile_cfg <= 25 && (precision & 0xff) == TD_PRECISION_FP16 && Cin % 64 == 0) {
+    if (a.tile_cfg >= 23 && a.tile_cfg <= 27 && (precision & 0xff) == TD_PRECISION_FP16 && Cin % 64 == 0) {
         // tests: the filter-direct tiles (conv_bdirect.hip) need the filters in fragment order: packed here from the caller's
         // [Cout][KH][KW][Cin] fp16 bank (the engine packs once at load time)
         hipStream_t s = static_cast<hipStream_t>(stream);

@@ -63,10 +63,10 @@ struct ConvArgs {
 // 11..13 = 256x256 with larger per-wave tiles, 14..16 = single-LDS-stage 256x256 / 128x128 / 128x256 (thin 1x1 layers),
 // 17 = conv_pp8_kernel: 256x256, 8 waves, ping-pong phases, DMA 1.5 k-chunks ahead (fp16 only),
 // 18..20 = plane_gemm_kernel: persistent 64x128 / 128x128 / 64x64 tile walk for the fp32 Winograd plane contractions,
-// 21 / 22 = conv_sk_kernel (stream-K, tests only through td_conv2d_nhwc), 23 / 24 / 25 = conv_bd_kernel: 64x256 / 64x128 / 64x128 with two k-chunks per barrier, filter fragments
+// 21 / 22 = conv_sk_kernel (stream-K, tests only through td_conv2d_nhwc), 23 / 24 / 25 / 26 / 27 = conv_bd_kernel: 64x256 / 64x128 / 64x128 with two k-chunks per barrier / 64x128 with three k-steps of loads in flight / 64x256 with two, filter fragments
 // straight from a fragment-ordered copy of the filters into registers (fp16 only, conv_bdirect.hip)
-#define TD_CONV_TILE_CFG_MAX 25
-static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17, 18, 19, 20, 23, 24, 25};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16, 18-20 only for plane contractions, 23-25 only with packed fp16 filters
+#define TD_CONV_TILE_CFG_MAX 27
+static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17, 18, 19, 20, 23, 24, 25, 26, 27};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16, 18-20 only for plane contractions, 23-27 only with packed fp16 filters
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
 // stream-K form for the fp16 engine's small-map layers (conv_streamk.hip): variant 0 = 128 x 128 tiles / 4 waves / 512 resident
 // blocks, 1 = 256 x 128 / 8 waves / 256 blocks. a.sk_ws: conv_sk_workspace_floats() floats; a.sk_cnt: conv_sk_max_tiles() zeroed ints.

@@ -19,12 +19,21 @@
 // BIT-IDENTICAL results (tests/test_conv_gpu.py), so the engine's tuner may pick it per layer shape by measurement.
 #include "common.h"
 #include "conv_tiles.h"
+#include <type_traits>
 
 namespace {
 
 // KS = k-chunks (128-B rows) per barrier interval: 1, or 2 ("super-steps": half the barriers and exposed round trips per MFMA —
 // the per-kernel PMC view shows the waves of these tiles parked at s_waitcnt / s_barrier for 50-70 % of their cycles)
-template <typename TO, int MT, int NT, int WN, int KS>
+// DEEP = k-steps of loads kept in flight beyond the one being consumed (0: the simple form — everything of step it + 1 issued at
+// the start of step it and waited for, vmcnt(0), at its end). The per-kernel PMC view and the layer table agree on what bounds
+// these tiles: ONE k-step round trip — DMA issue → L2 → LDS → block-wide barrier — takes ~0.65 us even on an idle CU (res5-sized
+// layers with one block per CU: 36 k-steps in 24 us) against 0.12 us of MFMAs, and with one step of prefetch nothing covers it.
+// With DEEP = 3 the loads of step it + 3 are issued before step it is consumed: DEEP + 2 LDS stages of 8 KB (A only — that is
+// what the filter-direct layout buys: the stages are small), DEEP + 1 register sets for the filter fragments, ONE barrier per
+// k-step (the stage a DMA overwrites was consumed two barriers ago), and COUNTED s_waitcnt vmcnt: the filter loads are inline
+// asm so that hipcc, which waits vmcnt(0) for any VGPR load it knows of next to an LDS-DMA, does not drain the pipeline.
+template <typename TO, int MT, int NT, int WN, int KS, int DEEP>
 __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
     typedef _Float16 T;
     constexpr int THREADS = 64 * WN;
@@ -153,6 +162,65 @@ __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
         }
     };
 
+    if constexpr (DEEP > 0) {
+        static_assert(KS == 1, "deep pipeline: one k-chunk per step");
+        constexpr int NS = DEEP + 2;                  // LDS stages
+        constexpr int NR = DEEP + 1;                  // register sets
+        constexpr int OPS = NT * 4 + AROWS;           // vector-memory operations a wave issues per k-step
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        // the filter bank's buffer descriptor as four SGPRs for the inline-asm loads (base, stride 0, num_records, raw dword access)
+        const unsigned long long wbase = (unsigned long long)a.w_frag;
+        i32x4 wdesc;
+        wdesc[0] = __builtin_amdgcn_readfirstlane((int)(wbase & 0xffffffffu));
+        wdesc[1] = __builtin_amdgcn_readfirstlane((int)((wbase >> 32) & 0xffffu));
+        wdesc[2] = __builtin_amdgcn_readfirstlane((int)((size_t)ntiles32 * nit * 4096));
+        wdesc[3] = 0x00020000;
+        f32x4 fb[NR][NT][4];
+        auto issue = [&](auto set_c, int it) {        // loads of k-step `it`: filter fragments → register set, A rows → LDS stage it % NS
+            constexpr int S = decltype(set_c)::value;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const unsigned off = w_off[j] == OOB ? OOB : w_off[j] + (unsigned)it * 4096u + (unsigned)kk * 1024u;
+                    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(fb[S][j][kk]) : "v"(off), "s"(wdesc) : "memory");
+                }
+            stage_a(it % NS);
+        };
+        auto wait_for = [&](int younger) {            // all but the `younger` newest k-steps' operations have completed
+            if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * OPS) : "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        static_assert(DEEP <= 3 && 3 * OPS < 64, "vmcnt immediates");
+        auto step = [&](auto set_c, int it) {
+            constexpr int S = decltype(set_c)::value;
+            if (it + DEEP < nit) issue(std::integral_constant<int, (S + DEEP) % NR>{}, it + DEEP);
+            const int younger = nit - 1 - it < DEEP ? nit - 1 - it : DEEP;
+            wait_for(younger);
+            __builtin_amdgcn_s_barrier();             // every wave's A rows of step `it` have landed; stage (it - 1) % NS is free
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(fb[S][j][kk]));      // the fragments exist from here on
+            compute(it % NS, fb[S]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        // prologue: steps 0 .. DEEP - 1 in flight
+        if (0 < nit) issue(std::integral_constant<int, 0>{}, 0);
+        if constexpr (DEEP >= 2) { if (1 < nit) issue(std::integral_constant<int, 1 % NR>{}, 1); }
+        if constexpr (DEEP >= 3) { if (2 < nit) issue(std::integral_constant<int, 2 % NR>{}, 2); }
+        for (int it = 0; it < nit; it += NR) {
+            step(std::integral_constant<int, 0>{}, it);
+            if constexpr (NR > 1) { if (it + 1 < nit) step(std::integral_constant<int, 1 % NR>{}, it + 1); }
+            if constexpr (NR > 2) { if (it + 2 < nit) step(std::integral_constant<int, 2 % NR>{}, it + 2); }
+            if constexpr (NR > 3) { if (it + 3 < nit) step(std::integral_constant<int, 3 % NR>{}, it + 3); }
+        }
+        __builtin_amdgcn_s_barrier();                 // all fragment reads are done: LDS is the epilogue's
+        conv_epilogue<T, TO, MT, NT, 1, WN, 1>(a, acc, lds, M, m0, n0, tid, lane, 0, wave);
+        return;
+    }
     // two register sets for the filter fragments (the loop is unrolled by two so that they never have to be copied): set P
     // holds super-step `s`, set Q is being filled for `s + 1` while P is consumed
     f32x4 fbP[KS][NT][4], fbQ[KS][NT][4];
@@ -189,22 +257,22 @@ __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
     conv_epilogue<T, TO, MT, NT, 1, WN, 1>(a, acc, lds, M, m0, n0, tid, lane, 0, wave);
 }
 
-template <typename TO, int MT, int NT, int WN, int BPC, int KS>
+template <typename TO, int MT, int NT, int WN, int BPC, int KS, int DEEP>
 __global__ __launch_bounds__(64 * WN, (BPC * WN + 3) / 4)
 void conv_bd_kernel(const ConvArgs a) {
     constexpr int BM = 32 * MT;
-    constexpr int STAGE_BYTES = 2 * KS * BM * CHUNK_BYTES;
+    constexpr int STAGE_BYTES = (DEEP > 0 ? DEEP + 2 : 2 * KS) * BM * CHUNK_BYTES;
     constexpr int EPI_BYTES = conv_epilogue_lds_bytes<TO, MT, NT, 1, WN, 1>();
     constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
     static_assert(BPC * LDS_BYTES <= 160 * 1024, "LDS footprint does not allow that many blocks per CU");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-    conv_bd_body<TO, MT, NT, WN, KS>(a, lds);
+    conv_bd_body<TO, MT, NT, WN, KS, DEEP>(a, lds);
 }
 
-template <typename TO, int MT, int NT, int WN, int BPC, int KS>
+template <typename TO, int MT, int NT, int WN, int BPC, int KS, int DEEP = 0>
 td_status launch_bd(const ConvArgs& a, hipStream_t stream) {
     const int tiles = td_cdiv(a.M, 32 * MT) * td_cdiv(a.Cout, 32 * NT * WN);
-    hipLaunchKernelGGL((conv_bd_kernel<TO, MT, NT, WN, BPC, KS>), dim3(tiles), dim3(64 * WN), 0, stream, a);
+    hipLaunchKernelGGL((conv_bd_kernel<TO, MT, NT, WN, BPC, KS, DEEP>), dim3(tiles), dim3(64 * WN), 0, stream, a);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
@@ -238,9 +306,17 @@ bool conv_bd_ok(const ConvArgs& a, int precision) {
 }
 
 // variant 0: 64 x 256 block tile (4 waves of 64 x 64), 1: 64 x 128 (4 waves of 64 x 32: narrow layers, more blocks), 2: 64 x 128 with
-// two k-chunks per barrier interval
+// two k-chunks per barrier interval, 3 / 4: deep load pipelines (64 x 128 with three k-steps in flight, 64 x 256 with two)
 td_status conv_bd_launch(const ConvArgs& a, int variant, hipStream_t stream) {
     TD_REQUIRE(conv_bd_ok(a, TD_PRECISION_FP16), "filter-direct convolution: unsupported launch (fp16, packed filters, plain output only)");
+    if (variant == 3) {           // 64 x 128, three k-steps of loads in flight (five 8-KB LDS stages, four filter register sets)
+        if (a.out_f32) return launch_bd<float, 2, 1, 4, 3, 1, 3>(a, stream);
+        return launch_bd<_Float16, 2, 1, 4, 3, 1, 3>(a, stream);
+    }
+    if (variant == 4) {           // 64 x 256, two k-steps in flight
+        if (a.out_f32) return launch_bd<float, 2, 2, 4, 2, 1, 2>(a, stream);
+        return launch_bd<_Float16, 2, 2, 4, 2, 1, 2>(a, stream);
+    }
     if (variant == 2) {
         if (a.out_f32) return launch_bd<float, 2, 1, 4, 3, 2>(a, stream);
         return launch_bd<_Float16, 2, 1, 4, 3, 2>(a, stream);

@@ -858,7 +858,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
             if (c >= 14 && c <= 16 && ksteps > 4) continue;      // single-stage tiles only pay on the thin 1x1 layers
             if (c == 17 && !pp8_ok) continue;                    // fp16 256x256 ping-pong tile
             if (c >= 18 && c <= 20 && !plane_ok) continue;       // persistent tile walk: Winograd plane contractions only
-            if (c >= 23 && c <= 25 && !bd_ok) continue;         // filter-direct tiles: fp16 layers with a fragment-ordered filter copy
+            if (c >= 23 && c <= 27 && !bd_ok) continue;         // filter-direct tiles: fp16 layers with a fragment-ordered filter copy
             float ms = 1e30f;
             td_status st2 = time_launch(s_, ea, eb, [&]() { return launch_cfg(c); }, &ms);
             if (st2 < 0) return st2;
