@@ -416,12 +416,13 @@ def test_conv_streamk_matches_the_reference_tile(case, cfg):
 
 # ---- filter-direct tiles (conv_bdirect.hip): tile_cfg 23 = 64 x 256, 24 = 64 x 128; A through LDS-DMA, filter fragments from a
 # fragment-ordered copy of the bank straight into registers ----
+@pytest.mark.parametrize("prec", [1, 0])
 @pytest.mark.parametrize("cfg", [23, 24, 25, 26, 27])
 @pytest.mark.parametrize("case", PP8_CASES + [(8, 256, 50, 50, 256, 3, 1, 1, 0, True), (8, 2048, 25, 25, 512, 1, 1, 0, 0, True),
                                               (2, 256, 13, 13, 15, 1, 1, 0, 0, False)])
-def test_conv_filter_direct_equals_the_reference_tile_bit_for_bit(case, cfg):
-    """conv_bd_kernel keeps the k order, the MFMA and the epilogue of conv_igemm_kernel: on the same fp16 inputs its output is
-    IDENTICAL to the 128 x 128 tile's (cfg 0) — which is what lets the engine's tuner choose it per layer by measurement."""
+def test_conv_filter_direct_equals_the_reference_tile_bit_for_bit(case, cfg, prec):
+    """conv_bd_kernel keeps the k order, the MFMA and the epilogue of conv_igemm_kernel: on the same inputs (fp16 and fp32) its
+    output is IDENTICAL to the 128 x 128 tile's (cfg 0) — which is what lets the engine's tuner choose it per layer by measurement."""
     B, Cin, H, W, Cout, k, stride, pad, res, relu = case
     rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
     x = rng.standard_normal((B, Cin, H, W), dtype=np.float32)
@@ -434,7 +435,7 @@ def test_conv_filter_direct_equals_the_reference_tile_bit_for_bit(case, cfg):
         r = rng.standard_normal((B, Cout, Ho, Wo), dtype=np.float32)
     elif res == 2:
         r = rng.standard_normal((B, Cout, Ho // 2, Wo // 2), dtype=np.float32)
-    kw = dict(scale=scale, bias=bias, residual_nchw=r, res_shift=1 if res == 2 else 0, stride=stride, pad=pad, relu=relu, precision=1)
+    kw = dict(scale=scale, bias=bias, residual_nchw=r, res_shift=1 if res == 2 else 0, stride=stride, pad=pad, relu=relu, precision=prec)
     ref = conv2d_hip(x, w, tile_cfg=0, **kw)
     for _ in range(2):
         got = conv2d_hip(x, w, tile_cfg=cfg, **kw)

@@ -47,19 +47,20 @@ td_status td_conv2d_nhwc(const void* x, const void* w, const float* scale, const
     a.res_shift = res_shift; a.relu = relu; a.out_mode = 0;
     a.M = B * a.Ho * a.Wo; a.m_dyn = nullptr; a.m_mul = 1; a.out_f32 = 0;
     a.tile_cfg = ((precision >> 8) & 0xff) - 1;          // tests: force one block-tile variant (0 = the library chooses)
-    if (a.tile_cfg >= 23 && a.tile_cfg <= 27 && (precision & 0xff) == TD_PRECISION_FP16 && Cin % 64 == 0) {
+    if (a.tile_cfg >= 23 && a.tile_cfg <= 27 && Cin % ((precision & 0xff) == TD_PRECISION_FP16 ? 64 : 32) == 0) {
         // tests: the filter-direct tiles (conv_bdirect.hip) need the filters in fragment order: packed here from the caller's
-        // [Cout][KH][KW][Cin] fp16 bank (the engine packs once at load time)
+        // [Cout][KH][KW][Cin] bank (the engine packs once at load time)
         hipStream_t s = static_cast<hipStream_t>(stream);
+        const int es = (precision & 0xff) == TD_PRECISION_FP16 ? 2 : 4;
         const size_t n = (size_t)Cout * KH * KW * Cin;
-        std::vector<unsigned short> bits(n), packed;
+        std::vector<unsigned char> bits(n * es), packed;
         TD_HIP_CHECK(hipStreamSynchronize(s));
-        TD_HIP_CHECK(hipMemcpy(bits.data(), w, n * 2, hipMemcpyDeviceToHost));
-        conv_bd_pack(bits.data(), Cout, KH, KW, Cin, packed);
+        TD_HIP_CHECK(hipMemcpy(bits.data(), w, n * es, hipMemcpyDeviceToHost));
+        conv_bd_pack(bits.data(), es, Cout, KH, KW, Cin, packed);
         void* wf = nullptr;
-        td_status st = scratch(&wf, packed.size() * 2);
+        td_status st = scratch(&wf, packed.size());
         if (st < 0) return st;
-        hipError_t herr = hipMemcpy(wf, packed.data(), packed.size() * 2, hipMemcpyHostToDevice);
+        hipError_t herr = hipMemcpy(wf, packed.data(), packed.size(), hipMemcpyHostToDevice);
         a.w_frag = wf;
         if (herr == hipSuccess) st = conv2d_launch(a, precision & 0xff, s);
         hipError_t herr2 = hipStreamSynchronize(s);

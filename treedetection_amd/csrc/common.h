@@ -51,7 +51,7 @@ struct ConvArgs {
     // whose 16 transform planes are 16 independent 1x1 contractions (winograd.hip). 0 / 1 = a plain launch.
     int batch_count;
     long long x_bs, w_bs, y_bs;
-    const void* w_frag;   // fp16 engine: the same filters in MFMA fragment order (conv_bdirect.hip: tile ids 23 / 24), or nullptr
+    const void* w_frag;   // the same filters in MFMA fragment order (conv_bdirect.hip: tile ids 23 - 27), or nullptr
     // stream-K launches (conv_streamk.hip): partial-tile slots and per-tile ticket counters (zero between launches)
     float* sk_ws;
     int* sk_cnt;
@@ -71,9 +71,9 @@ td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
 // stream-K form for the fp16 engine's small-map layers (conv_streamk.hip): variant 0 = 128 x 128 tiles / 4 waves / 512 resident
 // blocks, 1 = 256 x 128 / 8 waves / 256 blocks. a.sk_ws: conv_sk_workspace_floats() floats; a.sk_cnt: conv_sk_max_tiles() zeroed ints.
 // filter-direct form (conv_bdirect.hip)
-void conv_bd_pack(const unsigned short* w_ohwi_half_bits, int cout, int kh, int kw, int cin, std::vector<unsigned short>& out);
+void conv_bd_pack(const void* w_ohwi, int elem_bytes, int cout, int kh, int kw, int cin, std::vector<unsigned char>& out);
 bool conv_bd_ok(const ConvArgs& a, int precision);
-td_status conv_bd_launch(const ConvArgs& a, int variant, hipStream_t stream);
+td_status conv_bd_launch(const ConvArgs& a, int precision, int variant, hipStream_t stream);
 int conv_sk_grid(int bm, int bn);
 size_t conv_sk_workspace_floats(void);
 int conv_sk_max_tiles(void);

@@ -1,4 +1,5 @@
-// conv_bd_kernel: fp16 implicit-GEMM convolution whose FILTER fragments bypass LDS (tile ids 23 / 24).
+// conv_bd_kernel: implicit-GEMM convolution whose FILTER fragments bypass LDS (tile ids 23 - 27; fp16 and, since the deep load
+// pipelines, fp32 as well: the data path is counted in bytes — a k-chunk is 128 B, a fragment 16 B — and Elem<T> picks the MFMA).
 //
 // Why: the fp16 engine's mid-size layers (res4 / res5, FPN and RPN at p4 - p6, the 1x1 layers of res3) are bound by the
 // LDS-DMA fill of their block tiles: a CU's `buffer_load ... lds` path moves ~60-70 GB/s (MI355X_MICROARCH.md "ldsdma-fill"),
@@ -33,15 +34,14 @@ namespace {
 // what the filter-direct layout buys: the stages are small), DEEP + 1 register sets for the filter fragments, ONE barrier per
 // k-step (the stage a DMA overwrites was consumed two barriers ago), and COUNTED s_waitcnt vmcnt: the filter loads are inline
 // asm so that hipcc, which waits vmcnt(0) for any VGPR load it knows of next to an LDS-DMA, does not drain the pipeline.
-template <typename TO, int MT, int NT, int WN, int KS, int DEEP>
+template <typename T, typename TO, int MT, int NT, int WN, int KS, int DEEP>
 __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
-    typedef _Float16 T;
     constexpr int THREADS = 64 * WN;
     constexpr int BM = 32 * MT, BN = 32 * NT * WN;
     constexpr int LDROWS = THREADS / 8;
     constexpr int AROWS = BM / LDROWS;
     static_assert(BM % LDROWS == 0 && AROWS >= 1, "tile / thread-count mismatch");
-    constexpr int ES = 2, KE = 64;
+    constexpr int ES = sizeof(T), KE = Elem<T>::PER_CHUNK;      // a k-chunk is 128 B either way: 64 halves or 32 floats
     char* As = lds;                                   // [2 stages][KS chunks][BM][128 B]
 
     int M = a.M;
@@ -257,7 +257,7 @@ __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
     conv_epilogue<T, TO, MT, NT, 1, WN, 1>(a, acc, lds, M, m0, n0, tid, lane, 0, wave);
 }
 
-template <typename TO, int MT, int NT, int WN, int BPC, int KS, int DEEP>
+template <typename T, typename TO, int MT, int NT, int WN, int BPC, int KS, int DEEP>
 __global__ __launch_bounds__(64 * WN, (BPC * WN + 3) / 4)
 void conv_bd_kernel(const ConvArgs a) {
     constexpr int BM = 32 * MT;
@@ -266,25 +266,28 @@ void conv_bd_kernel(const ConvArgs a) {
     constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
     static_assert(BPC * LDS_BYTES <= 160 * 1024, "LDS footprint does not allow that many blocks per CU");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-    conv_bd_body<TO, MT, NT, WN, KS, DEEP>(a, lds);
+    conv_bd_body<T, TO, MT, NT, WN, KS, DEEP>(a, lds);
 }
 
-template <typename TO, int MT, int NT, int WN, int BPC, int KS, int DEEP = 0>
+template <typename T, typename TO, int MT, int NT, int WN, int BPC, int KS, int DEEP = 0>
 td_status launch_bd(const ConvArgs& a, hipStream_t stream) {
     const int tiles = td_cdiv(a.M, 32 * MT) * td_cdiv(a.Cout, 32 * NT * WN);
-    hipLaunchKernelGGL((conv_bd_kernel<TO, MT, NT, WN, BPC, KS, DEEP>), dim3(tiles), dim3(64 * WN), 0, stream, a);
+    hipLaunchKernelGGL((conv_bd_kernel<T, TO, MT, NT, WN, BPC, KS, DEEP>), dim3(tiles), dim3(64 * WN), 0, stream, a);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
 
 }  // namespace
 
-// Filter bank [Cout][KH][KW][Cin] (fp16 bit patterns) → fragment order [ceil(Cout/32)][nit][4][64 lanes][8 halves], nit = KH*KW*(Cin/64)
-// k-steps in the kernels' order (channel chunk outer, filter tap inner). Lane l = (r = l & 31, h = l >> 5) of (tile t, step it, kk)
-// holds W[t*32 + r][tap][cc*64 + (2 kk + h)*8 .. +8]; columns past Cout are zero.
-void conv_bd_pack(const unsigned short* w_ohwi, int cout, int kh, int kw, int cin, std::vector<unsigned short>& out) {
-    const int ntaps = kh * kw, cchunks = cin / 64, nit = ntaps * cchunks, nt32 = (cout + 31) / 32;
-    out.assign((size_t)nt32 * nit * 4 * 64 * 8, (unsigned short)0);
+// Filter bank [Cout][KH][KW][Cin] (elements of `es` bytes: 2 = fp16 bit patterns, 4 = fp32) → fragment order
+// [ceil(Cout/32)][nit][4][64 lanes][16 B], nit = KH*KW*(Cin/KE) k-steps of KE = 128 / es elements in the kernels' order (channel chunk
+// outer, filter tap inner). Lane l = (r = l & 31, h = l >> 5) of (tile t, step it, kk) holds the 16-B piece 2 kk + h of row
+// W[t*32 + r][tap][cc*KE .. +KE] — what the LDS fragment read hands that lane; columns past Cout are zero.
+void conv_bd_pack(const void* w_ohwi, int es, int cout, int kh, int kw, int cin, std::vector<unsigned char>& out) {
+    const int ke = 128 / es;
+    const int ntaps = kh * kw, cchunks = cin / ke, nit = ntaps * cchunks, nt32 = (cout + 31) / 32;
+    out.assign((size_t)nt32 * nit * 4096, (unsigned char)0);
+    const unsigned char* w = static_cast<const unsigned char*>(w_ohwi);
     for (int t = 0; t < nt32; ++t)
         for (int cc = 0; cc < cchunks; ++cc)
             for (int tap = 0; tap < ntaps; ++tap) {
@@ -293,38 +296,36 @@ void conv_bd_pack(const unsigned short* w_ohwi, int cout, int kh, int kw, int ci
                     for (int l = 0; l < 64; ++l) {
                         const int n = t * 32 + (l & 31), h = l >> 5;
                         if (n >= cout) continue;
-                        const unsigned short* src = w_ohwi + ((size_t)n * ntaps + tap) * cin + cc * 64 + (2 * kk + h) * 8;
-                        unsigned short* dst = out.data() + ((((size_t)t * nit + it) * 4 + kk) * 64 + l) * 8;
-                        for (int j = 0; j < 8; ++j) dst[j] = src[j];
+                        const unsigned char* src = w + (((size_t)n * ntaps + tap) * cin + (size_t)cc * ke) * es + (size_t)(2 * kk + h) * 16;
+                        unsigned char* dst = out.data() + ((((size_t)t * nit + it) * 4 + kk) * 64 + l) * 16;
+                        for (int j = 0; j < 16; ++j) dst[j] = src[j];
                     }
             }
 }
 
 bool conv_bd_ok(const ConvArgs& a, int precision) {
-    return precision == TD_PRECISION_FP16 && a.w_frag && a.out_mode == 0 && a.batch_count <= 1 && a.Cin % 64 == 0 && a.KH * a.KW <= 32 &&
-           (size_t)((a.Cout + 31) / 32) * (size_t)(a.KH * a.KW * (a.Cin / 64)) * 4096 < 0xfffffff0ull - (1u << 20);
+    const int ke = precision == TD_PRECISION_FP16 ? 64 : 32;
+    return (precision == TD_PRECISION_FP16 || precision == TD_PRECISION_FP32) && a.w_frag && a.out_mode == 0 && a.batch_count <= 1 &&
+           a.Cin % ke == 0 && a.KH * a.KW <= 32 && !(precision == TD_PRECISION_FP32 && a.out_f32) &&
+           (size_t)((a.Cout + 31) / 32) * (size_t)(a.KH * a.KW * (a.Cin / ke)) * 4096 < 0xfffffff0ull - (1u << 20);
 }
 
-// variant 0: 64 x 256 block tile (4 waves of 64 x 64), 1: 64 x 128 (4 waves of 64 x 32: narrow layers, more blocks), 2: 64 x 128 with
-// two k-chunks per barrier interval, 3 / 4: deep load pipelines (64 x 128 with three k-steps in flight, 64 x 256 with two)
-td_status conv_bd_launch(const ConvArgs& a, int variant, hipStream_t stream) {
-    TD_REQUIRE(conv_bd_ok(a, TD_PRECISION_FP16), "filter-direct convolution: unsupported launch (fp16, packed filters, plain output only)");
-    if (variant == 3) {           // 64 x 128, three k-steps of loads in flight (five 8-KB LDS stages, four filter register sets)
-        if (a.out_f32) return launch_bd<float, 2, 1, 4, 3, 1, 3>(a, stream);
-        return launch_bd<_Float16, 2, 1, 4, 3, 1, 3>(a, stream);
+namespace {
+template <typename T, typename TO>
+td_status bd_variant(const ConvArgs& a, int variant, hipStream_t stream) {
+    switch (variant) {
+        case 3: return launch_bd<T, TO, 2, 1, 4, 3, 1, 3>(a, stream);   // 64 x 128, three k-steps of loads in flight (five 8-KB LDS stages, four filter register sets)
+        case 4: return launch_bd<T, TO, 2, 2, 4, 2, 1, 2>(a, stream);   // 64 x 256, two k-steps in flight
+        case 2: return launch_bd<T, TO, 2, 1, 4, 3, 2>(a, stream);      // 64 x 128, two k-chunks per barrier interval
+        case 1: return launch_bd<T, TO, 2, 1, 4, 4, 1>(a, stream);      // 64 x 128 (4 waves of 64 x 32: narrow layers, more blocks)
+        default: return launch_bd<T, TO, 2, 2, 4, 2, 1>(a, stream);     // 64 x 256 (4 waves of 64 x 64)
     }
-    if (variant == 4) {           // 64 x 256, two k-steps in flight
-        if (a.out_f32) return launch_bd<float, 2, 2, 4, 2, 1, 2>(a, stream);
-        return launch_bd<_Float16, 2, 2, 4, 2, 1, 2>(a, stream);
-    }
-    if (variant == 2) {
-        if (a.out_f32) return launch_bd<float, 2, 1, 4, 3, 2>(a, stream);
-        return launch_bd<_Float16, 2, 1, 4, 3, 2>(a, stream);
-    }
-    if (variant == 1) {
-        if (a.out_f32) return launch_bd<float, 2, 1, 4, 4, 1>(a, stream);
-        return launch_bd<_Float16, 2, 1, 4, 4, 1>(a, stream);
-    }
-    if (a.out_f32) return launch_bd<float, 2, 2, 4, 2, 1>(a, stream);
-    return launch_bd<_Float16, 2, 2, 4, 2, 1>(a, stream);
+}
+}  // namespace
+
+td_status conv_bd_launch(const ConvArgs& a, int precision, int variant, hipStream_t stream) {
+    TD_REQUIRE(conv_bd_ok(a, precision), "filter-direct convolution: unsupported launch (packed filters, plain output only)");
+    if (precision == TD_PRECISION_FP32) return bd_variant<float, float>(a, variant, stream);
+    if (a.out_f32) return bd_variant<_Float16, float>(a, variant, stream);
+    return bd_variant<_Float16, _Float16>(a, variant, stream);
 }

@@ -1045,7 +1045,7 @@ td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream) {
     if (cfg == 17 && (precision != TD_PRECISION_FP16 || a.out_mode != 0 || a.batch_count > 1)) cfg = -1;      // fp16-only variant
     if (cfg >= 18 && cfg <= 20 && !conv_plane_ok(a, precision)) cfg = -1;                                       // plane contractions only
     if (cfg >= 23 && cfg <= 27 && !conv_bd_ok(a, precision)) cfg = -1;                                         // needs the fragment-ordered fp16 filters
-    if (cfg >= 23 && cfg <= 27) return conv_bd_launch(a, cfg - 23, stream);
+    if (cfg >= 23 && cfg <= 27) return conv_bd_launch(a, precision, cfg - 23, stream);
     TD_REQUIRE(a.batch_count <= 1 || (a.KH == 1 && a.KW == 1 && !a.res), "conv2d: batched launches are 1x1 contractions");
     if (cfg < 0) {
         // heuristic (the engine replaces it by a measured choice per layer shape): wide N for wide layers, 64-row

@@ -208,16 +208,22 @@ td_status upload_w(td_engine* e, const std::vector<float>& h, void** d) {
     return st;
 }
 
-// fp16 engine: second copy of a filter bank in fragment order for conv_bd_kernel (tile ids 23 / 24)
+// second copy of a filter bank in MFMA fragment order for conv_bd_kernel (tile ids 23 - 27), both precisions
 td_status upload_frag(td_engine* e, const std::vector<float>& h, ConvLayer& L) {
     L.w_frag = nullptr;
     static const bool off = getenv("TD_BDIRECT") && atoi(getenv("TD_BDIRECT")) == 0;
-    if (off || e->desc.precision != TD_PRECISION_FP16 || L.cin % 64 != 0 || L.kh * L.kw > 32 || (size_t)L.cout * L.kh * L.kw * L.cin != h.size())
-        return TD_OK;
-    std::vector<unsigned short> bits(h.size()), packed;
-    for (size_t i = 0; i < h.size(); ++i) bits[i] = __builtin_bit_cast(unsigned short, (_Float16)h[i]);
-    conv_bd_pack(bits.data(), L.cout, L.kh, L.kw, L.cin, packed);
-    unsigned short* d = nullptr;
+    const bool f16 = e->desc.precision == TD_PRECISION_FP16;
+    const int ke = f16 ? 64 : 32;
+    if (off || L.cin % ke != 0 || L.kh * L.kw > 32 || (size_t)L.cout * L.kh * L.kw * L.cin != h.size()) return TD_OK;
+    std::vector<unsigned char> packed;
+    if (f16) {
+        std::vector<unsigned short> bits(h.size());
+        for (size_t i = 0; i < h.size(); ++i) bits[i] = __builtin_bit_cast(unsigned short, (_Float16)h[i]);
+        conv_bd_pack(bits.data(), 2, L.cout, L.kh, L.kw, L.cin, packed);
+    } else {
+        conv_bd_pack(h.data(), 4, L.cout, L.kh, L.kw, L.cin, packed);
+    }
+    unsigned char* d = nullptr;
     td_status st = upload(e, packed, &d);
     L.w_frag = d;
     return st;
@@ -978,7 +984,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
             const auto key = std::make_tuple(L.cout, L.cin, L.kh * 16 + L.kw, B_ * Ho * Wo, stride * 4 + out_mode * 2 + (res_ ? 1 : 0));
             const int ksteps = L.kh * L.kw * L.cin / (prec_ == TD_PRECISION_FP16 ? 64 : 32);
             const bool pp8_ok = prec_ == TD_PRECISION_FP16 && out_mode == 0 && L.cout >= 128;
-            bd_ok = prec_ == TD_PRECISION_FP16 && out_mode == 0 && L.w_frag != nullptr;
+            bd_ok = out_mode == 0 && L.w_frag != nullptr;
             // persistent tile walk (tile ids 18-20): fp32 1x1 / stride-1 layers, same-size residual at most
             const bool plane_ok = prec_ == TD_PRECISION_FP32 && L.kh == 1 && L.kw == 1 && stride == 1 && pad == 0 && out_mode == 0 && res_shift == 0 &&
                                   !L.out_f32 && L.cin >= 32 && L.cin % 32 == 0;

@@ -27,7 +27,7 @@ from .geotiff import GeoTiff
 from .weights import load_checkpoint
 
 
-TILE_TABLE_VERSION = 10      # bump when the tile ids of csrc/conv_igemm.hip:dispatch() change meaning
+TILE_TABLE_VERSION = 11      # bump when the tile ids of csrc/conv_igemm.hip:dispatch() change meaning
 
 
 def _tune_cache_path(device_index: int) -> str:
