@@ -79,7 +79,7 @@ def parse():
     ap.add_argument("--no-two-model", action="store_true", help="skip the two-model (urban + forest, exclude flags) region of BASELINE configs[2]")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end region: warm Predictor.__call__ over a synthetic GeoTIFF on tmpfs "
                     "(window reads → device → Prediction_*.json files)")
-    ap.add_argument("--e2e-side", type=int, default=12, help="the e2e raster is side x side tiles of --tile pixels")
+    ap.add_argument("--e2e-side", type=int, default=20, help="the e2e raster is side x side tiles of --tile pixels")
     ap.add_argument("--streams", type=int, default=0, help="engines / HIP streams the batches alternate over (default 3 for "
                     "--schedule streams, 1 for plain): the HBM-bound kernels and the kernel tails of one forward run under the "
                     "MFMA-bound contractions of the others")
@@ -423,11 +423,12 @@ def main():
         log(f"two-model region done: {dtm:.3f} s")
         return dtm, len(visit["urban"]), len(visit["forest"]), n_tiles, dets
 
-    def run_e2e(precision, side):
+    def run_e2e(precisions, side):
         """predict_tiles' model stage end to end, files to files (reference prediction.py:47-77,197-265): a warm
-        Predictor.__call__ over ONE synthetic GeoTIFF on tmpfs — side x side tiles of S x S pixels, 4-band RGBI uint8, tile
-        metadata from the package's own tile producer — window reads into pinned memory, H2D, resize, forward, paste, D2H of the
-        packed masks, contours → polygons → Prediction_<tile>.json written and counted. First call = warm-up (weights, tile
+        Predictor.__call__ over ONE synthetic GeoTIFF on tmpfs — side x side tiles of S x S pixels (default 20 x 20: the 400 tiles
+        the reference cuts from one 1 km² image, example/config.yml:26-28), 4-band RGBI uint8, tile metadata from the package's
+        own tile producer — window reads into pinned memory, H2D, resize, forward, paste, D2H of the rows the paste wrote,
+        contours → polygons → Prediction_<tile>.json written and counted. Per precision: first call = warm-up (weights, tile
         choices, buffers), then three timed calls (value = the fastest)."""
         import shutil
         import tempfile
@@ -436,6 +437,7 @@ def main():
         from treedetection_amd.preprocessing import tile_data
         base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
         root = tempfile.mkdtemp(prefix="td_e2e_", dir=base)
+        out = {}
         try:
             os.makedirs(f"{root}/rgb")
             img = np.zeros((4, side * S, side * S), np.uint8)
@@ -452,23 +454,28 @@ def main():
             tjson = f"{root}/tiles/324125317.json"
             ntiles = len(json.load(open(tjson)))
             cfg = T.setup_model_cfg(update_model="synthetic", device=str(local_rank))
-            pred = T.Predictor(cfg, device_type=str(local_rank), max_batch_size=B, output_dir=f"{root}/out", precision=precision,
-                               state_dict=sd, return_predictions=False)
-            pred(tif, tjson)                        # warm-up call
-            times = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                pred(tif, tjson)
-                times.append(time.perf_counter() - t0)
-            stats = dict(pred.stats)
-            pred.close()
-            files = [f for f in os.listdir(f"{root}/out/324125317") if f.startswith("Prediction_")]
-            nbytes = sum(os.path.getsize(f"{root}/out/324125317/{f}") for f in files)
-            dt_e = min(times)
-            log(f"e2e region ({precision}): {ntiles} tiles per call, calls {[round(t, 3) for t in times]} s")
-            return {"value": ntiles / dt_e, "unit": "tiles/s", "tiles_per_call": ntiles, "calls_s": times, "files_written": len(files),
-                    "prediction_bytes": nbytes, "batch": B, "raster": f"{side * S}x{side * S}x4 uint8 GeoTIFF on {'tmpfs' if base else 'disk'}",
-                    "host_stage_seconds_last_call": stats}
+            for precision in precisions:
+                pred = T.Predictor(cfg, device_type=str(local_rank), max_batch_size=B, output_dir=f"{root}/out_{precision}",
+                                   precision=precision, state_dict=sd, return_predictions=False)
+                pred(tif, tjson)                        # warm-up call
+                times = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    pred(tif, tjson)
+                    times.append(time.perf_counter() - t0)
+                stats = dict(pred.stats)
+                pred.close()
+                folder = f"{root}/out_{precision}/324125317"
+                files = [f for f in os.listdir(folder) if f.startswith("Prediction_")]
+                nbytes = sum(os.path.getsize(f"{folder}/{f}") for f in files)
+                shutil.rmtree(f"{root}/out_{precision}", ignore_errors=True)
+                dt_e = min(times)
+                log(f"e2e region ({precision}): {ntiles} tiles per call, calls {[round(t, 3) for t in times]} s")
+                out[precision] = {"value": ntiles / dt_e, "unit": "tiles/s", "tiles_per_call": ntiles, "calls_s": times,
+                                  "files_written": len(files), "prediction_bytes": nbytes, "batch": B,
+                                  "raster": f"{side * S}x{side * S}x4 uint8 GeoTIFF on {'tmpfs' if base else 'disk'}",
+                                  "host_stage_seconds_last_call": stats}
+            return out
         finally:
             shutil.rmtree(root, ignore_errors=True)
 
@@ -529,9 +536,7 @@ def main():
             if args.precision == "fp32" and not args.no_fp16:
                 two["fp16"] = run_two_model("fp16")
         if not args.no_e2e:
-            e2e = {args.precision: run_e2e(args.precision, args.e2e_side)}
-            if args.precision == "fp32" and not args.no_fp16:
-                e2e["fp16"] = run_e2e("fp16", args.e2e_side)
+            e2e = run_e2e([args.precision] + (["fp16"] if args.precision == "fp32" and not args.no_fp16 else []), args.e2e_side)
 
     # what the collective layer saw (for the reader of an N > 1 line: did RCCL really run N ranks on N different GPUs?)
     props = torch.cuda.get_device_properties(local_rank)

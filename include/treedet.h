@@ -256,12 +256,30 @@ int td_tile_polygons_json(const int32_t* mask_region, const int64_t* mask_offset
                           int64_t mask_words, const float* scores, const int32_t* classes, int n,
                           const double* transform, const char* image_id, char* buf, int64_t cap, int64_t* needed);
 
+/* The same epilogue for a tile whose packed rows are still on the device (reference prediction.py:197-265 end to end for
+ * one tile: the masks leave the GPU, become polygons and are written to Prediction_<tile>.json): mask_region / mask_offset /
+ * scores / classes are the host copies of the image's small records, mask_bits_dev the DEVICE pointer of its bit rows
+ * (td_detections.mask_bits + b * mask_words_per_image) and rows_host a pinned host buffer of mask_words words. Only the
+ * words the paste wrote (mask_offset[n-1] + size of the last region; 0.1-5 MB against a 12.8 MB capacity at 1000 x 1000)
+ * cross PCIe: copied on one of the library's own copy streams of `device`, waited for by this thread alone. Then
+ * td_tile_polygons_json's text is written to `path` (created / truncated). *bytes_written receives the file size.
+ * Returns the number of entries or a negative status. Thread-safe; the caller has made sure the forward that produced
+ * the rows has completed (the host copies it passes were read after that event). */
+int td_tile_prediction_file(int device, const int32_t* mask_region, const int64_t* mask_offset, const uint32_t* mask_bits_dev,
+                            uint32_t* rows_host, int64_t mask_words, const float* scores, const int32_t* classes, int n,
+                            const double* transform, const char* image_id, const char* path, int64_t* bytes_written);
+
 /* ---- raster input (reference prediction.py:61,164: rasterio.open / rasterio.mask.mask → GDAL → libtiff) ---- */
 /* Decompress one TIFF strip or tile: LZW (compression 5) and PackBits (32773) per TIFF 6.0; DEFLATE strips go
  * through zlib on the host side. Return the number of bytes written to dst (capacity cap), or a negative status
  * (TD_ERR_CAPACITY when the stream decodes to more than cap bytes, TD_ERR_INVALID for a corrupt stream). */
 int64_t td_tiff_lzw_decode(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap);
 int64_t td_tiff_packbits_decode(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap);
+/* Window of an uncompressed pixel-interleaved raster with contiguous strips (the tile windows of reference
+ * prediction.py:164, rasterio.mask.mask(..., crop=True)): `rows` pieces of `row_bytes` bytes lying `row_stride` bytes apart
+ * from `file_off` on, read with pread(2) into the dense buffer dst (e.g. pinned staging memory). Returns the bytes read or
+ * TD_ERR_INVALID (bad argument, read error, file shorter than the window). Thread-safe (no file position is used). */
+int64_t td_read_window(int fd, int64_t file_off, int64_t row_stride, int64_t row_bytes, int64_t rows, uint8_t* dst);
 /* Undo TIFF predictor 2 (horizontal differencing) in place on one decoded block of rows x cols pixels with
  * `samples` interleaved samples of 1, 2 or 4 bytes (host byte order). */
 int td_tiff_unpredict(void* data, int64_t rows, int64_t cols, int samples, int bytes_per_sample);

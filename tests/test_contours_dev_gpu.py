@@ -161,3 +161,37 @@ def test_json_from_device_contours_is_bytewise_the_host_path():
         got = tile_polygons_json_dev(pts[b], det_info[b], cont_info[b], region[b], offset[b], bits[b].view(np.int32), scores, classes, t, "img.tif")
         assert got == want and len(want) > 2
     assert (det_info[1, :3, 0] != 0).sum() == 2 and (det_info[0, :, 0] == 0).all()
+
+
+def test_prediction_file_from_device_rows_is_bytewise_the_host_path(tmp_path):
+    """td_tile_prediction_file (fetches only the words the records cover from the DEVICE buffer, traces, formats, writes the
+    file) == td_tile_polygons_json on a host copy of the whole buffer; the words past the last region never leave the GPU
+    (the pinned buffer keeps its sentinel there); an empty tile writes "[]"; records that overrun the buffer are refused."""
+    from treedetection_amd.contours import tile_polygons_json, tile_prediction_file
+    rng = np.random.default_rng(5)
+    images = [[(int(rng.integers(0, 300)), int(rng.integers(0, 300)), _blob(rng, int(rng.integers(5, 120)), int(rng.integers(5, 120)))) for _ in range(9)],
+              [(10, 20, _blob(rng, 50, 70)), (0, 0, _blob(rng, 180, 190))], []]
+    Dn = 9
+    region, offset, bits, counts = _pack(images, Dn)
+    d_bits = torch.from_numpy(bits.view(np.int32)).cuda()
+    pinned = torch.full(bits.shape, -1, dtype=torch.int32).pin_memory()
+    host = pinned.numpy()
+    t = (0.2, 0.0, 412000.0, 0.0, -0.2, 5319000.0)
+    stride = bits.shape[1] * 4
+    for b, dets in enumerate(images):
+        n = len(dets)
+        scores = rng.random(n).astype(np.float32)
+        classes = np.zeros(n, np.int32)
+        want = tile_polygons_json(region[b], offset[b], bits[b].view(np.int32), scores, classes, t, "img.tif")
+        path = str(tmp_path / f"Prediction_{b}.json")
+        wrote = tile_prediction_file(0, region[b], offset[b], d_bits.data_ptr() + b * stride, host[b], scores, classes, t, "img.tif", path)
+        got = open(path, "rb").read()
+        assert got == want and wrote == len(want)
+        used = 0 if n == 0 else int(offset[b, n - 1]) + ((region[b, n - 1, 2] - region[b, n - 1, 0] + 31) // 32) * int(region[b, n - 1, 3] - region[b, n - 1, 1])
+        assert (host[b, used:] == -1).all() and (n == 0 or (host[b, :used].view(np.uint32) == bits[b, :used]).all())
+    assert open(str(tmp_path / "Prediction_2.json"), "rb").read() == b"[]"
+    bad = offset[1].copy()
+    bad[1] = bits.shape[1]            # last region would start at the end of the buffer
+    with pytest.raises(_lib.TdError):
+        tile_prediction_file(0, region[1], bad, d_bits.data_ptr() + stride, host[1], np.ones(2, np.float32), np.zeros(2, np.int32), t,
+                             "img.tif", str(tmp_path / "bad.json"))

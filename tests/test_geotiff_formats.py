@@ -175,3 +175,30 @@ def test_big_endian_and_bigtiff_headers(tmp_path, big_endian, bigtiff, kw):
     g = GeoTiff(dst)
     assert (g.width, g.height, g.count, g.epsg) == (101, 77, 3, 25832) and g.transform == T
     assert np.array_equal(g.read(), img) and np.array_equal(g._window_hwc(10, 20, 30, 40), img[:, 10:40, 20:60].transpose(1, 2, 0))
+
+
+def test_flat_windows_are_pread_into_the_callers_buffer(tmp_path):
+    """Uncompressed contiguous rasters: window reads go through td_read_window (pread per window row, no page touched in
+    the mapping) and equal the mapped pixels, also straight into a caller-provided flat buffer at an offset; a file cut
+    short of the window is an error, not garbage."""
+    rng = np.random.default_rng(4)
+    img = _image(rng, 4, 150, 130, np.uint8)
+    path = str(tmp_path / "flat.tif")
+    write_geotiff(path, img, T)
+    with GeoTiff(path) as g:
+        g._setup_blocks()
+        assert g._fd is not None and g._flat is not None
+        staging = np.full(4 + 40 * 50 * 4 + 4, 7, np.uint8)
+        bounds = (T[2] + 30 * 0.2, T[5] - 60 * 0.2, T[2] + 80 * 0.2, T[5] - 20 * 0.2)      # cols 30..80, rows 20..60
+        got = g.read_bounds_hwc(bounds, out=staging, out_off=4)
+        assert got.shape == (40, 50, 4) and (got == img[:, 20:60, 30:80].transpose(1, 2, 0)).all()
+        assert (staging[:4] == 7).all() and (staging[-4:] == 7).all() and np.shares_memory(got, staging)
+        assert (g.read_bounds_hwc(bounds) == got).all()
+        fd, off = g._fd, g._flat_off
+        lib = _lib.load()
+        buf = np.zeros(130 * 4 * 2, np.uint8)
+        assert lib.td_read_window(fd, off + 149 * 130 * 4, 130 * 4, 130 * 4, 1, buf.ctypes.data) == 130 * 4      # the last row
+        assert lib.td_read_window(fd, off + 149 * 130 * 4, 130 * 4, 130 * 4, 2, buf.ctypes.data) == _lib.ERR_INVALID
+        assert lib.td_read_window(-1, 0, 8, 8, 1, buf.ctypes.data) == _lib.ERR_INVALID
+    assert g._fd is None
+

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtreedet_hip.so")
 
 _lib: Optional[C.CDLL] = None
+ERR_INVALID = -1    # TD_ERR_INVALID
 ERR_CAPACITY = -4   # TD_ERR_CAPACITY
 ERR_STATE = -5      # TD_ERR_STATE
 
@@ -91,6 +92,9 @@ SIGNATURES = {
     "td_tile_polygons_json_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_void_p, C.c_int64,
                                             C.POINTER(C.c_int64)]),
+    "td_read_window": (C.c_int64, [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "td_tile_prediction_file": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_char_p, C.POINTER(C.c_int64)]),
     "td_tile_polygons_json": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
                                         C.POINTER(C.c_double), C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
 }

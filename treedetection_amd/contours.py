@@ -7,6 +7,7 @@ on pixel-corner integer coordinates, float64) without the cupy round trip.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -60,6 +61,28 @@ def tile_polygons_json(regions: np.ndarray, offsets: np.ndarray, bits: np.ndarra
             continue
         _lib.check(st, "td_tile_polygons_json")
         return buf.raw[: need.value]
+
+
+def tile_prediction_file(device: int, regions: np.ndarray, offsets: np.ndarray, bits_dev_ptr: int, rows_host: np.ndarray,
+                         scores: np.ndarray, classes: np.ndarray, transform: Sequence[float], image_id: str, path: str) -> int:
+    """One tile from the device to its ``Prediction_*.json`` (reference prediction.py:197-265): td_tile_prediction_file
+    copies the words the paste wrote from ``bits_dev_ptr`` (device address of the image's bit rows) into the pinned
+    ``rows_host``, traces, formats and writes ``path`` — all with the GIL released. → bytes written."""
+    lib = _lib.load()
+    n = int(len(scores))
+    regions = np.ascontiguousarray(regions[:n], dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets[:n], dtype=np.int64)
+    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    classes = np.ascontiguousarray(classes[:n], dtype=np.int32)
+    words = rows_host.view(np.uint32).reshape(-1)
+    assert words.flags.c_contiguous
+    tr = (C.c_double * 6)(*[float(v) for v in transform[:6]])
+    wrote = C.c_int64(0)
+    st = lib.td_tile_prediction_file(int(device), regions.ctypes.data, offsets.ctypes.data, int(bits_dev_ptr), words.ctypes.data,
+                                     words.size, scores.ctypes.data, classes.ctypes.data, n, tr,
+                                     image_id.encode("utf-8", "surrogateescape"), os.fsencode(path), C.byref(wrote))
+    _lib.check(st, "td_tile_prediction_file")
+    return int(wrote.value)
 
 
 def tile_polygons_json_dev(points: np.ndarray, det_info: np.ndarray, contour_info: np.ndarray, regions: np.ndarray,

@@ -5,9 +5,15 @@
 #include <cstdint>
 #include <cstddef>
 #include "../../include/treedet.h"
+#include <string>
 #include <vector>
 
 void td_set_error(const char* fmt, ...);
+
+// epilogue.cpp: the text of one tile's prediction file from its packed rows on the host; returns the entry count or < 0
+int td_polygons_json_text(const int32_t* mask_region, const int64_t* mask_offset, const uint32_t* mask_bits, int64_t mask_words,
+                          const float* scores, const int32_t* classes, int n, const double* transform, const char* image_id,
+                          std::string& out, const char* who);
 
 #define TD_HIP_CHECK(expr)                                                                         \
     do {                                                                                           \

@@ -132,9 +132,9 @@ struct DevContours {
     const int32_t* contour_info; // [n][TD_CONTOUR_MAX][2] (offset, count) in RETR_TREE order
 };
 
-int polygons_json_core(const int32_t* mask_region, const int64_t* mask_offset, const uint32_t* mask_bits, int64_t mask_words,
+int polygons_json_text(const int32_t* mask_region, const int64_t* mask_offset, const uint32_t* mask_bits, int64_t mask_words,
                        const DevContours* dev, const float* scores, const int32_t* classes, int n, const double* transform,
-                       const char* image_id, char* buf, int64_t cap, int64_t* needed, const char* who) {
+                       const char* image_id, std::string& out, const char* who) {
     const double a = transform[0], b = transform[1], c = transform[2], d = transform[3], e = transform[4], f = transform[5];
     // North-up rasters (b == d == 0, the usual case): x depends on the column only and y on the row only, so each
     // distinct column / row is converted to text once per tile and copied from then on (number formatting is
@@ -163,7 +163,7 @@ int polygons_json_core(const int32_t* mask_region, const int64_t* mask_offset, c
     };
     std::string id;
     append_json_string(id, image_id);
-    std::string out;
+    out.clear();
     out.reserve(1 << 16);
     out += '[';
     int entries = 0;
@@ -245,6 +245,16 @@ int polygons_json_core(const int32_t* mask_region, const int64_t* mask_offset, c
         }
     }
     out += ']';
+    return entries;
+}
+
+int polygons_json_core(const int32_t* mask_region, const int64_t* mask_offset, const uint32_t* mask_bits, int64_t mask_words,
+                       const DevContours* dev, const float* scores, const int32_t* classes, int n, const double* transform,
+                       const char* image_id, char* buf, int64_t cap, int64_t* needed, const char* who) {
+    std::string out;
+    const int entries = polygons_json_text(mask_region, mask_offset, mask_bits, mask_words, dev, scores, classes, n, transform,
+                                           image_id, out, who);
+    if (entries < 0) return entries;
     *needed = (int64_t)out.size();
     if ((int64_t)out.size() > cap) {
         td_set_error("%s: %lld bytes needed, capacity %lld", who, (long long)out.size(), (long long)cap);
@@ -255,6 +265,15 @@ int polygons_json_core(const int32_t* mask_region, const int64_t* mask_offset, c
 }
 
 }  // namespace
+
+// The text of one tile's prediction file from its packed rows on the host (common.h; td_tile_prediction_file in api.cpp
+// fetches the rows from the device first and writes the text to the file itself).
+int td_polygons_json_text(const int32_t* mask_region, const int64_t* mask_offset, const uint32_t* mask_bits, int64_t mask_words,
+                          const float* scores, const int32_t* classes, int n, const double* transform, const char* image_id,
+                          std::string& out, const char* who) {
+    return polygons_json_text(mask_region, mask_offset, mask_bits, mask_words, nullptr, scores, classes, n, transform, image_id, out,
+                              who);
+}
 
 extern "C" int td_tile_polygons_json(const int32_t* mask_region, const int64_t* mask_offset, const uint32_t* mask_bits,
                                      int64_t mask_words, const float* scores, const int32_t* classes, int n,

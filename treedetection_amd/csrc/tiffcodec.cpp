@@ -143,3 +143,32 @@ extern "C" int td_tiff_unpredict(void* data, int64_t rows, int64_t cols, int sam
     }
     return TD_OK;
 }
+
+// Window of an uncompressed, pixel-interleaved raster whose strips lie back to back (include/treedet.h): `rows` pieces of
+// `row_bytes` bytes, `row_stride` apart in the file, read with pread into a dense destination. A memory map of the same
+// file pays a page fault per window row (a 1000-px row of a 12 000-px raster touches a page of its own: ~1.2 us against
+// ~0.1 us for the 4 KB copy) and its munmap tears all those entries down again at close; pread copies straight from the
+// page cache. Returns the bytes read, TD_ERR_INVALID when the file ends early or a read fails.
+#include <cerrno>
+#include <unistd.h>
+
+extern "C" int64_t td_read_window(int fd, int64_t file_off, int64_t row_stride, int64_t row_bytes, int64_t rows, uint8_t* dst) {
+    if (fd < 0 || file_off < 0 || row_bytes < 0 || rows < 0 || row_stride < row_bytes || (rows > 0 && row_bytes > 0 && !dst)) {
+        td_set_error("td_read_window: bad argument");
+        return TD_ERR_INVALID;
+    }
+    for (int64_t r = 0; r < rows; ++r) {
+        uint8_t* d = dst + r * row_bytes;
+        int64_t got = 0;
+        while (got < row_bytes) {
+            const ssize_t n = pread(fd, d + got, (size_t)(row_bytes - got), (off_t)(file_off + r * row_stride + got));
+            if (n < 0 && errno == EINTR) continue;
+            if (n <= 0) {
+                td_set_error("td_read_window: row %lld: %s", (long long)r, n == 0 ? "file ends inside the window" : strerror(errno));
+                return TD_ERR_INVALID;
+            }
+            got += n;
+        }
+    }
+    return rows * row_bytes;
+}

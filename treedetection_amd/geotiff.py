@@ -153,12 +153,17 @@ class GeoTiff:
         self._lock = threading.Lock()
         self._pool = None
         self._flat = None
+        self._fd = None
         item = self.dtype.itemsize
         if self.compression == 1 and self.planar == 1 and self._strips:
             row_bytes = W * self.count * item
             offs = self._offs
             if all(offs[i + 1] - offs[i] == self._bh * row_bytes for i in range(len(offs) - 1)):
                 self._flat = np.memmap(self.path, dtype=self.dtype, mode="r", offset=offs[0], shape=(H, W, self.count))
+                if self.dtype.byteorder in ("=", "|") and os.path.getsize(self.path) >= offs[0] + H * row_bytes:
+                    # windows are read with pread (td_read_window): no page fault per window row, no munmap of a touched
+                    # mapping at close; the map stays for whole-raster reads and foreign byte orders
+                    self._fd, self._flat_off = os.open(self.path, os.O_RDONLY), offs[0]
         if self.compression not in (1, 5, 8, 32946, 32773) or self._predictor not in (1, 2):
             self._pil_fallback()
         self._blocks_ready = True
@@ -183,6 +188,10 @@ class GeoTiff:
         self._pool = None
         self._data = None
         self._blocks_ready = False
+        fd = getattr(self, "_fd", None)
+        if fd is not None:
+            self._fd = None
+            os.close(fd)
         for name in ("_cache", "_mm", "_flat"):
             if hasattr(self, name):
                 setattr(self, name, None)
@@ -198,6 +207,10 @@ class GeoTiff:
             pool = getattr(self, "_pool", None)
             if pool is not None:
                 pool.shutdown(wait=False)
+            fd = getattr(self, "_fd", None)
+            if fd is not None:
+                self._fd = None
+                os.close(fd)
         except Exception:
             pass
 
@@ -259,6 +272,16 @@ class GeoTiff:
     def _window_hwc(self, r0: int, c0: int, h: int, w: int, out: Optional[np.ndarray] = None) -> np.ndarray:
         """Pixels [r0:r0+h, c0:c0+w] of every band as [h, w, bands] (into ``out`` when given)."""
         self._setup_blocks()
+        if self._flat is not None and getattr(self, "_fd", None) is not None:
+            if out is None:
+                out = np.empty((h, w, self.count), dtype=self.dtype)
+            if out.flags.c_contiguous and out.dtype == self.dtype:
+                from . import _lib
+                px = self.count * self.dtype.itemsize
+                n = _lib.load().td_read_window(self._fd, self._flat_off + (r0 * self.width + c0) * px, self.width * px, w * px, h,
+                                               out.ctypes.data)
+                _lib.check(n, "td_read_window")
+                return out
         if self._flat is not None:
             src = self._flat[r0:r0 + h, c0:c0 + w, :]
             if out is None:

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import distributed as D
-from .contours import find_contours, tile_polygons_json, tile_polygons_json_dev, xy
+from .contours import find_contours, tile_polygons_json, tile_polygons_json_dev, tile_prediction_file, xy
 from .engine import Engine, INPUT_F32_CHW, INPUT_U8_HWC
 from .geotiff import GeoTiff
 from .weights import load_checkpoint
@@ -124,17 +124,26 @@ class _Slot:
             cur = sets[src] = {"key": key, "dev": d, "pin": p, "np": {k: v.numpy() for k, v in p.items()}}
         n = len(hw)
         engine.paste_masks_batch(g["mask_probs"], g["boxes"], g["count"], hw, cur["dev"])
-        for k in ("mask_region", "mask_offset", "mask_bits"):
+        for k in ("mask_region", "mask_offset"):       # the bit rows: fetched per tile by the epilogue worker (used words only)
             cur["pin"][k][:n].copy_(cur["dev"][k][:n], non_blocking=True)
         cur["pin"]["count"][:n].copy_(g["count"][:n], non_blocking=True)
         cur["pin"]["scores"][:n].copy_(g["scores"][:n], non_blocking=True)
-        return cur["np"]
+        bits = cur["dev"]["mask_bits"]
+        return dict(cur["np"], bits_base=bits.data_ptr(), bits_stride=bits.shape[1] * bits.element_size())
 
+
+    def bits_ptr(self, i: int) -> int:
+        """Device address of image i's packed mask rows in this slot's outputs."""
+        v = self.dev_out["mask_bits"]
+        return v.data_ptr() + i * v.shape[1] * v.element_size()
 
     def copy_results(self, n: int, device_contours: bool) -> None:
-        """Queues the D2H copies of what the host epilogue reads (current stream): with device contours the traced points
-        and records replace the packed mask rows (fetched only for detections the device tracer left to the host)."""
-        skip = ("mask_bits",) if device_contours else ()
+        """Queues the D2H copies of the small per-detection records the host epilogue reads (current stream). The packed
+        mask rows are NOT copied here: their buffer is sized for the worst case (12.8 MB per 1000 x 1000 tile, 102 MB per
+        8-tile batch — what a Gen5 x16 link moves in the 4 ms a fp16 batch takes) and each epilogue worker fetches just the
+        words its tile's records say the paste wrote (td_tile_prediction_file). With device contours the traced points and
+        records travel instead (rows fetched only for detections the device tracer left to the host)."""
+        skip = ("mask_bits", "mask_probs")
         for k, v in self.dev_out.items():
             if k not in skip:
                 self.pin_out[k][:n].copy_(v[:n], non_blocking=True)
@@ -216,6 +225,12 @@ class Predictor:
         self._stats_lock = threading.Lock()
         # seconds spent per stage of the last __call__ (reader thread, launcher thread, sum over epilogue workers)
         self.stats = {"read": 0.0, "launch": 0.0, "launch_wait": 0.0, "epilogue": 0.0, "epilogue_wait": 0.0}
+        # TD_E2E_TRACE=1: (what, batch / tile index, perf_counter) marks of the last __call__ (tools/e2e_timeline.py)
+        self._trace = [] if os.environ.get("TD_E2E_TRACE") else None
+
+    def _mark(self, what, k=-1) -> None:
+        if self._trace is not None:
+            self._trace.append((what, k, time.perf_counter()))
 
     def close(self) -> None:
         """Stops the host worker threads and releases the engine's device memory."""
@@ -322,10 +337,9 @@ class Predictor:
                 need += max(w, 0) * max(h, 0) * img.count
             staging = slot.staging(max(need, 1), self.device)
         # offsets of the tiles in the staging buffer follow from the window sizes alone, so the windows can be copied side by
-        # side: an uncompressed (memory-mapped) raster is read by a few threads at once — one thread's memcpy moves ~8 GB/s, which
-        # is 2 000 tiles/s of 1000x1000x4-byte windows: exactly what three fp16 engines consume (bench.py e2e, round 3: the
-        # launcher waited for the reader 40 % of the call); numpy's copies release the GIL. Compressed rasters keep the
-        # sequential walk: their blocks are decoded by the reader's own thread pool already.
+        # side: an uncompressed raster is read by several threads at once (pread per window row, GIL released) — one thread
+        # alone moves ~2.5 GB/s of 4 KB rows, three fp16 engines consume 8 GB/s of 1000x1000x4-byte windows. Compressed
+        # rasters keep the sequential walk: their blocks are decoded by the reader's own thread pool already.
         offs, o = [], 0
         for idx in indices:
             offs.append(o)
@@ -335,7 +349,10 @@ class Predictor:
         img._setup_blocks()
         if staging is not None and getattr(img, "_flat", None) is not None and len(indices) > 1:
             if getattr(self, "_read_pool", None) is None:
-                self._read_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="td-window")
+                # windows are copied row by row out of the page cache (td_read_window: ~3 us per 4 KB row on tmpfs), eight of them
+                # side by side: e2e fp16, 400 tiles — 2 threads 1 758 tiles/s (reader-bound), 4: 1 851, 8: 1 905
+                nthreads = int(os.environ.get("TD_READ_THREADS", "0")) or max(2, min(8, len(os.sched_getaffinity(0)) // 2))
+                self._read_pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="td-window")
             results = list(self._read_pool.map(lambda k: self._process_tile(tiles[indices[k]], img, staging, offs[k]), range(len(indices))))
         else:
             results = [self._process_tile(tiles[idx], img, staging, offs[k]) for k, idx in enumerate(indices)]
@@ -378,6 +395,7 @@ class Predictor:
             t0 = time.perf_counter()
             slot.event.synchronize()
             t1 = time.perf_counter()
+            self._mark("epi", i)
             host = slot.host
             output_file = os.path.join(pred_subdir, f"Prediction_{os.path.basename(b['tile_id'])}.json")
             n = int(host["count"][i])
@@ -389,11 +407,21 @@ class Predictor:
                 if text is None:        # a detection too large / too fragmented for the device tracer: fetch this tile's rows
                     text = tile_polygons_json_dev(*args, slot.dev_out["mask_bits"][i].cpu().numpy(), *tail)
             else:
-                text = tile_polygons_json(host["mask_region"][i], host["mask_offset"][i], host["mask_bits"][i],
-                                          host["scores"][i][:n], host["classes"][i], b["meta"]["transform"], tifpath)
-            with open(output_file, "wb") as f:
-                f.write(text)
-            res = json.loads(text) if self.return_predictions else []
+                # rows fetched (only the words written), traced, formatted and written by one call without the GIL
+                text = None
+                tile_prediction_file(self.device_index, host["mask_region"][i], host["mask_offset"][i], slot.bits_ptr(i),
+                                     host["mask_bits"][i], host["scores"][i][:n], host["classes"][i], b["meta"]["transform"],
+                                     tifpath, output_file)
+            if text is not None:
+                with open(output_file, "wb") as f:
+                    f.write(text)
+            res = []
+            if self.return_predictions:
+                if text is None:
+                    with open(output_file, "rb") as f:
+                        text = f.read()
+                res = json.loads(text)
+            self._mark("epi_done", i)
             with self._stats_lock:
                 self.stats["epilogue_wait"] += t1 - t0
                 self.stats["epilogue"] += time.perf_counter() - t1
@@ -510,6 +538,7 @@ class Predictor:
             if isinstance(batch, BaseException):
                 item["failed"], item["batch"] = batch, []
             launched += 1
+            self._mark("launch", launched - 1)
             t0 = time.perf_counter()
             slot.side = stream               # where finish() enqueues this batch's copies / gather
             if item["batch"] and item["failed"] is None:
@@ -524,6 +553,7 @@ class Predictor:
                     item["failed"] = e       # sharded: the round still takes part in its gather, with no detections
             finish(item)
             self.stats["launch"] += time.perf_counter() - t0
+            self._mark("launch_done", launched - 1)
 
     @staticmethod
     def _transient_slot() -> _Slot:
@@ -569,13 +599,16 @@ class Predictor:
 
         def reader():
             try:
-                for indices in rounds:
+                for k, indices in enumerate(rounds):
+                    self._mark("slot_wait", k)
                     slot = self._free.get()
                     if stop.is_set():
                         return
+                    self._mark("read", k)
                     t0 = time.perf_counter()
                     batch = self._read_batch(tiles, indices, img, slot)
                     self.stats["read"] += time.perf_counter() - t0
+                    self._mark("read_done", k)
                     ready.put((batch, slot))
                 ready.put((None, None))
             except BaseException as e:      # surfaces in the launcher thread
@@ -808,11 +841,14 @@ class Predictor:
         try:
             slot.event.synchronize()
             n = int(pin["count"][j])
-            text = tile_polygons_json(pin["mask_region"][j], pin["mask_offset"][j], pin["mask_bits"][j], pin["scores"][j][:n],
-                                      np.zeros(n, np.int32), tile["meta"]["transform"], tifpath)
-            with open(os.path.join(pred_subdir, f"Prediction_{os.path.basename(tile['tile_id'])}.json"), "wb") as f:
-                f.write(text)
-            return json.loads(text) if self.return_predictions else []
+            path = os.path.join(pred_subdir, f"Prediction_{os.path.basename(tile['tile_id'])}.json")
+            tile_prediction_file(self.device_index, pin["mask_region"][j], pin["mask_offset"][j],
+                                 pin["bits_base"] + j * pin["bits_stride"], pin["mask_bits"][j], pin["scores"][j][:n],
+                                 np.zeros(n, np.int32), tile["meta"]["transform"], tifpath, path)
+            if not self.return_predictions:
+                return []
+            with open(path, "rb") as f:
+                return json.loads(f.read())
         finally:
             with slot.lock:
                 slot.pending -= 1
@@ -823,12 +859,18 @@ class Predictor:
         pred_subdir = os.path.join(self.output_dir, os.path.basename(tifpath).replace(".tif", "").replace(".json", ""))
         os.makedirs(pred_subdir, exist_ok=True)
         if D.world() == 1:
+            if self._trace is not None:
+                del self._trace[:]
+            self._mark("call")
             tiles = self._load_tiles(tilepath)
+            self._mark("tiles_loaded")
             img = GeoTiff(tifpath)
+            self._mark("raster_open")
             try:
                 return self._run_single(tiles, img, pred_subdir, tifpath)
             finally:
                 img.close()
+                self._mark("call_done")
         # sharded: every rank must enter (or skip) the image together — the per-round gathers only pair up if all
         # ranks read the same tile list from the same raster
         tiles, img, err = None, None, None
