@@ -133,11 +133,27 @@ void td_trace_contours_u8(const uint8_t* img, int h, int w, std::vector<int32_t>
 void td_trace_contours_bits(const uint32_t* rows, int words_per_row, int h, int w, std::vector<int32_t>& pts,
                             std::vector<int32_t>& starts) {
     const int step = w + 2;
-    std::vector<int32_t> F((size_t)(h + 2) * step, 0);
+    // the label image of the calling thread, grown as needed and reused: a fresh vector per detection is a fresh
+    // mapping for every region above 128 KB (page faults, kernel zeroing, munmap) — a third of this function's time
+    static thread_local std::vector<int32_t> F;
+    const size_t need = (size_t)(h + 2) * step;
+    if (F.size() < need) F.resize(need);
+    std::memset(F.data(), 0, (size_t)step * sizeof(int32_t));                              // top frame row
+    std::memset(F.data() + (size_t)(h + 1) * step, 0, (size_t)step * sizeof(int32_t));     // bottom frame row
     for (int y = 0; y < h; ++y) {
         const uint32_t* r = rows + (size_t)y * words_per_row;
         int32_t* f = &F[(size_t)(y + 1) * step + 1];
-        for (int x = 0; x < w; ++x) f[x] = (r[x >> 5] >> (x & 31)) & 1u;
+        f[-1] = 0;
+        f[w] = 0;
+        for (int x0 = 0; x0 < w; x0 += 32) {
+            const uint32_t word = r[x0 >> 5];
+            const int nb = w - x0 < 32 ? w - x0 : 32;
+            if (word == 0u) {
+                std::memset(f + x0, 0, (size_t)nb * sizeof(int32_t));
+            } else {
+                for (int b = 0; b < nb; ++b) f[x0 + b] = (int32_t)((word >> b) & 1u);
+            }
+        }
     }
     trace_padded(F, h, w, pts, starts);
 }
