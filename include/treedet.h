@@ -187,11 +187,20 @@ td_status td_bottleneck_tail_nhwc(const void* x, const void* w2, const float* sc
  * (rs = res_shift: 1 = nearest-2x upsampled add, the FPN top-down path), y [B,Ho,Wo,Cout].
  * Cin must be a multiple of 32. precision selects float32 or float16 tensors (weights follow); bits 8..15 of
  * `precision` may carry (block-tile id + 1) to force one kernel variant (parity tests of every variant; 0 = the
- * library chooses). */
+ * library chooses); bit 16 with float16 tensors: y is float32 (how the engine runs the RPN / box-predictor heads). */
 td_status td_conv2d_nhwc(const void* x, const void* w, const float* scale, const float* bias,
                          const void* residual, int res_shift, void* y, int B, int H, int W, int Cin,
                          int Cout, int KH, int KW, int stride, int pad, int relu, int precision,
                          void* stream);
+/* A 256-channel float16 convolution (stride 1, + bias, ReLU) whose output feeds ONLY a 1x1 head (reference: detectron2's
+ * StandardRPNHead behind prediction.py:183 — conv3x3 + ReLU, then the objectness / anchor-delta 1x1 layers, SURVEY.md
+ * Appendix A item 5): the head is contracted from the finished tile inside the same launch and only
+ * head_y [B*Ho*Wo][head_n] (float32) = conv_out . head_w^T + head_b is written. head_w [head_n <= 32][256] float16.
+ * bits 8..15 of `precision` must carry (tile id + 1) of a block tile that owns all 256 output channels and stages them as one float16 tile
+ * (9, 10, 12, 13, 17, 23, 27). Bit-identical to td_conv2d_nhwc(relu) followed by a 1x1 td_conv2d_nhwc with float32 output. */
+td_status td_conv2d_head_nhwc(const void* x, const void* w, const float* bias, const void* head_w, const float* head_b,
+                              float* head_y, int B, int H, int W, int Cin, int KH, int KW, int pad, int head_n, int precision,
+                              void* stream);
 /* The same 3x3 / stride 1 / pad 1 convolution (float32) through the Winograd F(2x2,3x3) path the fp32 engine uses where it
  * measures faster (input transform, 16 batched plane contractions on the MFMA kernel, output transform): x [B,H,W,Cin],
  * w [Cout,3,3,Cin], y [B,H,W,Cout] = act(conv * scale + bias), all DEVICE pointers; Cin % 32 == 0, Cout % 4 == 0.

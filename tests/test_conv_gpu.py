@@ -441,3 +441,63 @@ def test_conv_filter_direct_equals_the_reference_tile_bit_for_bit(case, cfg, pre
         got = conv2d_hip(x, w, tile_cfg=cfg, **kw)
         assert got.shape == ref.shape and np.array_equal(got, ref), float(np.abs(got - ref).max())
     assert np.abs(ref).max() > 0.5
+
+
+# ---- fused 1x1 head (ConvArgs::head_w): the RPN's 3x3 conv + ReLU and its 15-row objectness / delta head in one launch ----
+@pytest.mark.parametrize("cfg", [9, 10, 12, 13, 17, 23, 27])
+@pytest.mark.parametrize("case", [(2, 256, 50, 50, 3, 1, 15), (1, 256, 200, 200, 3, 1, 15), (8, 256, 13, 13, 3, 1, 15), (1, 64, 37, 21, 1, 0, 32),
+                                  (3, 128, 25, 25, 3, 1, 6)])
+def test_conv_with_fused_head_equals_the_two_launches_bit_for_bit(case, cfg):
+    """Every block tile that owns all 256 output channels can contract the head from its finished fp16 tile: the head's output must
+    be IDENTICAL to conv (fp16 output, cfg 0) followed by the 1x1 head as a launch of its own (fp16 in, fp32 out) — same fp16
+    rounding of the intermediate, same k order, same MFMA. Rows past M, head columns past head_n and the zero padding are covered
+    by the odd shapes. A tile that cannot fuse (here: a single-stage one) is refused, not silently run unfused."""
+    from tests.gpu_util import conv2d_head_hip
+    from treedetection_amd import _lib
+    B, Cin, H, W, k, pad, n = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.standard_normal((B, Cin, H, W), dtype=np.float32)
+    w = rng.standard_normal((256, Cin, k, k), dtype=np.float32) / np.float32(np.sqrt(Cin * k * k))
+    bias = rng.standard_normal(256).astype(np.float32)
+    hw = rng.standard_normal((n, 256, 1, 1), dtype=np.float32) / np.float32(16.0)
+    hb = rng.standard_normal(n).astype(np.float32)
+    t = conv2d_hip(x, w, bias=bias, pad=pad, relu=True, precision=1, tile_cfg=0)              # fp16 values as float32
+    ref = conv2d_hip(t, hw, bias=hb, precision=1, tile_cfg=3, out_f32=True)
+    for _ in range(2):
+        got = conv2d_head_hip(x, w, bias, hw, hb, pad, cfg)
+        assert got.shape == ref.shape and not np.isnan(got).any()
+        assert np.array_equal(got, ref), float(np.abs(got - ref).max())
+    assert np.abs(ref).max() > 0.5
+    with pytest.raises(_lib.TdError):
+        conv2d_head_hip(x, w, bias, hw, hb, pad, 14)
+
+
+def test_engine_with_fused_rpn_head_equals_engine_without_it():
+    """TD_FUSE_HEAD=0 runs the RPN head as its own launch at every level; the default fuses it where the measured tile allows.
+    Same detections, boxes, scores and mask probabilities bit for bit (fp16 engine; the fp32 engine has no fused head)."""
+    import os
+    from treedetection_amd.engine import Engine, INPUT_U8_HWC
+    from treedetection_amd.synth import make_tile
+    from treedetection_amd.weights import make_synthetic_state_dict
+    sd = make_synthetic_state_dict(50, seed=0)
+    tiles = [torch.from_numpy(make_tile(i, 600)[0]).cuda() for i in range(2)]
+    outs = []
+    for flag in ("1", "0"):
+        os.environ["TD_FUSE_HEAD"] = flag
+        try:
+            eng = Engine(sd, device=0, precision="fp16")
+            images, hw_valid, hw_out = eng.preprocess_tiles_u8(tiles)
+            o = eng.alloc_outputs(2, 600, 600, paste=False)
+            eng.forward_raw(images, INPUT_U8_HWC, hw_valid, hw_out, o)
+            eng.forward_raw(images, INPUT_U8_HWC, hw_valid, hw_out, o)          # second pass: measured tile choices in use
+            torch.cuda.synchronize()
+            outs.append({k: v.cpu().numpy().copy() for k, v in o.items()})
+            eng.close()
+        finally:
+            os.environ.pop("TD_FUSE_HEAD", None)
+    a, b = outs
+    assert a["count"].sum() > 0 and np.array_equal(a["count"], b["count"])
+    for k in ("boxes", "scores", "mask_probs"):
+        for i in range(2):
+            n = int(a["count"][i])
+            assert np.array_equal(a[k][i][:n], b[k][i][:n]), k

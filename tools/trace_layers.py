@@ -4,7 +4,7 @@ import csv
 import sys
 
 
-def schedule(depth=50, B=8, Hp=800, Wp=800, P=1000, fp32=False, fuse_tail=True):
+def schedule(depth=50, B=8, Hp=800, Wp=800, P=1000, fp32=False, fuse_tail=True, fused_heads=()):
     blocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}[depth]
     mids, outs = (64, 128, 256, 512), (256, 512, 1024, 2048)
     L = []
@@ -31,8 +31,11 @@ def schedule(depth=50, B=8, Hp=800, Wp=800, P=1000, fp32=False, fuse_tail=True):
     hs.append((hs[3] - 1) // 2 + 1)
     ws.append((ws[3] - 1) // 2 + 1)
     for l in range(5):
-        L.append((f"rpn_conv p{l+2}", B * hs[l] * ws[l], 256, 2304))
-        L.append((f"rpn_head p{l+2}", B * hs[l] * ws[l], 15, 256))
+        if l in fused_heads:      # the head contracted inside the 3x3 conv's launch (ConvArgs::head_w): its FLOPs ride in the 5th field
+            L.append((f"rpn_conv+head p{l+2}", B * hs[l] * ws[l], 256, 2304, 2.0 * B * hs[l] * ws[l] * 15 * 256 / 1e9))
+        else:
+            L.append((f"rpn_conv p{l+2}", B * hs[l] * ws[l], 256, 2304))
+            L.append((f"rpn_head p{l+2}", B * hs[l] * ws[l], 15, 256))
     L.append(("fc1", B * P, 1024, 12544))
     L.append(("fc2", B * P, 1024, 1024))
     L.append(("box_pred", B * P, 6, 1024))
@@ -60,7 +63,21 @@ def main(path, depth=50, fp32=False):
     min43 = int(os.environ.get("TD_WINO43_MIN", "12"))
     fam = ("conv_igemm", "conv_pp8", "plane_gemm", "wino_gemm", "wino_output", "wino_input", "wino43_input", "wino43_output", "bottleneck_tail", "conv_sk", "conv_bd")
     rows = [r for r in csv.DictReader(open(path)) if any(f in r["Kernel_Name"] for f in fam)]
-    L = schedule(depth, fp32=fp32, fuse_tail=int(os.environ.get("TD_FUSE_TAIL", "1")))
+    fuse_tail = int(os.environ.get("TD_FUSE_TAIL", "1"))
+    fused_heads = set()
+    if not fp32:
+        # which RPN levels ran with the head fused is the tuner's tile choice: read it off the trace, walking back from the
+        # box head (fc1, fc2, box_pred, 4 mask convs, deconv = 8 launches): a level's last launch is either its head (an
+        # fp16-in / fp32-out conv_igemm launch) or the fused 3x3 itself
+        i = len(rows) - 8
+        is_head = lambda kn: "conv_igemm" in kn and ("DF16_f" in kn or "_Float16, float" in kn)
+        for l in (4, 3, 2, 1, 0):
+            if is_head(rows[i - 1]["Kernel_Name"]):
+                i -= 2
+            else:
+                fused_heads.add(l)
+                i -= 1
+    L = schedule(depth, fp32=fp32, fuse_tail=fuse_tail, fused_heads=fused_heads)
     need = sum(launches_of(e[0], e[1], e[2], e[3], fp32, 8, min43)[0] for e in L)
     last = rows[-need:]
     tot_f = tot_t = 0.0

@@ -32,6 +32,8 @@ void td_model_desc_default(td_model_desc* d) {
     d->mask_thresh = 0.5f;
 }
 
+static td_status conv2d_api(ConvArgs& a, int precision, void* stream);
+
 td_status td_conv2d_nhwc(const void* x, const void* w, const float* scale, const float* bias,
                          const void* residual, int res_shift, void* y, int B, int H, int W, int Cin,
                          int Cout, int KH, int KW, int stride, int pad, int relu, int precision,
@@ -45,8 +47,36 @@ td_status td_conv2d_nhwc(const void* x, const void* w, const float* scale, const
     a.Ho = (H + 2 * pad - KH) / stride + 1;
     a.Wo = (W + 2 * pad - KW) / stride + 1;
     a.res_shift = res_shift; a.relu = relu; a.out_mode = 0;
-    a.M = B * a.Ho * a.Wo; a.m_dyn = nullptr; a.m_mul = 1; a.out_f32 = 0;
+    a.M = B * a.Ho * a.Wo; a.m_dyn = nullptr; a.m_mul = 1;
+    a.out_f32 = (precision & 0x10000) && (precision & 0xff) == TD_PRECISION_FP16 ? 1 : 0;      // float16 tensors, float32 y (the heads)
     a.tile_cfg = ((precision >> 8) & 0xff) - 1;          // tests: force one block-tile variant (0 = the library chooses)
+    return conv2d_api(a, precision, stream);
+}
+
+td_status td_conv2d_head_nhwc(const void* x, const void* w, const float* bias, const void* head_w, const float* head_b,
+                              float* head_y, int B, int H, int W, int Cin, int KH, int KW, int pad, int head_n, int precision,
+                              void* stream) {
+    TD_REQUIRE(x && w && head_w && head_y, "td_conv2d_head_nhwc: null pointer");
+    TD_REQUIRE((precision & 0xff) == TD_PRECISION_FP16, "td_conv2d_head_nhwc: float16 tensors only");
+    TD_REQUIRE(KH >= 1 && KW >= 1 && B >= 1 && head_n >= 1 && head_n <= 32, "td_conv2d_head_nhwc: bad geometry");
+    ConvArgs a{};
+    a.x = x; a.w = w; a.bias = bias;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = 256; a.KH = KH; a.KW = KW;
+    a.stride = 1; a.pad = pad;
+    a.Ho = H + 2 * pad - KH + 1;
+    a.Wo = W + 2 * pad - KW + 1;
+    a.relu = 1; a.M = B * a.Ho * a.Wo; a.m_mul = 1;
+    a.tile_cfg = ((precision >> 8) & 0xff) - 1;
+    TD_REQUIRE(conv_head_capable(a.tile_cfg, TD_PRECISION_FP16), "td_conv2d_head_nhwc: tile id %d does not own 256 output channels per block", a.tile_cfg);
+    a.head_w = head_w; a.head_b = head_b; a.head_y = head_y; a.head_n = head_n;
+    // the layer's own output is never written by a fused launch; `y` still has to be a valid pointer for the argument checks
+    a.y = head_y;
+    return conv2d_api(a, precision, stream);
+}
+
+static td_status conv2d_api(ConvArgs& a, int precision, void* stream) {
+    const int Cin = a.Cin, Cout = a.Cout, KH = a.KH, KW = a.KW;
+    const void* w = a.w;
     if (a.tile_cfg >= 23 && a.tile_cfg <= 27 && Cin % ((precision & 0xff) == TD_PRECISION_FP16 ? 64 : 32) == 0) {
         // tests: the filter-direct tiles (conv_bdirect.hip) need the filters in fragment order: packed here from the caller's
         // [Cout][KH][KW][Cin] bank (the engine packs once at load time)

@@ -63,7 +63,19 @@ struct ConvArgs {
     int* sk_cnt;
     int tile_cfg;         // -1 = heuristic; 0..3 = block tile 128x128, 128x64, 64x128, 64x64 with 2 LDS stages,
                           // 4..7 = the same tiles with 3 stages (engine autotunes)
+    // fused 1x1 head (fp16 engine, block tiles that own all 256 output channels: conv_head_capable): the finished fp16
+    // tile — this layer's output — is contracted with head_w [head_n <= 32][Cout = 256] straight from its LDS staging and
+    // only head_y [M][head_n] (fp32, + head_b) is written; y is NOT written. The RPN's 3x3 conv + its 15-row head.
+    const void* head_w;
+    const float* head_b;
+    float* head_y;
+    int head_n;
 };
+// tile ids whose block owns 256 output channels at once (fp16): the head fusion above applies
+static inline bool conv_head_capable(int cfg, int precision) {
+    // (the single-stage 256-wide tiles 14 / 16 stage their output as fp32 wave-rows, not as one fp16 tile: not capable)
+    return precision == TD_PRECISION_FP16 && (cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 17 || cfg == 23 || cfg == 27);
+}
 // tile_cfg ids (conv_igemm.hip:dispatch): 0..3 4-wave tiles 128x128 / 128x64 / 64x128 / 64x64 (2 LDS stages), 4..7 the same
 // with 3 stages (measured no better: not tuned over), 8 = 256x128 / 9 = 128x256 (8 waves), 10 = 256x256 (16 waves),
 // 11..13 = 256x256 with larger per-wave tiles, 14..16 = single-LDS-stage 256x256 / 128x128 / 128x256 (thin 1x1 layers),

@@ -132,6 +132,42 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                 }
             }
             __syncthreads();
+            if constexpr (BN == 256 && sizeof(T) == 2) {
+                if (a.head_w) {
+                    // ---- fused 1x1 head: rows of the staged tile x head_w^T, k = the tile's 256 channels in ascending order with
+                    // the MFMA of every other fp16 tile (bit-identical to a separate launch over the stored tile) ----
+                    constexpr int NWAVE = THREADS / 64, RT = BM / 32;
+                    const int wv = tid >> 6;
+                    const int col = lane & 31, kh8 = (lane >> 5) * 8;
+                    const _Float16* __restrict__ Wh = static_cast<const _Float16*>(a.head_w);
+                    const bool live = col < a.head_n;
+                    const float hb = live && a.head_b ? a.head_b[col] : 0.f;
+                    f32x4 fbh[16];
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) {
+                        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        fbh[kk] = live ? *reinterpret_cast<const f32x4*>(Wh + (size_t)col * BN + kk * 16 + kh8) : z;
+                    }
+                    for (int rt = wv; rt < RT; rt += NWAVE) {
+                        f32x16 hacc;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+#pragma unroll
+                        for (int kk = 0; kk < 16; ++kk) {
+                            const f32x4 fah = *reinterpret_cast<const f32x4*>(&Hs[(rt * 32 + col) * HS + kk * 16 + kh8]);
+                            Elem<T>::mma(fah, fbh[kk], hacc);
+                        }
+                        if (live) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int m = m0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                                if (m < M) a.head_y[(size_t)m * a.head_n + col] = a.head_b ? __fadd_rn(hacc[r], hb) : hacc[r];
+                            }
+                        }
+                    }
+                    return;
+                }
+            }
             constexpr int PIECES = BN / 8;            // 16-B pieces per tile row
             constexpr int ROWS_PER_PASS = THREADS / PIECES;
             static_assert(BM % ROWS_PER_PASS == 0, "fp16 epilogue rows must split evenly over the threads");

@@ -127,6 +127,7 @@ struct td_engine {
     bool stream_k = false;
     float* sk_ws = nullptr;       // stream-K partial-tile slots / per-tile ticket counters (fp16 engine; reserve())
     int* sk_cnt = nullptr;
+    bool fuse_head = true;        // TD_FUSE_HEAD=0: the RPN's 1x1 head as a launch of its own at every level (diagnostics, tests)
     bool fuse_tail = true;        // TD_FUSE_TAIL=0: conv2 / conv3 of res2 as two launches (diagnostics, tests); 2: fuse the fp16 engine's res3 too
     bool fuse_tail_fp16 = false;
     bool wino_fused = true;       // TD_WINO_FUSED=0: separate input-transform kernel + batched conv_igemm launch (diagnostics)
@@ -345,8 +346,11 @@ td_status load_conv_bias(td_engine* e, const TensorMap& tm, const std::string& p
 
 td_status run_conv_raw(const ConvLayer& L, const void* x, int B, int H, int W, int stride, int pad, bool relu, void* y,
                        const void* res, int res_shift, hipStream_t s, int precision, const int* m_dyn, int m_mul,
-                       int out_mode, int tile_cfg = -1) {
+                       int out_mode, int tile_cfg = -1, const ConvLayer* head = nullptr, float* head_y = nullptr) {
     ConvArgs a{};
+    if (head) {          // fused 1x1 head (ConvArgs::head_w): the caller checked conv_head_capable(tile_cfg)
+        a.head_w = head->w; a.head_b = head->bias; a.head_y = head_y; a.head_n = head->cout;
+    }
     a.x = x; a.w = L.w; a.w_frag = L.w_frag; a.scale = L.scale; a.bias = L.bias; a.res = res; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = L.cin; a.Cout = L.cout; a.KH = L.kh; a.KW = L.kw;
     a.stride = stride; a.pad = pad;
@@ -475,6 +479,7 @@ td_status td_engine_create(const td_model_desc* desc, int device, td_engine** ou
     if (const char* wg = getenv("TD_WINOGRAD")) e->winograd = atoi(wg) != 0;
     if (const char* ws = getenv("TD_WINO_SLAB")) e->wino_slab = atoi(ws);
     if (const char* wf = getenv("TD_WINO_FUSED")) e->wino_fused = atoi(wf) != 0;
+    if (const char* fh = getenv("TD_FUSE_HEAD")) e->fuse_head = atoi(fh) != 0;
     if (const char* ft = getenv("TD_FUSE_TAIL")) { e->fuse_tail = atoi(ft) != 0; e->fuse_tail_fp16 = atoi(ft) == 2; }
     if (const char* sk = getenv("TD_STREAMK")) e->stream_k = atoi(sk) != 0;
     if (const char* skv = getenv("TD_STREAMK_VARIANT")) e->sk_variant = atoi(skv);
@@ -952,7 +957,8 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
     };
     auto run_conv = [&](const ConvLayer& L, const void* x_, int B_, int H_, int W_, int stride, int pad, bool relu,
                         void* y_, const void* res_, int res_shift, hipStream_t s_, int prec_,
-                        const int* m_dyn = nullptr, int m_mul = 1, int out_mode = 0) -> td_status {
+                        const int* m_dyn = nullptr, int m_mul = 1, int out_mode = 0,
+                        const ConvLayer* head = nullptr, float* head_y = nullptr, bool* head_fused = nullptr) -> td_status {
         const int Ho = (H_ + 2 * pad - L.kh) / stride + 1, Wo = (W_ + 2 * pad - L.kw) / stride + 1;
         const double M = (double)B_ * Ho * Wo, K = (double)L.kh * L.kw * L.cin;
         const double flops = 2.0 * M * L.cout * K;
@@ -1027,6 +1033,25 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         if (use_43) return run_wino43(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, wino_cfg);
         if (use_wino) return run_wino(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, m_mul, wino_cfg);
         const int cls = m_dyn ? TD_CLS_MASK_HEAD : (H_ == 1 && W_ == 1 ? TD_CLS_FC : (L.kh == 1 && L.kw == 1 ? TD_CLS_CONV1X1 : TD_CLS_CONV3X3));
+        // A 1x1 head contracted from the finished tile inside the same launch (the RPN's 15-row head after its 3x3 conv): only
+        // when the measured tile owns all 256 output channels — bit-identical to the separate launch either way, so the tile
+        // choice (a timing) may decide it. The head's FLOPs / bytes join this launch's; its own input read and this layer's
+        // output write disappear.
+        const bool fuse_head = head && e->fuse_head && !m_dyn && out_mode == 0 && !res_ && relu && L.cout == 256 && head->cin == 256 &&
+                               head->kh == 1 && head->kw == 1 && head->cout <= 32 && head->out_f32 && !head->scale && conv_head_capable(cfg, prec_);
+        if (head_fused) *head_fused = fuse_head;
+        if (fuse_head) {
+            const double hflops = 2.0 * M * head->cout * L.cout, hbytes = 4.0 * M * head->cout + es * head->cout * L.cout;
+            const double bytes_f = bytes - es * M * L.cout + hbytes;
+            if (e->prof) {
+                e->prof_flops[0] += hflops;
+                e->prof_flops[8] += hflops;
+                e->prof_launches[0] += 1;          // two layers of the reference in one launch: "launches" keeps counting layers
+                e->prof_bytes[0] += hbytes + es * M * L.cout;       // the unfused pair's algorithmic bytes (every tensor of every layer once)
+            }
+            ClassScope cs(e, s_, cls, flops + hflops, bytes_f);
+            return run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, cfg, head, head_y);
+        }
         ClassScope cs(e, s_, cls, m_dyn ? 0.0 : flops, m_dyn ? 0.0 : bytes);
         return run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, cfg);
     };
@@ -1157,8 +1182,10 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
     {
         ProfScope rpn_group(e, s, 0, 0.0, 0.0, true);
         for (int l = 0; l < 5; ++l) {
-            if ((st = run_conv(e->rpn_conv, e->pfeat[l], B, hs[l], wsz[l], 1, 1, true, e->rpn_t, nullptr, 0, s, prec)) < 0) return st;
-            if ((st = run_conv(e->rpn_head, e->rpn_t, B, hs[l], wsz[l], 1, 0, false, e->rpn_headbuf[l], nullptr, 0, s, prec)) < 0) return st;
+            bool fused = false;
+            if ((st = run_conv(e->rpn_conv, e->pfeat[l], B, hs[l], wsz[l], 1, 1, true, e->rpn_t, nullptr, 0, s, prec, nullptr, 1, 0,
+                               &e->rpn_head, e->rpn_headbuf[l], &fused)) < 0) return st;
+            if (!fused && (st = run_conv(e->rpn_head, e->rpn_t, B, hs[l], wsz[l], 1, 0, false, e->rpn_headbuf[l], nullptr, 0, s, prec)) < 0) return st;
             const std::string nm = "rpn_head" + std::to_string(l + 2);
             set_named(e, nm.c_str(), e->rpn_headbuf[l], B, hs[l], wsz[l], RPN_HEAD_C);
         }
