@@ -301,3 +301,51 @@ def test_predictor_loads_pth_checkpoint(tmp_path):
         outs[tag] = {f: open(tmp_path / tag / "7" / f, "rb").read() for f in sorted(os.listdir(tmp_path / tag / "7"))}
     assert len(outs["pth"]) == 4 and outs["pth"] == outs["dict"]
     assert sum(len(json.loads(v)) for v in outs["pth"].values()) > 3
+
+
+def test_chained_images_equal_image_by_image_and_survive_a_bad_image(tmp_path):
+    """Predictor.submit starts the next image while the previous one drains (what predict_on_model does in a single process):
+    the tile files are byte-identical to calling the predictor image by image; an image that cannot be started (missing tile
+    metadata) raises from submit, a tile task that fails raises from result() — in both cases the images around it are
+    complete and the predictor keeps all its buffer slots."""
+    import treedetection_amd as T
+    from treedetection_amd.preprocessing import tile_single_file
+    sd = make_synthetic_state_dict(50, seed=3, width_div=2)
+    t = (0.2, 0.0, 412000.0, 0.0, -0.2, 5318100.0)
+    tifs = []
+    for k in range(3):
+        rgb, _ = make_tile(310 + k, 500)
+        tif = str(tmp_path / f"{k}.tif")
+        write_geotiff(tif, np.ascontiguousarray(np.concatenate([rgb, rgb[..., 1:2]], axis=2).transpose(2, 0, 1)), t, 25832)
+        tile_single_file(tif, str(tmp_path / "tiles"), buffer=10, tile_width=40, tile_height=40)
+        tifs.append(tif)
+    tj = lambda tif: str(tmp_path / "tiles" / (os.path.basename(tif).replace(".tif", ".json")))      # noqa: E731
+    cfg = T.setup_model_cfg(update_model="x", device="0")
+    read = lambda d: {f"{sub}/{f}": open(d / sub / f, "rb").read() for sub in sorted(os.listdir(d)) for f in sorted(os.listdir(d / sub))}   # noqa: E731
+    with T.Predictor(cfg, device_type="0", max_batch_size=2, output_dir=str(tmp_path / "seq"), state_dict=sd) as pred:
+        seq = [pred(tif, tj(tif)) for tif in tifs]
+    with T.Predictor(cfg, device_type="0", max_batch_size=2, output_dir=str(tmp_path / "chain"), state_dict=sd) as pred:
+        nslots = pred._free.qsize()
+        handles = [pred.submit(tif, tj(tif)) for tif in tifs]            # three images in flight
+        chained = [h.result() for h in handles]
+        assert handles[0].result() is chained[0]                        # result() may be asked twice
+        assert pred._free.qsize() == nslots
+        # a bad image between two good ones
+        h0 = pred.submit(tifs[0], tj(tifs[0]))
+        with pytest.raises(FileNotFoundError):
+            pred.submit(tifs[1], str(tmp_path / "tiles" / "missing.json"))
+        h2 = pred.submit(tifs[2], tj(tifs[2]))
+        assert h0.result() == chained[0] and h2.result() == chained[2]
+        # tile tasks that fail (their output folder vanishes under them): result() may raise, every slot comes back
+        import shutil
+        h1 = pred.submit(tifs[1], tj(tifs[1]))
+        shutil.rmtree(tmp_path / "chain" / "1", ignore_errors=True)
+        try:
+            h1.result()
+        except Exception:
+            pass
+        shutil.rmtree(tmp_path / "chain" / "1", ignore_errors=True)
+        assert pred(tifs[1], tj(tifs[1])) == chained[1]
+        assert pred._free.qsize() == nslots
+    assert chained == seq and sum(len(c) for c in chained) > 10
+    assert read(tmp_path / "seq") == read(tmp_path / "chain")

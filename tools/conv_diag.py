@@ -6,10 +6,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "treedetection_amd", "csrc")
 
 def build(tag, defs):
-    out = f"/tmp/libdiag_{tag}.so"
-    srcs = [os.path.join(CS, f) for f in ("conv_igemm.hip", "api.cpp", "error.cpp", "stem.hip", "rpn.hip", "roi.hip", "engine.cpp", "contours.cpp")]
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form", "-x", "hip"] + defs + srcs + ["-o", out]
-    subprocess.run(cmd, check=True)
+    """conv_igemm.hip rebuilt with the diagnostic defines, linked with the product build's other objects (csrc/*.o)."""
+    import glob
+    out, obj = f"/tmp/libdiag_{tag}.so", f"/tmp/diag_{tag}.o"
+    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+    subprocess.run(["/opt/rocm/bin/hipcc"] + flags + defs + ["-c", os.path.join(CS, "conv_igemm.hip"), "-o", obj], check=True)
+    others = [o for o in sorted(glob.glob(os.path.join(CS, "*.o"))) if os.path.basename(o) != "conv_igemm.o"]
+    subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", obj] + others + ["-o", out], check=True)
     return out
 
 def bench(lib, prec, B, H, W, Cin, Cout, k, cfg_name, residual=False):
@@ -68,6 +71,8 @@ if __name__ == "__main__":
                     "pp8 no_dma_no_reads": ["-DTD_DIAG_PP8_NO_DMA", "-DTD_DIAG_PP8_NO_READS"],
                     "pp8 no_reads": ["-DTD_DIAG_PP8_NO_READS"],
                     "pp8 mfma_only": ["-DTD_DIAG_PP8_NO_DMA", "-DTD_DIAG_PP8_NO_READS", "-DTD_DIAG_PP8_NO_BARRIER"],
+                    "pp8 mfma_nobar_noepi": ["-DTD_DIAG_PP8_NO_DMA", "-DTD_DIAG_PP8_NO_READS", "-DTD_DIAG_PP8_NO_BARRIER", "-DTD_DIAG_PP8_NO_EPILOGUE"],
+                    "pp8 nobar": ["-DTD_DIAG_PP8_NO_BARRIER"],
                     "pp8 no_epilogue": ["-DTD_DIAG_PP8_NO_EPILOGUE"],
                     "pp8 v1_dma_first": ["-DTD_PP8_V1"], "pp8 v2_dma_light_phases": ["-DTD_PP8_V2"],
                     "pp8 mfma16": ["-DTD_DIAG_MFMA16"],

@@ -62,15 +62,38 @@ def predict_on_model(config, model_path, tiles_path, output_path, batch_size=10,
             logger.info("All files have already been predicted. Exiting Prediction.")
             return
         total = len(images_paths)
+        # Single process: image i+1 is started (read, launched) while image i's last forwards and tile files finish —
+        # Predictor.submit; the per-image outcome (files written, or the error logged and the walk continuing, reference
+        # detection.py:117-120) is the same as calling the predictor image by image. Sharded runs keep the image-by-image walk:
+        # every image is one collective structure all ranks enter together.
+        chain = D.world() == 1
+        pending = None
+
+        def finish(item):
+            path, handle = item
+            try:
+                handle.result()
+            except Exception as e:
+                logger.error(f"Error processing {path}: {e}")
+
         for i, fp in enumerate(images_paths):
             cur, prev = int(100 * (i + 1) / total), int(100 * i / total)
             if logger and ((cur // 5) != (prev // 5) or cur == 100 or i == 0):
                 logger.info(f"Predicting file {i + 1}/{total} ({cur}%)")
             tile_json = os.path.join(tiles_path, os.path.basename(fp).replace(".tif", ".json"))
+            handle = None
             try:
-                predictor(fp, tile_json)
+                if chain:
+                    handle = predictor.submit(fp, tile_json)
+                else:
+                    predictor(fp, tile_json)
             except Exception as e:
                 logger.error(f"Error processing {fp}: {e}")
+            if pending is not None:
+                finish(pending)
+            pending = (fp, handle) if handle is not None else None
+        if pending is not None:
+            finish(pending)
         logger.info(f"Completed prediction for {len(images_paths)} images.")
         if D.rank() == 0:
             save_prediction_recovery_data(output_path, tiles_path, model_path, processed_files, images_paths)

@@ -222,6 +222,11 @@ class Predictor:
         # buffer slots (pinned staging + outputs) in rotation: three per engine keep the fp16 engines fed while the host epilogue
         # of earlier batches still reads its slots (e2e fp16: 6 slots 1 410 tiles/s, 9 slots 1 531, 12 slots 1 502; fp32 unchanged)
         self._slots = [_Slot() for _ in range(int(os.environ.get("TD_SLOTS", "0")) or (9 if self.pipeline else 3))]
+        # single-process runs: ONE free list for the predictor's lifetime — a slot returns to it whichever image it served, so
+        # the next image can be started (submit) while the last batches of the previous one are still in flight
+        self._free = queue.Queue()
+        for s in self._slots:
+            self._free.put(s)
         self._stats_lock = threading.Lock()
         # seconds spent per stage of the last __call__ (reader thread, launcher thread, sum over epilogue workers)
         self.stats = {"read": 0.0, "launch": 0.0, "launch_wait": 0.0, "epilogue": 0.0, "epilogue_wait": 0.0}
@@ -567,9 +572,12 @@ class Predictor:
         must not be refilled by the next image while a worker of this one still reads them, and a late worker must
         not hand a slot to the next call's free list a second time."""
         stop.set()
+        def put_back(item):
+            if isinstance(item, tuple) and len(item) == 2 and isinstance(item[1], _Slot):
+                self._give_back(item[1], self._free)        # a batch that was read but never launched
         while reader.is_alive():
             try:
-                ready.get(timeout=0.05)
+                put_back(ready.get(timeout=0.05))
             except queue.Empty:
                 pass
             # the reader may also be waiting for a free slot: hand it one it will not use (never a real slot: those
@@ -577,6 +585,11 @@ class Predictor:
             if self._free.empty():
                 self._free.put(self._transient_slot())
         reader.join()
+        while True:
+            try:
+                put_back(ready.get_nowait())
+            except queue.Empty:
+                break
         for f in futures:
             try:
                 f.result()
@@ -588,12 +601,16 @@ class Predictor:
             pass
 
     def _run_single(self, tiles, img: GeoTiff, pred_subdir, tifpath):
+        return self._start_single(tiles, img, pred_subdir, tifpath).result()
+
+    def _start_single(self, tiles, img: GeoTiff, pred_subdir, tifpath) -> "_PendingImage":
+        """Reads and launches every batch of one image; returns when the last batch is ENQUEUED (the raster is no longer
+        needed then). What is still running — the last forwards on the GPU, the epilogue workers of the last batches — is
+        waited for by ``.result()`` of the returned handle; meanwhile the next image may be started: its batches queue up
+        behind these on the engines' streams and its reader takes slots as the epilogue workers return them."""
         B = self.max_batch_size
         rounds = [list(range(r * B, min((r + 1) * B, len(tiles)))) for r in range((len(tiles) + B - 1) // B)]
         self.stats = dict.fromkeys(self.stats, 0.0)
-        self._free = queue.Queue()
-        for s in self._slots:
-            self._free.put(s)
         ready: "queue.Queue" = queue.Queue(maxsize=2)
         stop = threading.Event()
 
@@ -603,10 +620,15 @@ class Predictor:
                     self._mark("slot_wait", k)
                     slot = self._free.get()
                     if stop.is_set():
+                        self._give_back(slot, self._free)
                         return
                     self._mark("read", k)
                     t0 = time.perf_counter()
-                    batch = self._read_batch(tiles, indices, img, slot)
+                    try:
+                        batch = self._read_batch(tiles, indices, img, slot)
+                    except BaseException:
+                        self._give_back(slot, self._free)
+                        raise
                     self.stats["read"] += time.perf_counter() - t0
                     self._mark("read_done", k)
                     ready.put((batch, slot))
@@ -616,7 +638,7 @@ class Predictor:
 
         t = threading.Thread(target=reader, name="td-tile-reader", daemon=True)
         t.start()
-        futures, predictions = [], []
+        futures: list = []
         try:
             while not self.pipeline:
                 t0 = time.perf_counter()
@@ -640,9 +662,7 @@ class Predictor:
                 self._launch_pipelined(ready, prepare,
                                        lambda item: self._finish_local(item, pred_subdir, tifpath, futures, item["slot"].side))
             t.join()
-            for f in futures:
-                predictions.extend(f.result())
-            return predictions
+            return _PendingImage(self, futures)
         except BaseException:
             self._drain(t, ready, futures, stop)
             raise
@@ -855,22 +875,35 @@ class Predictor:
                 if slot.pending == 0:
                     self._give_back(slot, free)
 
-    def __call__(self, tifpath, tilepath):
+    def submit(self, tifpath, tilepath) -> "_PendingImage":
+        """Single-process runs: starts an image and returns once its last batch is enqueued; ``.result()`` of the handle waits
+        for its tile files (and returns the predictions list). Between the two the caller may submit the next image, so one
+        image's drain (its last forwards and epilogues, ≈ 20 ms) overlaps the next image's fill — what
+        ``detection.predict_on_model`` does. ``predictor(tif, tiles)`` = ``predictor.submit(tif, tiles).result()``."""
+        if D.world() != 1:
+            raise RuntimeError("Predictor.submit is for single-process runs; sharded runs go image by image (one collective structure per image)")
         pred_subdir = os.path.join(self.output_dir, os.path.basename(tifpath).replace(".tif", "").replace(".json", ""))
         os.makedirs(pred_subdir, exist_ok=True)
+        if self._trace is not None:
+            del self._trace[:]
+        self._mark("call")
+        tiles = self._load_tiles(tilepath)
+        self._mark("tiles_loaded")
+        img = GeoTiff(tifpath)
+        self._mark("raster_open")
+        try:
+            return self._start_single(tiles, img, pred_subdir, tifpath)
+        finally:
+            img.close()
+
+    def __call__(self, tifpath, tilepath):
         if D.world() == 1:
-            if self._trace is not None:
-                del self._trace[:]
-            self._mark("call")
-            tiles = self._load_tiles(tilepath)
-            self._mark("tiles_loaded")
-            img = GeoTiff(tifpath)
-            self._mark("raster_open")
             try:
-                return self._run_single(tiles, img, pred_subdir, tifpath)
+                return self.submit(tifpath, tilepath).result()
             finally:
-                img.close()
                 self._mark("call_done")
+        pred_subdir = os.path.join(self.output_dir, os.path.basename(tifpath).replace(".tif", "").replace(".json", ""))
+        os.makedirs(pred_subdir, exist_ok=True)
         # sharded: every rank must enter (or skip) the image together — the per-round gathers only pair up if all
         # ranks read the same tile list from the same raster
         tiles, img, err = None, None, None
@@ -888,6 +921,31 @@ class Predictor:
         finally:
             if img is not None:
                 img.close()
+
+
+class _PendingImage:
+    """An image whose batches are all enqueued (Predictor.submit): ``result()`` waits for its epilogue tasks — every
+    ``Prediction_*.json`` of the image is on disk when it returns — and gives the predictions list (empty with
+    ``return_predictions=False``). The first failed tile task is re-raised after ALL tasks have finished, so no worker of this
+    image is still reading its slot when the caller moves on."""
+
+    def __init__(self, predictor: "Predictor", futures):
+        self._predictor, self._futures, self._done = predictor, futures, None
+
+    def result(self):
+        if self._done is None:
+            preds, err = [], None
+            for f in self._futures:
+                try:
+                    preds.extend(f.result())
+                except BaseException as e:      # keep waiting for the others: their slots must be back before anyone re-uses them
+                    err = err or e
+            self._done = (preds, err)
+            self._futures = None
+        preds, err = self._done
+        if err is not None:
+            raise err
+        return preds
 
 
 class _null_ctx:
