@@ -207,6 +207,12 @@ td_status td_conv2d_head_nhwc(const void* x, const void* w, const float* bias, c
  * Synchronous (allocates its own scratch): parity tests only. */
 td_status td_conv2d_winograd_nhwc(const float* x, const float* w, const float* scale, const float* bias, float* y, int B,
                                   int H, int W, int Cin, int Cout, int relu, void* stream);
+/* F(4x4,3x3) form of td_conv2d_head_nhwc for float32 tensors (how the fp32 engine runs the RPN, reference StandardRPNHead behind
+ * prediction.py:183): 3x3 / stride 1 / pad 1 conv to 256 channels + bias + ReLU, whose output feeds only the 1x1 head
+ * head_w [head_n <= 32][256]; the head is contracted inside the output transform and only head_y [B*H*W][head_n] is written.
+ * Bit-identical to td_conv2d_winograd_nhwc (TD_WINO_TILE=4) followed by a 1x1 td_conv2d_nhwc. */
+td_status td_conv2d_winograd_head_nhwc(const float* x, const float* w, const float* bias, const float* head_w, const float* head_b,
+                                       float* head_y, int B, int H, int W, int Cin, int head_n, void* stream);
 /* Greedy NMS of n boxes (dev [n,4], scores dev [n]); keep_idx dev int32 [n] receives the kept
  * indices in descending-score order (ties: lower index first), *keep_count (dev) their number. */
 td_status td_nms(const float* boxes, const float* scores, int n, float iou_thresh, int32_t* keep_idx,

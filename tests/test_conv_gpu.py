@@ -473,19 +473,26 @@ def test_conv_with_fused_head_equals_the_two_launches_bit_for_bit(case, cfg):
 
 
 def test_engine_with_fused_rpn_head_equals_engine_without_it():
-    """TD_FUSE_HEAD=0 runs the RPN head as its own launch at every level; the default fuses it where the measured tile allows.
-    Same detections, boxes, scores and mask probabilities bit for bit (fp16 engine; the fp32 engine has no fused head)."""
+    """TD_FUSE_HEAD=0 runs the RPN head as its own launch at every level; the default fuses it where the measured tile allows (fp16)
+    / into the F(4x4) output transform (fp32). Same detections, boxes, scores and mask probabilities bit for bit, both engines."""
     import os
     from treedetection_amd.engine import Engine, INPUT_U8_HWC
     from treedetection_amd.synth import make_tile
     from treedetection_amd.weights import make_synthetic_state_dict
     sd = make_synthetic_state_dict(50, seed=0)
     tiles = [torch.from_numpy(make_tile(i, 600)[0]).cuda() for i in range(2)]
+    for precision in ("fp16", "fp32"):
+        _fused_head_engines_agree(sd, tiles, precision)
+
+
+def _fused_head_engines_agree(sd, tiles, precision):
+    import os
+    from treedetection_amd.engine import Engine, INPUT_U8_HWC
     outs = []
     for flag in ("1", "0"):
         os.environ["TD_FUSE_HEAD"] = flag
         try:
-            eng = Engine(sd, device=0, precision="fp16")
+            eng = Engine(sd, device=0, precision=precision)
             images, hw_valid, hw_out = eng.preprocess_tiles_u8(tiles)
             o = eng.alloc_outputs(2, 600, 600, paste=False)
             eng.forward_raw(images, INPUT_U8_HWC, hw_valid, hw_out, o)
@@ -501,3 +508,39 @@ def test_engine_with_fused_rpn_head_equals_engine_without_it():
         for i in range(2):
             n = int(a["count"][i])
             assert np.array_equal(a[k][i][:n], b[k][i][:n]), k
+
+
+@pytest.mark.parametrize("case", [(2, 256, 50, 50, 15), (1, 128, 200, 200, 15), (8, 256, 13, 13, 15), (3, 64, 37, 21, 32), (1, 256, 25, 25, 6)])
+def test_winograd_output_transform_with_fused_head_equals_the_two_launches_bit_for_bit(case):
+    """fp32 engine: the RPN head rides in the F(4x4) output transform (wino43_output_head_kernel). Its output must be IDENTICAL to
+    the F(4x4) layer written out followed by the 1x1 head as a conv_igemm launch — the head's k chunks, sub-steps and MFMA order
+    are those of conv_igemm_kernel. Partial tiles (sizes not divisible by 4) and tile counts not divisible by 4 included."""
+    import os
+    from treedetection_amd import _lib
+    from tests.gpu_util import dev
+    B, Cin, H, W, n = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = np.maximum(rng.standard_normal((B, Cin, H, W), dtype=np.float32), -0.5)
+    w = rng.standard_normal((256, Cin, 3, 3), dtype=np.float32) / np.float32(np.sqrt(Cin * 9))
+    bias = rng.standard_normal(256).astype(np.float32)
+    hw = rng.standard_normal((n, 256, 1, 1), dtype=np.float32) / np.float32(16.0)
+    hb = rng.standard_normal(n).astype(np.float32)
+    lib = _lib.load()
+    xd, wd, bd = dev(x.transpose(0, 2, 3, 1)), dev(w.transpose(0, 2, 3, 1)), dev(bias)
+    hwd, hbd = dev(hw.reshape(n, 256)), dev(hb)
+    os.environ["TD_WINO_TILE"] = "4"
+    try:
+        y = torch.empty((B, H, W, 256), dtype=torch.float32, device="cuda")
+        _lib.check(lib.td_conv2d_winograd_nhwc(xd.data_ptr(), wd.data_ptr(), None, bd.data_ptr(), y.data_ptr(), B, H, W, Cin, 256, 1, _lib.stream_ptr()),
+                   "td_conv2d_winograd_nhwc")
+    finally:
+        del os.environ["TD_WINO_TILE"]
+    ref = conv2d_hip(y.cpu().numpy().transpose(0, 3, 1, 2), hw, bias=hb, precision=0, tile_cfg=3)
+    for _ in range(2):
+        got = torch.full((B, H, W, n), float("nan"), dtype=torch.float32, device="cuda")
+        _lib.check(lib.td_conv2d_winograd_head_nhwc(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), hwd.data_ptr(), hbd.data_ptr(), got.data_ptr(),
+                                                    B, H, W, Cin, n, _lib.stream_ptr()), "td_conv2d_winograd_head_nhwc")
+        torch.cuda.synchronize()
+        g = got.cpu().numpy().transpose(0, 3, 1, 2)
+        assert not np.isnan(g).any() and np.array_equal(g, ref), float(np.abs(g - ref).max())
+    assert np.abs(ref).max() > 0.5

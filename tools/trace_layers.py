@@ -62,7 +62,9 @@ def main(path, depth=50, fp32=False):
     import os
     min43 = int(os.environ.get("TD_WINO43_MIN", "12"))
     fam = ("conv_igemm", "conv_pp8", "plane_gemm", "wino_gemm", "wino_output", "wino_input", "wino43_input", "wino43_output", "bottleneck_tail", "conv_sk", "conv_bd")
-    rows = [r for r in csv.DictReader(open(path)) if any(f in r["Kernel_Name"] for f in fam)]
+    # launch order = start order on the one stream of the plain loop (the CSV itself is not written in that order)
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
+    rows = [r for r in rows if any(f in r["Kernel_Name"] for f in fam)]
     fuse_tail = int(os.environ.get("TD_FUSE_TAIL", "1"))
     fused_heads = set()
     if not fp32:
@@ -77,6 +79,11 @@ def main(path, depth=50, fp32=False):
             else:
                 fused_heads.add(l)
                 i -= 1
+    if fp32 and os.environ.get("TD_FUSE_HEAD", "1") != "0":
+        # fp32 engine: a fixed rule — every RPN level that takes the F(4x4) path carries its head in the output transform
+        hs = [800 >> (l + 2) for l in range(4)]
+        hs.append((hs[3] - 1) // 2 + 1)
+        fused_heads = {l for l in range(5) if min43 > 0 and hs[l] >= min43}
     L = schedule(depth, fp32=fp32, fuse_tail=fuse_tail, fused_heads=fused_heads)
     need = sum(launches_of(e[0], e[1], e[2], e[3], fp32, 8, min43)[0] for e in L)
     last = rows[-need:]

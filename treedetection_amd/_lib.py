@@ -70,6 +70,7 @@ SIGNATURES = {
     "td_conv2d_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
                        + [C.c_int] * 11 + [C.c_void_p]),
     "td_conv2d_head_nhwc": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 9 + [C.c_void_p]),
+    "td_conv2d_winograd_head_nhwc": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
     "td_conv2d_winograd_nhwc": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]),
     "td_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "td_roi_align": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int,

@@ -122,13 +122,28 @@ static td_status conv2d_api(ConvArgs& a, int precision, void* stream) {
     return conv2d_launch(a, precision & 0xff, static_cast<hipStream_t>(stream));
 }
 
+static td_status wino_api(const float* x, const float* w, const float* scale, const float* bias, float* y, int B, int H, int W, int Cin,
+                          int Cout, int relu, void* stream, const float* head_w, const float* head_b, float* head_y, int head_n);
+
 td_status td_conv2d_winograd_nhwc(const float* x, const float* w, const float* scale, const float* bias, float* y, int B, int H,
                                   int W, int Cin, int Cout, int relu, void* stream) {
-    TD_REQUIRE(x && w && y && B >= 1 && H >= 1 && W >= 1, "td_conv2d_winograd_nhwc: bad arguments");
+    TD_REQUIRE(y, "td_conv2d_winograd_nhwc: bad arguments");
+    return wino_api(x, w, scale, bias, y, B, H, W, Cin, Cout, relu, stream, nullptr, nullptr, nullptr, 0);
+}
+
+td_status td_conv2d_winograd_head_nhwc(const float* x, const float* w, const float* bias, const float* head_w, const float* head_b,
+                                       float* head_y, int B, int H, int W, int Cin, int head_n, void* stream) {
+    TD_REQUIRE(head_w && head_y && head_n >= 1 && head_n <= 32, "td_conv2d_winograd_head_nhwc: bad arguments");
+    return wino_api(x, w, nullptr, bias, nullptr, B, H, W, Cin, 256, 1, stream, head_w, head_b, head_y, head_n);
+}
+
+static td_status wino_api(const float* x, const float* w, const float* scale, const float* bias, float* y, int B, int H, int W, int Cin,
+                          int Cout, int relu, void* stream, const float* head_w, const float* head_b, float* head_y, int head_n) {
+    TD_REQUIRE(x && w && B >= 1 && H >= 1 && W >= 1, "td_conv2d_winograd_nhwc: bad arguments");
     TD_REQUIRE(Cin % 32 == 0 && Cout % 4 == 0, "td_conv2d_winograd_nhwc: Cin must be a multiple of 32, Cout of 4");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const char* tenv = getenv("TD_WINO_TILE");            // tests: 4 = the F(4x4,3x3) form the engine uses on the large maps
-    const bool f43 = tenv && atoi(tenv) == 4;
+    const bool f43 = head_w || (tenv && atoi(tenv) == 4);  // the head rides in the F(4x4) output transform only
     const int P = f43 ? 36 : 16;                          // transform planes
     const size_t T = f43 ? (size_t)B * ((H + 3) / 4) * ((W + 3) / 4) : (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
     std::vector<float> wh((size_t)Cout * 9 * Cin), uh((size_t)P * Cout * Cin);
@@ -161,7 +176,9 @@ td_status td_conv2d_winograd_nhwc(const float* x, const float* w, const float* s
             st = conv2d_launch(a, TD_PRECISION_FP32, s);
         }
     }
-    if (st == TD_OK)
+    if (st == TD_OK && head_w)
+        st = wino43_output_head_launch(static_cast<float*>(Mb), B, H, W, Cout, scale, bias, relu, head_w, head_b, head_y, head_n, s);
+    else if (st == TD_OK)
         st = f43 ? wino43_output_launch(static_cast<float*>(Mb), B, H, W, Cout, scale, bias, relu, y, nullptr, s)
                  : wino_output_launch(static_cast<float*>(Mb), B, H, W, Cout, scale, bias, relu, y, nullptr, 1, 0, (int)T, s);
     hipError_t herr = hipStreamSynchronize(s);

@@ -127,6 +127,10 @@ void wino_filter_transform(const float* w_ohwi, int N, int C, float* U);     // 
 td_status wino43_input_launch(const float* x, int B, int H, int W, int C, float* V, const int* m_dyn, hipStream_t s);
 td_status wino43_output_launch(const float* Mb, int B, int H, int W, int N, const float* scale, const float* bias, int relu,
                                float* y, const int* m_dyn, hipStream_t s);
+// the same for a 256-channel layer whose only consumer is a 1x1 head [head_n <= 32][256]: head_y [B*H*W][head_n] = y . head_w^T + head_b,
+// y itself is not written (bit-identical to wino43_output_launch followed by the head as a conv2d_launch of its own)
+td_status wino43_output_head_launch(const float* Mb, int B, int H, int W, int N, const float* scale, const float* bias, int relu,
+                                    const float* head_w, const float* head_b, float* head_y, int head_n, hipStream_t s);
 void wino43_filter_transform(const float* w_ohwi, int N, int C, float* U);   // host: U [36][N][C]
 
 // ---- stem / pooling / resize (stem.hip) ---------------------------------------------------------

@@ -933,7 +933,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
     // Winograd F(4x4,3x3) of a whole layer: x → V [36][T][cin] → 36 batched plane contractions → M → y. m_dyn = device-side
     // image count (the mask head's live RoIs): the planes keep the stride of the full batch, only the live tiles are computed.
     auto run_wino43 = [&](const ConvLayer& L, const void* x_, int B_, int H_, int W_, bool relu, void* y_, hipStream_t s_,
-                          const int* m_dyn, int gemm_cfg) -> td_status {
+                          const int* m_dyn, int gemm_cfg, const ConvLayer* head = nullptr, float* head_y = nullptr) -> td_status {
         const int tiles_img = ((H_ + 3) / 4) * ((W_ + 3) / 4);
         const long long T = (long long)B_ * tiles_img;
         td_status st2;
@@ -952,6 +952,18 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         a.tile_cfg = gemm_cfg;
         { ClassScope cs(e, s_, dyn ? TD_CLS_MASK_HEAD : TD_CLS_WINO_GEMM, dyn ? 0.0 : pf, dyn ? 0.0 : vb + ub + mb);
         if ((st2 = conv2d_launch(a, TD_PRECISION_FP32, s_)) < 0) return st2; }
+        if (head) {        // the 1x1 head contracted inside the output transform (wino43_output_head_kernel): y_ is not written
+            const double hflops = 2.0 * B_ * H_ * W_ * (double)head->cout * L.cout, hb = 4.0 * B_ * H_ * W_ * head->cout + 4.0 * head->cout * L.cout;
+            if (e->prof) {
+                e->prof_flops[0] += hflops;
+                e->prof_flops[8] += hflops;
+                e->prof_launches[0] += 1;          // two layers of the reference in one launch: "launches" keeps counting layers
+                e->prof_bytes[0] += hb + yb;       // the unfused pair's algorithmic bytes
+            }
+            ClassScope cs(e, s_, TD_CLS_WINO_XFORM, hflops, mb + hb);
+            return wino43_output_head_launch(e->wino_m, B_, H_, W_, L.cout, L.scale, L.bias, relu ? 1 : 0, static_cast<const float*>(head->w),
+                                             head->bias, head_y, head->cout, s_);
+        }
         ClassScope cs(e, s_, dyn ? TD_CLS_MASK_HEAD : TD_CLS_WINO_XFORM, 0.0, dyn ? 0.0 : mb + yb);
         return wino43_output_launch(e->wino_m, B_, H_, W_, L.cout, L.scale, L.bias, relu ? 1 : 0, static_cast<float*>(y_), m_dyn, s_);
     };
@@ -1030,7 +1042,14 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
             e->prof_flops[8] += use_43 ? flops * padded * 0.25 : (use_wino ? flops * 4.0 / 9.0 : flops);
             e->prof_launches[8] += use_wino ? 1 : 0;
         }
-        if (use_43) return run_wino43(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, wino_cfg);
+        if (use_43) {
+            // fp32 engine: the head rides in the F(4x4) output transform — a FIXED rule (layer shapes only), bit-identical to the
+            // separate launch anyway
+            const bool fuse43 = head && e->fuse_head && !m_dyn && relu && L.cout == 256 && head->cin == 256 && head->kh == 1 && head->kw == 1 &&
+                                head->cout <= 32 && !head->scale;
+            if (head_fused) *head_fused = fuse43;
+            return run_wino43(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, wino_cfg, fuse43 ? head : nullptr, fuse43 ? head_y : nullptr);
+        }
         if (use_wino) return run_wino(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, m_mul, wino_cfg);
         const int cls = m_dyn ? TD_CLS_MASK_HEAD : (H_ == 1 && W_ == 1 ? TD_CLS_FC : (L.kh == 1 && L.kw == 1 ? TD_CLS_CONV1X1 : TD_CLS_CONV3X3));
         // A 1x1 head contracted from the finished tile inside the same launch (the RPN's 15-row head after its 3x3 conv): only

@@ -278,6 +278,90 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
         }
     }
 }
+// The same output transform for a 256-channel layer whose ONLY consumer is a 1x1 head (the RPN's 3x3 conv and its 15-row
+// objectness / delta head): a block = 4 tiles x all 256 channels = 64 pixels, so the finished pixels go to LDS instead of
+// memory and two waves contract them with the head filters on the matrix cores — chunk by chunk of 32 channels, k-sub-steps
+// and MFMA order exactly as conv_igemm_kernel runs a 1x1 layer (bit-identical to the separate head launch on the stored
+// tensor). Only head_y [B*H*W][hn] is written: the layer's own output (327 MB per 8 tiles at p2) never exists.
+__global__ __launch_bounds__(256) void wino43_output_head_kernel(const float* __restrict__ Mb, int B, int H, int W,
+                                                                 const float* __restrict__ scale, const float* __restrict__ bias,
+                                                                 int relu, long long T, const float* __restrict__ head_w,
+                                                                 const float* __restrict__ head_b, float* __restrict__ head_y, int hn) {
+    constexpr int N = 256, RS = N + 4;                 // row stride: 4 banks of skew per pixel row (conflict-free 16-B fragment reads)
+    __shared__ __attribute__((aligned(16))) float tile[64 * RS];
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef float v16f __attribute__((ext_vector_type(16)));
+    const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;
+    const int lt = threadIdx.x >> 6, c = (threadIdx.x & 63) * 4;
+    const long long t = (long long)blockIdx.x * 4 + lt;
+    const bool live = t < T;
+    float4 s[4][6];
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float4 col[6], r[4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) col[i] = *reinterpret_cast<const float4*>(Mb + ((size_t)(6 * i + j) * T + t) * N + c);
+            wino43_at(col, r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i][j] = r[i];
+        }
+    }
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale) sc = *reinterpret_cast<const float4*>(scale + c);
+    if (bias) bi = *reinterpret_cast<const float4*>(bias + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float4 o[4];
+        if (live) wino43_at(s[i], o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);          // dead tiles / pixels past the map: rows nobody stores
+            if (live) {
+                v = o[j];
+                if (scale) v = make_float4(__fmul_rn(v.x, sc.x), __fmul_rn(v.y, sc.y), __fmul_rn(v.z, sc.z), __fmul_rn(v.w, sc.w));
+                if (bias) v = TD_ADD(v, bi);
+                if (relu) v = make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f, v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
+            }
+            *reinterpret_cast<float4*>(&tile[(lt * 16 + i * 4 + j) * RS + c]) = v;
+        }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave >= 2) return;                                  // two 32-pixel row tiles, one wave each (k stays in one accumulator chain)
+    const int col = lane & 31, hi4 = (lane >> 5) * 4;
+    const bool lcol = col < hn;
+    v16f acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* arow = &tile[(wave * 32 + col) * RS + hi4];
+    const float* brow = head_w + (size_t)(lcol ? col : 0) * N + hi4;
+#pragma unroll 2
+    for (int ch = 0; ch < N / 32; ++ch) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const v4f fa = *reinterpret_cast<const v4f*>(arow + ch * 32 + 8 * kk);
+            v4f fb = {0.f, 0.f, 0.f, 0.f};
+            if (lcol) fb = *reinterpret_cast<const v4f*>(brow + ch * 32 + 8 * kk);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc, 0, 0, 0);
+        }
+    }
+    if (!lcol) return;
+    const float hb = head_b ? head_b[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const long long tt = (long long)blockIdx.x * 4 + (row >> 4);
+        if (tt >= T) continue;
+        const unsigned tyx = (unsigned)(tt % (unsigned)(TW * TH));
+        const int b = (int)(tt / (unsigned)(TW * TH));
+        const int ty = (int)(tyx / (unsigned)TW), tx = (int)(tyx - (unsigned)ty * (unsigned)TW);
+        const int yy = 4 * ty + ((row >> 2) & 3), xx = 4 * tx + (row & 3);
+        if (yy >= H || xx >= W) continue;
+        head_y[(((size_t)b * H + yy) * W + xx) * hn + col] = head_b ? __fadd_rn(acc[r], hb) : acc[r];
+    }
+}
 #undef TD_SUB
 #undef TD_ADD
 #undef TD_MUL
@@ -338,6 +422,18 @@ td_status wino43_output_launch(const float* Mb, int B, int H, int W, int N, cons
     TD_REQUIRE(threads < (1ll << 31), "winograd F(4x4) output transform: grid too large");
     hipLaunchKernelGGL(wino43_output_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, Mb, B, H, W, N, scale, bias,
                        relu, y, T, m_dyn);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
+td_status wino43_output_head_launch(const float* Mb, int B, int H, int W, int N, const float* scale, const float* bias, int relu,
+                                    const float* head_w, const float* head_b, float* head_y, int head_n, hipStream_t s) {
+    TD_REQUIRE(Mb && head_w && head_y && B >= 1 && H >= 1 && W >= 1, "winograd F(4x4) output transform + head: bad arguments");
+    TD_REQUIRE(N == 256 && head_n >= 1 && head_n <= 32, "winograd F(4x4) output transform + head: 256 channels, at most 32 head rows (got %d, %d)", N, head_n);
+    const long long T = (long long)B * ((H + 3) / 4) * ((W + 3) / 4);
+    TD_REQUIRE((T + 3) / 4 < (1ll << 31), "winograd F(4x4) output transform + head: grid too large");
+    hipLaunchKernelGGL(wino43_output_head_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, s, Mb, B, H, W, scale, bias, relu, T,
+                       head_w, head_b, head_y, head_n);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
