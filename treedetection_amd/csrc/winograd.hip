@@ -287,12 +287,16 @@ __global__ __launch_bounds__(256) void wino43_output_head_kernel(const float* __
                                                                  const float* __restrict__ scale, const float* __restrict__ bias,
                                                                  int relu, long long T, const float* __restrict__ head_w,
                                                                  const float* __restrict__ head_b, float* __restrict__ head_y, int hn) {
-    constexpr int N = 256, RS = N + 4;                 // row stride: 4 banks of skew per pixel row (conflict-free 16-B fragment reads)
+    // The 64 x 256 tile passes through LDS in two halves of 128 channels (lanes 0-31 of a wave own channels 0-127, lanes 32-63
+    // the rest): 33 KB instead of 66 KB per block, four blocks per CU instead of two — the kernel is an HBM stream and needs
+    // the waves in flight. The head's accumulator chain runs over the halves in order, so k stays ascending.
+    constexpr int N = 256, NH = 128, RS = NH + 4;      // row stride: 4 banks of skew per pixel row (conflict-free 16-B fragment reads)
     __shared__ __attribute__((aligned(16))) float tile[64 * RS];
     typedef float v4f __attribute__((ext_vector_type(4)));
     typedef float v16f __attribute__((ext_vector_type(16)));
     const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;
     const int lt = threadIdx.x >> 6, c = (threadIdx.x & 63) * 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long t = (long long)blockIdx.x * 4 + lt;
     const bool live = t < T;
     float4 s[4][6];
@@ -310,6 +314,7 @@ __global__ __launch_bounds__(256) void wino43_output_head_kernel(const float* __
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
     if (scale) sc = *reinterpret_cast<const float4*>(scale + c);
     if (bias) bi = *reinterpret_cast<const float4*>(bias + c);
+    float4 px[4][4];                                       // this thread's 16 finished pixels x 4 channels
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float4 o[4];
@@ -323,31 +328,41 @@ __global__ __launch_bounds__(256) void wino43_output_head_kernel(const float* __
                 if (bias) v = TD_ADD(v, bi);
                 if (relu) v = make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f, v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
             }
-            *reinterpret_cast<float4*>(&tile[(lt * 16 + i * 4 + j) * RS + c]) = v;
+            px[i][j] = v;
         }
     }
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave >= 2) return;                                  // two 32-pixel row tiles, one wave each (k stays in one accumulator chain)
     const int col = lane & 31, hi4 = (lane >> 5) * 4;
     const bool lcol = col < hn;
     v16f acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* arow = &tile[(wave * 32 + col) * RS + hi4];
+    const float* arow = &tile[((wave & 1) * 32 + col) * RS + hi4];
     const float* brow = head_w + (size_t)(lcol ? col : 0) * N + hi4;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();                          // the first half's fragment reads are done
+        if ((c >= NH) == (half == 1)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&tile[(lt * 16 + i * 4 + j) * RS + (c - half * NH)]) = px[i][j];
+        }
+        __syncthreads();
+        if (wave < 2) {                                     // two 32-pixel row tiles, one wave each (k stays in one accumulator chain)
 #pragma unroll 2
-    for (int ch = 0; ch < N / 32; ++ch) {
+            for (int ch = 0; ch < NH / 32; ++ch) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const v4f fa = *reinterpret_cast<const v4f*>(arow + ch * 32 + 8 * kk);
-            v4f fb = {0.f, 0.f, 0.f, 0.f};
-            if (lcol) fb = *reinterpret_cast<const v4f*>(brow + ch * 32 + 8 * kk);
+                for (int kk = 0; kk < 4; ++kk) {
+                    const v4f fa = *reinterpret_cast<const v4f*>(arow + ch * 32 + 8 * kk);
+                    v4f fb = {0.f, 0.f, 0.f, 0.f};
+                    if (lcol) fb = *reinterpret_cast<const v4f*>(brow + half * NH + ch * 32 + 8 * kk);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc, 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc, 0, 0, 0);
+                }
+            }
         }
     }
-    if (!lcol) return;
+    if (wave >= 2 || !lcol) return;
     const float hb = head_b ? head_b[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
