@@ -544,3 +544,38 @@ def test_winograd_output_transform_with_fused_head_equals_the_two_launches_bit_f
         g = got.cpu().numpy().transpose(0, 3, 1, 2)
         assert not np.isnan(g).any() and np.array_equal(g, ref), float(np.abs(g - ref).max())
     assert np.abs(ref).max() > 0.5
+
+
+def test_engine_with_grouped_pyramid_launches_equals_engine_without_them():
+    """TD_GROUP_LEVELS=0: the FPN output convs and the RPN conv + head run level by level; the default (fp16 engine) runs each family
+    as ONE conv_pp8_kernel grid over the levels, laterals first. Every pyramid map, every RPN head output and the detections are
+    bit-identical (batch of 2, odd tile size → maps whose row counts are not multiples of the 256-row tile)."""
+    import os
+    from treedetection_amd.engine import Engine, INPUT_U8_HWC
+    from treedetection_amd.synth import make_tile
+    from treedetection_amd.weights import make_synthetic_state_dict
+    sd = make_synthetic_state_dict(50, seed=0)
+    tiles = [torch.from_numpy(make_tile(i, 650)[0]).cuda() for i in range(2)]
+    outs, named = [], []
+    for flag in ("1", "0"):
+        os.environ["TD_GROUP_LEVELS"] = flag
+        try:
+            eng = Engine(sd, device=0, precision="fp16")
+            images, hw_valid, hw_out = eng.preprocess_tiles_u8(tiles)
+            o = eng.alloc_outputs(2, 650, 650, paste=False)
+            eng.forward_raw(images, INPUT_U8_HWC, hw_valid, hw_out, o)
+            eng.forward_raw(images, INPUT_U8_HWC, hw_valid, hw_out, o)
+            torch.cuda.synchronize()
+            outs.append({k: v.cpu().numpy().copy() for k, v in o.items()})
+            named.append({nm: eng.tensor(nm).float().cpu().numpy().copy() for nm in ["p2", "p3", "p4", "p5", "p6"] + [f"rpn_head{l}" for l in range(2, 7)]})
+            eng.close()
+        finally:
+            os.environ.pop("TD_GROUP_LEVELS", None)
+    for nm in named[0]:
+        assert named[0][nm].shape == named[1][nm].shape and np.array_equal(named[0][nm], named[1][nm]), nm
+    a, b = outs
+    assert a["count"].sum() > 0 and np.array_equal(a["count"], b["count"])
+    for k in ("boxes", "scores", "mask_probs"):
+        for i in range(2):
+            n = int(a["count"][i])
+            assert np.array_equal(a[k][i][:n], b[k][i][:n]), k

@@ -4,7 +4,7 @@ import csv
 import sys
 
 
-def schedule(depth=50, B=8, Hp=800, Wp=800, P=1000, fp32=False, fuse_tail=True, fused_heads=()):
+def schedule(depth=50, B=8, Hp=800, Wp=800, P=1000, fp32=False, fuse_tail=True, fused_heads=(), grouped=False):
     blocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}[depth]
     mids, outs = (64, 128, 256, 512), (256, 512, 1024, 2048)
     L = []
@@ -27,10 +27,15 @@ def schedule(depth=50, B=8, Hp=800, Wp=800, P=1000, fp32=False, fuse_tail=True, 
     ws = [Wp >> (l + 2) for l in range(4)]
     for l in (3, 2, 1, 0):
         L.append((f"fpn_lateral{l+2}", B * hs[l] * ws[l], 256, outs[l]))
-        L.append((f"fpn_output{l+2}", B * hs[l] * ws[l], 256, 2304))
+        if not grouped:
+            L.append((f"fpn_output{l+2}", B * hs[l] * ws[l], 256, 2304))
     hs.append((hs[3] - 1) // 2 + 1)
     ws.append((ws[3] - 1) // 2 + 1)
-    for l in range(5):
+    if grouped:       # conv_pp8_kernel<_Float16, true>: one grid over the levels (fp16 engine)
+        L.append(("fpn_output p2-p5 (grouped)", B * sum(hs[l] * ws[l] for l in range(4)), 256, 2304))
+        Mr = B * sum(hs[l] * ws[l] for l in range(5))
+        L.append(("rpn_conv+head p2-p6 (grouped)", Mr, 256, 2304, 2.0 * Mr * 15 * 256 / 1e9))
+    for l in range(5 if not grouped else 0):
         if l in fused_heads:      # the head contracted inside the 3x3 conv's launch (ConvArgs::head_w): its FLOPs ride in the 5th field
             L.append((f"rpn_conv+head p{l+2}", B * hs[l] * ws[l], 256, 2304, 2.0 * B * hs[l] * ws[l] * 15 * 256 / 1e9))
         else:
@@ -67,7 +72,8 @@ def main(path, depth=50, fp32=False):
     rows = [r for r in rows if any(f in r["Kernel_Name"] for f in fam)]
     fuse_tail = int(os.environ.get("TD_FUSE_TAIL", "1"))
     fused_heads = set()
-    if not fp32:
+    grouped = any("conv_pp8_kernel" in r["Kernel_Name"] and ("Lb1" in r["Kernel_Name"] or ", true>" in r["Kernel_Name"]) for r in rows[-40:])
+    if not fp32 and not grouped:
         # which RPN levels ran with the head fused is the tuner's tile choice: read it off the trace, walking back from the
         # box head (fc1, fc2, box_pred, 4 mask convs, deconv = 8 launches): a level's last launch is either its head (an
         # fp16-in / fp32-out conv_igemm launch) or the fused 3x3 itself
@@ -84,7 +90,7 @@ def main(path, depth=50, fp32=False):
         hs = [800 >> (l + 2) for l in range(4)]
         hs.append((hs[3] - 1) // 2 + 1)
         fused_heads = {l for l in range(5) if min43 > 0 and hs[l] >= min43}
-    L = schedule(depth, fp32=fp32, fuse_tail=fuse_tail, fused_heads=fused_heads)
+    L = schedule(depth, fp32=fp32, fuse_tail=fuse_tail, fused_heads=fused_heads, grouped=grouped)
     need = sum(launches_of(e[0], e[1], e[2], e[3], fp32, 8, min43)[0] for e in L)
     last = rows[-need:]
     tot_f = tot_t = 0.0
@@ -100,7 +106,7 @@ def main(path, depth=50, fp32=False):
         kn = rs[0]["Kernel_Name"]
         if "conv2+3" in name:
             assert "bottleneck_tail" in kn, (name, kn)
-        kern = label if label else ("pp8" if "conv_pp8" in kn else "bottleneck_tail" if "bottleneck_tail" in kn else
+        kern = label if label else ("pp8 grouped" if "grouped" in name else "pp8" if "conv_pp8" in kn else "bottleneck_tail" if "bottleneck_tail" in kn else
                                     "conv_sk" if "conv_sk" in kn else ("conv_bd 64x256" if "Li2ELi2ELi4" in kn or "2, 2, 4" in kn else "conv_bd 64x128") if "conv_bd" in kn else
                                     "plane_gemm" + kn.split("plane_gemm_kernel")[1].split("(")[0][:12] if "plane_gemm" in kn else
                                     kn.split("conv_igemm_")[1].split("(")[0][:28])

@@ -70,6 +70,19 @@ struct ConvArgs {
     const float* head_b;
     float* head_y;
     int head_n;
+    // grouped launch over pyramid levels (conv_pp8_grouped_launch; fp16, 3x3 / stride 1 / pad 1, 256 -> 256): ONE grid whose tiles
+    // walk nlev independent problems of the same layer shape on different maps — the FPN's four output convs (own filters per
+    // level) or the RPN conv + head on p2..p6 (shared filters). Per level: input, filters, bias, output (or head output), map size.
+    int nlev;
+    struct Level {
+        const void* x;
+        const void* w;
+        const float* bias;
+        void* y;
+        float* head_y;
+        int H, W, M, tile0;       // M = B*H*W rows; tile0 = index of the level's first 256-row tile in the grid
+    } lev[5];
+    int ntiles;                   // tiles of all levels
 };
 // tile ids whose block owns 256 output channels at once (fp16): the head fusion above applies
 static inline bool conv_head_capable(int cfg, int precision) {
@@ -86,6 +99,10 @@ static inline bool conv_head_capable(int cfg, int precision) {
 #define TD_CONV_TILE_CFG_MAX 27
 static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17, 18, 19, 20, 23, 24, 25, 26, 27};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16, 18-20 only for plane contractions, 23-27 only with packed fp16 filters
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
+// a.nlev levels (x / w / bias / y / head_y / H / W filled in; M, tile0, ntiles are computed here) in one conv_pp8_kernel grid;
+// everything else (B, Cin, Cout = 256, KH = KW = 3, relu, head_w / head_b / head_n) from the common fields. Bit-identical to one
+// conv2d_launch per level on any tile.
+td_status conv_pp8_grouped_launch(ConvArgs a, hipStream_t stream);
 // stream-K form for the fp16 engine's small-map layers (conv_streamk.hip): variant 0 = 128 x 128 tiles / 4 waves / 512 resident
 // blocks, 1 = 256 x 128 / 8 waves / 256 blocks. a.sk_ws: conv_sk_workspace_floats() floats; a.sk_cnt: conv_sk_max_tiles() zeroed ints.
 // filter-direct form (conv_bdirect.hip)

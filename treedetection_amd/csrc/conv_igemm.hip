@@ -648,7 +648,7 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const ConvArgs a) {
 //     m - 2 — one barrier before the first wave reads it (RAW: counted vmcnt, then a barrier, then the read; WAR: a
 //     slot is re-filled at least two phases after its last read). vmcnt never drains to 0 inside the loop.
 // Rows / taps in the zero padding read beyond num_records and land as zeros, as in conv_igemm_kernel.
-template <typename TO>
+template <typename TO, bool GROUPED = false>
 __global__ __launch_bounds__(512) void conv_pp8_kernel(const ConvArgs a) {
     typedef _Float16 T;
     constexpr int MT = 4, NT = 2, WM = 2, WN = 4;
@@ -663,13 +663,33 @@ __global__ __launch_bounds__(512) void conv_pp8_kernel(const ConvArgs a) {
         md = md < 0 ? 0 : md;
         M = md < M ? md : M;
     }
-    const int tiles_n = (a.Cout + BN - 1) / BN;
-    const int tiles_m = (M + BM - 1) / BM;
-    const int nblk = tiles_m * tiles_n;
-    if ((int)blockIdx.x >= nblk) return;
-    const int pid = xcd_remap(blockIdx.x, nblk);
-    const int tm = pid / tiles_n, tn = pid - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    // the map this block works on: the launch's own, or (GROUPED) the pyramid level its tile index falls into
+    const void* xp = a.x;
+    const void* wp = a.w;
+    int mapH = a.H, mapW = a.W, mapHo = a.Ho, mapWo = a.Wo;
+    int lvl = 0, m0, n0;
+    if constexpr (GROUPED) {
+        if ((int)blockIdx.x >= a.ntiles) return;
+        const int pid = xcd_remap(blockIdx.x, a.ntiles);
+        while (lvl + 1 < a.nlev && pid >= a.lev[lvl + 1].tile0) ++lvl;
+        lvl = __builtin_amdgcn_readfirstlane(lvl);
+        xp = a.lev[lvl].x;
+        wp = a.lev[lvl].w;
+        mapH = mapHo = a.lev[lvl].H;
+        mapW = mapWo = a.lev[lvl].W;
+        M = a.lev[lvl].M;
+        m0 = (pid - a.lev[lvl].tile0) * BM;
+        n0 = 0;
+    } else {
+        const int tiles_n = (a.Cout + BN - 1) / BN;
+        const int tiles_m = (M + BM - 1) / BM;
+        const int nblk = tiles_m * tiles_n;
+        if ((int)blockIdx.x >= nblk) return;
+        const int pid = xcd_remap(blockIdx.x, nblk);
+        const int tm = pid / tiles_n, tn = pid - tm * tiles_n;
+        m0 = tm * BM;
+        n0 = tn * BN;
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -682,9 +702,9 @@ __global__ __launch_bounds__(512) void conv_pp8_kernel(const ConvArgs a) {
     const int nchunks = ntaps * cchunks;
     const unsigned pix_bytes = (unsigned)a.Cin * 2;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(a.x), 0, (int)((size_t)a.B * a.H * a.W * pix_bytes), 0x00020000);
+        const_cast<void*>(xp), 0, (int)((size_t)a.B * mapH * mapW * pix_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(a.w), 0, (int)((size_t)a.Cout * K * 2), 0x00020000);
+        const_cast<void*>(wp), 0, (int)((size_t)a.Cout * K * 2), 0x00020000);
     constexpr unsigned OOB = 0xfffffff0u;
 
     // ---- staged rows of this thread: 2 per pair (lane = 8 rows x 8 pieces of one DMA instruction) -----------------
@@ -705,16 +725,16 @@ __global__ __launch_bounds__(512) void conv_pp8_kernel(const ConvArgs a) {
         a_off[k] = 0;
         a_ok[k] = 0;
         if (m < M) {
-            const int hw = a.Ho * a.Wo;
+            const int hw = mapHo * mapWo;
             const int b = m / hw;
             const int rem = m - b * hw;
-            const int oy = rem / a.Wo;
-            const int ox = rem - oy * a.Wo;
+            const int oy = rem / mapWo;
+            const int ox = rem - oy * mapWo;
             const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-            a_off[k] = (unsigned)((b * a.H + iy0) * a.W + ix0) * pix_bytes + piece;
+            a_off[k] = (unsigned)((b * mapH + iy0) * mapW + ix0) * pix_bytes + piece;
             for (int ky = 0; ky < a.KH; ++ky)
                 for (int kx = 0; kx < a.KW; ++kx)
-                    if ((unsigned)(iy0 + ky) < (unsigned)a.H && (unsigned)(ix0 + kx) < (unsigned)a.W)
+                    if ((unsigned)(iy0 + ky) < (unsigned)mapH && (unsigned)(ix0 + kx) < (unsigned)mapW)
                         a_ok[k] |= 1u << (ky * a.KW + kx);
         }
         const int brow0 = (2 * i + (wave >> 2)) * 64 + hi * 32 + (wave & 3) * 8;
@@ -739,7 +759,7 @@ __global__ __launch_bounds__(512) void conv_pp8_kernel(const ConvArgs a) {
 #endif
         char* st = lds + ((dm >> 2) & 1) * STAGE;
         if constexpr (pr == 0 || pr == 3) {
-            const unsigned xs = (unsigned)(d_ky * a.W + d_kx) * pix_bytes + (unsigned)d_cc * CHUNK_BYTES;
+            const unsigned xs = (unsigned)(d_ky * mapW + d_kx) * pix_bytes + (unsigned)d_cc * CHUNK_BYTES;
             constexpr int k0 = pr == 0 ? 0 : 2;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -936,7 +956,17 @@ __global__ __launch_bounds__(512) void conv_pp8_kernel(const ConvArgs a) {
     if (keep == 12345.678f) static_cast<TO*>(a.y)[tid] = (TO)keep;
     return;
 #endif
-    conv_epilogue<T, TO, MT, NT, WM, WN, 1>(a, acc, lds, M, m0, n0, tid, lane, wm, wn);
+    if constexpr (GROUPED) {
+        ConvArgs ea = a;                                // this level's bias / output / head output
+        ea.bias = a.lev[lvl].bias;
+        ea.y = a.lev[lvl].y;
+        ea.head_y = a.lev[lvl].head_y;
+        ea.H = ea.Ho = mapH;
+        ea.W = ea.Wo = mapW;
+        conv_epilogue<T, TO, MT, NT, WM, WN, 1>(ea, acc, lds, M, m0, n0, tid, lane, wm, wn);
+    } else {
+        conv_epilogue<T, TO, MT, NT, WM, WN, 1>(a, acc, lds, M, m0, n0, tid, lane, wm, wn);
+    }
 }
 
 template <typename T, typename TO, int MT, int NT, int NSTAGE, int WM = 2, int WN = 2>
@@ -1025,6 +1055,32 @@ bool conv_plane_ok(const ConvArgs& a, int precision) {
            a.res_shift == 0 && !a.out_f32 && a.m_off == 0 && a.Cin >= 32 && a.Cin % 32 == 0 && a.M > 0 && a.Cout > 0 &&
            (a.batch_count <= 1 || !a.res) &&
            (size_t)a.M * a.Cin * 4 < 0xfffffff0ull - (1u << 20);
+}
+
+td_status conv_pp8_grouped_launch(ConvArgs a, hipStream_t stream) {
+    TD_REQUIRE(a.nlev >= 1 && a.nlev <= 5, "grouped conv: 1 to 5 levels (got %d)", a.nlev);
+    TD_REQUIRE(a.Cout == 256 && a.Cin % 64 == 0 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.res && a.out_mode == 0 && !a.m_dyn &&
+                   a.batch_count <= 1 && !a.scale && !a.out_f32,
+               "grouped conv: 3x3 / stride 1 / pad 1 layers to 256 channels with a bias only");
+    TD_REQUIRE(!a.head_w || (a.head_n >= 1 && a.head_n <= 32), "grouped conv: at most 32 head rows");
+    int tiles = 0;
+    for (int l = 0; l < a.nlev; ++l) {
+        ConvArgs::Level& L = a.lev[l];
+        TD_REQUIRE(L.x && L.w && L.H >= 1 && L.W >= 1 && (a.head_w ? L.head_y != nullptr : L.y != nullptr), "grouped conv: level %d is incomplete", l);
+        TD_REQUIRE((size_t)a.B * L.H * L.W * (size_t)a.Cin * 2 < 0xfffffff0ull - (1u << 20), "grouped conv: level %d input must stay below 4 GB", l);
+        L.M = a.B * L.H * L.W;
+        L.tile0 = tiles;
+        tiles += td_cdiv(L.M, 256);
+    }
+    a.ntiles = tiles;
+    a.H = a.Ho = a.lev[0].H;          // unused by the grouped kernel; kept coherent for error messages
+    a.W = a.Wo = a.lev[0].W;
+    a.M = a.lev[0].M;
+    a.x = a.lev[0].x;
+    a.w = a.lev[0].w;
+    hipLaunchKernelGGL((conv_pp8_kernel<_Float16, true>), dim3(tiles), dim3(512), 0, stream, a);
+    TD_KERNEL_CHECK();
+    return TD_OK;
 }
 
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream) {

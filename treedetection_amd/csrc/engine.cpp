@@ -127,6 +127,7 @@ struct td_engine {
     bool stream_k = false;
     float* sk_ws = nullptr;       // stream-K partial-tile slots / per-tile ticket counters (fp16 engine; reserve())
     int* sk_cnt = nullptr;
+    bool group_levels = true;     // TD_GROUP_LEVELS=0: the FPN output convs / the RPN conv + head as one launch per pyramid level (fp16 engine)
     bool fuse_head = true;        // TD_FUSE_HEAD=0: the RPN's 1x1 head as a launch of its own at every level (diagnostics, tests)
     bool fuse_tail = true;        // TD_FUSE_TAIL=0: conv2 / conv3 of res2 as two launches (diagnostics, tests); 2: fuse the fp16 engine's res3 too
     bool fuse_tail_fp16 = false;
@@ -480,6 +481,7 @@ td_status td_engine_create(const td_model_desc* desc, int device, td_engine** ou
     if (const char* ws = getenv("TD_WINO_SLAB")) e->wino_slab = atoi(ws);
     if (const char* wf = getenv("TD_WINO_FUSED")) e->wino_fused = atoi(wf) != 0;
     if (const char* fh = getenv("TD_FUSE_HEAD")) e->fuse_head = atoi(fh) != 0;
+    if (const char* gl = getenv("TD_GROUP_LEVELS")) e->group_levels = atoi(gl) != 0;
     if (const char* ft = getenv("TD_FUSE_TAIL")) { e->fuse_tail = atoi(ft) != 0; e->fuse_tail_fp16 = atoi(ft) == 2; }
     if (const char* sk = getenv("TD_STREAMK")) e->stream_k = atoi(sk) != 0;
     if (const char* skv = getenv("TD_STREAMK_VARIANT")) e->sk_variant = atoi(skv);
@@ -1074,6 +1076,36 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         ClassScope cs(e, s_, cls, m_dyn ? 0.0 : flops, m_dyn ? 0.0 : bytes);
         return run_conv_raw(L, x_, B_, H_, W_, stride, pad, relu, y_, res_, res_shift, s_, prec_, m_dyn, m_mul, out_mode, cfg);
     };
+    // The same 3x3 layer shape on several pyramid levels as ONE launch (conv_pp8_grouped_launch, fp16 engine): the FPN's output
+    // convs, the RPN conv with its head. The small levels (p4-p6: 79 / 20 / 6 tiles of 256 rows) cannot fill 256 CUs on their own;
+    // in one grid their tiles run beside the big levels' last wave. A fixed rule (layer shapes only); bit-identical per level.
+    auto groupable = [&](const ConvLayer& L) {
+        return L.kh == 3 && L.kw == 3 && L.cout == 256 && L.cin % 64 == 0 && !L.scale && L.bias && !L.out_f32;
+    };
+    auto run_grouped = [&](const ConvLayer* const* Ls, const void* const* xs, void* const* ys, float* const* head_ys, int nl, const int* Hs,
+                           const int* Ws, bool relu, const ConvLayer* head, hipStream_t s_) -> td_status {
+        ConvArgs a{};
+        a.B = B; a.Cin = Ls[0]->cin; a.Cout = 256; a.KH = a.KW = 3; a.stride = 1; a.pad = 1; a.relu = relu ? 1 : 0; a.m_mul = 1; a.nlev = nl;
+        a.tile_cfg = 17;
+        double flops = 0.0, bytes = 0.0, unfused_bytes = 0.0;
+        for (int l = 0; l < nl; ++l) {
+            a.lev[l].x = xs[l]; a.lev[l].w = Ls[l]->w; a.lev[l].bias = Ls[l]->bias;
+            a.lev[l].y = ys ? ys[l] : nullptr; a.lev[l].head_y = head_ys ? head_ys[l] : nullptr;
+            a.lev[l].H = Hs[l]; a.lev[l].W = Ws[l];
+            const double M = (double)B * Hs[l] * Ws[l], K = 9.0 * a.Cin;
+            flops += 2.0 * M * 256 * K + (head ? 2.0 * M * head->cout * 256 : 0.0);
+            bytes += 2.0 * (M * a.Cin + (head ? 0.0 : M * 256) + 256 * K) + (head ? 4.0 * M * head->cout + 2.0 * head->cout * 256 : 0.0);
+            unfused_bytes += head ? 2.0 * 2.0 * M * 256 : 0.0;          // the 256-channel map written and read back by a separate head
+        }
+        if (head) { a.head_w = head->w; a.head_b = head->bias; a.head_n = head->cout; }
+        ProfScope ps(e, s_, 0, flops, bytes + unfused_bytes);
+        if (e->prof) {
+            e->prof_flops[8] += flops;
+            e->prof_launches[0] += nl * (head ? 2 : 1) - 1;      // "launches" keeps counting the reference's layers
+        }
+        ClassScope cs(e, s_, TD_CLS_CONV3X3, flops, bytes);
+        return conv_pp8_grouped_launch(a, s_);
+    };
     // conv2 (3x3) → conv3 (1x1) + shortcut + ReLU of a bottleneck block as one launch (bottleneck_tail_kernel)
     auto run_tail = [&](const Block& blk, const void* t1_, int B_, int H_, int W_, void* y_, const void* shortcut_, hipStream_t s_) -> td_status {
         TailArgs a{};
@@ -1185,10 +1217,20 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
     // ---- FPN (top-down; the nearest-2x upsampled add rides in the lateral conv's epilogue) ---------------------
     {
     ProfScope fpn_group(e, s, 0, 0.0, 0.0, true);
+    // fp16: the four output convs do not depend on each other (only the lateral sums chain top-down), so the laterals run first
+    // and the outputs follow as one grouped launch
+    const bool group_fpn = prec == TD_PRECISION_FP16 && e->group_levels && groupable(e->fpn_out[0]) && groupable(e->fpn_out[1]) &&
+                           groupable(e->fpn_out[2]) && groupable(e->fpn_out[3]);
     for (int l = 3; l >= 0; --l) {
         const void* td_res = l == 3 ? nullptr : e->inner[l + 1];
         if ((st = run_conv(e->lateral[l], e->res[l], B, hs[l], wsz[l], 1, 0, false, e->inner[l], td_res, td_res ? 1 : 0, s, prec)) < 0) return st;
-        if ((st = run_conv(e->fpn_out[l], e->inner[l], B, hs[l], wsz[l], 1, 1, false, e->pfeat[l], nullptr, 0, s, prec)) < 0) return st;
+        if (!group_fpn && (st = run_conv(e->fpn_out[l], e->inner[l], B, hs[l], wsz[l], 1, 1, false, e->pfeat[l], nullptr, 0, s, prec)) < 0) return st;
+    }
+    if (group_fpn) {
+        const ConvLayer* Ls[4] = {&e->fpn_out[0], &e->fpn_out[1], &e->fpn_out[2], &e->fpn_out[3]};
+        const void* xs[4] = {e->inner[0], e->inner[1], e->inner[2], e->inner[3]};
+        void* ys[4] = {e->pfeat[0], e->pfeat[1], e->pfeat[2], e->pfeat[3]};
+        if ((st = run_grouped(Ls, xs, ys, nullptr, 4, hs, wsz, false, nullptr, s)) < 0) return st;
     }
     }
     { ProfScope ps(e, s, 2);
@@ -1200,7 +1242,20 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
     // ---- RPN -----------------------------------------------------------------------------------------------------
     {
         ProfScope rpn_group(e, s, 0, 0.0, 0.0, true);
+        const bool group_rpn = prec == TD_PRECISION_FP16 && e->group_levels && e->fuse_head && groupable(e->rpn_conv) && e->rpn_head.cin == 256 &&
+                               e->rpn_head.kh == 1 && e->rpn_head.kw == 1 && e->rpn_head.cout <= 32 && e->rpn_head.out_f32 && !e->rpn_head.scale;
+        if (group_rpn) {
+            const ConvLayer* Ls[5] = {&e->rpn_conv, &e->rpn_conv, &e->rpn_conv, &e->rpn_conv, &e->rpn_conv};
+            const void* xs[5] = {e->pfeat[0], e->pfeat[1], e->pfeat[2], e->pfeat[3], e->pfeat[4]};
+            float* hy[5] = {e->rpn_headbuf[0], e->rpn_headbuf[1], e->rpn_headbuf[2], e->rpn_headbuf[3], e->rpn_headbuf[4]};
+            if ((st = run_grouped(Ls, xs, nullptr, hy, 5, hs, wsz, true, &e->rpn_head, s)) < 0) return st;
+        }
         for (int l = 0; l < 5; ++l) {
+            if (group_rpn) {
+                const std::string nm = "rpn_head" + std::to_string(l + 2);
+                set_named(e, nm.c_str(), e->rpn_headbuf[l], B, hs[l], wsz[l], RPN_HEAD_C);
+                continue;
+            }
             bool fused = false;
             if ((st = run_conv(e->rpn_conv, e->pfeat[l], B, hs[l], wsz[l], 1, 1, true, e->rpn_t, nullptr, 0, s, prec, nullptr, 1, 0,
                                &e->rpn_head, e->rpn_headbuf[l], &fused)) < 0) return st;
