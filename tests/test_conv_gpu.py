@@ -112,10 +112,12 @@ PP8_CASES = [
 ]
 
 
+@pytest.mark.parametrize("cfg256", [17, 28])
 @pytest.mark.parametrize("case", PP8_CASES)
-def test_conv_pp8_equals_the_reference_tile_bit_for_bit(case):
-    """conv_pp8_kernel (cfg 17) keeps the k order of conv_igemm_kernel, so on the same fp16 inputs its output must be
-    IDENTICAL to the 128 x 128 tile's (cfg 0), which test_conv_fp16_matches_torch checks against torch."""
+def test_conv_pp8_equals_the_reference_tile_bit_for_bit(case, cfg256):
+    """conv_pp8_kernel (cfg 17: 8 waves, ping-pong phases) and conv_w4_kernel (cfg 28: 4 waves of 128 x 128, sub-steps pipelined
+    in registers) keep the k order of conv_igemm_kernel, so on the same fp16 inputs their output must be IDENTICAL to the
+    128 x 128 tile's (cfg 0), which test_conv_fp16_matches_torch checks against torch."""
     B, Cin, H, W, Cout, k, stride, pad, res, relu = case
     rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
     x = rng.standard_normal((B, Cin, H, W), dtype=np.float32)
@@ -131,7 +133,7 @@ def test_conv_pp8_equals_the_reference_tile_bit_for_bit(case):
     kw = dict(scale=scale, bias=bias, residual_nchw=r, res_shift=1 if res == 2 else 0, stride=stride, pad=pad, relu=relu, precision=1)
     ref = conv2d_hip(x, w, tile_cfg=0, **kw)
     for _ in range(3):                                  # a racy schedule would not repeat
-        got = conv2d_hip(x, w, tile_cfg=17, **kw)
+        got = conv2d_hip(x, w, tile_cfg=cfg256, **kw)
         assert got.shape == ref.shape and np.array_equal(got, ref)
     assert np.abs(ref).max() > 0.5
 
@@ -444,7 +446,7 @@ def test_conv_filter_direct_equals_the_reference_tile_bit_for_bit(case, cfg, pre
 
 
 # ---- fused 1x1 head (ConvArgs::head_w): the RPN's 3x3 conv + ReLU and its 15-row objectness / delta head in one launch ----
-@pytest.mark.parametrize("cfg", [9, 10, 12, 13, 17, 23, 27])
+@pytest.mark.parametrize("cfg", [9, 10, 12, 13, 17, 23, 27, 28])
 @pytest.mark.parametrize("case", [(2, 256, 50, 50, 3, 1, 15), (1, 256, 200, 200, 3, 1, 15), (8, 256, 13, 13, 3, 1, 15), (1, 64, 37, 21, 1, 0, 32),
                                   (3, 128, 25, 25, 3, 1, 6)])
 def test_conv_with_fused_head_equals_the_two_launches_bit_for_bit(case, cfg):

@@ -87,7 +87,7 @@ struct ConvArgs {
 // tile ids whose block owns 256 output channels at once (fp16): the head fusion above applies
 static inline bool conv_head_capable(int cfg, int precision) {
     // (the single-stage 256-wide tiles 14 / 16 stage their output as fp32 wave-rows, not as one fp16 tile: not capable)
-    return precision == TD_PRECISION_FP16 && (cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 17 || cfg == 23 || cfg == 27);
+    return precision == TD_PRECISION_FP16 && (cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 17 || cfg == 23 || cfg == 27 || cfg == 28);
 }
 // tile_cfg ids (conv_igemm.hip:dispatch): 0..3 4-wave tiles 128x128 / 128x64 / 64x128 / 64x64 (2 LDS stages), 4..7 the same
 // with 3 stages (measured no better: not tuned over), 8 = 256x128 / 9 = 128x256 (8 waves), 10 = 256x256 (16 waves),
@@ -95,14 +95,16 @@ static inline bool conv_head_capable(int cfg, int precision) {
 // 17 = conv_pp8_kernel: 256x256, 8 waves, ping-pong phases, DMA 1.5 k-chunks ahead (fp16 only),
 // 18..20 = plane_gemm_kernel: persistent 64x128 / 128x128 / 64x64 tile walk for the fp32 Winograd plane contractions,
 // 21 / 22 = conv_sk_kernel (stream-K, tests only through td_conv2d_nhwc), 23 / 24 / 25 / 26 / 27 = conv_bd_kernel: 64x256 / 64x128 / 64x128 with two k-chunks per barrier / 64x128 with three k-steps of loads in flight / 64x256 with two, filter fragments
-// straight from a fragment-ordered copy of the filters into registers (fp16 only, conv_bdirect.hip)
-#define TD_CONV_TILE_CFG_MAX 27
+// straight from a fragment-ordered copy of the filters into registers (conv_bdirect.hip), 28 = conv_w4_kernel: 256x256, 4 waves of 128x128,
+// k-sub-steps pipelined in registers, one barrier per chunk (fp16 only)
+#define TD_CONV_TILE_CFG_MAX 28
 static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17, 18, 19, 20, 23, 24, 25, 26, 27};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16, 18-20 only for plane contractions, 23-27 only with packed fp16 filters
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
 // a.nlev levels (x / w / bias / y / head_y / H / W filled in; M, tile0, ntiles are computed here) in one conv_pp8_kernel grid;
 // everything else (B, Cin, Cout = 256, KH = KW = 3, relu, head_w / head_b / head_n) from the common fields. Bit-identical to one
 // conv2d_launch per level on any tile.
 td_status conv_pp8_grouped_launch(ConvArgs a, hipStream_t stream);
+td_status conv_w4_launch(const ConvArgs& a, bool out_f32, hipStream_t stream);      // tile id 28 (conv_w4.hip)
 // stream-K form for the fp16 engine's small-map layers (conv_streamk.hip): variant 0 = 128 x 128 tiles / 4 waves / 512 resident
 // blocks, 1 = 256 x 128 / 8 waves / 256 blocks. a.sk_ws: conv_sk_workspace_floats() floats; a.sk_cnt: conv_sk_max_tiles() zeroed ints.
 // filter-direct form (conv_bdirect.hip)

@@ -1011,6 +1011,13 @@ td_status dispatch(const ConvArgs& a, int cfg, hipStream_t stream) {
                 td_set_error("conv2d: tile_cfg 17 is an fp16 kernel");
                 return TD_ERR_INVALID;
             }
+        case 28:                                                     // 256 x 256, 4 waves of 128 x 128, pipelined in the wave (fp16 only)
+            if constexpr (std::is_same<T, _Float16>::value) {
+                return conv_w4_launch(a, std::is_same<TO, float>::value, stream);
+            } else {
+                td_set_error("conv2d: tile_cfg 28 is an fp16 kernel");
+                return TD_ERR_INVALID;
+            }
         case 18:                                                     // persistent plane contractions (fp32 Winograd planes)
         case 19:
         case 20:
@@ -1098,7 +1105,9 @@ td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream) {
         const char* forced = getenv("TD_CONV_CFG");            // diagnostics / tests only (read per call: tests switch it)
         if (forced) cfg = atoi(forced);
     }
-    if (cfg == 17 && (precision != TD_PRECISION_FP16 || a.out_mode != 0 || a.batch_count > 1)) cfg = -1;      // fp16-only variant
+    const bool no_fp16_tile = precision != TD_PRECISION_FP16 || a.out_mode != 0 || a.batch_count > 1;
+    if (cfg == 17 && no_fp16_tile) cfg = -1;                       // fp16-only variant
+    if (cfg == 28 && (no_fp16_tile || a.m_dyn)) cfg = -1;          // fp16-only, static row counts only
     if (cfg >= 18 && cfg <= 20 && !conv_plane_ok(a, precision)) cfg = -1;                                       // plane contractions only
     if (cfg >= 23 && cfg <= 27 && !conv_bd_ok(a, precision)) cfg = -1;                                         // needs the fragment-ordered fp16 filters
     // a fused head (ConvArgs::head_w) exists only in the tiles that stage all 256 output channels as one fp16 tile: any other
