@@ -1,18 +1,20 @@
 """Does the matrix pipe run at its nominal clock under the fp16 contractions? Runs one conv launch shape in a loop for a few seconds
-and samples `rocm-smi` (sclk, power) meanwhile: python tools/clock_probe.py [tile id, default 17]."""
+and samples `rocm-smi` (sclk, power) meanwhile: python tools/clock_probe.py [tile id, default 17] [fp16|fp32]."""
 import os, subprocess, sys, threading, time
 sys.path.insert(0, ".")
 import torch
 from treedetection_amd import _lib
 
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 17
+fp32 = len(sys.argv) > 2 and sys.argv[2] == "fp32"
+dt_ = torch.float32 if fp32 else torch.float16
 lib = _lib.load()
 B, H, W, Cin, Cout = 8, 200, 200, 256, 256
-x = torch.randn(B, H, W, Cin, device="cuda").relu().half()
-w = (torch.randn(Cout, 3, 3, Cin, device="cuda") / (9 * Cin) ** 0.5).half()
-y = torch.empty(B, H, W, Cout, device="cuda", dtype=torch.half)
+x = torch.randn(B, H, W, Cin, device="cuda").relu().to(dt_)
+w = (torch.randn(Cout, 3, 3, Cin, device="cuda") / (9 * Cin) ** 0.5).to(dt_)
+y = torch.empty(B, H, W, Cout, device="cuda", dtype=dt_)
 bias = torch.zeros(Cout, device="cuda")
-args = (x.data_ptr(), w.data_ptr(), None, bias.data_ptr(), None, 0, y.data_ptr(), B, H, W, Cin, Cout, 3, 3, 1, 1, 1, 1 | ((cfg + 1) << 8), None)
+args = (x.data_ptr(), w.data_ptr(), None, bias.data_ptr(), None, 0, y.data_ptr(), B, H, W, Cin, Cout, 3, 3, 1, 1, 1, (0 if fp32 else 1) | ((cfg + 1) << 8), None)
 stop = False
 samples = []
 def poll():
