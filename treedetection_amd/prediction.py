@@ -217,7 +217,7 @@ class Predictor:
             os.environ["TD_TUNE_CACHE"] = _tune_cache_path(self.device_index)
         self.engine = Engine(sd, **eng_args)
         self._engines = [self.engine] + ([Engine(sd, **eng_args) for _ in range(2)] if self.pipeline else [])
-        workers = host_workers or max(2, min(16, len(os.sched_getaffinity(0)) - 2))
+        workers = host_workers or int(os.environ.get("TD_HOST_WORKERS", "0")) or max(2, min(16, len(os.sched_getaffinity(0)) - 2))
         self._pool = ThreadPoolExecutor(max_workers=workers)
         # buffer slots (pinned staging + outputs) in rotation: three per engine keep the fp16 engines fed while the host epilogue
         # of earlier batches still reads its slots (e2e fp16: 6 slots 1 410 tiles/s, 9 slots 1 531, 12 slots 1 502; fp32 unchanged)
