@@ -43,7 +43,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MATRIX_TFLOPS = 2500.0
-PMC_TAG = "r03" if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_conv_fp32.json")) else "r02"
+_PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+PMC_TAG = next((t for t in ("r04", "r03", "r02") if os.path.exists(os.path.join(_PROFILES, f"{t}_pmc_conv_fp32.json"))), "r02")
 HBM_ACHIEVABLE_TBS = 6.3            # MI355X_MICROARCH.md: measured streaming rate (8.0 TB/s spec)
 MASK_HEAD_GFLOP_PER_DET = 1.028
 SCHED = {"streams": "{n} engines, each a whole forward on its own HIP stream, batches round-robin (HBM-bound kernels and kernel tails of one "
@@ -66,6 +67,10 @@ def parse():
     ap.add_argument("--distinct", type=int, default=16, help="distinct seeds generated (cycled over the stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=16)   # ≈ 13 s of CPU work on 16 threads
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="every timed region lasts at least this long: the K-step block is repeated R times inside ONE timed region "
+                         "(barrier + synchronize on both sides of the R x K steps) and ms_per_step = seconds / (R x K); 0 = exactly K steps")
+    ap.add_argument("--detail", default=None, help="where the full (uncompacted) result goes; default bench_detail.json beside this script")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-fp16", action="store_true", help="skip the second timed region with the fp16 engine")
     ap.add_argument("--schedule", default="streams", choices=("streams", "phases", "plain"),
@@ -117,28 +122,140 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(sd, rgb_np, n_tiles):
+def cpu_baseline(sd, rgb_np, n_tiles, sd_r101=None):
     """The torch-CPU oracle (oracle/ = test infrastructure, used here only as the timed CPU baseline) on the first
-    n_tiles of the same stream: Pillow-restated resize + forward + paste, batch 1, all host cores."""
+    n_tiles of the same stream: Pillow-restated resize + forward + paste, all host cores. The object the driver reads is
+    R50 / batch 1 (`self.model([one tile])`, reference prediction.py:183 with max_batch_size 1); `extra` holds the other three
+    cells of SURVEY.md §8d's table — batch 8 (two batches of the same 16 tiles) and the reference's own depth R101 (8 tiles)
+    at batch 1 and 8 — timed in the same run on the same host."""
     from oracle import ops_ref as R
     from oracle.maskrcnn_ref import MaskRCNNOracle
 
     cores = host_cores()
     torch.set_num_threads(cores)
+
+    def timed(oracle, n, batch, tag):
+        t0 = time.perf_counter()
+        dets = 0
+        for k in range(0, n, batch):
+            inputs = []
+            for i in range(k, min(k + batch, n)):
+                img, h, w = R.preprocess_tile_u8(rgb_np[i % len(rgb_np)].transpose(2, 0, 1))
+                inputs.append({"image": img, "height": h, "width": w})
+            out = oracle.forward(inputs)
+            dets += sum(len(o["scores"]) for o in out)
+            log(f"cpu baseline {tag}: {min(k + batch, n)}/{n} tiles")
+        return n / (time.perf_counter() - t0), time.perf_counter() - t0, dets
+
     oracle = MaskRCNNOracle(sd)
     img, h, w = R.preprocess_tile_u8(rgb_np[0].transpose(2, 0, 1))
     oracle.forward([{"image": img, "height": h, "width": w}])          # warm-up (thread pools, allocator)
-    t0 = time.perf_counter()
-    dets = 0
-    for i in range(n_tiles):
-        img, h, w = R.preprocess_tile_u8(rgb_np[i % len(rgb_np)].transpose(2, 0, 1))
-        out = oracle.forward([{"image": img, "height": h, "width": w}])
-        dets += len(out[0]["scores"])
-        log(f"cpu baseline tile {i + 1}/{n_tiles}")
-    dt = time.perf_counter() - t0
-    return {"value": n_tiles / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"first {n_tiles} tiles of the same synthetic stream, batch 1, torch {torch.__version__} CPU fp32 "
-                      f"restatement (oracle/), resize+forward+paste, {dt:.1f} s, {dets} detections"}
+    v1, dt, dets = timed(oracle, n_tiles, 1, "R50 batch 1")
+    extra = {"r50_b1": v1}
+    if n_tiles >= 8:
+        extra["r50_b8"] = timed(oracle, n_tiles, 8, "R50 batch 8")[0]
+    if sd_r101 is not None and n_tiles >= 8:
+        o101 = MaskRCNNOracle(sd_r101)
+        n101 = max(8, n_tiles // 2)
+        extra["r101_b1"] = timed(o101, n101, 1, "R101 batch 1")[0]
+        extra["r101_b8"] = timed(o101, n101, 8, "R101 batch 8")[0]
+        extra["r101_tiles"] = n101
+    return {"value": v1, "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"first {n_tiles} tiles of the same stream, R50, batch 1, torch {torch.__version__} CPU fp32 oracle port "
+                      f"(resize+forward+paste), {dt:.1f} s, {dets} detections",
+            "extra": extra}
+
+
+def _r(x, n=4):
+    """Round a float to n significant digits (the compact line carries scalars, not noise digits)."""
+    if x is None or isinstance(x, (bool, int, str)):
+        return x
+    return float(f"{float(x):.{n}g}")
+
+
+COMPACT_LIMIT = 4096        # the driver keeps a bounded tail of stdout: the LAST line must fit with room to spare
+
+
+def compact_line(full):
+    """The ONE JSON object bench.py prints as its last stdout line, built from the full result dict (which goes to
+    bench_detail.json and stderr): the contract keys, the headline `roofline` and `cpu_baseline` objects, what the collective
+    layer saw, and one scalar per extra timed region. No prose beyond one short string per object; < COMPACT_LIMIT bytes."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    c = {k: (_r(full[k], 6) if isinstance(full.get(k), float) else full.get(k)) for k in keep}
+    cfg = full["config"]
+    c["config"] = {k: cfg.get(k) for k in ("workload", "depth", "batch_per_gpu", "tile", "net_input", "parallelism", "schedule",
+                                          "concurrent_forwards") if k in cfg}
+    c["timed_steps"] = full.get("timed_steps")
+    c["timed_seconds"] = _r(full.get("timed_seconds"))
+    rf = full.get("roofline")
+    if rf:
+        o = {k: (_r(rf.get(k), 5) if isinstance(rf.get(k), float) else rf.get(k)) for k in
+             ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch",
+              "executed_flops_per_launch", "kernel", "launches_per_step", "method")}
+        o["avg_launch_us"] = _r(rf.get("span", {}).get("avg_launch_us"))
+        o["effective_tflops"] = _r(rf.get("effective_tflops"))
+        o["hbm_gbytes_per_step"] = _r(rf.get("hbm_gbytes_per_step"))
+        ex = rf.get("exclusive")
+        if ex:
+            o["exclusive_frac"] = _r(ex["frac"])
+            o["exclusive_sol_frac"] = _r(ex["sol_frac"])
+            o["exclusive_ms_per_step"] = _r(ex["span_ms_per_step"])
+        c["roofline"] = o
+    cb = full.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                             "sample": cb["sample"][:200], "extra": {k: _r(v) for k, v in cb.get("extra", {}).items()}}
+    rk = full.get("ranks")
+    if rk:
+        c["ranks"] = {k: rk.get(k) for k in ("world", "backend", "devices", "distinct_gpus", "gather_bytes_per_step")}
+
+    def val(*path):
+        o = full
+        for k in path:
+            if not isinstance(o, dict) or k not in o:
+                return None
+            o = o[k]
+        return _r(o)
+
+    scal = {"fp16": val("fp16", "value"), "fp16_frac": val("fp16", "roofline", "frac"),
+            "fp16_exclusive_frac": val("fp16", "roofline", "exclusive", "frac"),
+            "fp16_batch32": val("fp16_batch32", "value"), "fp16_batch32_frac": val("fp16_batch32", "roofline", "frac"),
+            "r101_f32": val("r101", "f32", "value"), "r101_f32_frac": val("r101", "f32", "roofline", "frac"),
+            "r101_f16": val("r101", "f16", "value"), "r101_f16_frac": val("r101", "f16", "roofline", "frac"),
+            "single_stream": val("single_stream", "value"), "fp16_single_stream": val("fp16", "single_stream", "value"),
+            "phase_pipeline": val("phase_pipeline", "value"),
+            "two_model_f32": val("two_model", "f32", "value"), "two_model_f16": val("two_model", "f16", "value"),
+            "e2e_f32": val("e2e", "f32", "value"), "e2e_f32_ratio": val("e2e", "f32", "ratio_to_model_stage"),
+            "e2e_f16": val("e2e", "f16", "value"), "e2e_f16_ratio": val("e2e", "f16", "ratio_to_model_stage"),
+            "e2e_chained_f32": val("e2e", "f32", "chained", "value"), "e2e_chained_f32_ratio": val("e2e", "f32", "chained", "ratio_to_model_stage"),
+            "e2e_chained_f16": val("e2e", "f16", "chained", "value"), "e2e_chained_f16_ratio": val("e2e", "f16", "chained", "ratio_to_model_stage"),
+            "e2e_crowns_f32": val("e2e_crowns", "f32", "value"), "e2e_crowns_f32_ratio": val("e2e_crowns", "f32", "ratio_to_model_stage"),
+            "e2e_crowns_f16": val("e2e_crowns", "f16", "value"), "e2e_crowns_f16_ratio": val("e2e_crowns", "f16", "ratio_to_model_stage"),
+            "e2e_crowns_chained_f32_ratio": val("e2e_crowns", "f32", "chained", "ratio_to_model_stage"),
+            "e2e_crowns_chained_f16_ratio": val("e2e_crowns", "f16", "chained", "ratio_to_model_stage")}
+    c["regions"] = {k: v for k, v in scal.items() if v is not None}
+    c["regions_unit"] = "tiles/s (two_model: tile visits/s; *_frac: executed FLOPs / MFMA peak; *_ratio: e2e / model stage)"
+    c["detail"] = full.get("detail_file")
+    return c
+
+
+def emit(full, detail_path=None):
+    """Full result → detail file (+ stderr); compact line → stdout (the last line, alone). Returns the compact string."""
+    c = compact_line(full)
+    s = json.dumps(c, separators=(",", ":"))
+    assert len(s) < COMPACT_LIMIT, f"compact bench line is {len(s)} bytes (limit {COMPACT_LIMIT}): move something into the detail file"
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config"):
+        assert c.get(key) is not None, f"compact bench line lacks '{key}'"
+    if detail_path:
+        try:
+            with open(detail_path, "w") as f:
+                json.dump(full, f, indent=1)
+        except OSError as exc:
+            print(f"[bench] could not write {detail_path}: {exc}", file=sys.stderr)
+    print("[bench] full result: " + json.dumps(full), file=sys.stderr, flush=True)
+    print(s, flush=True)
+    return s
 
 
 def main():
@@ -188,8 +305,59 @@ def main():
 
     nsteps = args.steps      # the extra regions below re-bind sd / B / nsteps before calling run_pipelined again
 
-    def collect_profile(engs):
-        """Sum of the engines' per-category accumulators; "_classes" = the speed-of-light accounting by kernel class."""
+    repeats = {}       # region name -> R (how many K-step blocks its timed region held)
+
+    def measure(enqueue, n, engs, profile, name):
+        """The timed region: `enqueue(first, count)` enqueues steps [first, first + count). One K-step block is timed first
+        (it doubles as extra warm-up and tells how long K steps take); if that is shorter than --min-seconds the region proper
+        holds R blocks, R = ceil(min_seconds / block time) agreed over the ranks. Barrier + synchronize on both sides, one clock
+        around all R x K steps. → (seconds per K steps = region seconds / R, host enqueue seconds per K steps, R)."""
+        def region(first, count):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            enqueue(first, count)
+            t_enq = time.perf_counter() - t0          # host time to enqueue everything (launch-bound if close to dt)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, t_enq
+
+        R = 1
+        first = 0
+        if args.min_seconds > 0:
+            d1, _ = region(0, n)
+            first = n
+            t1 = torch.tensor([d1], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            if world > 1:
+                dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+            d1 = float(t1.item())
+            R = max(1, int(np.ceil(args.min_seconds / max(d1, 1e-6))))
+            if profile:
+                for e in engs:
+                    e.profile_read(reset=True)
+                    e.profile_classes(reset=True)
+        dtr, t_enq = region(first, n * R)
+        repeats[name] = R
+        return dtr / R, t_enq / R, R
+
+    def collect_profile(engs, R=1):
+        """Sum of the engines' per-category accumulators over the region, divided by its R blocks (so every figure downstream
+        is per K steps); "_classes" = the speed-of-light accounting by kernel class."""
+        prof = _collect_profile(engs)
+        if R > 1:
+            for k in prof:
+                for f in prof[k]:
+                    if isinstance(prof[k][f], dict):
+                        for g in prof[k][f]:
+                            prof[k][f][g] /= R
+                    else:
+                        prof[k][f] /= R
+        return prof
+
+    def _collect_profile(engs):
         prof = None
         for e in engs:
             p1 = e.profile_read(reset=True)
@@ -207,7 +375,7 @@ def main():
                             prof[k][f] += p1[k][f]
         return prof
 
-    def run(precision, ns, profile):
+    def run(precision, ns, profile, name=None):
         """Warm-up + timed region for one engine precision over `ns` engines / HIP streams → (seconds max over
         ranks, profile dict or None, detections)."""
         log(f"creating engine ({precision}, {ns} stream(s))")
@@ -244,20 +412,13 @@ def main():
                 e.profile_enable(profile)            # True / 2 (detail: an event pair per contraction launch)
                 e.profile_read(reset=True)
                 e.profile_classes(reset=True)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(nsteps):
-            step(args.warmup + i)
-        t_enq = time.perf_counter() - t0          # host time to enqueue everything (launch-bound if close to dt)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        log(f"timed region done ({precision}): {dt:.3f} s (host enqueue {t_enq:.3f} s)")
-        prof = collect_profile(engs) if profile else None
+
+        def enqueue(first, count):
+            for i in range(first, first + count):
+                step(args.warmup + i)
+        dt, t_enq, R = measure(enqueue, nsteps, engs, profile, name or precision)
+        log(f"timed region done ({precision}): {dt * R:.3f} s for {R} x {nsteps} steps (host enqueue {t_enq * R:.3f} s)")
+        prof = collect_profile(engs, R) if profile else None
         ndet = int(out["count"].sum().item())     # detections of one batch (for the mask-head FLOP estimate)
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         if world > 1:
@@ -266,7 +427,7 @@ def main():
             e.close()
         return float(tmax.item()), prof, ndet
 
-    def run_pipelined(precision, profile):
+    def run_pipelined(precision, profile, name=None):
         """Three engines, one main HIP stream and one side stream per engine: every tick enqueues, on the main stream,
         the trunk of batch t, the mask-head convs of batch t-2 and the box-head FCs of batch t-1 (contractions back to
         back, never overlapping each other), and on each batch's own side stream the selection phase that follows
@@ -359,19 +520,9 @@ def main():
                 e.profile_enable(True)
                 e.profile_read(reset=True)
                 e.profile_classes(reset=True)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_batches(nw, nw + nsteps)
-        t_enq = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        log(f"timed region done ({precision}, pipelined): {dt:.3f} s (host enqueue {t_enq:.3f} s)")
-        prof = collect_profile(engs) if profile else None
+        dt, t_enq, R = measure(lambda first, count: run_batches(nw + first, nw + first + count), nsteps, engs, profile, name or f"{precision}_phases")
+        log(f"timed region done ({precision}, pipelined): {dt * R:.3f} s for {R} x {nsteps} steps (host enqueue {t_enq * R:.3f} s)")
+        prof = collect_profile(engs, R) if profile else None
         ndet = int(outs[0]["count"].sum().item())
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         if world > 1:
@@ -410,17 +561,16 @@ def main():
 
         for m in sds:                                   # warm-up: the same passes once (tile choices of the full AND the tail batch shape)
             model_pass(m, visit[m])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for m in ("urban", "forest"):
-            model_pass(m, visit[m])
-        torch.cuda.synchronize()
-        dtm = time.perf_counter() - t0
+        def both(first, count):
+            for _ in range(count):
+                for m in ("urban", "forest"):
+                    model_pass(m, visit[m])
+        dtm, _, R = measure(both, 1, [e for m in sds for e in engs[m]], False, f"two_model_{precision}")
         dets = {m: int(outs[m][0]["count"].sum().item()) for m in sds}
         for m in sds:
             for e in engs[m]:
                 e.close()
-        log(f"two-model region done: {dtm:.3f} s")
+        log(f"two-model region done: {dtm * R:.3f} s for {R} x (urban pass + forest pass)")
         return dtm, len(visit["urban"]), len(visit["forest"]), n_tiles, dets
 
     def run_e2e(precisions, side):
@@ -506,37 +656,37 @@ def main():
     if "TD_TUNE_CACHE" not in os.environ:     # engines of one run share their measured block-tile choices
         import tempfile
         os.environ["TD_TUNE_CACHE"] = os.path.join(tempfile.mkdtemp(prefix="td_tune_"), f"tiles_rank{rank}.txt")
-    def go(precision, profile):
+    def go(precision, profile, name):
         if args.schedule == "phases":
-            return run_pipelined(precision, profile)
-        return run(precision, args.streams, profile)
+            return run_pipelined(precision, profile, name)
+        return run(precision, args.streams, profile, name)
 
-    dt, prof, ndet = go(args.precision, not args.no_profile)
+    dt, prof, ndet = go(args.precision, not args.no_profile, "headline")
     extra = piped = None
     if args.precision == "fp32" and not args.no_fp16:
-        extra = go("fp16", not args.no_profile)
+        extra = go("fp16", not args.no_profile, "fp16")
     if args.schedule != "plain" and not args.no_serial:
         # one forward at a time on one stream: the same kernels with nothing overlapping — the per-launch spans of THIS region
         # are the kernels' own durations (the `exclusive` roofline object)
-        piped = run(args.precision, 1, not args.no_profile)
+        piped = run(args.precision, 1, not args.no_profile, "single_stream")
     # speed-of-light class table: a short plain-loop region with one HIP-event pair per contraction launch (it perturbs the
     # forward, so it is a region of its own and nothing else is quoted from it); fp16: its own plain loop + table
     detail = detail16 = piped16 = None
     detail_steps = max(1, min(4, args.steps))
     if not args.no_serial and not args.no_profile and world == 1:
-        keep = nsteps
+        keep, keep_min = nsteps, args.min_seconds
         if extra is not None:
-            piped16 = run("fp16", 1, True)
-        nsteps = detail_steps
-        detail = run(args.precision, 1, 2)
+            piped16 = run("fp16", 1, True, "fp16_single_stream")
+        nsteps, args.min_seconds = detail_steps, 0.0      # an event pair per launch perturbs the forward: a short region of its own
+        detail = run(args.precision, 1, 2, "detail")
         if extra is not None:
-            detail16 = run("fp16", 1, 2)
-        nsteps = keep
+            detail16 = run("fp16", 1, 2, "fp16_detail")
+        nsteps, args.min_seconds = keep, keep_min
     phased = None
     if args.schedule == "streams" and not args.no_serial and world == 1:
         # informational: the phase pipeline — three batches in flight whose CONTRACTION kernels never overlap each other, so its
         # event spans are the kernels' own durations (the literal roofline of a schedule that still overlaps the selection work)
-        phased = run_pipelined(args.precision, not args.no_profile)
+        phased = run_pipelined(args.precision, not args.no_profile, "phase_pipeline")
     r101 = b32 = None
     if args.precision == "fp32" and args.depth == 50 and args.schedule != "plain" and world == 1:
         if not args.no_r101:
@@ -544,14 +694,14 @@ def main():
             log("generating R101 weights")
             sd = make_synthetic_state_dict(101, seed=0)
             nsteps = -(-max(4, args.steps // 2) // args.streams) * args.streams      # whole rounds of the engines (these regions choose their own K)
-            r101 = {"fp32": go("fp32", not args.no_profile) + (nsteps,)}
+            r101 = {"fp32": go("fp32", not args.no_profile, "r101_f32") + (nsteps,)}
             if not args.no_fp16:
-                r101["fp16"] = go("fp16", not args.no_profile) + (nsteps,)
+                r101["fp16"] = go("fp16", not args.no_profile, "r101_f16") + (nsteps,)
             sd = make_synthetic_state_dict(args.depth, seed=0)
         if not args.no_fp16 and not args.no_fp16_b32:
             # BASELINE configs[4]: the fp16 MFMA path at batch 32 per GPU (same tiles, four times the rows per launch)
             B, nsteps = 32, -(-max(4, args.steps // 4) // args.streams) * args.streams
-            b32 = go("fp16", not args.no_profile) + (nsteps,)
+            b32 = go("fp16", not args.no_profile, "fp16_batch32") + (nsteps,)
             B, nsteps = args.batch, args.steps
     two = e2e = None
     if args.depth == 50 and world == 1 and args.schedule == "streams":
@@ -593,7 +743,7 @@ def main():
                                    f"resize 800x800 + forward + paste on device, inputs resident in HBM",
                        "depth": args.depth, "batch_per_gpu": B, "tile": S, "net_input": "3x800x800",
                        "parallelism": f"tile-shard x{world} (replicated weights, RCCL gather of detections to rank 0)",
-                       "schedule": SCHED[args.schedule].format(n=args.streams),
+                       "schedule": f"{args.schedule} x{args.streams}", "schedule_note": SCHED[args.schedule].format(n=args.streams),
                        "concurrent_forwards": conc, "detections_last_batch": ndet},
         }
 
@@ -653,7 +803,7 @@ def main():
             wall = gflop / (1000.0 * dtx / k) if dtx > 0 else 0.0
             eff = wall if conc > 1 else literal
             ach = eff * exec_ratio
-            traffic, traffic_src = None, None
+            traffic, traffic_src, hbm_gb = None, None, None
             if pmc_name and os.path.exists(os.path.join(ROOT, "profiles", pmc_name)):
                 # HBM bytes per launch from the committed rocprofv3 --pmc passes of the plain-loop form of this command
                 # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_summary2.py) — counters cannot be read in here
@@ -661,6 +811,7 @@ def main():
                     pj = json.load(f)
                 # per launch of THIS object's launch count (one per layer; a Winograd layer's transform kernels belong to it)
                 traffic = pj["hbm_traffic_gb_per_step"] * 1e9 / max(cx["launches"] / k, 1.0)
+                hbm_gb = pj["hbm_traffic_gb_per_step"]
                 traffic_src = (f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; conv family: "
                                f"{pj['hbm_traffic_gb_per_step']:.2f} GB per step)")
             cls = profx["_classes"]
@@ -676,12 +827,15 @@ def main():
                  "algorithmic_bytes_per_launch": cx["bytes"] / max(cx["launches"], 1),
                  "algorithmic_flops_per_launch": cx["flops"] / max(cx["launches"], 1),
                  "executed_flops_per_launch": ex["flops"] / max(cx["launches"], 1),
-                 "kernel": "conv family: conv_igemm_kernel / conv_pp8_kernel / conv_sk_kernel / bottleneck_tail_kernel (all trunk / FPN / RPN / "
-                           "box-head contractions) + the Winograd transform kernels of the layers that take that path",
+                 "kernel": "conv family (all MFMA contraction kernels + Winograd transforms)",
+                 "kernel_detail": "conv_igemm_kernel / conv_pp8_kernel / conv_bd_kernel / bottleneck_tail_kernel / plane_gemm_kernel / wino43_fused_kernel "
+                                  "(all trunk / FPN / RPN / box-head contractions) + the Winograd transform kernels of the layers that take that path",
+                 "hbm_gbytes_per_step": hbm_gb,
                  "launches_per_step": cx["launches"] / k, "gflop_per_step": gflop, "executed_gflop_per_step": gflop * exec_ratio,
                  "algorithmic_gbytes_per_step": cx["bytes"] / k / 1e9,
-                 "method": ("wall: executed FLOPs per step / wall time per step (%d forwards overlap on %d HIP streams)" % (conc, conc))
-                           if conc > 1 else "span: executed FLOPs / summed HIP-event spans of the family (nothing overlaps)",
+                 "method": "wall" if conc > 1 else "span",
+                 "method_note": ("wall: executed FLOPs per step / wall time per step (%d forwards overlap on %d HIP streams)" % (conc, conc))
+                                if conc > 1 else "span: executed FLOPs / summed HIP-event spans of the family (nothing overlaps)",
                  "span": {"achieved": literal * exec_ratio, "frac": literal * exec_ratio / peak, "effective_tflops": literal,
                           "span_ms_per_step": span_ms,
                           "avg_launch_us": 1e3 * cx["ms"] / max(cx["launches"], 1), "concurrent_forwards": conc,
@@ -798,8 +952,17 @@ def main():
                 o["f32" if pk == "fp32" else "f16"] = r
             line["e2e"] = o
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd, rgb_np, args.cpu_tiles)
-        print(json.dumps(line), flush=True)
+            sd101 = None
+            if args.depth == 50 and not args.no_r101:
+                log("generating R101 weights for the CPU baseline")
+                sd101 = make_synthetic_state_dict(101, seed=0)
+            line["cpu_baseline"] = cpu_baseline(sd, rgb_np, args.cpu_tiles, sd101)
+        line["repeats"] = repeats
+        line["timed_steps"] = args.steps * repeats.get("headline", 1)
+        line["timed_seconds"] = dt * repeats.get("headline", 1)
+        detail_path = args.detail or os.path.join(ROOT, "bench_detail.json")
+        line["detail_file"] = os.path.basename(detail_path)
+        emit(line, detail_path)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

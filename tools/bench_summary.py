@@ -1,8 +1,12 @@
-"""One-line-per-region view of bench.py's JSON line (stdin)."""
+"""One-line-per-region view of bench.py's FULL result: python tools/bench_summary.py bench_detail.json (the detail file
+bench.py writes beside its compact stdout line), or the full JSON on stdin."""
 import json
 import sys
 
-j = json.loads(sys.stdin.read().strip().splitlines()[-1])
+if len(sys.argv) > 1:
+    j = json.load(open(sys.argv[1]))
+else:
+    j = json.loads(sys.stdin.read().strip().splitlines()[-1])
 
 
 def show(tag, o):
