@@ -145,3 +145,55 @@ def test_one_tile_per_model_matches_the_oracle(two_model, model, flag, folder):
     # the OTHER model never wrote this tile
     other = "forrest_predictions" if folder == "urban_predictions" else "urban_predictions"
     assert not os.path.exists(root / "output" / other / "1" / f"Prediction_{tile_id}.json")
+
+
+@pytest.fixture(scope="module")
+def two_model_fp16(two_model):
+    """The same two-model run through the fp16 engine (config key `precision: fp16`) into its own output folder — the flow
+    bench.py times as `two_model_f16`."""
+    import treedetection_amd as T
+    root, config, sds, meta = two_model
+    cfg = yaml.safe_load((root / "config.yml").read_text())
+    cfg["precision"] = "fp16"
+    cfg["output_directory"] = str(root / "output_fp16")
+    (root / "config_fp16.yml").write_text(yaml.safe_dump(cfg))
+    config16, _ = T.get_config(str(root / "config_fp16.yml"))
+    T.predict_tiles(config16)
+    return root, sds, meta
+
+
+@pytest.mark.parametrize("model,flag,folder", [("urban", "only_urban", "urban_predictions"), ("forest", "only_forest", "forrest_predictions")])
+def test_one_tile_per_model_matches_the_oracle_fp16(two_model_fp16, model, flag, folder):
+    """Two-model flow x fp16 (reference detection.py:154-164 with the fp16 MFMA engine): per model, a tile only THAT model
+    predicts — the fp16 engine with that model's weights against the fp32 oracle at the fp16 tolerances of
+    tests/test_engine_fp16_gpu.py, and the file predict_tiles(precision=fp16) wrote for it: one entry per contour of the
+    engine's own detections (same scores bit for bit), the other model never wrote it."""
+    from tests.test_engine_fp16_gpu import check_fp16_detections
+    from treedetection_amd.engine import Engine, INPUT_U8_HWC, unpack_outputs
+    root, sds, meta = two_model_fp16
+    tile_id = sorted(k for k, v in meta.items() if v[flag])[0]
+    td = meta[tile_id]
+    tif = str(root / "rgb" / "1.tif")
+    bands = GeoTiff(tif).read_bounds(td["bounds"])
+    x, h, w = R.preprocess_tile_u8(bands)
+    ref = MaskRCNNOracle(sds[model]).forward([{"image": x, "height": h, "width": w}])[0]
+    eng = Engine(sds[model], precision="fp16")
+    tile = torch.from_numpy(np.ascontiguousarray(bands[:3].transpose(1, 2, 0))).cuda()
+    batch, hv, ho = eng.preprocess_tiles_u8([tile])
+    out = eng.alloc_outputs(1, 1000, 1000, paste=True)
+    eng.forward_raw(batch, INPUT_U8_HWC, hv, ho, out)
+    torch.cuda.synchronize()
+    g = unpack_outputs(out, ho, True)[0]
+    eng.close()
+    check_fp16_detections([g], [ref], f"configs[2] {model} model, fp16")
+    got = json.load(open(root / "output_fp16" / folder / "1" / f"Prediction_{tile_id}.json"))
+    assert len(got) >= len(g["scores"]) * 0.5
+    eng_scores = {float(s) for s in g["scores"]}
+    assert {e["score"] for e in got} <= eng_scores               # every written entry belongs to a detection of the fp16 engine
+    for e in got:
+        assert e["image_id"] == tif and e["category_id"] == 0 and len(e["polygon_coords"][0]) >= 4
+    other = "forrest_predictions" if folder == "urban_predictions" else "urban_predictions"
+    assert not os.path.exists(root / "output_fp16" / other / "1" / f"Prediction_{tile_id}.json")
+    # the fp16 run visits exactly the tiles the fp32 run visits
+    for f in ("urban_predictions", "forrest_predictions"):
+        assert set(os.listdir(root / "output_fp16" / f / "1")) == set(os.listdir(root / "output" / f / "1"))

@@ -102,3 +102,36 @@ def test_process_files_binds_before_its_first_collective(monkeypatch, tmp_path):
     first_collective = min(i for i, k in enumerate(kinds) if k in ("barrier", "broadcast"))
     assert "set_device" in kinds[:first_collective], f.calls
     assert all(c[1] in (3, (3,)) for c in f.calls), f.calls
+
+
+def test_host_pools_are_sized_by_the_ranks_share_of_the_node(monkeypatch):
+    """epilogue workers / window readers were sized per rank from the whole node. With 8 ranks on a node the plan is
+    cores // 8 per rank (LOCAL_WORLD_SIZE; srun-style launches without it: the ranks that fit the node's GPUs)."""
+    import os
+    from treedetection_amd import prediction as P
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(128)))
+    FakeNccl(monkeypatch, rank=3, world=8, n_gpus=8, local_rank=3)
+    assert D.local_world() == 8 and D.single_node()
+    assert P.host_core_share() == 16
+    assert max(2, min(16, P.host_core_share() - 2)) == 14 and max(2, min(8, P.host_core_share() // 2)) == 8
+    # 16 ranks over two 8-GPU nodes, torchrun: 8 local ranks, not one node
+    FakeNccl(monkeypatch, rank=11, world=16, n_gpus=8, local_rank=3)
+    assert D.local_world() == 8 and not D.single_node() and P.host_core_share() == 16
+    # srun / mpirun: no LOCAL_WORLD_SIZE → the ranks that fit the node's GPUs; "one node" is NOT assumed
+    FakeNccl(monkeypatch, rank=11, world=16, n_gpus=8, local_rank=None)
+    assert D.local_world() == 8 and not D.single_node()
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(8)))
+    assert P.host_core_share() == 1                       # never zero
+    # single process: everything
+    monkeypatch.setattr(dist, "is_initialized", lambda: False)
+    assert D.local_world() == 1 and P.host_core_share() == 8
+
+
+def test_auto_epilogue_goes_local_only_where_rank0_can_read_the_files():
+    """"auto" resolved to "local" from 4 ranks on whatever the node layout; on several nodes without a shared output
+    folder rank 0 (which alone stitches) would never see the other nodes' tile files."""
+    from treedetection_amd.prediction import resolve_sharded_epilogue
+    assert resolve_sharded_epilogue(1) == "rank0" and resolve_sharded_epilogue(2) == "rank0"
+    assert resolve_sharded_epilogue(8, "fp16", shared_output=True) == "local"
+    assert resolve_sharded_epilogue(8, "fp16", shared_output=False) == "rank0"
+    assert resolve_sharded_epilogue(16, "fp32", shared_output=False) == "rank0"

@@ -103,6 +103,10 @@ def _fs_worker(rank, world, port, root, q):
         assert D.all_ok(True) is True
         assert D.all_ok(rank != 1) is False             # one rank's failure is everybody's
         assert D.broadcast_object({"x": rank}) == {"x": 0}
+        # "auto" epilogue: a folder every rank sees is proven shared (token file from rank 0); one that only rank 0 has is not
+        assert D.output_is_shared(os.path.join(root, "out_shared")) is True
+        assert not [f for f in os.listdir(os.path.join(root, "out_shared")) if f.startswith(".td_shared_")]
+        assert D.output_is_shared(os.path.join(root, f"out_private_rank{rank}")) is False
         # a failure on the writing rank surfaces on every rank (nobody is left waiting in a collective)
         bad = dict(config, image_directory=os.path.join(root, "empty"))
         try:

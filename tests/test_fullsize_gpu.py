@@ -377,3 +377,46 @@ def test_full_width_r101_tile_matches_oracle():
             assert torch.equal(o1[k][0], o8[k][i]), (i, k)
         assert _same_bits(o1, {k: v[i:i + 1] for k, v in o8.items()}), i
     eng.close()
+
+
+def test_full_width_r101_fp16_tile_matches_oracle():
+    """R101 x fp16 — the configuration bench.py times as `r101_f16` (the reference's depth, TreeDetection/config.py:25, through
+    the fp16 MFMA engine): 23 res4 blocks are where one fp16 rounding per layer would accumulate. Two full-width 1000x1000
+    tiles through resize → forward → paste against the fp32 oracle with the fp16 tolerances of tests/test_engine_fp16_gpu.py
+    (boxes <= 0.5 px, score rule, mask probabilities <= 3e-2, flips only near the cut, IoU rule), plus the batch the bench
+    runs (8) == batch-1 forwards bit for bit."""
+    from tests.test_engine_fp16_gpu import check_fp16_detections
+    from treedetection_amd.engine import Engine, INPUT_U8_HWC, unpack_outputs
+    torch.set_num_threads(8)
+    sd = make_synthetic_state_dict(101, seed=0)
+    tiles_np = [make_tile(3, 1000)[0], make_tile(61, 1000)[0]]
+    eng = Engine(sd, precision="fp16")
+    tiles = [torch.from_numpy(t).cuda() for t in tiles_np]
+    batch, hw_valid, hw_out = eng.preprocess_tiles_u8(tiles)
+    out = eng.alloc_outputs(2, 1000, 1000, paste=True)
+    eng.forward_raw(batch, INPUT_U8_HWC, hw_valid, hw_out, out)
+    torch.cuda.synchronize()
+    got = unpack_outputs(out, hw_out, True)
+    _invariants(got, hw_out)
+    oracle = MaskRCNNOracle(sd)
+    assert oracle.blocks == [3, 4, 23, 3]
+    ref = []
+    for t in tiles_np:
+        x, h, w = R.preprocess_tile_u8(t.transpose(2, 0, 1))
+        ref.append(oracle.forward([{"image": x, "height": h, "width": w}])[0])
+    assert all(len(r["scores"]) >= 5 for r in ref)
+    check_fp16_detections(got, ref, "R101 fp16 1000x1000")
+    tiles8 = tiles + [torch.from_numpy(make_tile(62 + i, 1000)[0]).cuda() for i in range(6)]
+    x8, hv8, ho8 = eng.preprocess_tiles_u8(tiles8)
+    o8 = eng.alloc_outputs(8, 1000, 1000, paste=True)
+    eng.forward_raw(x8.clone(), INPUT_U8_HWC, hv8, ho8, o8)
+    torch.cuda.synchronize()
+    for k in ("count", "boxes", "scores", "mask_probs", "mask_region"):
+        assert torch.equal(o8[k][:2], out[k][:2]), k
+    x1, hv1, ho1 = eng.preprocess_tiles_u8(tiles8[5:6])
+    o1 = eng.alloc_outputs(1, 1000, 1000, paste=True)
+    eng.forward_raw(x1.clone(), INPUT_U8_HWC, hv1, ho1, o1)
+    torch.cuda.synchronize()
+    for k in ("count", "boxes", "scores", "mask_probs", "mask_region"):
+        assert torch.equal(o1[k][0], o8[k][5]), k
+    eng.close()

@@ -349,3 +349,46 @@ def test_chained_images_equal_image_by_image_and_survive_a_bad_image(tmp_path):
         assert pred._free.qsize() == nslots
     assert chained == seq and sum(len(c) for c in chained) > 10
     assert read(tmp_path / "seq") == read(tmp_path / "chain")
+
+
+@pytest.mark.parametrize("mode", ["streams", "phases", "plain"])
+def test_launch_failures_do_not_leak_buffer_slots(tmp_path, mode):
+    """the buffer slots live in ONE free list for the Predictor's lifetime. A launch that fails after the launcher took
+    (batch, slot) from the reader has no epilogue task to return the slot — so the launcher must. The engine's forward is made to
+    fail for MORE images than there are slots (predict_on_model logs and walks on, reference detection.py:117-120); afterwards every
+    slot is back, no stand-in slot stays in the list, and a good image gives the same files as on a fresh predictor."""
+    import treedetection_amd as T
+    from treedetection_amd.preprocessing import tile_single_file
+    sd = make_synthetic_state_dict(50, seed=3, width_div=2)
+    rgb, _ = make_tile(320, 500)
+    tif = str(tmp_path / "0.tif")
+    write_geotiff(tif, np.ascontiguousarray(np.concatenate([rgb, rgb[..., 1:2]], axis=2).transpose(2, 0, 1)),
+                  (0.2, 0.0, 412000.0, 0.0, -0.2, 5318100.0), 25832)
+    tile_single_file(tif, str(tmp_path / "tiles"), buffer=10, tile_width=40, tile_height=40)
+    tj = str(tmp_path / "tiles" / "0.json")
+    cfg = T.setup_model_cfg(update_model="x", device="0")
+    kw = dict(pipeline=mode != "plain", schedule=mode if mode != "plain" else "streams")
+    with T.Predictor(cfg, device_type="0", max_batch_size=2, output_dir=str(tmp_path / "good"), state_dict=sd, **kw) as pred:
+        good = pred(tif, tj)
+    assert len(good) > 3
+    with T.Predictor(cfg, device_type="0", max_batch_size=2, output_dir=str(tmp_path / "out"), state_dict=sd, **kw) as pred:
+        nslots = pred._free.qsize()
+        calls = {"n": 0}
+
+        def boom(*a, **k):
+            calls["n"] += 1
+            raise RuntimeError("injected launch failure")
+        saved = [(e, e.forward_raw, e.forward_phase) for e in pred._engines]
+        for e in pred._engines:
+            e.forward_raw = boom
+            e.forward_phase = boom
+        for _ in range(nslots + 3):              # more failed images than slots
+            with pytest.raises(RuntimeError, match="injected launch failure"):
+                pred(tif, tj)
+        assert calls["n"] >= nslots + 3
+        for e, fr, fp in saved:
+            e.forward_raw, e.forward_phase = fr, fp
+        assert pred._free.qsize() == nslots
+        assert not any(s.transient for s in list(pred._free.queue))
+        assert pred(tif, tj) == good
+        assert pred._free.qsize() == nslots

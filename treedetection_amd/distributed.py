@@ -36,6 +36,57 @@ def barrier() -> None:
             dist.barrier()
 
 
+def single_node() -> bool:
+    """True when the launcher says every rank runs on THIS node (torch.distributed.run sets LOCAL_WORLD_SIZE); unknown
+    (srun / mpirun give the global rank only) counts as False."""
+    import os
+    if world() == 1:
+        return True
+    lws = os.environ.get("LOCAL_WORLD_SIZE")
+    return lws is not None and int(lws) == world()
+
+
+def local_world() -> int:
+    """Ranks that share this node's host cores: LOCAL_WORLD_SIZE where the launcher sets it, else the ranks that fit the
+    node's GPUs (srun / mpirun), 1 in a single process."""
+    import os
+    if world() == 1:
+        return 1
+    lws = os.environ.get("LOCAL_WORLD_SIZE")
+    if lws is not None:
+        return max(1, int(lws))
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    return max(1, min(world(), n) if n else world())
+
+
+def output_is_shared(folder: str) -> bool:
+    """Proof that rank 0 can read what any rank writes into ``folder``: rank 0 drops a token file, broadcasts its name,
+    every rank looks for it (collective: all ranks call it). True only if ALL ranks see the token."""
+    import os
+    import uuid
+    if world() == 1:
+        return True
+    name = None
+    if rank() == 0:
+        name = f".td_shared_{uuid.uuid4().hex}"
+        try:
+            os.makedirs(folder, exist_ok=True)
+            with open(os.path.join(folder, name), "w") as f:
+                f.write("x")
+        except OSError:
+            name = ""
+    name = broadcast_object(name, 0)
+    seen = bool(name) and os.path.exists(os.path.join(folder, name))
+    ok = all_ok(seen)              # an all-reduce: returns only after EVERY rank has looked
+    if rank() == 0 and name:
+        try:
+            os.remove(os.path.join(folder, name))
+        except OSError:
+            pass
+    barrier()                      # nobody goes on to list the folder before the token is gone
+    return ok
+
+
 def all_ok(ok: bool) -> bool:
     """True iff ``ok`` holds on EVERY rank (one tiny all-reduce; the collective calls of the sharded predictor only
     stay paired if all ranks take the same decision about an image or a round)."""

@@ -161,8 +161,18 @@ class _Slot:
 SHARDED_LOCAL_FROM_WORLD = 4
 
 
-def resolve_sharded_epilogue(world: int, precision: str = "fp32") -> str:
-    return "local" if world >= SHARDED_LOCAL_FROM_WORLD else "rank0"
+def host_core_share() -> int:
+    """Host cores this rank may plan with: the process's affinity mask divided by the ranks that share the node
+    (LOCAL_WORLD_SIZE; distributed.local_world). Single process: all of them."""
+    return max(1, len(os.sched_getaffinity(0)) // D.local_world())
+
+
+def resolve_sharded_epilogue(world: int, precision: str = "fp32", shared_output: bool = True) -> str:
+    """"auto" → who pastes / traces / writes the tile files. "local" (every rank writes the files of its own tiles) needs an
+    output folder that rank 0 — which alone stitches afterwards — can read: ``shared_output`` = all ranks on one node
+    (LOCAL_WORLD_SIZE == WORLD_SIZE) or the folder proven shared (distributed.output_is_shared); otherwise "rank0", whatever
+    the world size — on several nodes without a shared folder "local" would silently drop every other node's tiles."""
+    return "local" if world >= SHARDED_LOCAL_FROM_WORLD and shared_output else "rank0"
 
 
 class Predictor:
@@ -191,10 +201,16 @@ class Predictor:
         self.output_dir = output_dir
         self.exclude_vars = exclude_vars or []
         self.return_predictions = return_predictions
-        # borders followed on the GPU (td_trace_contours_dev); rank 0's gathered-batch epilogue uses the host tracer
-        self.device_contours = bool(device_contours) and (D.world() == 1 or sharded_epilogue == "local" or
-                                                          (sharded_epilogue == "auto" and resolve_sharded_epilogue(D.world(), precision) == "local"))
         os.makedirs(self.output_dir, exist_ok=True)
+        if sharded_epilogue not in ("rank0", "local", "auto"):
+            raise ValueError(f"sharded_epilogue must be 'rank0', 'local' or 'auto', got {sharded_epilogue!r}")
+        if sharded_epilogue == "auto":
+            # (collective when world >= 4 and the launcher did not say that all ranks share a node: every rank builds its
+            # Predictor with the same arguments, predict_on_model does)
+            shared = D.world() < SHARDED_LOCAL_FROM_WORLD or D.single_node() or D.output_is_shared(self.output_dir)
+            sharded_epilogue = resolve_sharded_epilogue(D.world(), precision, shared)
+        # borders followed on the GPU (td_trace_contours_dev); rank 0's gathered-batch epilogue uses the host tracer
+        self.device_contours = bool(device_contours) and (D.world() == 1 or sharded_epilogue == "local")
         sd = state_dict if state_dict is not None else load_checkpoint(cfg.MODEL.WEIGHTS)
         rh = cfg.MODEL.ROI_HEADS
         eng_args = dict(device=self.device_index, precision=precision, score_thresh=rh.SCORE_THRESH_TEST,
@@ -205,10 +221,6 @@ class Predictor:
         if schedule not in ("streams", "phases"):
             raise ValueError(f"schedule must be 'streams' or 'phases', got {schedule!r}")
         self.schedule = schedule
-        if sharded_epilogue not in ("rank0", "local", "auto"):
-            raise ValueError(f"sharded_epilogue must be 'rank0', 'local' or 'auto', got {sharded_epilogue!r}")
-        if sharded_epilogue == "auto":
-            sharded_epilogue = resolve_sharded_epilogue(D.world(), precision)
         self.sharded_epilogue = sharded_epilogue     # torch.distributed runs only: who pastes / traces / writes the tile files
         if "TD_TUNE_CACHE" not in os.environ:
             # Measured block-tile choices are shared between the engines of this process and kept for later runs (the
@@ -217,7 +229,9 @@ class Predictor:
             os.environ["TD_TUNE_CACHE"] = _tune_cache_path(self.device_index)
         self.engine = Engine(sd, **eng_args)
         self._engines = [self.engine] + ([Engine(sd, **eng_args) for _ in range(2)] if self.pipeline else [])
-        workers = host_workers or int(os.environ.get("TD_HOST_WORKERS", "0")) or max(2, min(16, len(os.sched_getaffinity(0)) - 2))
+        # host threads are sized by THIS rank's share of the node: cores // ranks on the node (8 ranks on a 128-core host get 16
+        # cores each, not 8 x 16 epilogue workers + 8 x 8 window readers on whatever the node has)
+        workers = host_workers or int(os.environ.get("TD_HOST_WORKERS", "0")) or max(2, min(16, host_core_share() - 2))
         self._pool = ThreadPoolExecutor(max_workers=workers)
         # buffer slots (pinned staging + outputs) in rotation: three per engine keep the fp16 engines fed while the host epilogue
         # of earlier batches still reads its slots (e2e fp16: 6 slots 1 410 tiles/s, 9 slots 1 531, 12 slots 1 502; fp32 unchanged)
@@ -356,7 +370,7 @@ class Predictor:
             if getattr(self, "_read_pool", None) is None:
                 # windows are copied row by row out of the page cache (td_read_window: ~3 us per 4 KB row on tmpfs), eight of them
                 # side by side: e2e fp16, 400 tiles — 2 threads 1 758 tiles/s (reader-bound), 4: 1 851, 8: 1 905
-                nthreads = int(os.environ.get("TD_READ_THREADS", "0")) or max(2, min(8, len(os.sched_getaffinity(0)) // 2))
+                nthreads = int(os.environ.get("TD_READ_THREADS", "0")) or max(2, min(8, host_core_share() // 2))
                 self._read_pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="td-window")
             results = list(self._read_pool.map(lambda k: self._process_tile(tiles[indices[k]], img, staging, offs[k]), range(len(indices))))
         else:
@@ -382,14 +396,20 @@ class Predictor:
     def _launch_batch(self, batch, slot: _Slot, pred_subdir, tifpath):
         """Forward + asynchronous copy of the packed results to pinned memory; the per-tile host epilogue is queued on
         the worker pool and waits on the slot's event, so this thread goes straight on to the next batch."""
-        images, fmt, hw_valid, hw_out = self._to_model_input(batch, slot)
-        dev_out = slot.outputs(self.engine, len(batch), max(h for h, _ in hw_out), max(w for _, w in hw_out), self.device_contours)
-        view = {k: v[: len(batch)] for k, v in dev_out.items()}     # leading-dim slices stay contiguous
-        self.engine.forward_raw(images, fmt, hw_valid, hw_out, view)
-        if self.device_contours:
-            self.engine.trace_contours(view, slot.dev_cont, len(batch))
-        slot.copy_results(len(batch), self.device_contours)
-        slot.event.record()
+        try:
+            images, fmt, hw_valid, hw_out = self._to_model_input(batch, slot)
+            dev_out = slot.outputs(self.engine, len(batch), max(h for h, _ in hw_out), max(w for _, w in hw_out), self.device_contours)
+            view = {k: v[: len(batch)] for k, v in dev_out.items()}     # leading-dim slices stay contiguous
+            self.engine.forward_raw(images, fmt, hw_valid, hw_out, view)
+            if self.device_contours:
+                self.engine.trace_contours(view, slot.dev_cont, len(batch))
+            slot.copy_results(len(batch), self.device_contours)
+            slot.event.record()
+        except BaseException:
+            # no epilogue task exists yet that would return the slot: the launcher does (the free list lives as long as the
+            # Predictor; predict_on_model logs the image's error and walks on, so a slot lost here would be lost for good)
+            self._give_back(slot, self._free)
+            raise
         slot.pending = len(batch)
         return [self._pool.submit(self._process_and_save_single, b, i, slot, pred_subdir, tifpath, self._free)
                 for i, b in enumerate(batch)]
@@ -441,11 +461,15 @@ class Predictor:
         """A batch's last phase is enqueued: packed results → pinned memory (on ``stream``), epilogue tasks queued."""
         batch, slot, eng = item["batch"], item["slot"], item["eng"]
         ctx = torch.cuda.stream(stream) if stream is not None else _null_ctx()
-        with ctx:
-            if self.device_contours:
-                eng.trace_contours({k: v[: len(batch)] for k, v in slot.dev_out.items()}, slot.dev_cont, len(batch))
-            slot.copy_results(len(batch), self.device_contours)
-            slot.event.record()
+        try:
+            with ctx:
+                if self.device_contours:
+                    eng.trace_contours({k: v[: len(batch)] for k, v in slot.dev_out.items()}, slot.dev_cont, len(batch))
+                slot.copy_results(len(batch), self.device_contours)
+                slot.event.record()
+        except BaseException:
+            self._give_back(slot, self._free)       # no epilogue task will: see _launch_batch
+            raise
         slot.pending = len(batch)
         futures.extend(self._pool.submit(self._process_and_save_single, b, i, slot, pred_subdir, tifpath, self._free)
                        for i, b in enumerate(batch))
@@ -510,6 +534,10 @@ class Predictor:
                         eng.forward_phase(phase + 1, slot.side)
                     except Exception as e:
                         if total_rounds is None:
+                            # single process: the image fails as a whole. Every batch still in the window holds a slot that
+                            # no epilogue task will return (finish() never ran for it) — hand them back before raising
+                            for it in window:
+                                self._give_back(it["slot"], self._free)
                             raise
                         item["failed"] = e       # sharded: the round still takes part in its gather, with no detections
                 item["phase"] = phase + 2
@@ -554,6 +582,7 @@ class Predictor:
                         eng.forward_raw(images, fmt, hw_valid, hw_out, view)
                 except Exception as e:
                     if total_rounds is None:
+                        self._give_back(slot, self._free)       # taken from `ready`, never handed to an epilogue task
                         raise
                     item["failed"] = e       # sharded: the round still takes part in its gather, with no detections
             finish(item)
@@ -590,6 +619,18 @@ class Predictor:
                 put_back(ready.get_nowait())
             except queue.Empty:
                 break
+        # a stand-in the reader did not consume must not stay in the lifetime free list: the next image would use it as a
+        # real slot (a full pinned + device buffer set for one use; under schedule="phases" it has no side stream)
+        kept = []
+        while True:
+            try:
+                sl = self._free.get_nowait()
+            except queue.Empty:
+                break
+            if not sl.transient:
+                kept.append(sl)
+        for sl in kept:
+            self._free.put(sl)
         for f in futures:
             try:
                 f.result()
