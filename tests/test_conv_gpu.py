@@ -112,11 +112,10 @@ PP8_CASES = [
 ]
 
 
-@pytest.mark.parametrize("cfg256", [17, 28])
+@pytest.mark.parametrize("cfg256", [17])
 @pytest.mark.parametrize("case", PP8_CASES)
 def test_conv_pp8_equals_the_reference_tile_bit_for_bit(case, cfg256):
-    """conv_pp8_kernel (cfg 17: 8 waves, ping-pong phases) and conv_w4_kernel (cfg 28: 4 waves of 128 x 128, sub-steps pipelined
-    in registers) keep the k order of conv_igemm_kernel, so on the same fp16 inputs their output must be IDENTICAL to the
+    """conv_pp8_kernel (cfg 17: 8 waves, ping-pong phases) keeps the k order of conv_igemm_kernel, so on the same fp16 inputs its output must be IDENTICAL to the
     128 x 128 tile's (cfg 0), which test_conv_fp16_matches_torch checks against torch."""
     B, Cin, H, W, Cout, k, stride, pad, res, relu = case
     rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
@@ -369,51 +368,14 @@ def test_engine_with_fused_tail_equals_engine_without_it():
                 assert np.array_equal(a[k], b[k]), (prec, k)
 
 
-# ---- stream-K form (conv_streamk.hip; the fp16 engine's small-map layers): tile_cfg 21 = 128 x 128, 22 = 256 x 128 ----
-SK_CASES = [
-    # B, Cin, H, W, Cout, k, stride, pad, res, relu
-    (8, 256, 50, 50, 256, 3, 1, 1, 0, True),          # res4 conv2 at BASELINE size: 36 k-steps, every resident block gets a range
-    (8, 512, 25, 25, 512, 3, 1, 1, 0, True),          # res5 conv2: 72 k-steps, 40 - 160 tiles on 256 - 512 blocks
-    (8, 2048, 25, 25, 512, 1, 1, 0, 0, True),         # res5 conv1
-    (8, 512, 25, 25, 2048, 1, 1, 0, 1, True),         # res5 conv3: residual + ReLU in the last arriver's epilogue
-    (8, 512, 100, 100, 1024, 1, 2, 0, 0, False),      # res4 shortcut: stride 2
-    (2, 256, 13, 13, 256, 3, 1, 1, 0, True),          # p6-sized map: fewer units than resident blocks
-    (1, 1024, 8, 10, 300, 1, 1, 0, 2, False),         # M and N tails, nearest-2x residual, one or two tiles
-]
-
-
-@pytest.mark.parametrize("cfg", [21, 22])
-@pytest.mark.parametrize("case", SK_CASES)
-def test_conv_streamk_matches_the_reference_tile(case, cfg):
-    """Stream-K cuts a tile's k range into pieces that different blocks sum and the last arriver adds in segment order: same
-    products, another association than the one-chain tiles — compared with the 128 x 128 reference tile (cfg 0, checked against
-    torch above) to fp32-accumulation noise BEFORE the fp16 rounding of the output (|diff| <= 1 fp16 ulp of the value, equal
-    almost everywhere), deterministic across repeats (a racy reduction would not repeat), counters back at zero after every
-    launch (the entry point launches twice)."""
-    B, Cin, H, W, Cout, k, stride, pad, res, relu = case
-    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
-    x = rng.standard_normal((B, Cin, H, W), dtype=np.float32)
-    w = rng.standard_normal((Cout, Cin, k, k), dtype=np.float32) / np.float32(np.sqrt(Cin * k * k))
-    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
-    bias = rng.standard_normal(Cout).astype(np.float32)
-    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    r = None
-    if res == 1:
-        r = rng.standard_normal((B, Cout, Ho, Wo), dtype=np.float32)
-    elif res == 2:
-        r = rng.standard_normal((B, Cout, Ho // 2, Wo // 2), dtype=np.float32)
-    kw = dict(scale=scale, bias=bias, residual_nchw=r, res_shift=1 if res == 2 else 0, stride=stride, pad=pad, relu=relu, precision=1)
-    ref = conv2d_hip(x, w, tile_cfg=0, **kw)
-    first = conv2d_hip(x, w, tile_cfg=cfg, **kw)
-    assert first.shape == ref.shape and np.isfinite(first).all()
-    # one fp16 ulp of the larger of the two values (a sum that lands on the other side of a rounding boundary or of a power
-    # of two), 1e-4 absolute for sums that the ReLU cuts at zero
-    ulp = np.spacing(np.maximum(np.abs(ref), np.abs(first)).astype(np.float16)).astype(np.float32)
-    assert (np.abs(first - ref) <= ulp + 1e-4).all(), float(np.abs(first - ref).max())
-    assert (first == ref).mean() >= 0.98
-    for _ in range(2):
-        assert np.array_equal(conv2d_hip(x, w, tile_cfg=cfg, **kw), first)
-    assert np.abs(ref).max() > 0.5
+def test_retired_tile_ids_are_refused():
+    """Stream-K (ids 21 / 22) and the 4-wave 256x256 tile (id 28) lost to the block tiles in round 3 and left the product library
+    (csrc/experimental/): the entry point says so instead of silently running another tile."""
+    x = np.zeros((1, 64, 8, 8), np.float32)
+    w = np.zeros((64, 64, 1, 1), np.float32)
+    for cfg in (21, 22, 28):
+        with pytest.raises(Exception, match="experiment"):
+            conv2d_hip(x, w, tile_cfg=cfg, precision=1)
 
 
 # ---- filter-direct tiles (conv_bdirect.hip): tile_cfg 23 = 64 x 256, 24 = 64 x 128; A through LDS-DMA, filter fragments from a
@@ -446,7 +408,7 @@ def test_conv_filter_direct_equals_the_reference_tile_bit_for_bit(case, cfg, pre
 
 
 # ---- fused 1x1 head (ConvArgs::head_w): the RPN's 3x3 conv + ReLU and its 15-row objectness / delta head in one launch ----
-@pytest.mark.parametrize("cfg", [9, 10, 12, 13, 17, 23, 27, 28])
+@pytest.mark.parametrize("cfg", [9, 10, 12, 13, 17, 23, 27])
 @pytest.mark.parametrize("case", [(2, 256, 50, 50, 3, 1, 15), (1, 256, 200, 200, 3, 1, 15), (8, 256, 13, 13, 3, 1, 15), (1, 64, 37, 21, 1, 0, 32),
                                   (3, 128, 25, 25, 3, 1, 6)])
 def test_conv_with_fused_head_equals_the_two_launches_bit_for_bit(case, cfg):

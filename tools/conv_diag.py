@@ -64,26 +64,6 @@ if __name__ == "__main__":
             bench(lib, prec, 8, 100, 100, 128, 512, 1, tag + " res3.conv3 128->512 +res", residual=True)
             bench(lib, prec, 8, 200, 200, 256, 256, 1, tag + " fpn_lateral2 256->256 +res", residual=True)
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "w4diag":
-        # where does conv_w4_kernel (cfg 28) spend its time? builds without its in-loop DMA / fragment reads / epilogue
-        os.environ["TD_CONV_CFG"] = "28"
-        variants = {"w4 product": [], "w4 no_dma": ["-DTD_DIAG_W4_NO_DMA"], "w4 no_reads": ["-DTD_DIAG_W4_NO_READS"],
-                    "w4 no_dma_no_reads": ["-DTD_DIAG_W4_NO_DMA", "-DTD_DIAG_W4_NO_READS"], "w4 no_epilogue": ["-DTD_DIAG_W4_NO_EPILOGUE"],
-                    "w4 loop_only": ["-DTD_DIAG_W4_NO_DMA", "-DTD_DIAG_W4_NO_READS", "-DTD_DIAG_W4_NO_EPILOGUE"]}
-        for tag, defs in variants.items():
-            lib = C.CDLL(build(tag.replace(" ", "_"), defs, src="conv_w4"))
-            bench(lib, 1, 8, 200, 200, 256, 256, 3, tag + " 3x3 256->256 M=320k")
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "w4":
-        # conv_w4_kernel (cfg 28) against conv_pp8_kernel (cfg 17) on the shapes they compete for (product build, random data)
-        lib = C.CDLL(os.path.join(ROOT, "treedetection_amd", "libtreedet_hip.so"))
-        for cfg in ("17", "28"):
-            os.environ["TD_CONV_CFG"] = cfg
-            bench(lib, 1, 8, 200, 200, 256, 256, 3, f"cfg{cfg} 3x3 256->256 M=320k")
-            bench(lib, 1, 8, 100, 100, 256, 256, 3, f"cfg{cfg} 3x3 256->256 M=80k")
-            bench(lib, 1, 8, 200, 200, 256, 256, 1, f"cfg{cfg} 1x1 256->256 M=320k")
-            bench(lib, 1, 8000, 1, 1, 12544, 1024, 1, f"cfg{cfg} fc1 M=8000")
-        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "pp8":
         # where does conv_pp8_kernel (cfg 17) spend its time? builds without its in-loop DMA / fragment reads / barriers
         os.environ["TD_CONV_CFG"] = "17"

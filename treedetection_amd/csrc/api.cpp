@@ -100,24 +100,10 @@ static td_status conv2d_api(ConvArgs& a, int precision, void* stream) {
         TD_HIP_CHECK(herr2);
         return TD_OK;
     }
-    if (a.tile_cfg == 21 || a.tile_cfg == 22) {
-        // tests: the stream-K form (conv_streamk.hip) with a scratch workspace of its own (the engine owns one per engine)
-        hipStream_t s = static_cast<hipStream_t>(stream);
-        void *ws = nullptr, *cnt = nullptr;
-        td_status st = scratch(&ws, conv_sk_workspace_floats() * sizeof(float));
-        if (st < 0) return st;
-        if ((st = scratch(&cnt, (size_t)conv_sk_max_tiles() * sizeof(int))) < 0) { (void)hipFree(ws); return st; }
-        hipError_t herr = hipMemsetAsync(cnt, 0, (size_t)conv_sk_max_tiles() * sizeof(int), s);
-        a.sk_ws = static_cast<float*>(ws);
-        a.sk_cnt = static_cast<int*>(cnt);
-        if (herr == hipSuccess) st = conv_sk_launch(a, precision & 0xff, a.tile_cfg - 21, s);
-        if (herr == hipSuccess && st == TD_OK) st = conv_sk_launch(a, precision & 0xff, a.tile_cfg - 21, s);     // twice: the counters must be back at zero
-        hipError_t herr2 = hipStreamSynchronize(s);
-        (void)hipFree(ws); (void)hipFree(cnt);
-        if (st < 0) return st;
-        TD_HIP_CHECK(herr);
-        TD_HIP_CHECK(herr2);
-        return TD_OK;
+    if (a.tile_cfg == 21 || a.tile_cfg == 22 || a.tile_cfg == 28) {
+        td_set_error("conv2d: tile_cfg %d (stream-K / 4-wave 256x256) is an experiment that lost to the block tiles; it lives in "
+                     "csrc/experimental/ and is not part of the product library", a.tile_cfg);
+        return TD_ERR_INVALID;
     }
     return conv2d_launch(a, precision & 0xff, static_cast<hipStream_t>(stream));
 }

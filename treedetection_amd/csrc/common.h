@@ -58,7 +58,7 @@ struct ConvArgs {
     int batch_count;
     long long x_bs, w_bs, y_bs;
     const void* w_frag;   // the same filters in MFMA fragment order (conv_bdirect.hip: tile ids 23 - 27), or nullptr
-    // stream-K launches (conv_streamk.hip): partial-tile slots and per-tile ticket counters (zero between launches)
+    // only read by csrc/experimental/conv_streamk.hip (not in the product library): partial-tile slots / ticket counters
     float* sk_ws;
     int* sk_cnt;
     int tile_cfg;         // -1 = heuristic; 0..3 = block tile 128x128, 128x64, 64x128, 64x64 with 2 LDS stages,
@@ -94,9 +94,9 @@ static inline bool conv_head_capable(int cfg, int precision) {
 // 11..13 = 256x256 with larger per-wave tiles, 14..16 = single-LDS-stage 256x256 / 128x128 / 128x256 (thin 1x1 layers),
 // 17 = conv_pp8_kernel: 256x256, 8 waves, ping-pong phases, DMA 1.5 k-chunks ahead (fp16 only),
 // 18..20 = plane_gemm_kernel: persistent 64x128 / 128x128 / 64x64 tile walk for the fp32 Winograd plane contractions,
-// 21 / 22 = conv_sk_kernel (stream-K, tests only through td_conv2d_nhwc), 23 / 24 / 25 / 26 / 27 = conv_bd_kernel: 64x256 / 64x128 / 64x128 with two k-chunks per barrier / 64x128 with three k-steps of loads in flight / 64x256 with two, filter fragments
-// straight from a fragment-ordered copy of the filters into registers (conv_bdirect.hip), 28 = conv_w4_kernel: 256x256, 4 waves of 128x128,
-// k-sub-steps pipelined in registers, one barrier per chunk (fp16 only)
+// 21 / 22 / 28 = retired ids (stream-K and the 4-wave 256x256 tile: measured slower in round 3, sources kept under csrc/experimental/, not built
+// into the product; conv2d_launch refuses them), 23 / 24 / 25 / 26 / 27 = conv_bd_kernel: 64x256 / 64x128 / 64x128 with two k-chunks per barrier / 64x128 with three k-steps of loads in flight / 64x256 with two, filter fragments
+// straight from a fragment-ordered copy of the filters into registers (conv_bdirect.hip)
 #define TD_CONV_TILE_CFG_MAX 28
 static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17, 18, 19, 20, 23, 24, 25, 26, 27};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16, 18-20 only for plane contractions, 23-27 only with packed fp16 filters
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
@@ -104,17 +104,10 @@ td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
 // everything else (B, Cin, Cout = 256, KH = KW = 3, relu, head_w / head_b / head_n) from the common fields. Bit-identical to one
 // conv2d_launch per level on any tile.
 td_status conv_pp8_grouped_launch(ConvArgs a, hipStream_t stream);
-td_status conv_w4_launch(const ConvArgs& a, bool out_f32, hipStream_t stream);      // tile id 28 (conv_w4.hip)
-// stream-K form for the fp16 engine's small-map layers (conv_streamk.hip): variant 0 = 128 x 128 tiles / 4 waves / 512 resident
-// blocks, 1 = 256 x 128 / 8 waves / 256 blocks. a.sk_ws: conv_sk_workspace_floats() floats; a.sk_cnt: conv_sk_max_tiles() zeroed ints.
 // filter-direct form (conv_bdirect.hip)
 void conv_bd_pack(const void* w_ohwi, int elem_bytes, int cout, int kh, int kw, int cin, std::vector<unsigned char>& out);
 bool conv_bd_ok(const ConvArgs& a, int precision);
 td_status conv_bd_launch(const ConvArgs& a, int precision, int variant, hipStream_t stream);
-int conv_sk_grid(int bm, int bn);
-size_t conv_sk_workspace_floats(void);
-int conv_sk_max_tiles(void);
-td_status conv_sk_launch(const ConvArgs& a, int precision, int variant, hipStream_t stream);
 bool conv_plane_ok(const ConvArgs& a, int precision);       // tile ids 18-20 apply to this launch
 td_status wino_gemm_launch(const ConvArgs& a, hipStream_t stream);     // Winograd plane contractions, input transform fused (fp32)
 

@@ -1011,13 +1011,6 @@ td_status dispatch(const ConvArgs& a, int cfg, hipStream_t stream) {
                 td_set_error("conv2d: tile_cfg 17 is an fp16 kernel");
                 return TD_ERR_INVALID;
             }
-        case 28:                                                     // 256 x 256, 4 waves of 128 x 128, pipelined in the wave (fp16 only)
-            if constexpr (std::is_same<T, _Float16>::value) {
-                return conv_w4_launch(a, std::is_same<TO, float>::value, stream);
-            } else {
-                td_set_error("conv2d: tile_cfg 28 is an fp16 kernel");
-                return TD_ERR_INVALID;
-            }
         case 18:                                                     // persistent plane contractions (fp32 Winograd planes)
         case 19:
         case 20:

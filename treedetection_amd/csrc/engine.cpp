@@ -118,15 +118,6 @@ struct td_engine {
     bool winograd = true;         // TD_WINOGRAD=0 disables the Winograd path (diagnostics)
     float *wino_v = nullptr, *wino_m = nullptr;
     size_t wino_elems = 0;
-    int sk_variant = -1;          // TD_STREAMK_VARIANT: force 0 (128 x 128) / 1 (256 x 128) everywhere the rule applies (experiments)
-    // TD_STREAMK=1: the fp16 engine's small-map layers through conv_sk_kernel. OFF by default — measured (round 3, plain loop,
-    // batch 8, profiles/r03_streamk_layers.txt): with write-through slab stores the layers the rule takes sum to 1 588 us against
-    // 1 218 us for the measured block tiles (res4 conv2 38 -> 52 us, res4 conv1 22 -> 34; only res5 conv2 gains, 56 -> 51); the
-    // first hand-off form (agent-scope release / acquire) was slower still (2 154 us). A block's partial-tile publish, the last
-    // arriver's slab reads and the per-segment prologue cost more than the evener k-step distribution saves.
-    bool stream_k = false;
-    float* sk_ws = nullptr;       // stream-K partial-tile slots / per-tile ticket counters (fp16 engine; reserve())
-    int* sk_cnt = nullptr;
     bool group_levels = true;     // TD_GROUP_LEVELS=0: the FPN output convs / the RPN conv + head as one launch per pyramid level (fp16 engine)
     bool fuse_head = true;        // TD_FUSE_HEAD=0: the RPN's 1x1 head as a launch of its own at every level (diagnostics, tests)
     bool fuse_tail = true;        // TD_FUSE_TAIL=0: conv2 / conv3 of res2 as two launches (diagnostics, tests); 2: fuse the fp16 engine's res3 too
@@ -483,8 +474,6 @@ td_status td_engine_create(const td_model_desc* desc, int device, td_engine** ou
     if (const char* fh = getenv("TD_FUSE_HEAD")) e->fuse_head = atoi(fh) != 0;
     if (const char* gl = getenv("TD_GROUP_LEVELS")) e->group_levels = atoi(gl) != 0;
     if (const char* ft = getenv("TD_FUSE_TAIL")) { e->fuse_tail = atoi(ft) != 0; e->fuse_tail_fp16 = atoi(ft) == 2; }
-    if (const char* sk = getenv("TD_STREAMK")) e->stream_k = atoi(sk) != 0;
-    if (const char* skv = getenv("TD_STREAMK_VARIANT")) e->sk_variant = atoi(skv);
     if (const char* w4 = getenv("TD_WINO43_MIN")) e->wino43_min = atoi(w4);
     if (const char* wc = getenv("TD_WINO_MINC")) e->wino_minc = atoi(wc);
     e->desc = d;
@@ -774,13 +763,6 @@ td_status td_engine_reserve(td_engine* e, int B, int Hp, int Wp) {
     if ((st = A(&e->o_classes, b * D)) < 0) return st;
     if ((st = A(&e->o_count, b)) < 0) return st;
     if ((st = A(&e->o_mask_probs, mrows * 784)) < 0) return st;
-    e->sk_ws = nullptr;
-    e->sk_cnt = nullptr;
-    if (e->desc.precision == TD_PRECISION_FP16 && e->stream_k) {
-        if ((st = A(&e->sk_ws, conv_sk_workspace_floats())) < 0) return st;
-        if ((st = A(&e->sk_cnt, (size_t)conv_sk_max_tiles())) < 0) return st;
-        TD_HIP_CHECK(hipMemset(e->sk_cnt, 0, (size_t)conv_sk_max_tiles() * sizeof(int)));     // every launch leaves them at zero again
-    }
     e->wino_v = e->wino_m = nullptr;
     e->wino_elems = 0;
     if (e->desc.precision == TD_PRECISION_FP32 && e->winograd) {
@@ -843,8 +825,9 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         return TD_OK;
     };
     // measured block tile of one launch shape (cached per engine, shared through the TD_TUNE_CACHE file)
-    bool bd_ok = false;        // set by run_conv for the launch being tuned (fp16 layer with packed filters, plain output)
-    auto tuned_cfg = [&](const std::tuple<int, int, int, int, int>& key, int prec_, int ksteps, bool pp8_ok, bool plane_ok, hipStream_t s_,
+    // bd_ok: the launch being tuned has a fragment-ordered filter copy and a plain output (filter-direct tiles 23-27); the
+    // Winograd plane contractions pass false (their ConvArgs carry no w_frag: conv2d_launch would remap the id to the heuristic tile)
+    auto tuned_cfg = [&](const std::tuple<int, int, int, int, int>& key, int prec_, int ksteps, bool pp8_ok, bool plane_ok, bool bd_ok, hipStream_t s_,
                          auto&& launch_cfg, int* cfg_out, float* best_ms) -> td_status {
         static const int forced = getenv("TD_FORCE_CFG") ? atoi(getenv("TD_FORCE_CFG")) : -1;      // diagnostics: one block tile everywhere it applies
         if (forced >= 0 && forced <= TD_CONV_TILE_CFG_MAX && !best_ms && !(forced >= 14 && forced <= 16 && ksteps > 4) && !(forced == 17 && !pp8_ok) &&
@@ -874,7 +857,11 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
             if (c >= 23 && c <= 27 && !bd_ok) continue;         // filter-direct tiles: fp16 layers with a fragment-ordered filter copy
             float ms = 1e30f;
             td_status st2 = time_launch(s_, ea, eb, [&]() { return launch_cfg(c); }, &ms);
-            if (st2 < 0) return st2;
+            if (st2 < 0) {
+                (void)hipEventDestroy(ea);
+                (void)hipEventDestroy(eb);
+                return st2;
+            }
             if (ms < best) { best = ms; best_cfg = c; }
         }
         (void)hipEventDestroy(ea);
@@ -981,30 +968,11 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         int cfg = -1, wino_cfg = -1;
         bool use_wino = false, use_43 = false;
         td_status st2;
-        // Stream-K (conv_streamk.hip) for the fp16 engine's small-map layers (opt-in, TD_STREAMK=1). A FIXED RULE on the launch shape, never a timing
-        // decision: its partial sums are associated differently from the plain block tiles, so a measured choice would make
-        // results differ between processes. Rule: rows <= 20 000 x batch-8-sized maps (M <= 24 000: res4 / res5, p4 - p6), at
-        // least 8 k-steps (K >= 512), no device-side row count; 256 x 128 tiles when the layer has the rows and channels for them.
-        const int sk_ksteps = prec_ == TD_PRECISION_FP16 ? L.kh * L.kw * L.cin / 64 : 0;
-        if (prec_ == TD_PRECISION_FP16 && e->stream_k && e->sk_ws && !m_dyn && out_mode == 0 && sk_ksteps >= 8 && (long long)B_ * Ho * Wo <= 24000 &&
-            L.cout >= 128 && L.cin % 64 == 0) {
-            ConvArgs a{};
-            a.x = x_; a.w = L.w; a.scale = L.scale; a.bias = L.bias; a.res = res_; a.y = y_;
-            a.B = B_; a.H = H_; a.W = W_; a.Cin = L.cin; a.Cout = L.cout; a.KH = L.kh; a.KW = L.kw; a.stride = stride; a.pad = pad;
-            a.Ho = Ho; a.Wo = Wo; a.res_shift = res_shift; a.relu = relu ? 1 : 0; a.out_mode = 0; a.M = B_ * Ho * Wo; a.m_mul = 1;
-            a.out_f32 = L.out_f32 ? 1 : 0; a.sk_ws = e->sk_ws; a.sk_cnt = e->sk_cnt;
-            const int variant = e->sk_variant >= 0 ? e->sk_variant : (a.M >= 2048 ? 1 : 0);
-            ProfScope ps(e, s_, 0, flops, bytes);
-            if (e->prof) e->prof_flops[8] += flops;
-            const int cls = H_ == 1 && W_ == 1 ? TD_CLS_FC : (L.kh == 1 && L.kw == 1 ? TD_CLS_CONV1X1 : TD_CLS_CONV3X3);
-            ClassScope cs(e, s_, cls, flops, bytes);
-            return conv_sk_launch(a, prec_, variant, s_);
-        }
         if (e->autotune) {
             const auto key = std::make_tuple(L.cout, L.cin, L.kh * 16 + L.kw, B_ * Ho * Wo, stride * 4 + out_mode * 2 + (res_ ? 1 : 0));
             const int ksteps = L.kh * L.kw * L.cin / (prec_ == TD_PRECISION_FP16 ? 64 : 32);
             const bool pp8_ok = prec_ == TD_PRECISION_FP16 && out_mode == 0 && L.cout >= 128;
-            bd_ok = out_mode == 0 && L.w_frag != nullptr;
+            const bool bd_ok = out_mode == 0 && L.w_frag != nullptr;
             // persistent tile walk (tile ids 18-20): fp32 1x1 / stride-1 layers, same-size residual at most
             const bool plane_ok = prec_ == TD_PRECISION_FP32 && L.kh == 1 && L.kw == 1 && stride == 1 && pad == 0 && out_mode == 0 && res_shift == 0 &&
                                   !L.out_f32 && L.cin >= 32 && L.cin % 32 == 0;
@@ -1032,11 +1000,11 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                 if (use_43) {
                     const auto key43 = std::make_tuple(L.cout, L.cin, 1 * 16 + 1, (int)T43, 4 + 64);
                     auto w43 = [&](int c) { return run_wino43(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, c); };
-                    if ((st2 = tuned_cfg(key43, prec_, L.cin / 32, false, true, s_, w43, &wino_cfg, nullptr)) < 0) return st2;
+                    if ((st2 = tuned_cfg(key43, prec_, L.cin / 32, false, true, false, s_, w43, &wino_cfg, nullptr)) < 0) return st2;
                 }
-                if (use_wino && !use_43 && !e->wino_fused && (st2 = tuned_cfg(wkey, prec_, L.cin / 32, false, true, s_, wino, &wino_cfg, nullptr)) < 0) return st2;
+                if (use_wino && !use_43 && !e->wino_fused && (st2 = tuned_cfg(wkey, prec_, L.cin / 32, false, true, false, s_, wino, &wino_cfg, nullptr)) < 0) return st2;
             }
-            if (!use_wino && (st2 = tuned_cfg(key, prec_, ksteps, pp8_ok, plane_ok, s_, direct, &cfg, nullptr)) < 0) return st2;
+            if (!use_wino && (st2 = tuned_cfg(key, prec_, ksteps, pp8_ok, plane_ok, bd_ok, s_, direct, &cfg, nullptr)) < 0) return st2;
         }
         ProfScope ps(e, s_, m_dyn ? 7 : 0, m_dyn ? 0.0 : flops, m_dyn ? 0.0 : bytes);
         if (e->prof && !m_dyn) {          // category 8: FLOPs the MFMA pipe really executes

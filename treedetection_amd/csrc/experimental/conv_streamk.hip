@@ -29,8 +29,8 @@
 // tiles, and the split points move with the batch size. That is why only the fp16 engine uses it, by a FIXED RULE on the
 // layer shape (engine.cpp), never by timing: fp16 activations carry 1e-3 of rounding noise per layer anyway
 // (tests/test_engine_fp16_gpu.py), while the fp32 engine keeps its bit-for-bit batch invariance.
-#include "common.h"
-#include "conv_tiles.h"
+#include "experimental.h"
+#include "../conv_tiles.h"
 
 namespace {
 

@@ -4,8 +4,8 @@
 // window around every MFMA (11 000 lines of v_accvgpr_mov for this kernel: 564 us against conv_pp8_kernel's 465 on the big
 // 3x3). Built without the flag the accumulators sit in the 256 AGPRs and the 256 VGPRs hold everything else — the split
 // this kernel's register budget was drawn for.
-#include "common.h"
-#include "conv_tiles.h"
+#include "experimental.h"
+#include "../conv_tiles.h"
 
 namespace {
 
