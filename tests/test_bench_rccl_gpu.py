@@ -16,17 +16,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(nproc, env_extra, port):
+def _launch(nproc, env_extra, port, detail=None):
     env = dict(os.environ)
     env.update(env_extra)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "4", "--warmup", "1",
            "--no-cpu-baseline", "--no-serial", "--no-r101", "--no-fp16-b32", "--no-fp16"]
+    if detail:
+        cmd += ["--detail", detail]
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == lines[0] and len(lines[0]) < 4096      # the compact line is the LAST stdout line
     return json.loads(lines[0])
 
 
@@ -41,11 +44,14 @@ def test_bench_two_ranks_over_rccl():
     assert rk["gather_bytes_per_step"] > 0 and line["value"] > 0 and line["scaling"] == "weak"
 
 
-def test_bench_two_ranks_gloo_rehearsal_reports_what_the_collective_layer_saw():
+def test_bench_two_ranks_gloo_rehearsal_reports_what_the_collective_layer_saw(tmp_path):
     """The same launch with TD_BENCH_BACKEND=gloo and both ranks on this box's GPU: the N > 1 code path of bench.py (shard of the
     stream per rank, per-step gather to rank 0, barrier + max-over-ranks timing, the `ranks` object) on hardware that has one GPU."""
-    line = _launch(2, {"TD_BENCH_BACKEND": "gloo"}, 29612)
+    detail = str(tmp_path / "detail.json")
+    line = _launch(2, {"TD_BENCH_BACKEND": "gloo"}, 29612, detail)
     rk = line["ranks"]
-    assert line["n_gpus"] == 2 and rk["world"] == 2 and rk["backend"] == "gloo"
-    assert len(rk["ranks"]) == 2 and {r["rank"] for r in rk["ranks"]} == {0, 1}
-    assert line["value"] > 0 and line["steps"] == 4
+    assert line["n_gpus"] == 2 and rk["world"] == 2 and rk["backend"] == "gloo" and len(rk["devices"]) == 2
+    assert line["value"] > 0 and line["steps"] == 4 and line["timed_steps"] >= 4
+    assert "roofline" in line and line["roofline"]["frac"] <= 1.0
+    full = json.load(open(detail))                      # the per-rank records live in the detail file
+    assert len(full["ranks"]["ranks"]) == 2 and {r["rank"] for r in full["ranks"]["ranks"]} == {0, 1}

@@ -143,6 +143,9 @@ static td_status wino_api(const float* x, const float* w, const float* scale, co
         return st;
     }
     TD_HIP_CHECK(hipMemcpy(U, uh.data(), uh.size() * 4, hipMemcpyHostToDevice));
+    const char* folde = getenv("TD_WINO_FOLD");           // tests: F(4x4) contraction + output transform in one launch (wino_fused.hip)
+    const bool fold = f43 && !head_w && folde && atoi(folde) != 0;
+    if (fold) TD_REQUIRE(wino43_fused_ok(B, H, W, Cin, Cout), "td_conv2d_winograd_nhwc: TD_WINO_FOLD needs Cin %% 128 == 0, Cout %% 64 == 0");
     const char* fenv = getenv("TD_WINO_FUSED");           // tests compare the two forms of the contraction (bit-identical)
     const bool fused = !f43 && (!fenv || atoi(fenv) != 0);
     ConvArgs a{};
@@ -156,13 +159,16 @@ static td_status wino_api(const float* x, const float* w, const float* scale, co
     } else {
         st = f43 ? wino43_input_launch(x, B, H, W, Cin, static_cast<float*>(V), nullptr, s)
                  : wino_input_launch(x, B, H, W, Cin, static_cast<float*>(V), nullptr, 1, 0, (int)T, s);
-        if (st == TD_OK) {
+        if (st == TD_OK && fold) {
+            st = wino43_fused_launch(static_cast<float*>(V), static_cast<float*>(U), B, H, W, Cin, Cout, scale, bias, relu, y, nullptr, s);
+        } else if (st == TD_OK) {
             a.x = V; a.B = 1; a.H = 1; a.W = (int)T; a.Ho = 1; a.Wo = (int)T;
             a.batch_count = P; a.x_bs = (long long)T * Cin;
             st = conv2d_launch(a, TD_PRECISION_FP32, s);
         }
     }
-    if (st == TD_OK && head_w)
+    if (fold) {
+    } else if (st == TD_OK && head_w)
         st = wino43_output_head_launch(static_cast<float*>(Mb), B, H, W, Cout, scale, bias, relu, head_w, head_b, head_y, head_n, s);
     else if (st == TD_OK)
         st = f43 ? wino43_output_launch(static_cast<float*>(Mb), B, H, W, Cout, scale, bias, relu, y, nullptr, s)

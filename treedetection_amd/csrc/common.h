@@ -137,6 +137,11 @@ void wino_filter_transform(const float* w_ohwi, int N, int C, float* U);     // 
 // F(4x4,3x3): whole layers only; V / Mb hold 36 planes of [T][C], T = B * ceil(H/4) * ceil(W/4)
 // (m_dyn: optional device-side image count <= B, the mask head's live RoIs)
 td_status wino43_input_launch(const float* x, int B, int H, int W, int C, float* V, const int* m_dyn, hipStream_t s);
+// F(4x4,3x3) contraction + output transform in ONE launch (wino_fused.hip): V [36][T][C] x U [36][N][C] → y, the M planes never
+// reach memory. Another association of the transform sums than wino43_output_launch: a fixed rule picks the layers (engine.cpp).
+bool wino43_fused_ok(int B, int H, int W, int C, int N);
+td_status wino43_fused_launch(const float* V, const float* U, int B, int H, int W, int C, int N, const float* scale, const float* bias,
+                              int relu, float* y, const int* m_dyn, hipStream_t s);
 td_status wino43_output_launch(const float* Mb, int B, int H, int W, int N, const float* scale, const float* bias, int relu,
                                float* y, const int* m_dyn, hipStream_t s);
 // the same for a 256-channel layer whose only consumer is a 1x1 head [head_n <= 32][256]: head_y [B*H*W][head_n] = y . head_w^T + head_b,
