@@ -277,25 +277,24 @@ def test_winograd_f4x4_conv_matches_torch(case):
 
 
 WINO_FOLD_CASES = [
-    # B, Cin, H, W, Cout, scale, bias, relu — Cin % 128 == 0, Cout % 64 == 0 (wino43_fused_ok)
+    # B, Cin, H, W, Cout, scale, bias, relu — Cin = 128 or 256, Cout % 64 == 0 (wino43_fused_ok)
     (1, 128, 100, 100, 128, True, True, True),        # res3 conv2: 4 k-chunks per plane (the 4-stage pipeline), whole tiles
     (2, 256, 50, 50, 256, False, True, True),         # res4 conv2 / FPN output 4: a half tile per row / column
     (1, 256, 200, 200, 256, False, True, False),      # FPN output 2 / RPN conv p2: 2 500 tiles = 39 blocks + 4 tiles
     (1, 128, 47, 61, 192, True, False, True),         # 3 and 1 pixels into the last tile; three channel blocks
-    (3, 512, 25, 25, 512, True, True, True),          # res5 conv2: 16 k-chunks per plane, 147 tiles (a partial block of 19)
+    (3, 256, 25, 25, 512, True, True, True),          # 147 tiles (a partial block of 19), eight channel blocks
     (5, 256, 14, 14, 256, False, True, True),         # mask-head RoIs: 16 tiles per image
-    (1, 384, 9, 5, 64, False, False, False),          # 12 k-chunks per plane (not a multiple of 8: the 4-stage form), 6 tiles
+    (1, 128, 9, 5, 64, False, False, False),          # 6 tiles: one block, mostly dead rows
 ]
 
 
-@pytest.mark.parametrize("stages", ["8", "4"])
 @pytest.mark.parametrize("case", WINO_FOLD_CASES)
-def test_winograd_f4x4_folded_conv_matches_torch(case, stages):
+def test_winograd_f4x4_folded_conv_matches_torch(case):
     """wino43_fused_kernel (wino_fused.hip): the 36 plane contractions AND the output transform in one launch — each plane's
     product is folded into the 4x4 outputs as its k loop ends, the M planes never reach memory. Against torch float64 with the
     SAME stated bound as every fp32 convolution here, |err| <= 5e-5 * max|ref| (the fold associates the transform sums plane by
     plane instead of column by column: measured at the level of the three-launch F(4x4) form); deterministic; within 2e-5 * max
-    of the three-launch form; both pipeline depths (8 / 4 LDS stages)."""
+    of the three-launch form; both pipeline depths (8 LDS stages at 256 input channels, 4 at 128)."""
     import os
     from treedetection_amd import _lib
     from tests.gpu_util import dev
@@ -322,14 +321,13 @@ def test_winograd_f4x4_folded_conv_matches_torch(case, stages):
     def run(fold):
         os.environ["TD_WINO_TILE"] = "4"
         os.environ["TD_WINO_FOLD"] = "1" if fold else "0"
-        os.environ["TD_WF_STAGES"] = stages
         try:
             y = torch.full((B, H, W, Cout), float("nan"), dtype=torch.float32, device="cuda")
             _lib.check(lib.td_conv2d_winograd_nhwc(p(xd), p(wd), p(sd), p(bd), y.data_ptr(), B, H, W, Cin, Cout, int(relu), _lib.stream_ptr()),
                        "td_conv2d_winograd_nhwc")
             return y
         finally:
-            del os.environ["TD_WINO_TILE"], os.environ["TD_WINO_FOLD"], os.environ["TD_WF_STAGES"]
+            del os.environ["TD_WINO_TILE"], os.environ["TD_WINO_FOLD"]
     ys = [run(True) for _ in range(3)]
     assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])          # a racy pipeline would not repeat
     got = ys[0].cpu().numpy().transpose(0, 3, 1, 2)
@@ -338,7 +336,7 @@ def test_winograd_f4x4_folded_conv_matches_torch(case, stages):
     err = np.abs(got - ref).max()
     three = run(False).cpu().numpy().transpose(0, 3, 1, 2)
     err3 = np.abs(three - ref).max()
-    print(f"\n[F(4x4) folded, {stages} stages] {case}: max abs err {err:.3e} = {err / scale_ref:.2e} of max|ref| (three-launch form {err3 / scale_ref:.2e})")
+    print(f"\n[F(4x4) folded] {case}: max abs err {err:.3e} = {err / scale_ref:.2e} of max|ref| (three-launch form {err3 / scale_ref:.2e})")
     assert err <= 5e-5 * scale_ref, f"max abs err {err}"
     assert np.abs(got - three).max() <= 2e-5 * scale_ref
 

@@ -32,8 +32,9 @@ def main():
         w = torch.from_numpy(rng.standard_normal((N, 3, 3, C), dtype=np.float32) / np.float32(np.sqrt(9 * C))).cuda()
         b = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).cuda()
         y = torch.empty((B, H, W, N), dtype=torch.float32, device="cuda")
-        for fold in ("0", "1"):
-            os.environ["TD_WINO_TILE"], os.environ["TD_WINO_FOLD"] = "4", fold
+        variants = [("0", "0", "8")] + [("1", v, "8") for v in os.environ.get("WF_VARS", "0").split(",")]
+        for fold, var, st in variants:
+            os.environ["TD_WINO_TILE"], os.environ["TD_WINO_FOLD"], os.environ["TD_WF_VAR"], os.environ["TD_WF_STAGES"] = "4", fold, var, st
             for _ in range(4):
                 _lib.check(lib.td_conv2d_winograd_nhwc(x.data_ptr(), w.data_ptr(), None, b.data_ptr(), y.data_ptr(), B, H, W, C, N, 1,
                                                        _lib.stream_ptr()), "td_conv2d_winograd_nhwc")

@@ -21,6 +21,10 @@ for r in rows:
     if key is None:
         continue
     g = (r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", ""), r.get("Workgroup_Size_X", ""))
+    if key == "wino43_fused_kernel":
+        import re
+        m = re.search(r"ILi(\d+)ELi(\d+)E", n) or re.search(r"<(\d+), (\d+)>", n)
+        key += f"<{m.group(1)},{m.group(2)}>" if m else ""
     out.setdefault((key, g), []).append(d)
 for (k, g), v in out.items():
     v = sorted(v)

@@ -126,6 +126,15 @@ struct td_engine {
     int wino_slab = 0;            // TD_WINO_SLAB: tiles per slab (diagnostics); 0 = sized for the Infinity Cache
     int wino_minc = 128;          // fewest channels (both sides) of a 3x3 layer on the Winograd path (TD_WINO_MINC: experiments)
     int wino43_min = 12;          // maps at least this large on both sides take F(4x4,3x3) (TD_WINO43_MIN; 0 = never)
+    // F(4x4) layers whose plane contractions and output transform run as ONE launch (wino43_fused_kernel: the M planes never reach
+    // memory). A FIXED rule on the layer's own shape — per-image map size and channels, never the batch and never a timing: the
+    // fold associates the transform sums differently from the three-launch form, and a batch of 8 must equal eight batches of 1
+    // bit for bit. Measured (profiles/r04_wino_fold.txt, batch 8): 256 -> 256 on the 200 x 200 maps 1 007 -> 895 us, 128 -> 128
+    // on 100 x 100 (res3 conv2) 103 -> 95 us; it loses where its 64-tile x 64-channel blocks cannot fill the chip (res4 / res5,
+    // p3 - p6: 88 - 316 blocks on 256 CUs) and on the RPN layers, whose head rides in the three-launch form's output transform.
+    // TD_WINO_FOLD (bit mask; experiments): 0 = never, 1 = the rule (default), +2 the mask head (device-side RoI count), +4 256-channel
+    // maps from 80 x 80, +8 every map from 40 x 40, +16 every layer the kernel can run.
+    int wino_fold = 1;
     std::string tune_cache;       // TD_TUNE_CACHE: load / append measured choices (keeps profiled runs free of tuning launches)
 
     // forward context (kept between the phases of td_engine_forward_phase) and the per-phase completion events
@@ -475,6 +484,7 @@ td_status td_engine_create(const td_model_desc* desc, int device, td_engine** ou
     if (const char* gl = getenv("TD_GROUP_LEVELS")) e->group_levels = atoi(gl) != 0;
     if (const char* ft = getenv("TD_FUSE_TAIL")) { e->fuse_tail = atoi(ft) != 0; e->fuse_tail_fp16 = atoi(ft) == 2; }
     if (const char* w4 = getenv("TD_WINO43_MIN")) e->wino43_min = atoi(w4);
+    if (const char* wf2 = getenv("TD_WINO_FOLD")) e->wino_fold = atoi(wf2);
     if (const char* wc = getenv("TD_WINO_MINC")) e->wino_minc = atoi(wc);
     e->desc = d;
     load_tune_cache(e);
@@ -922,7 +932,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
     // Winograd F(4x4,3x3) of a whole layer: x → V [36][T][cin] → 36 batched plane contractions → M → y. m_dyn = device-side
     // image count (the mask head's live RoIs): the planes keep the stride of the full batch, only the live tiles are computed.
     auto run_wino43 = [&](const ConvLayer& L, const void* x_, int B_, int H_, int W_, bool relu, void* y_, hipStream_t s_,
-                          const int* m_dyn, int gemm_cfg, const ConvLayer* head = nullptr, float* head_y = nullptr) -> td_status {
+                          const int* m_dyn, int gemm_cfg, const ConvLayer* head = nullptr, float* head_y = nullptr, bool fold = false) -> td_status {
         const int tiles_img = ((H_ + 3) / 4) * ((W_ + 3) / 4);
         const long long T = (long long)B_ * tiles_img;
         td_status st2;
@@ -932,6 +942,11 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         const double vb = 4.0 * 36 * T * L.cin, mb = 4.0 * 36 * T * L.cout, pf = 2.0 * 36 * T * (double)L.cin * L.cout;
         { ClassScope cs(e, s_, dyn ? TD_CLS_MASK_HEAD : TD_CLS_WINO_XFORM, 0.0, dyn ? 0.0 : xb + vb);
         if ((st2 = wino43_input_launch(static_cast<const float*>(x_), B_, H_, W_, L.cin, e->wino_v, m_dyn, s_)) < 0) return st2; }
+        if (fold) {        // contraction + output transform in one launch: V and U in, y out (wino_fused.hip)
+            ClassScope cs(e, s_, dyn ? TD_CLS_MASK_HEAD : TD_CLS_WINO_GEMM, dyn ? 0.0 : pf, dyn ? 0.0 : vb + ub + yb);
+            return wino43_fused_launch(e->wino_v, static_cast<const float*>(L.wino_u43), B_, H_, W_, L.cin, L.cout, L.scale, L.bias, relu ? 1 : 0,
+                                       static_cast<float*>(y_), m_dyn, s_);
+        }
         ConvArgs a{};
         a.x = e->wino_v; a.w = L.wino_u43; a.y = e->wino_m;
         a.Cin = L.cin; a.Cout = L.cout; a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
@@ -966,7 +981,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         const double es = prec_ == TD_PRECISION_FP16 ? 2.0 : 4.0;
         const double bytes = es * ((double)B_ * H_ * W_ * L.cin / (stride * stride) + M * L.cout * (res_ ? 2.0 : 1.0) + L.cout * K);
         int cfg = -1, wino_cfg = -1;
-        bool use_wino = false, use_43 = false;
+        bool use_wino = false, use_43 = false, use_fold = false;
         td_status st2;
         if (e->autotune) {
             const auto key = std::make_tuple(L.cout, L.cin, L.kh * 16 + L.kw, B_ * Ho * Wo, stride * 4 + out_mode * 2 + (res_ ? 1 : 0));
@@ -997,7 +1012,13 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                 const long long T43 = (long long)B_ * ((H_ + 3) / 4) * ((W_ + 3) / 4);
                 use_43 = use_wino && L.wino_u43 && e->wino43_min > 0 && H_ >= e->wino43_min && W_ >= e->wino43_min &&
                          (size_t)36 * T43 * (size_t)std::max(L.cin, L.cout) <= e->wino_elems && T43 * std::max(L.cin, L.cout) < (1ll << 31);
-                if (use_43) {
+                // the fold rule: layer shape only (see td_engine::wino_fold)
+                const int hw_ = H_ * W_, wf_ = e->wino_fold;
+                use_fold = use_43 && wf_ > 0 && !head && wino43_fused_ok(B_, H_, W_, L.cin, L.cout) &&
+                           (((wf_ & 1) && !m_dyn && ((L.cin == 256 && hw_ >= 160 * 160) || (L.cin == 128 && hw_ >= 80 * 80))) ||
+                            ((wf_ & 2) && m_dyn) || ((wf_ & 4) && !m_dyn && L.cin == 256 && hw_ >= 80 * 80) ||
+                            ((wf_ & 8) && !m_dyn && hw_ >= 40 * 40) || ((wf_ & 16) && !m_dyn));
+                if (use_43 && !use_fold) {
                     const auto key43 = std::make_tuple(L.cout, L.cin, 1 * 16 + 1, (int)T43, 4 + 64);
                     auto w43 = [&](int c) { return run_wino43(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, c); };
                     if ((st2 = tuned_cfg(key43, prec_, L.cin / 32, false, true, false, s_, w43, &wino_cfg, nullptr)) < 0) return st2;
@@ -1018,7 +1039,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
             const bool fuse43 = head && e->fuse_head && !m_dyn && relu && L.cout == 256 && head->cin == 256 && head->kh == 1 && head->kw == 1 &&
                                 head->cout <= 32 && !head->scale;
             if (head_fused) *head_fused = fuse43;
-            return run_wino43(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, wino_cfg, fuse43 ? head : nullptr, fuse43 ? head_y : nullptr);
+            return run_wino43(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, wino_cfg, fuse43 ? head : nullptr, fuse43 ? head_y : nullptr, use_fold);
         }
         if (use_wino) return run_wino(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, m_mul, wino_cfg);
         const int cls = m_dyn ? TD_CLS_MASK_HEAD : (H_ == 1 && W_ == 1 ? TD_CLS_FC : (L.kh == 1 && L.kw == 1 ? TD_CLS_CONV1X1 : TD_CLS_CONV3X3));

@@ -56,7 +56,9 @@ __device__ __forceinline__ void wf_static_for(F&& f) {
     wf_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <int NS>
+// VAR (TD_WF_VAR) = timing diagnostics with WRONG results: bit 3 = no DMA inside the loop, bit 4 = no MFMAs, bit 5 = no fragment
+// reads, bit 6 = no barriers
+template <int NS, int VAR>
 __global__ __launch_bounds__(512, 2) void wino43_fused_kernel(const WinoFusedArgs a) {
     constexpr int AHEAD = NS - 1;                     // chunks of DMA in flight; NS LDS stages (see the WAR argument at the barrier)
     static_assert((NS == 4 || NS == 8) && NS * WF_STAGE <= 160 * 1024, "pipeline depth");
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void wino43_fused_kernel(const WinoFusedArg
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wt = wave & 3, wc = wave >> 2;
-    const int KC = a.C >> 5;                          // k-chunks of 32 floats per plane (a multiple of NS: launcher)
+    const int KC = NS;                                // k-chunks of 32 floats per plane: C = 32 NS (launcher)
 
     // ---- LDS-DMA source offsets (bytes into V / U; rows past the live tiles read beyond num_records → zeros) ----
     constexpr unsigned OOB = 0xfffffff0u;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(512, 2) void wino43_fused_kernel(const WinoFusedArg
     char* const dstU = lds + WF_BT * CHUNK_BYTES + wave * 8 * CHUNK_BYTES;
     int ld_kc = 0;
     unsigned ld_v = 0, ld_u = 0;                      // plane * plane bytes + chunk * 128 of the next chunk to issue
-    auto issue = [&](auto st_c) {
+    auto issue = [&](auto st_c) __attribute__((always_inline)) {
         constexpr int ST = decltype(st_c)::value;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(dstV + ST * WF_STAGE), 16, v_ok ? v_off + ld_v : OOB, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(dstU + ST * WF_STAGE), 16, u_off + ld_u, 0, 0, 0);
@@ -116,19 +118,36 @@ __global__ __launch_bounds__(512, 2) void wino43_fused_kernel(const WinoFusedArg
     const unsigned fv = (unsigned)(wt * 16 + r16) * CHUNK_BYTES;                               // V rows (MFMA B operand: tiles)
     const unsigned fu = (unsigned)(WF_BT + wc * 32 + r16) * CHUNK_BYTES;                       // U rows (MFMA A operand: channels)
     struct Frag { f32x4 u0, u1, v; };
-    auto read_frag = [&](Frag& f, auto st_c, unsigned pc) {
+    auto read_frag = [&](Frag& f, auto st_c, unsigned pc) __attribute__((always_inline)) {
+        if constexpr (VAR & 32) {
+            asm volatile("" : "+v"(f.u0), "+v"(f.u1), "+v"(f.v));
+            return;
+        }
         const char* sb = lds + decltype(st_c)::value * WF_STAGE;
         f.u0 = *reinterpret_cast<const f32x4*>(sb + fu + pc);
         f.u1 = *reinterpret_cast<const f32x4*>(sb + fu + 16 * CHUNK_BYTES + pc);
         f.v = *reinterpret_cast<const f32x4*>(sb + fv + pc);
     };
-    f32x4 acc[2];
-    auto mma = [&](const Frag& f) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.u0[e], f.v[e], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.u1[e], f.v[e], acc[1], 0, 0, 0);
+    // Two sets of plane accumulators: while the MFMAs of plane p run into set p & 1, the finished product of plane p - 1 (the
+    // other set) is folded into S — and, after the sixth plane of a row, S into Y — by VALU slices placed in the gaps between
+    // the MFMA pairs of plane p's first two chunk-steps (an MFMA holds the SIMD's vector issue for a quarter of its cycles; with
+    // the fold after the k loop both waves of a SIMD folded at the same time and the matrix pipe idled: 6 % of the kernel).
+    f32x4 acc[2][2];
+    auto mma = [&](const Frag& f, auto set_c, auto&& filler, auto slot0_c) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value, SLOT0 = decltype(slot0_c)::value;
+        if constexpr (VAR & 16) {
+            asm volatile("" ::"v"(f.u0), "v"(f.u1), "v"(f.v));
+            wf_static_for<4>([&](auto e_c) __attribute__((always_inline)) { filler(std::integral_constant<int, SLOT0 + decltype(e_c)::value>{}); });
+            return;
         }
+        wf_static_for<4>([&](auto e_c) __attribute__((always_inline)) {
+            constexpr int e = decltype(e_c)::value;
+            acc[SET][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.u0[e], f.v[e], acc[SET][0], 0, 0, 0);
+            acc[SET][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.u1[e], f.v[e], acc[SET][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);        // the two accumulator chains stay in alternation (dependent latency 40 > issue 32)
+            filler(std::integral_constant<int, SLOT0 + e>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
     };
 
     f32x4 Y[16][2], S[4][2];
@@ -136,78 +155,102 @@ __global__ __launch_bounds__(512, 2) void wino43_fused_kernel(const WinoFusedArg
     for (int i = 0; i < 16; ++i) Y[i][0] = Y[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) S[j][0] = S[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fold slices. A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1] (rows i, columns = plane component).
+    // S slice `sl` of 8: element (b, e) = (sl >> 2, sl & 3) of the finished plane XC: S[j] += A^T[j][XC] * m, zero terms skipped,
+    // +-1 as add / sub, 2 4 8 as one fma (exact constants): 1 - 4 VALU; the accumulator element is cleared for its next plane.
+    auto fold_s = [&](auto xc_c, auto set_c, auto sl_c) __attribute__((always_inline)) {
+        constexpr int XC = decltype(xc_c)::value, SET = decltype(set_c)::value, sl = decltype(sl_c)::value, b = sl >> 2, e = sl & 3;
+        const float m = acc[SET][b][e];
+        acc[SET][b][e] = 0.f;
+        if constexpr (XC <= 4) S[0][b][e] = __fadd_rn(S[0][b][e], m);
+        if constexpr (XC == 1) {
+            S[1][b][e] = __fadd_rn(S[1][b][e], m);
+            S[2][b][e] = __fadd_rn(S[2][b][e], m);
+            S[3][b][e] = __fadd_rn(S[3][b][e], m);
+        } else if constexpr (XC == 2) {
+            S[1][b][e] = __fsub_rn(S[1][b][e], m);
+            S[2][b][e] = __fadd_rn(S[2][b][e], m);
+            S[3][b][e] = __fsub_rn(S[3][b][e], m);
+        } else if constexpr (XC == 3) {
+            S[1][b][e] = __fmaf_rn(2.f, m, S[1][b][e]);
+            S[2][b][e] = __fmaf_rn(4.f, m, S[2][b][e]);
+            S[3][b][e] = __fmaf_rn(8.f, m, S[3][b][e]);
+        } else if constexpr (XC == 4) {
+            S[1][b][e] = __fmaf_rn(-2.f, m, S[1][b][e]);
+            S[2][b][e] = __fmaf_rn(4.f, m, S[2][b][e]);
+            S[3][b][e] = __fmaf_rn(-8.f, m, S[3][b][e]);
+        } else if constexpr (XC == 5) {
+            S[3][b][e] = __fadd_rn(S[3][b][e], m);
+        }
+    };
+    // Y slice `sl` of 8: element (b, e) of the finished row: Y[i][j] += A^T[i][row] * S[j] (runtime row: r0..r3 — fma(1, v, y) = y + v
+    // and fma(0, v, y) = y exactly, so this IS the sparse sum), S[j] = 0: 16 fma
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+    auto fold_y = [&](auto sl_c) __attribute__((always_inline)) {
+        constexpr int sl = decltype(sl_c)::value, b = sl >> 2, e = sl & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = S[j][b][e];
+            S[j][b][e] = 0.f;
+            Y[0 + j][b][e] = __fmaf_rn(r0, v, Y[0 + j][b][e]);
+            Y[4 + j][b][e] = __fmaf_rn(r1, v, Y[4 + j][b][e]);
+            Y[8 + j][b][e] = __fmaf_rn(r2, v, Y[8 + j][b][e]);
+            Y[12 + j][b][e] = __fmaf_rn(r3, v, Y[12 + j][b][e]);
+        }
+    };
 
     // ---- prologue: chunks 0 .. AHEAD-1 in flight (stages 0 .. AHEAD-1); chunk 0 landed and its first half-fragment read ----
-    wf_static_for<AHEAD>([&](auto i_c) { issue(i_c); });          // KC % NS == 0 (launcher): the stream is longer than the pipeline
+    wf_static_for<AHEAD>([&](auto i_c) __attribute__((always_inline)) { issue(i_c); });          // KC % NS == 0 (launcher): the stream is longer than the pipeline
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AHEAD - 1)) : "memory");
     __builtin_amdgcn_s_barrier();
     Frag f0, f1;
+    if constexpr (VAR & 32) {
+        f0.u0 = f0.u1 = f0.v = f32x4{1.f, 2.f, 3.f, 4.f};
+        f1 = f0;
+    }
     read_frag(f0, std::integral_constant<int, 0>{}, pc0);
 
     // Step s (chunk s of the flat stream, stage s % NS): on entry chunk s has landed for every wave and f0 holds its first
     // half (read during step s - 1). The DMA of chunk s + AHEAD goes into the stage chunk s - 1 occupied: every wave finished
     // its reads of chunk s - 1 before the barrier that ended step s - 1 (lgkmcnt(0) sits in front of each barrier), and this
     // wave is past that barrier. Before the barrier that ends step s every wave waits until its own DMAs of chunk s + 1 have
-    // landed (vmcnt: all but the chunks issued after it — AHEAD - 1 of them in the steady state, two DMAs each), so after the
-    // barrier chunk s + 1 is complete for all. The chunk loop is unrolled NS times: every LDS address is a base register + an
-    // immediate. TAIL = the stream's last NS steps: only the first of them still issues (the last chunk), the others wait for
-    // all but the NS - 2 - ST chunks issued after chunk s + 1. The very last step re-reads stage 0, which nobody needs (in
-    // bounds, harmless): every step has the same shape and hipcc counts its own lgkmcnt waits.
-    auto body = [&](auto tail_c) {
-        constexpr bool TAIL = decltype(tail_c)::value;
-        wf_static_for<NS>([&](auto st_c) {
+    // landed (vmcnt: all but the AHEAD - 1 chunks issued after it, two DMAs each), so after the barrier chunk s + 1 is complete
+    // for all. A plane is exactly NS chunks (C = 32 NS: launcher) and its loop is unrolled: every LDS address is a base register
+    // + an immediate. EVERY step issues a chunk: past the end of the stream the offsets lie beyond num_records and the DMA
+    // writes zeros into stages nobody reads again — no tail variant of the loop; the wave drains its DMAs before it ends.
+    // XC = this plane's component (its accumulators: set XC & 1). Its first two steps carry the fold of the plane before it
+    // (component (XC + 5) % 6, set (XC + 1) & 1): step 0 the S slices, step 1 — when that plane closed a row — the row's Y slices.
+    auto plane = [&](auto xc_c) __attribute__((always_inline)) {
+        constexpr int XC = decltype(xc_c)::value, SET = XC & 1, PXC = (XC + 5) % 6;
+        wf_static_for<NS>([&](auto st_c) __attribute__((always_inline)) {
             constexpr int ST = decltype(st_c)::value, NEXT = (ST + 1) % NS;
-            constexpr bool ISSUE = !TAIL || ST == 0;
-            constexpr int NEWER = ISSUE ? AHEAD - 1 : (NS - 2 - ST > 0 ? NS - 2 - ST : 0);
-            if constexpr (ISSUE) issue(std::integral_constant<int, (ST + AHEAD) % NS>{});
+            auto filler = [&](auto slot_c) __attribute__((always_inline)) {
+                if constexpr (ST == 0) fold_s(std::integral_constant<int, PXC>{}, std::integral_constant<int, 1 - SET>{}, slot_c);
+                if constexpr (ST == 1 && PXC == 5) fold_y(slot_c);
+            };
+            if constexpr (!(VAR & 8)) issue(std::integral_constant<int, (ST + AHEAD) % NS>{});
             read_frag(f1, st_c, pc1);
-            mma(f0);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NEWER) : "memory");
+            mma(f0, std::integral_constant<int, SET>{}, filler, std::integral_constant<int, 0>{});
+            if constexpr (!(VAR & 8)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AHEAD - 1)) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(VAR & 64)) __builtin_amdgcn_s_barrier();
             read_frag(f0, std::integral_constant<int, NEXT>{}, pc0);
-            mma(f1);
+            mma(f1, std::integral_constant<int, SET>{}, filler, std::integral_constant<int, 4>{});
         });
     };
-    const int nb_k = KC / NS;
-    for (int p = 0; p < 36; ++p) {
-        for (int kb = 0; kb + 1 < nb_k; ++kb) body(std::false_type{});
-        if (p < 35) body(std::false_type{});
-        else body(std::true_type{});
-        // plane p = 6 xr + xc complete: S[j] += A^T[j][xc] * M;  xc == 5: Y[i][j] += A^T[i][xr] * S[j], S = 0
-        // (runtime coefficients: fma(1, m, s) = s + m and fma(0, m, s) = s exactly, so this IS the sparse sum)
-        const int xr = p / 6, xc = p - 6 * xr;
-        const float c0 = WF_AT[0][xc], c1 = WF_AT[1][xc], c2 = WF_AT[2][xc], c3 = WF_AT[3][xc];
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float m = acc[b][e];
-                S[0][b][e] = __fmaf_rn(c0, m, S[0][b][e]);
-                S[1][b][e] = __fmaf_rn(c1, m, S[1][b][e]);
-                S[2][b][e] = __fmaf_rn(c2, m, S[2][b][e]);
-                S[3][b][e] = __fmaf_rn(c3, m, S[3][b][e]);
-            }
-        acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (xc == 5) {
-            const float r0 = WF_AT[0][xr], r1 = WF_AT[1][xr], r2 = WF_AT[2][xr], r3 = WF_AT[3][xr];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = S[j][b][e];
-                        S[j][b][e] = 0.f;
-                        Y[0 + j][b][e] = __fmaf_rn(r0, v, Y[0 + j][b][e]);
-                        Y[4 + j][b][e] = __fmaf_rn(r1, v, Y[4 + j][b][e]);
-                        Y[8 + j][b][e] = __fmaf_rn(r2, v, Y[8 + j][b][e]);
-                        Y[12 + j][b][e] = __fmaf_rn(r3, v, Y[12 + j][b][e]);
-                    }
-        }
+    for (int xr = 0; xr < 6; ++xr) {
+        // coefficients of the row that closed before this one (none before row 0: S is zero and so are they)
+        r0 = xr ? WF_AT[0][xr - 1] : 0.f; r1 = xr ? WF_AT[1][xr - 1] : 0.f; r2 = xr ? WF_AT[2][xr - 1] : 0.f; r3 = xr ? WF_AT[3][xr - 1] : 0.f;
+        wf_static_for<6>(plane);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the zero-fill DMAs past the stream's end: LDS is released only after they landed
+    // the last plane (component 5, set 1) and the last row
+    wf_static_for<8>([&](auto sl_c) __attribute__((always_inline)) { fold_s(std::integral_constant<int, 5>{}, std::integral_constant<int, 1>{}, sl_c); });
+    r0 = WF_AT[0][5]; r1 = WF_AT[1][5]; r2 = WF_AT[2][5]; r3 = WF_AT[3][5];
+    wf_static_for<8>([&](auto sl_c) __attribute__((always_inline)) { fold_y(sl_c); });
 
     // ---- epilogue: lane = tile (t0 + wt*16 + r16), channels n0 + wc*32 + blk*16 + 4 q .. +3; 16 pixels x 2 blocks of 16-B stores.
     // Branch-free: a pixel outside the map (or a dead tile) stores to an offset beyond num_records, which the buffer unit drops —
@@ -257,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void wino43_fused_kernel(const WinoFusedArg
 
 bool wino43_fused_ok(int B, int H, int W, int C, int N) {
     const long long T = (long long)B * ((H + 3) / 4) * ((W + 3) / 4);
-    return C >= 128 && C % 128 == 0 && N >= WF_BN && N % WF_BN == 0 && 36ull * (unsigned long long)T * C * 4 < 0xfffffff0ull - (1u << 20) &&
+    return (C == 128 || C == 256) && N >= WF_BN && N % WF_BN == 0 && 36ull * (unsigned long long)T * C * 4 < 0xfffffff0ull - (1u << 20) &&
            36ull * (unsigned long long)N * C * 4 < 0xfffffff0ull - (1u << 20) && (unsigned long long)B * H * W * N * 4 < 0xfffffff0ull - (1u << 20);
 }
 
@@ -265,17 +308,26 @@ bool wino43_fused_ok(int B, int H, int W, int C, int N) {
 td_status wino43_fused_launch(const float* V, const float* U, int B, int H, int W, int C, int N, const float* scale, const float* bias,
                               int relu, float* y, const int* m_dyn, hipStream_t s) {
     TD_REQUIRE(V && U && y && B >= 1 && H >= 1 && W >= 1, "winograd F(4x4) fused contraction: bad arguments");
-    TD_REQUIRE(wino43_fused_ok(B, H, W, C, N), "winograd F(4x4) fused contraction: needs C %% 128 == 0, N %% 64 == 0 and planes below 4 GB (C %d, N %d)", C, N);
+    TD_REQUIRE(wino43_fused_ok(B, H, W, C, N), "winograd F(4x4) fused contraction: needs C = 128 or 256, N %% 64 == 0 and planes below 4 GB (C %d, N %d)", C, N);
     WinoFusedArgs a{};
     a.V = V; a.U = U; a.scale = scale; a.bias = bias; a.y = y; a.m_dyn = m_dyn;
     a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.relu = relu;
     a.T = (long long)B * ((H + 3) / 4) * ((W + 3) / 4);
     const long long blocks = ((a.T + WF_BT - 1) / WF_BT) * (N / WF_BN);
     TD_REQUIRE(blocks < (1ll << 31), "winograd F(4x4) fused contraction: grid too large");
-    // LDS stages: 8 (seven chunks of DMA in flight, 128 KB) where the plane's chunk count allows the 8-fold unrolled loop, else 4
-    static const int stages = getenv("TD_WF_STAGES") ? atoi(getenv("TD_WF_STAGES")) : 8;
-    if (stages >= 8 && (C / 32) % 8 == 0) hipLaunchKernelGGL(wino43_fused_kernel<8>, dim3((unsigned)blocks), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(wino43_fused_kernel<4>, dim3((unsigned)blocks), dim3(512), 0, s, a);
+    // a plane = C / 32 chunk-steps = the LDS stages of the unrolled loop: 8 (C = 256: seven chunks of DMA in flight, 128 KB) or 4 (C = 128)
+    const int var = getenv("TD_WF_VAR") ? atoi(getenv("TD_WF_VAR")) : 0;
+    const bool s8 = C == 256;
+#define TD_WF_LAUNCH(NSV, VARV) hipLaunchKernelGGL((wino43_fused_kernel<NSV, VARV>), dim3((unsigned)blocks), dim3(512), 0, s, a)
+    switch (var) {
+        case 8: TD_WF_LAUNCH(8, 8); break;        // diagnostics (wrong results): no DMA in the loop
+        case 16: TD_WF_LAUNCH(8, 16); break;      // no MFMAs
+        case 32: TD_WF_LAUNCH(8, 32); break;      // no fragment reads
+        case 40: TD_WF_LAUNCH(8, 40); break;      // MFMAs + barriers (+ fold) only
+        case 104: TD_WF_LAUNCH(8, 104); break;    // MFMAs (+ fold) only
+        default: if (s8) TD_WF_LAUNCH(8, 0); else TD_WF_LAUNCH(4, 0); break;
+    }
+#undef TD_WF_LAUNCH
     TD_KERNEL_CHECK();
     return TD_OK;
 }
