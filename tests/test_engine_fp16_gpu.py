@@ -67,16 +67,21 @@ def test_fp16_trunk_close_to_fp32(setup16):
 SCORE_THRESH = 0.3            # cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST (reference config.py:60)
 
 
-def check_fp16_detections(got, ref, label=""):
+def check_fp16_detections(got, ref, label="", depth_factor=1.0):
     """Shared by the full-size / batch-32 / R101 / two-model tests. → per-detection statistics.
     A detection may exist on one side only where its score sits within the fp16 score tolerance of the 0.3 cut (the
     tolerance at s = 0.3 is 5e-3 * 4 s (1 - s) / 0.36 = 1.2e-2: a score that close to the threshold may land on either
     side of it); beyond those, at most max(2, 10 %) unmatched detections per image on either side: the seeded random heads put
     CLUSTERS of heavily overlapping proposals with near-tied scores on a tile, fp16 noise in the RPN logits reorders them, and
     the box that survives NMS in a cluster may descend from another proposal (IoU 0.5 - 0.7 with the oracle's survivor —
-    tools/fp16_set_diag.py lists them; the fp32 engine reproduces the oracle's set exactly on the same tiles)."""
+    tools/fp16_set_diag.py lists them; the fp32 engine reproduces the oracle's set exactly on the same tiles).
+    ``depth_factor`` scales the score / probability / box bounds for deeper trunks: every layer adds one fp16 rounding of its
+    output, so the feature error grows with depth (R50 p5: 4e-3 relative RMS; R101 has 33 bottleneck blocks against 16 — its
+    test passes 2.5 and prints what it measured)."""
+    f = float(depth_factor)
     rows = []
-    band = 5e-3 * 4.0 * SCORE_THRESH * (1.0 - SCORE_THRESH) / 0.36
+    band = f * 5e-3 * 4.0 * SCORE_THRESH * (1.0 - SCORE_THRESH) / 0.36
+    worst = {"score": 0.0, "box": 0.0, "prob": 0.0}
     for n, (g, r) in enumerate(zip(got, ref)):
         assert len(r["scores"]) > 5
         matched = 0
@@ -92,17 +97,22 @@ def check_fp16_detections(got, ref, label=""):
             used.add(bj)
             s = float(r["scores"][i])
             es = abs(float(g["scores"][bj]) - s)
-            assert es <= 5e-3 * max(1.0, 4.0 * s * (1.0 - s) / 0.36), (label, n, i, s, es)
-            assert np.abs(g["pred_boxes"][bj] - r["pred_boxes"][i]).max() <= 0.5
+            assert es <= f * 5e-3 * max(1.0, 4.0 * s * (1.0 - s) / 0.36), (label, n, i, s, es)
+            eb = float(np.abs(g["pred_boxes"][bj] - r["pred_boxes"][i]).max())
+            assert eb <= f * 0.5, (label, n, i, eb)
             pr, pg = r["mask_probs"][i], g["mask_probs"][bj]
-            assert np.abs(pg - pr).max() <= 3e-2
+            ep = float(np.abs(pg - pr).max())
+            assert ep <= f * 3e-2, (label, n, i, ep)
+            worst = {"score": max(worst["score"], es), "box": max(worst["box"], eb), "prob": max(worst["prob"], ep)}
             flip = (pg >= 0.5) != (pr >= 0.5)
-            assert (np.abs(pr - 0.5)[flip] <= 3e-2).all()                    # flips only where the oracle is undecided
-            near = float((np.abs(pr - 0.5) <= 3e-2).mean())
+            assert (np.abs(pr - 0.5)[flip] <= f * 3e-2).all()                # flips only where the oracle is undecided
+            near = float((np.abs(pr - 0.5) <= f * 3e-2).mean())
             a, b = g["pred_masks"][bj], r["pred_masks"][i]
             u = (a | b).sum()
             m_iou = (a & b).sum() / u if u else 1.0
-            assert m_iou >= (0.97 if near < 0.03 else 1.0 - 1.5 * near) - 1e-9, (label, n, i, m_iou, near)
+            # pasted masks: undecided 28x28 pixels (oracle probability within the bound of 0.5) may land on either side, and the
+            # bilinear paste spreads each over its neighbours: 1.5 x their fraction at R50's bounds (unchanged), 2 x at the wider ones
+            assert m_iou >= (0.97 if near < 0.03 else 1.0 - (1.5 if f <= 1.0 else 2.0) * near) - 1e-9, (label, n, i, m_iou, near)
             rows.append((es, m_iou, near, s))
         extra = [float(g["scores"][j]) for j in range(len(g["scores"])) if j not in used]
         lost_far = [s for s in lost if s > SCORE_THRESH + band]
@@ -116,11 +126,13 @@ def check_fp16_detections(got, ref, label=""):
                   f"{len(lost) - len(lost_far)} / {len(extra) - len(extra_far)} of them within {band:.1e} of the {SCORE_THRESH} cut")
     rows = np.array(rows)
     es = rows[:, 0]
-    print(f"\n[fp16 {label}] {len(rows)} matched detections: score err median {np.median(es):.4f} p90 {np.quantile(es, 0.9):.4f} "
+    print(f"\n[fp16 {label}] worst matched detection: score err {worst['score']:.2e}, box {worst['box']:.3f} px, mask probability {worst['prob']:.2e} "
+          f"(bounds x {f:g})")
+    print(f"[fp16 {label}] {len(rows)} matched detections: score err median {np.median(es):.4f} p90 {np.quantile(es, 0.9):.4f} "
           f"max {es.max():.4f} | mask IoU min {rows[:, 1].min():.3f} median {np.median(rows[:, 1]):.3f} | "
           f"near-cut pixel fraction median {np.median(rows[:, 2]):.3f} max {rows[:, 2].max():.3f}")
-    assert np.median(es) <= 2.5e-3 and np.quantile(es, 0.9) <= 6e-3
-    assert np.mean(rows[:, 1]) >= 0.95
+    assert np.median(es) <= f * 2.5e-3 and np.quantile(es, 0.9) <= f * 6e-3
+    assert np.mean(rows[:, 1]) >= 1.0 - f * 0.05
     return rows
 
 

@@ -132,9 +132,12 @@ struct td_engine {
     // bit for bit. Measured (profiles/r04_wino_fold.txt, batch 8): 256 -> 256 on the 200 x 200 maps 1 007 -> 895 us, 128 -> 128
     // on 100 x 100 (res3 conv2) 103 -> 95 us; it loses where its 64-tile x 64-channel blocks cannot fill the chip (res4 / res5,
     // p3 - p6: 88 - 316 blocks on 256 CUs) and on the RPN layers, whose head rides in the three-launch form's output transform.
-    // TD_WINO_FOLD (bit mask; experiments): 0 = never, 1 = the rule (default), +2 the mask head (device-side RoI count), +4 256-channel
-    // maps from 80 x 80, +8 every map from 40 x 40, +16 every layer the kernel can run.
-    int wino_fold = 1;
+    // TD_WINO_FOLD (bit mask): 1 = 256 channels from 160 x 160 and 128 channels from 80 x 80 (isolated winners), 2 = the mask head
+    // (device-side RoI count), 4 = 256-channel maps from 80 x 80 (FPN output 3) — the default 7: with three forwards in flight the
+    // fold also pays where its isolated time ties, it frees HBM bandwidth for the other streams (bench, fp32 tiles/s: 0 → 638,
+    // 1 → 650, 3 → 655, 7 → 656) —, 8 = every map from 40 x 40 and 16 = every layer the kernel can run: 660 - 661 under the
+    // stream schedule but 574 → 545 one forward at a time (88-block launches on 256 CUs), not taken.
+    int wino_fold = 7;
     std::string tune_cache;       // TD_TUNE_CACHE: load / append measured choices (keeps profiled runs free of tuning launches)
 
     // forward context (kept between the phases of td_engine_forward_phase) and the per-phase completion events
@@ -940,13 +943,28 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         const bool dyn = m_dyn != nullptr;
         const double xb = 4.0 * B_ * H_ * W_ * L.cin, yb = 4.0 * B_ * H_ * W_ * L.cout, ub = 4.0 * 36 * L.cout * L.cin;
         const double vb = 4.0 * 36 * T * L.cin, mb = 4.0 * 36 * T * L.cout, pf = 2.0 * 36 * T * (double)L.cin * L.cout;
+        if (fold) {
+            // contraction + output transform in one launch: V and U in, y out (wino_fused.hip). Its 32-bit plane offsets hold
+            // 4 GB of V: a larger batch runs in image groups, so the layer takes the SAME form at every batch size (batch invariance)
+            const unsigned long long per_img = 36ull * tiles_img * (unsigned long long)std::max(L.cin, L.cout) * 4ull;
+            const int gmax = (int)std::max<unsigned long long>(1ull, std::min<unsigned long long>((0xfffffff0ull - (2u << 20)) / per_img,
+                                                                                                 (0xfffffff0ull - (2u << 20)) / (16ull * tiles_img * L.cout * 4ull)));
+            for (int b0 = 0; b0 < B_; b0 += gmax) {
+                const int Bg = dyn ? B_ : std::min(gmax, B_ - b0);       // (device-side RoI count: one group — 800 RoIs of 14 x 14 are 0.5 GB)
+                const float* xg = static_cast<const float*>(x_) + (size_t)b0 * H_ * W_ * L.cin;
+                float* yg = static_cast<float*>(y_) + (size_t)b0 * H_ * W_ * L.cout;
+                const double share = (double)Bg / B_;
+                { ClassScope cs(e, s_, dyn ? TD_CLS_MASK_HEAD : TD_CLS_WINO_XFORM, 0.0, dyn ? 0.0 : (xb + vb) * share);
+                if ((st2 = wino43_input_launch(xg, Bg, H_, W_, L.cin, e->wino_v, m_dyn, s_)) < 0) return st2; }
+                ClassScope cs(e, s_, dyn ? TD_CLS_MASK_HEAD : TD_CLS_WINO_GEMM, dyn ? 0.0 : pf * share, dyn ? 0.0 : (vb + yb) * share + ub);
+                if ((st2 = wino43_fused_launch(e->wino_v, static_cast<const float*>(L.wino_u43), Bg, H_, W_, L.cin, L.cout, L.scale, L.bias, relu ? 1 : 0,
+                                               yg, m_dyn, s_)) < 0) return st2;
+                if (dyn) break;
+            }
+            return TD_OK;
+        }
         { ClassScope cs(e, s_, dyn ? TD_CLS_MASK_HEAD : TD_CLS_WINO_XFORM, 0.0, dyn ? 0.0 : xb + vb);
         if ((st2 = wino43_input_launch(static_cast<const float*>(x_), B_, H_, W_, L.cin, e->wino_v, m_dyn, s_)) < 0) return st2; }
-        if (fold) {        // contraction + output transform in one launch: V and U in, y out (wino_fused.hip)
-            ClassScope cs(e, s_, dyn ? TD_CLS_MASK_HEAD : TD_CLS_WINO_GEMM, dyn ? 0.0 : pf, dyn ? 0.0 : vb + ub + yb);
-            return wino43_fused_launch(e->wino_v, static_cast<const float*>(L.wino_u43), B_, H_, W_, L.cin, L.cout, L.scale, L.bias, relu ? 1 : 0,
-                                       static_cast<float*>(y_), m_dyn, s_);
-        }
         ConvArgs a{};
         a.x = e->wino_v; a.w = L.wino_u43; a.y = e->wino_m;
         a.Cin = L.cin; a.Cout = L.cout; a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
@@ -1014,7 +1032,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                          (size_t)36 * T43 * (size_t)std::max(L.cin, L.cout) <= e->wino_elems && T43 * std::max(L.cin, L.cout) < (1ll << 31);
                 // the fold rule: layer shape only (see td_engine::wino_fold)
                 const int hw_ = H_ * W_, wf_ = e->wino_fold;
-                use_fold = use_43 && wf_ > 0 && !head && wino43_fused_ok(B_, H_, W_, L.cin, L.cout) &&
+                use_fold = use_43 && wf_ > 0 && !head && wino43_fused_ok(1, H_, W_, L.cin, L.cout) &&
                            (((wf_ & 1) && !m_dyn && ((L.cin == 256 && hw_ >= 160 * 160) || (L.cin == 128 && hw_ >= 80 * 80))) ||
                             ((wf_ & 2) && m_dyn) || ((wf_ & 4) && !m_dyn && L.cin == 256 && hw_ >= 80 * 80) ||
                             ((wf_ & 8) && !m_dyn && hw_ >= 40 * 40) || ((wf_ & 16) && !m_dyn));
