@@ -233,9 +233,12 @@ def compact_line(full):
             "e2e_crowns_f32": val("e2e_crowns", "f32", "value"), "e2e_crowns_f32_ratio": val("e2e_crowns", "f32", "ratio_to_model_stage"),
             "e2e_crowns_f16": val("e2e_crowns", "f16", "value"), "e2e_crowns_f16_ratio": val("e2e_crowns", "f16", "ratio_to_model_stage"),
             "e2e_crowns_chained_f32_ratio": val("e2e_crowns", "f32", "chained", "ratio_to_model_stage"),
-            "e2e_crowns_chained_f16_ratio": val("e2e_crowns", "f16", "chained", "ratio_to_model_stage")}
+            "e2e_crowns_chained_f16_ratio": val("e2e_crowns", "f16", "chained", "ratio_to_model_stage"),
+            "e2e_contours_per_tile": val("e2e", "f32", "contours_per_tile"), "e2e_crowns_contours_per_tile": val("e2e_crowns", "f32", "contours_per_tile"),
+            "e2e_json_kb_per_tile": _r((full.get("e2e", {}).get("f32", {}).get("json_bytes_per_tile") or 0) / 1e3) or None,
+            "e2e_crowns_json_kb_per_tile": _r((full.get("e2e_crowns", {}).get("f32", {}).get("json_bytes_per_tile") or 0) / 1e3) or None}
     c["regions"] = {k: v for k, v in scal.items() if v is not None}
-    c["regions_unit"] = "tiles/s (two_model: tile visits/s; *_frac: executed FLOPs / MFMA peak; *_ratio: e2e / model stage)"
+    c["regions_unit"] = "tiles/s (two_model: tile visits/s; *_frac: executed FLOPs / MFMA peak; *_ratio: e2e / model stage; *_per_tile: counts / kB)"
     c["detail"] = full.get("detail_file")
     return c
 
@@ -573,13 +576,15 @@ def main():
         log(f"two-model region done: {dtm * R:.3f} s for {R} x (urban pass + forest pass)")
         return dtm, len(visit["urban"]), len(visit["forest"]), n_tiles, dets
 
-    def run_e2e(precisions, side):
+    def run_e2e(precisions, side, sd_e2e, tag):
         """predict_tiles' model stage end to end, files to files (reference prediction.py:47-77,197-265): a warm
         Predictor.__call__ over ONE synthetic GeoTIFF on tmpfs — side x side tiles of S x S pixels (default 20 x 20: the 400 tiles
         the reference cuts from one 1 km² image, example/config.yml:26-28), 4-band RGBI uint8, tile metadata from the package's
         own tile producer — window reads into pinned memory, H2D, resize, forward, paste, D2H of the rows the paste wrote,
         contours → polygons → Prediction_<tile>.json written and counted. Per precision: first call = warm-up (weights, tile
-        choices, buffers), then three timed calls (value = the fastest)."""
+        choices, buffers), then three timed calls (value = the fastest). `sd_e2e` = the weights: the seeded random set (noise-like
+        masks: thousands of contours and ~1 MB of JSON per tile — a stress fixture for the host epilogue) or the same set with
+        weights.blob_mask_head (compact crowns, tens of contours per tile: what a trained segmenter hands the epilogue)."""
         import shutil
         import tempfile
         import treedetection_amd as T
@@ -606,7 +611,7 @@ def main():
             cfg = T.setup_model_cfg(update_model="synthetic", device=str(local_rank))
             for precision in precisions:
                 pred = T.Predictor(cfg, device_type=str(local_rank), max_batch_size=B, output_dir=f"{root}/out_{precision}",
-                                   precision=precision, state_dict=sd, return_predictions=False)
+                                   precision=precision, state_dict=sd_e2e, return_predictions=False)
                 pred(tif, tjson)                        # warm-up call
                 times = []
                 for _ in range(3):
@@ -639,11 +644,14 @@ def main():
                 folder = f"{root}/out_{precision}/324125317"
                 files = [f for f in os.listdir(folder) if f.startswith("Prediction_")]
                 nbytes = sum(os.path.getsize(f"{folder}/{f}") for f in files)
+                sample = sorted(files)[:: max(1, len(files) // 16)][:16]            # contours per tile from a sample of the files
+                ncont = [len(json.load(open(f"{folder}/{f}"))) for f in sample]
                 shutil.rmtree(f"{root}/out_{precision}", ignore_errors=True)
                 dt_e = min(times)
-                log(f"e2e region ({precision}): {ntiles} tiles per call, calls {[round(t, 3) for t in times]} s")
+                log(f"e2e region ({tag}, {precision}): {ntiles} tiles per call, calls {[round(t, 3) for t in times]} s")
                 out[precision] = {"value": ntiles / dt_e, "unit": "tiles/s", "tiles_per_call": ntiles, "calls_s": times,
                                   "files_written": len(files), "prediction_bytes": nbytes, "batch": B,
+                                  "json_bytes_per_tile": nbytes / max(len(files), 1), "contours_per_tile": float(np.mean(ncont)) if ncont else 0.0,
                                   "raster": f"{side * S}x{side * S}x4 uint8 GeoTIFF on {'tmpfs' if base else 'disk'}",
                                   "host_stage_seconds_last_call": stats,
                                   "chained": {"value": len(chain) * ntiles / dt_chain, "unit": "tiles/s", "images": len(chain), "seconds": dt_chain,
@@ -703,14 +711,17 @@ def main():
             B, nsteps = 32, -(-max(4, args.steps // 4) // args.streams) * args.streams
             b32 = go("fp16", not args.no_profile, "fp16_batch32") + (nsteps,)
             B, nsteps = args.batch, args.steps
-    two = e2e = None
+    two = e2e = e2e_c = None
     if args.depth == 50 and world == 1 and args.schedule == "streams":
         if not args.no_two_model:
             two = {args.precision: run_two_model(args.precision)}
             if args.precision == "fp32" and not args.no_fp16:
                 two["fp16"] = run_two_model("fp16")
         if not args.no_e2e:
-            e2e = run_e2e([args.precision] + (["fp16"] if args.precision == "fp32" and not args.no_fp16 else []), args.e2e_side)
+            from treedetection_amd.weights import blob_mask_head
+            precs = [args.precision] + (["fp16"] if args.precision == "fp32" and not args.no_fp16 else [])
+            e2e = run_e2e(precs, args.e2e_side, sd, "noise-like masks")
+            e2e_c = run_e2e(precs, args.e2e_side, blob_mask_head(sd, seed=0), "compact crowns")
 
     # what the collective layer saw (for the reader of an N > 1 line: did RCCL really run N ranks on N different GPUs?)
     props = torch.cuda.get_device_properties(local_rank)
@@ -940,17 +951,20 @@ def main():
                                                        "visited_by_urban": nu, "visited_by_forest": nf,
                                                        "stream_tiles_per_s": nt / dtm, "detections_last_batch": dets}
             line["two_model"] = o
-        if e2e is not None:
+        for key, res, what in (("e2e", e2e, "the seeded random mask head: noise-like masks, a stress fixture for the host epilogue"),
+                               ("e2e_crowns", e2e_c, "weights.blob_mask_head: compact crowns, what a trained segmenter hands the epilogue")):
+            if res is None:
+                continue
             o = {"note": "predict_tiles' model stage files to files: warm Predictor.__call__ over a synthetic GeoTIFF (window reads, H2D, resize, "
                          "forward, paste, D2H, contours, Prediction_*.json written); ratio = e2e rate / the model-stage rate of the same precision "
-                         "in this line (inputs resident in HBM, results left in HBM)"}
-            for pk, r in e2e.items():
+                         "in this line (inputs resident in HBM, results left in HBM)", "fixture": what}
+            for pk, r in res.items():
                 ref_rate = line["value"] if pk == args.precision else (line.get("fp16") or {}).get("value")
                 r["ratio_to_model_stage"] = r["value"] / ref_rate if ref_rate else None
                 if "chained" in r:
                     r["chained"]["ratio_to_model_stage"] = r["chained"]["value"] / ref_rate if ref_rate else None
                 o["f32" if pk == "fp32" else "f16"] = r
-            line["e2e"] = o
+            line[key] = o
         if world == 1 and not args.no_cpu_baseline:
             sd101 = None
             if args.depth == 50 and not args.no_r101:

@@ -446,7 +446,7 @@ def test_retired_tile_ids_are_refused():
 # ---- filter-direct tiles (conv_bdirect.hip): tile_cfg 23 = 64 x 256, 24 = 64 x 128; A through LDS-DMA, filter fragments from a
 # fragment-ordered copy of the bank straight into registers ----
 @pytest.mark.parametrize("prec", [1, 0])
-@pytest.mark.parametrize("cfg", [23, 24, 25, 26, 27])
+@pytest.mark.parametrize("cfg", [23, 24, 25, 26, 27, 29, 30])
 @pytest.mark.parametrize("case", PP8_CASES + [(8, 256, 50, 50, 256, 3, 1, 1, 0, True), (8, 2048, 25, 25, 512, 1, 1, 0, 0, True),
                                               (2, 256, 13, 13, 15, 1, 1, 0, 0, False)])
 def test_conv_filter_direct_equals_the_reference_tile_bit_for_bit(case, cfg, prec):
@@ -473,7 +473,7 @@ def test_conv_filter_direct_equals_the_reference_tile_bit_for_bit(case, cfg, pre
 
 
 # ---- fused 1x1 head (ConvArgs::head_w): the RPN's 3x3 conv + ReLU and its 15-row objectness / delta head in one launch ----
-@pytest.mark.parametrize("cfg", [9, 10, 12, 13, 17, 23, 27])
+@pytest.mark.parametrize("cfg", [9, 10, 12, 13, 17, 23, 27, 29])
 @pytest.mark.parametrize("case", [(2, 256, 50, 50, 3, 1, 15), (1, 256, 200, 200, 3, 1, 15), (8, 256, 13, 13, 3, 1, 15), (1, 64, 37, 21, 1, 0, 32),
                                   (3, 128, 25, 25, 3, 1, 6)])
 def test_conv_with_fused_head_equals_the_two_launches_bit_for_bit(case, cfg):

@@ -76,6 +76,8 @@ if __name__ == "__main__":
                     "pp8 no_epilogue": ["-DTD_DIAG_PP8_NO_EPILOGUE"],
                     "pp8 v1_dma_first": ["-DTD_PP8_V1"], "pp8 v2_dma_light_phases": ["-DTD_PP8_V2"],
                     "pp8 mfma16": ["-DTD_DIAG_MFMA16"],
+                    "pp8 mfma16b_same_flops": ["-DTD_DIAG_MFMA16B"],
+                    "pp8 mfma16b_loop_only": ["-DTD_DIAG_MFMA16B", "-DTD_DIAG_PP8_NO_DMA", "-DTD_DIAG_PP8_NO_READS", "-DTD_DIAG_PP8_NO_EPILOGUE"],
                     "pp8 mfma16_loop_only": ["-DTD_DIAG_MFMA16", "-DTD_DIAG_PP8_NO_DMA", "-DTD_DIAG_PP8_NO_READS", "-DTD_DIAG_PP8_NO_EPILOGUE"],
                     "pp8 loop_only": ["-DTD_DIAG_PP8_NO_DMA", "-DTD_DIAG_PP8_NO_READS", "-DTD_DIAG_PP8_NO_EPILOGUE"]}
         if len(sys.argv) > 2:

@@ -77,7 +77,7 @@ td_status td_conv2d_head_nhwc(const void* x, const void* w, const float* bias, c
 static td_status conv2d_api(ConvArgs& a, int precision, void* stream) {
     const int Cin = a.Cin, Cout = a.Cout, KH = a.KH, KW = a.KW;
     const void* w = a.w;
-    if (a.tile_cfg >= 23 && a.tile_cfg <= 27 && Cin % ((precision & 0xff) == TD_PRECISION_FP16 ? 64 : 32) == 0) {
+    if (conv_cfg_is_bd(a.tile_cfg) && Cin % ((precision & 0xff) == TD_PRECISION_FP16 ? 64 : 32) == 0) {
         // tests: the filter-direct tiles (conv_bdirect.hip) need the filters in fragment order: packed here from the caller's
         // [Cout][KH][KW][Cin] bank (the engine packs once at load time)
         hipStream_t s = static_cast<hipStream_t>(stream);

@@ -87,7 +87,7 @@ struct ConvArgs {
 // tile ids whose block owns 256 output channels at once (fp16): the head fusion above applies
 static inline bool conv_head_capable(int cfg, int precision) {
     // (the single-stage 256-wide tiles 14 / 16 stage their output as fp32 wave-rows, not as one fp16 tile: not capable)
-    return precision == TD_PRECISION_FP16 && (cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 17 || cfg == 23 || cfg == 27 || cfg == 28);
+    return precision == TD_PRECISION_FP16 && (cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 17 || cfg == 23 || cfg == 27 || cfg == 29);
 }
 // tile_cfg ids (conv_igemm.hip:dispatch): 0..3 4-wave tiles 128x128 / 128x64 / 64x128 / 64x64 (2 LDS stages), 4..7 the same
 // with 3 stages (measured no better: not tuned over), 8 = 256x128 / 9 = 128x256 (8 waves), 10 = 256x256 (16 waves),
@@ -97,8 +97,10 @@ static inline bool conv_head_capable(int cfg, int precision) {
 // 21 / 22 / 28 = retired ids (stream-K and the 4-wave 256x256 tile: measured slower in round 3, sources kept under csrc/experimental/, not built
 // into the product; conv2d_launch refuses them), 23 / 24 / 25 / 26 / 27 = conv_bd_kernel: 64x256 / 64x128 / 64x128 with two k-chunks per barrier / 64x128 with three k-steps of loads in flight / 64x256 with two, filter fragments
 // straight from a fragment-ordered copy of the filters into registers (conv_bdirect.hip)
-#define TD_CONV_TILE_CFG_MAX 28
-static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17, 18, 19, 20, 23, 24, 25, 26, 27};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16, 18-20 only for plane contractions, 23-27 only with packed fp16 filters
+// 29 / 30 = conv_bd_kernel 128x256 / 128x128, three k-steps of loads in flight: taller tiles, half the filter re-reads (round 4)
+#define TD_CONV_TILE_CFG_MAX 30
+static inline bool conv_cfg_is_bd(int cfg) { return (cfg >= 23 && cfg <= 27) || cfg == 29 || cfg == 30; }
+static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17, 18, 19, 20, 23, 24, 25, 26, 27, 29, 30};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16, 18-20 only for plane contractions, 23-27 / 29 / 30 only with packed filters
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
 // a.nlev levels (x / w / bias / y / head_y / H / W filled in; M, tile0, ntiles are computed here) in one conv_pp8_kernel grid;
 // everything else (B, Cin, Cout = 256, KH = KW = 3, relu, head_w / head_b / head_n) from the common fields. Bit-identical to one

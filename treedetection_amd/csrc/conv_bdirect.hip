@@ -1,4 +1,4 @@
-// conv_bd_kernel: implicit-GEMM convolution whose FILTER fragments bypass LDS (tile ids 23 - 27; fp16 and, since the deep load
+// conv_bd_kernel: implicit-GEMM convolution whose FILTER fragments bypass LDS (tile ids 23 - 27, 29, 30; fp16 and, since the deep load
 // pipelines, fp32 as well: the data path is counted in bytes — a k-chunk is 128 B, a fragment 16 B — and Elem<T> picks the MFMA).
 //
 // Why: the fp16 engine's mid-size layers (res4 / res5, FPN and RPN at p4 - p6, the 1x1 layers of res3) are bound by the
@@ -314,6 +314,8 @@ namespace {
 template <typename T, typename TO>
 td_status bd_variant(const ConvArgs& a, int variant, hipStream_t stream) {
     switch (variant) {
+        case 6: return launch_bd<T, TO, 4, 1, 4, 2, 1, 3>(a, stream);   // 128 x 128 (4 waves of 128 x 32), three k-steps in flight: half the filter re-reads of the 64-row tiles
+        case 5: return launch_bd<T, TO, 4, 2, 4, 1, 1, 3>(a, stream);   // 128 x 256 (4 waves of 128 x 64, one per SIMD: ~300 registers), three k-steps in flight: long-K layers with few row tiles (fc1)
         case 3: return launch_bd<T, TO, 2, 1, 4, 3, 1, 3>(a, stream);   // 64 x 128, three k-steps of loads in flight (five 8-KB LDS stages, four filter register sets)
         case 4: return launch_bd<T, TO, 2, 2, 4, 2, 1, 2>(a, stream);   // 64 x 256, two k-steps in flight
         case 2: return launch_bd<T, TO, 2, 1, 4, 3, 2>(a, stream);      // 64 x 128, two k-chunks per barrier interval

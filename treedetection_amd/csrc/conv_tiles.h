@@ -37,7 +37,16 @@ template <>
 struct Elem<_Float16> {
     static constexpr int PER_CHUNK = 64;
     static __device__ __forceinline__ void mma(const f32x4& fa, const f32x4& fb, f32x16& acc) {
-#if defined(TD_DIAG_MFMA16)     // timing experiment only (tools/conv_diag.py): same FLOPs and registers as four 16x16x32
+#if defined(TD_DIAG_MFMA16B)    // timing experiment only (tools/conv_diag.py): TWO 16x16x32 = the FLOPs and issue cycles of one 32x32x16 (wrong sums)
+        f32x4 q[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            q[k] = f32x4{acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]};
+            q[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa), __builtin_bit_cast(f16x8, fb), q[k], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * k + e] = q[k][e];
+        }
+#elif defined(TD_DIAG_MFMA16)     // timing experiment only (tools/conv_diag.py): four 16x16x32 = TWICE the FLOPs of one 32x32x16
         f32x4 q[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

@@ -844,7 +844,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                          auto&& launch_cfg, int* cfg_out, float* best_ms) -> td_status {
         static const int forced = getenv("TD_FORCE_CFG") ? atoi(getenv("TD_FORCE_CFG")) : -1;      // diagnostics: one block tile everywhere it applies
         if (forced >= 0 && forced <= TD_CONV_TILE_CFG_MAX && !best_ms && !(forced >= 14 && forced <= 16 && ksteps > 4) && !(forced == 17 && !pp8_ok) &&
-            !(forced >= 18 && forced <= 20 && !plane_ok) && !(forced >= 23 && !bd_ok)) {
+            !(forced >= 18 && forced <= 20 && !plane_ok) && !(conv_cfg_is_bd(forced) && !bd_ok)) {
             *cfg_out = forced;
             return TD_OK;
         }
@@ -867,7 +867,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
             if (c >= 14 && c <= 16 && ksteps > 4) continue;      // single-stage tiles only pay on the thin 1x1 layers
             if (c == 17 && !pp8_ok) continue;                    // fp16 256x256 ping-pong tile
             if (c >= 18 && c <= 20 && !plane_ok) continue;       // persistent tile walk: Winograd plane contractions only
-            if (c >= 23 && c <= 27 && !bd_ok) continue;         // filter-direct tiles: fp16 layers with a fragment-ordered filter copy
+            if (conv_cfg_is_bd(c) && !bd_ok) continue;          // filter-direct tiles: layers with a fragment-ordered filter copy
             float ms = 1e30f;
             td_status st2 = time_launch(s_, ea, eb, [&]() { return launch_cfg(c); }, &ms);
             if (st2 < 0) {

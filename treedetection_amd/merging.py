@@ -51,7 +51,12 @@ def retrieve_neighboring_image_filenames(filename, other_filenames, meta_info: O
 
 def _fill_value(nodata: float, dt: np.dtype) -> float:
     """The value the mosaic starts from. rasterio.merge checks the nodata value against the range of the output dtype and,
-    when it does not fit (GDAL_NODATA -9999 on a uint8 raster), warns and leaves the destination at zero."""
+    when it does not fit (GDAL_NODATA -9999 on a uint8 raster), warns and leaves the destination at zero.
+    DELIBERATE DEVIATION for that case (read from rasterio's source, rasterio is not installed here to confirm):
+    rasterio then still compares the destination with the ORIGINAL out-of-range value (``region == -9999`` on uint8 is False
+    everywhere), so nothing is ever copied and its mosaic stays all zero — a reference result nobody can want. This port
+    compares against the value the destination really holds (0): both images are copied by the "first" rule. For every
+    nodata value that fits the dtype — the reference's own rasters — the two agree (tests/test_merging.py)."""
     if np.issubdtype(dt, np.integer):
         info = np.iinfo(dt)
         if np.isnan(nodata) or not (info.min <= nodata <= info.max) or float(nodata) != int(nodata):
