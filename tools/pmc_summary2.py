@@ -26,6 +26,8 @@ def family(name):
         return "conv_igemm_kernel"
     if "plane_gemm" in name:
         return "plane_gemm_kernel"
+    if "wino43_fused" in name:
+        return "wino43_fused_kernel"
     for k in ("wino_gemm", "wino43_input", "wino43_output", "wino_input", "wino_output", "stem_conv", "stem_mfma", "maxpool", "roi_align", "rpn_topk",
               "rpn_keys", "nms_", "paste", "resize_"):
         if k in name:
@@ -80,13 +82,13 @@ def main():
                "hbm_tb_per_s": hbm / (f["us"] * 1e-6) / 1e12 if f["us"] else 0.0}
         out["families"][name] = rec
         if name in ("conv_igemm_kernel", "conv_pp8_kernel", "conv_bd_kernel", "conv_sk_kernel", "bottleneck_tail_kernel", "plane_gemm_kernel", "wino_gemm_kernel", "wino_input_kernel", "wino_output_kernel",
-                    "wino43_input_kernel", "wino43_output_kernel"):
+                    "wino43_input_kernel", "wino43_output_kernel", "wino43_fused_kernel"):
             for k in ("launches", "us", "SQ_VALU_MFMA_BUSY_CYCLES"):
                 conv[k] += f[k]
             conv["hbm"] += hbm
             conv["simd"] += simd
     out["conv_family"] = {"members": "conv_igemm_kernel + conv_pp8_kernel + conv_bd_kernel + conv_sk_kernel + bottleneck_tail_kernel + plane_gemm_kernel + "
-                                     "wino_gemm_kernel + wino_input_kernel + wino_output_kernel + wino43_input_kernel + wino43_output_kernel",
+                                     "wino_gemm_kernel + wino_input_kernel + wino_output_kernel + wino43_input_kernel + wino43_output_kernel + wino43_fused_kernel",
                           "launches": conv["launches"] / steps, "ms_per_step": conv["us"] / steps / 1e3,
                           "hbm_traffic_gb_per_step": conv["hbm"] / steps / 1e9,
                           "hbm_bytes_per_launch": conv["hbm"] / max(conv["launches"], 1),

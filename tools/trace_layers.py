@@ -59,6 +59,15 @@ def launches_of(name, M, N, K, fp32, B=8, min43=12):
         return 1, None
     side = int(round((M / B) ** 0.5)) if M else 14          # M = 0: the mask head's 14 x 14 RoIs (device-side row count)
     if min43 > 0 and side >= min43:
+        # round 4: the fold rule of engine.cpp (TD_WINO_FOLD, default 7): never the RPN layers (their head rides in the three-launch
+        # form's output transform); 256 channels from 80 x 80, 128 channels from 80 x 80, the mask head → input transform + wino43_fused_kernel
+        import os
+        wf = int(os.environ.get("TD_WINO_FOLD", "7"))
+        cin = K // 9
+        fold = "rpn" not in name and (((wf & 1) and M and ((cin == 256 and side >= 160) or (cin == 128 and side >= 80))) or ((wf & 2) and not M) or
+                                      ((wf & 4) and M and cin == 256 and side >= 80) or ((wf & 8) and M and side >= 40) or ((wf & 16) and M))
+        if fold and cin in (128, 256) and N % 64 == 0:
+            return 2, "winograd F(4x4) folded"
         return 3, "winograd F(4x4)"
     return 2, "winograd F(2x2)"
 
@@ -66,7 +75,7 @@ def launches_of(name, M, N, K, fp32, B=8, min43=12):
 def main(path, depth=50, fp32=False):
     import os
     min43 = int(os.environ.get("TD_WINO43_MIN", "12"))
-    fam = ("conv_igemm", "conv_pp8", "plane_gemm", "wino_gemm", "wino_output", "wino_input", "wino43_input", "wino43_output", "bottleneck_tail", "conv_sk", "conv_bd")
+    fam = ("conv_igemm", "conv_pp8", "plane_gemm", "wino_gemm", "wino_output", "wino_input", "wino43_input", "wino43_output", "wino43_fused", "bottleneck_tail", "conv_sk", "conv_bd")
     # launch order = start order on the one stream of the plain loop (the CSV itself is not written in that order)
     rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
     rows = [r for r in rows if any(f in r["Kernel_Name"] for f in fam)]
@@ -107,12 +116,16 @@ def main(path, depth=50, fp32=False):
         if "conv2+3" in name:
             assert "bottleneck_tail" in kn, (name, kn)
         kern = label if label else ("pp8 grouped" if "grouped" in name else "pp8" if "conv_pp8" in kn else "bottleneck_tail" if "bottleneck_tail" in kn else
-                                    "conv_sk" if "conv_sk" in kn else ("conv_bd 64x256" if "Li2ELi2ELi4" in kn or "2, 2, 4" in kn else "conv_bd 64x128") if "conv_bd" in kn else
+                                    "conv_sk" if "conv_sk" in kn else ("conv_bd 64x256" if "Li2ELi2ELi4" in kn or "2, 2, 4" in kn else "conv_bd 128x256" if "Li4ELi2ELi4" in kn or "4, 2, 4" in kn else
+                                                 "conv_bd 128x128" if "Li4ELi1ELi4" in kn or "4, 1, 4" in kn else "conv_bd 64x128") if "conv_bd" in kn else
                                     "plane_gemm" + kn.split("plane_gemm_kernel")[1].split("(")[0][:12] if "plane_gemm" in kn else
                                     kn.split("conv_igemm_")[1].split("(")[0][:28])
         if k == 3:
             assert "wino43_input" in kn and "wino43_output" in rs[2]["Kernel_Name"], (name, kn)
             kern += f" [{ts[0]:.0f}+{ts[1]:.0f}+{ts[2]:.0f}]"
+        elif k == 2 and label and "folded" in label:
+            assert "wino43_input" in kn and "wino43_fused" in rs[1]["Kernel_Name"], (name, kn, rs[1]["Kernel_Name"])
+            kern += f" [{ts[0]:.0f}+{ts[1]:.0f}]"
         elif k == 2:
             assert "wino_gemm" in kn, (name, kn)
         print(f"{name:24s} M={M:7d} N={N:5d} K={K:6d} {kern:34s} {us:9.1f} us {gf:8.2f} GF {gf/us*1e3 if us else 0:7.1f} TF/s")
