@@ -62,9 +62,10 @@ def launches_of(name, M, N, K, fp32, B=8, min43=12):
         # round 4: the fold rule of engine.cpp (TD_WINO_FOLD, default 7): never the RPN layers (their head rides in the three-launch
         # form's output transform); 256 channels from 80 x 80, 128 channels from 80 x 80, the mask head → input transform + wino43_fused_kernel
         import os
-        wf = int(os.environ.get("TD_WINO_FOLD", "7"))
+        wf = int(os.environ.get("TD_WINO_FOLD", "39"))
         cin = K // 9
-        fold = "rpn" not in name and (((wf & 1) and M and ((cin == 256 and side >= 160) or (cin == 128 and side >= 80))) or ((wf & 2) and not M) or
+        rpn_fold = "rpn_conv p" in name and (wf & 1) and (wf & 32) and cin == 256 and side >= 160      # head as a launch of its own
+        fold = rpn_fold or "rpn" not in name and (((wf & 1) and M and ((cin == 256 and side >= 160) or (cin == 128 and side >= 80))) or ((wf & 2) and not M) or
                                       ((wf & 4) and M and cin == 256 and side >= 80) or ((wf & 8) and M and side >= 40) or ((wf & 16) and M))
         if fold and cin in (128, 256) and N % 64 == 0:
             return 2, "winograd F(4x4) folded"
@@ -98,7 +99,8 @@ def main(path, depth=50, fp32=False):
         # fp32 engine: a fixed rule — every RPN level that takes the F(4x4) path carries its head in the output transform
         hs = [800 >> (l + 2) for l in range(4)]
         hs.append((hs[3] - 1) // 2 + 1)
-        fused_heads = {l for l in range(5) if min43 > 0 and hs[l] >= min43}
+        wf = int(os.environ.get("TD_WINO_FOLD", "39"))
+        fused_heads = {l for l in range(5) if min43 > 0 and hs[l] >= min43 and not ((wf & 1) and (wf & 32) and hs[l] >= 160)}
     L = schedule(depth, fp32=fp32, fuse_tail=fuse_tail, fused_heads=fused_heads, grouped=grouped)
     need = sum(launches_of(e[0], e[1], e[2], e[3], fp32, 8, min43)[0] for e in L)
     last = rows[-need:]

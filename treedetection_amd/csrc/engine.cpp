@@ -137,7 +137,8 @@ struct td_engine {
     // fold also pays where its isolated time ties, it frees HBM bandwidth for the other streams (bench, fp32 tiles/s: 0 → 638,
     // 1 → 650, 3 → 655, 7 → 656) —, 8 = every map from 40 x 40 and 16 = every layer the kernel can run: 660 - 661 under the
     // stream schedule but 574 → 545 one forward at a time (88-block launches on 256 CUs), not taken.
-    int wino_fold = 7;
+    // 32 = the RPN conv on the 160 x 160+ maps folds too (its head becomes a launch of its own).
+    int wino_fold = 39;
     std::string tune_cache;       // TD_TUNE_CACHE: load / append measured choices (keeps profiled runs free of tuning launches)
 
     // forward context (kept between the phases of td_engine_forward_phase) and the per-phase completion events
@@ -1032,10 +1033,13 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                          (size_t)36 * T43 * (size_t)std::max(L.cin, L.cout) <= e->wino_elems && T43 * std::max(L.cin, L.cout) < (1ll << 31);
                 // the fold rule: layer shape only (see td_engine::wino_fold)
                 const int hw_ = H_ * W_, wf_ = e->wino_fold;
-                use_fold = use_43 && wf_ > 0 && !head && wino43_fused_ok(1, H_, W_, L.cin, L.cout) &&
-                           (((wf_ & 1) && !m_dyn && ((L.cin == 256 && hw_ >= 160 * 160) || (L.cin == 128 && hw_ >= 80 * 80))) ||
-                            ((wf_ & 2) && m_dyn) || ((wf_ & 4) && !m_dyn && L.cin == 256 && hw_ >= 80 * 80) ||
-                            ((wf_ & 8) && !m_dyn && hw_ >= 40 * 40) || ((wf_ & 16) && !m_dyn));
+                // (a layer with a 1x1 head — the RPN conv — folds only on the 160 x 160+ maps, bit 32: its head then runs as a launch
+                // of its own on the stored map, 1 000 + ~70 us against 1 280 us for the three-launch form with the head in its
+                // output transform; on the smaller maps that form wins)
+                use_fold = use_43 && wf_ > 0 && wino43_fused_ok(1, H_, W_, L.cin, L.cout) &&
+                           (((wf_ & 1) && !m_dyn && (!head || (wf_ & 32)) && ((L.cin == 256 && hw_ >= 160 * 160) || (L.cin == 128 && hw_ >= 80 * 80))) ||
+                            ((wf_ & 2) && m_dyn && !head) || ((wf_ & 4) && !m_dyn && !head && L.cin == 256 && hw_ >= 80 * 80) ||
+                            ((wf_ & 8) && !m_dyn && !head && hw_ >= 40 * 40) || ((wf_ & 16) && !m_dyn && !head));
                 if (use_43 && !use_fold) {
                     const auto key43 = std::make_tuple(L.cout, L.cin, 1 * 16 + 1, (int)T43, 4 + 64);
                     auto w43 = [&](int c) { return run_wino43(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, c); };
@@ -1054,7 +1058,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
         if (use_43) {
             // fp32 engine: the head rides in the F(4x4) output transform — a FIXED rule (layer shapes only), bit-identical to the
             // separate launch anyway
-            const bool fuse43 = head && e->fuse_head && !m_dyn && relu && L.cout == 256 && head->cin == 256 && head->kh == 1 && head->kw == 1 &&
+            const bool fuse43 = head && !use_fold && e->fuse_head && !m_dyn && relu && L.cout == 256 && head->cin == 256 && head->kh == 1 && head->kw == 1 &&
                                 head->cout <= 32 && !head->scale;
             if (head_fused) *head_fused = fuse43;
             return run_wino43(L, x_, B_, H_, W_, relu, y_, s_, m_dyn, wino_cfg, fuse43 ? head : nullptr, fuse43 ? head_y : nullptr, use_fold);
