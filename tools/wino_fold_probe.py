@@ -23,6 +23,14 @@ SHAPES = [  # name, B, C, H, W, N
 
 def main():
     lib = _lib.load()
+    if any(v not in ("", "0") for v in os.environ.get("WF_VARS", "0").split(",")):
+        # the ablation builds (TD_WF_VAR) live behind -DTD_WF_DIAG: build this one file into /tmp and bind the same entry point
+        import ctypes as C
+        from tools.conv_diag import build
+        so = build("wf_diag", ["-DTD_WF_DIAG"], src="wino_fused")
+        lib = C.CDLL(so)
+        lib.td_conv2d_winograd_nhwc.restype = C.c_int
+        lib.td_conv2d_winograd_nhwc.argtypes = [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]
     only = sys.argv[1:] or None
     rng = np.random.default_rng(0)
     for name, B, C, H, W, N in SHAPES:

@@ -316,17 +316,22 @@ td_status wino43_fused_launch(const float* V, const float* U, int B, int H, int 
     const long long blocks = ((a.T + WF_BT - 1) / WF_BT) * (N / WF_BN);
     TD_REQUIRE(blocks < (1ll << 31), "winograd F(4x4) fused contraction: grid too large");
     // a plane = C / 32 chunk-steps = the LDS stages of the unrolled loop: 8 (C = 256: seven chunks of DMA in flight, 128 KB) or 4 (C = 128)
-    const int var = getenv("TD_WF_VAR") ? atoi(getenv("TD_WF_VAR")) : 0;
     const bool s8 = C == 256;
 #define TD_WF_LAUNCH(NSV, VARV) hipLaunchKernelGGL((wino43_fused_kernel<NSV, VARV>), dim3((unsigned)blocks), dim3(512), 0, s, a)
+#if defined(TD_WF_DIAG)     // timing builds only (tools/wino_fold_probe.py builds this file with -DTD_WF_DIAG into /tmp; never shipped): TD_WF_VAR picks an ablation
+    const int var = getenv("TD_WF_VAR") ? atoi(getenv("TD_WF_VAR")) : 0;
     switch (var) {
-        case 8: TD_WF_LAUNCH(8, 8); break;        // diagnostics (wrong results): no DMA in the loop
+        case 8: TD_WF_LAUNCH(8, 8); break;        // wrong results: no DMA in the loop
         case 16: TD_WF_LAUNCH(8, 16); break;      // no MFMAs
         case 32: TD_WF_LAUNCH(8, 32); break;      // no fragment reads
         case 40: TD_WF_LAUNCH(8, 40); break;      // MFMAs + barriers (+ fold) only
         case 104: TD_WF_LAUNCH(8, 104); break;    // MFMAs (+ fold) only
         default: if (s8) TD_WF_LAUNCH(8, 0); else TD_WF_LAUNCH(4, 0); break;
     }
+#else
+    if (s8) TD_WF_LAUNCH(8, 0);
+    else TD_WF_LAUNCH(4, 0);
+#endif
 #undef TD_WF_LAUNCH
     TD_KERNEL_CHECK();
     return TD_OK;
