@@ -22,8 +22,9 @@ SHAPES = [  # name, B, C, H, W, N
 
 
 def main():
-    lib = _lib.load()
-    if any(v not in ("", "0") for v in os.environ.get("WF_VARS", "0").split(",")):
+    diag = any(v not in ("", "0") for v in os.environ.get("WF_VARS", "0").split(","))
+    lib = None if diag else _lib.load()      # (the diag library must be the ONLY one loaded: same symbols, first definition wins)
+    if diag:
         # the ablation builds (TD_WF_VAR) live behind -DTD_WF_DIAG: build this one file into /tmp and bind the same entry point
         import ctypes as C
         from tools.conv_diag import build
@@ -44,8 +45,9 @@ def main():
         for fold, var, st in variants:
             os.environ["TD_WINO_TILE"], os.environ["TD_WINO_FOLD"], os.environ["TD_WF_VAR"], os.environ["TD_WF_STAGES"] = "4", fold, var, st
             for _ in range(4):
-                _lib.check(lib.td_conv2d_winograd_nhwc(x.data_ptr(), w.data_ptr(), None, b.data_ptr(), y.data_ptr(), B, H, W, C, N, 1,
-                                                       _lib.stream_ptr()), "td_conv2d_winograd_nhwc")
+                st = lib.td_conv2d_winograd_nhwc(x.data_ptr(), w.data_ptr(), None, b.data_ptr(), y.data_ptr(), B, H, W, C, N, 1,
+                                                 torch.cuda.current_stream().cuda_stream)
+                assert st == 0, st
             torch.cuda.synchronize()
         print(name, "done", flush=True)
 
