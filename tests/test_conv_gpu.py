@@ -137,7 +137,7 @@ def test_conv_pp8_equals_the_reference_tile_bit_for_bit(case, cfg256):
     assert np.abs(ref).max() > 0.5
 
 
-@pytest.mark.parametrize("cfg", [4, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20])
+@pytest.mark.parametrize("cfg", [4, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 31, 32])
 def test_conv_every_block_tile_variant(cfg):
     """The engine picks a block tile per layer by measurement; every variant must compute the same convolution.
     TD_CONV_CFG forces one variant for a whole process (diagnostic hook), so the cases above re-run in a child."""

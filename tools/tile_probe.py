@@ -29,6 +29,7 @@ SHAPES = {  # name: (B, H, W, Cin, Cout, k, stride, residual)
     "res5_conv1": (8, 25, 25, 2048, 512, 1, 1, False),
     "fpn_lateral3": (8, 100, 100, 512, 256, 1, 1, False),
     "fc2": (8000, 1, 1, 1024, 1024, 1, 1, False),
+    "rpn_head_p2": (8, 200, 200, 256, 15, 1, 1, False),
 }
 
 

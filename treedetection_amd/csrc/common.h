@@ -98,9 +98,10 @@ static inline bool conv_head_capable(int cfg, int precision) {
 // into the product; conv2d_launch refuses them), 23 / 24 / 25 / 26 / 27 = conv_bd_kernel: 64x256 / 64x128 / 64x128 with two k-chunks per barrier / 64x128 with three k-steps of loads in flight / 64x256 with two, filter fragments
 // straight from a fragment-ordered copy of the filters into registers (conv_bdirect.hip)
 // 29 / 30 = conv_bd_kernel 128x256 / 128x128, three k-steps of loads in flight: taller tiles, half the filter re-reads (round 4)
-#define TD_CONV_TILE_CFG_MAX 30
+// 31 / 32 = conv_igemm_kernel 256x32 / 128x32 (4 x 1 waves): layers with at most 32 output channels (round 4)
+#define TD_CONV_TILE_CFG_MAX 32
 static inline bool conv_cfg_is_bd(int cfg) { return (cfg >= 23 && cfg <= 27) || cfg == 29 || cfg == 30; }
-static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17, 18, 19, 20, 23, 24, 25, 26, 27, 29, 30};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16, 18-20 only for plane contractions, 23-27 / 29 / 30 only with packed filters
+static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17, 18, 19, 20, 23, 24, 25, 26, 27, 29, 30, 31, 32};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16, 18-20 only for plane contractions, 23-27 / 29 / 30 only with packed filters, 31 / 32 only for <= 32 output channels
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
 // a.nlev levels (x / w / bias / y / head_y / H / W filled in; M, tile0, ntiles are computed here) in one conv_pp8_kernel grid;
 // everything else (B, Cin, Cout = 256, KH = KW = 3, relu, head_w / head_b / head_n) from the common fields. Bit-identical to one

@@ -1001,6 +1001,10 @@ td_status dispatch(const ConvArgs& a, int cfg, hipStream_t stream) {
         case 14: return launch<T, TO, 2, 2, 1, 4, 4>(a, stream);    // 256 x 256
         case 15: return launch<T, TO, 2, 2, 1, 2, 2>(a, stream);    // 128 x 128
         case 16: return launch<T, TO, 2, 2, 1, 2, 4>(a, stream);    // 128 x 256
+        // 32-column tiles for the thin heads (RPN objectness + deltas: 15 rows, box predictor: 6): a 64-column tile spends three
+        // quarters of its MFMAs on padding — the RPN head at p2 (M = 320 000, K = 256) was MFMA-bound on it (round 4)
+        case 31: return launch<T, TO, 2, 1, 2, 4, 1>(a, stream);    // 256 x 32, 4 waves of 64 x 32
+        case 32: return launch<T, TO, 1, 1, 2, 4, 1>(a, stream);    // 128 x 32, 4 waves of 32 x 32
         case 17:                                                     // 256 x 256, 8 waves, ping-pong phases (fp16 only)
             if constexpr (std::is_same<T, _Float16>::value) {
                 const int tiles = td_cdiv(a.M, 256) * td_cdiv(a.Cout, 256);
