@@ -345,8 +345,9 @@ def test_winograd_f4x4_folded_conv_matches_torch(case):
 TAIL_CASES = [  # (precision, B, H, W, mid)
     (0, 2, 37, 41, 64),       # fp32 res2 shape class; M = 3034 is not a multiple of the 128-row tile
     (0, 1, 200, 200, 64),     # one res2 image at BASELINE size
-    (1, 2, 37, 41, 64),
-    (1, 1, 100, 100, 128),    # fp16 res3 shape class
+    (1, 2, 37, 41, 64),       # fp16: the wave-private epilogue with the shortcut prefetch (two output pieces), ragged last block
+    (1, 1, 200, 200, 64),     # fp16 res2 image at BASELINE size
+    (1, 1, 100, 100, 128),    # fp16 res3 shape class (four output pieces: the rolling shortcut prefetch)
     (1, 3, 13, 9, 128),       # fewer rows than one tile per image, padding everywhere
 ]
 

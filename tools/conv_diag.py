@@ -9,7 +9,7 @@ def build(tag, defs, src="conv_igemm"):
     """One kernel file rebuilt with the diagnostic defines, linked with the product build's other objects (csrc/*.o)."""
     import glob
     out, obj = f"/tmp/libdiag_{tag}.so", f"/tmp/diag_{tag}.o"
-    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off"] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if src == "conv_igemm" else [])
+    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off"] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if src in ("conv_igemm", "bottleneck") else [])
     subprocess.run(["/opt/rocm/bin/hipcc"] + flags + defs + ["-c", os.path.join(CS, src + ".hip"), "-o", obj], check=True)
     others = [o for o in sorted(glob.glob(os.path.join(CS, "*.o"))) if os.path.basename(o) != src + ".o"]
     subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", obj] + others + ["-o", out], check=True)

@@ -19,12 +19,23 @@
 #include "common.h"
 #include "conv_tiles.h"
 #include <cstdlib>
+#include <utility>
 
 namespace {
 
 constexpr int cmax(int x, int y) { return x > y ? x : y; }
 
-template <typename T, int MID, bool OVERLAP, int MT>
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {            // f(integral_constant<int, 0>) .. f(integral_constant<int, N - 1>)
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// FAST (fp16, 64-row blocks): the wave-private wide epilogue below instead of conv_epilogue
+template <typename T, int MID, bool OVERLAP, int MT, bool FAST = false>
 struct TailGeom {
     static constexpr int ES = sizeof(T);
     static constexpr int KE = Elem<T>::PER_CHUNK;            // elements per 128-B k-chunk
@@ -33,8 +44,9 @@ struct TailGeom {
     static constexpr int NT1 = MID / 64;                     // phase 1: wave tile 64 x (32 NT1), block tile 128 x MID
     static constexpr int STAGE1 = 2 * (BM + MID) * CHUNK_BYTES;
     static constexpr int W3_BYTES = KC * 128 * CHUNK_BYTES;  // the 1x1 filters of one 128-channel output piece: [KC][128][128 B]
-    static constexpr int EPI_BYTES = conv_epilogue_lds_bytes<T, MT, 2, 2, 2, 1, false>();
-    static constexpr int EPI_OFF = OVERLAP ? W3_BYTES : 0;   // OVERLAP: the next piece's filters arrive while this piece is finished
+    static_assert(!FAST || (ES == 2 && MT == 1), "the wave-private epilogue is written for fp16 and 64-row blocks");
+    static constexpr int EPI_BYTES = FAST ? 4 * 16 * 64 * 4 : conv_epilogue_lds_bytes<T, MT, 2, 2, 2, 1, false>();    // FAST: 16 rows x 64 floats per wave
+    static constexpr int EPI_OFF = OVERLAP || FAST ? W3_BYTES : 0;   // OVERLAP / FAST: the next piece's filters arrive while this piece is finished
     // region 0 = the phase-1 stages, later the filters of a piece and the epilogue's staging tile (side by side or aliased)
     static constexpr int R0 = cmax(STAGE1, cmax(W3_BYTES, EPI_OFF + EPI_BYTES));
     static constexpr int T2_BYTES = KC * BM * CHUNK_BYTES;   // the mid tile as the 1x1's A image: [KC][128][128 B]
@@ -44,9 +56,9 @@ struct TailGeom {
 
 // The body is a __device__ function (the __global__ entry below only owns the LDS array): with the staging lambdas called
 // straight from a __global__ template, hipcc (ROCm 7.2) silently dropped the kernel's HOST stub from the object file.
-template <typename T, int MID, bool OVERLAP, int MT>
+template <typename T, int MID, bool OVERLAP, int MT, bool FAST>
 __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* lds) {
-    typedef TailGeom<T, MID, OVERLAP, MT> G;
+    typedef TailGeom<T, MID, OVERLAP, MT, FAST> G;
     constexpr int ES = G::ES, KE = G::KE, KC = G::KC, BM = G::BM, LDROWS = G::LDROWS, NT1 = G::NT1;
     constexpr int AROWS = BM / LDROWS, BROWS1 = MID / LDROWS, BROWS3 = 128 / LDROWS;
     char* As = lds;                                   // phase 1: [2][BM][128 B]
@@ -135,6 +147,28 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) frag_off[kk] = (unsigned)(lane & 31) * CHUNK_BYTES + (((unsigned)(2 * kk) + hi) ^ swz) * 16;
 
+    // FrozenBN constants in the accumulator layout (a lane owns one channel per 32-column block), loaded ahead of every
+    // counted wait below: a later load would force a vmcnt(0) on the shortcut prefetch of the FAST epilogue
+    float sc2[NT1], bi2[NT1];
+#pragma unroll
+    for (int j = 0; j < NT1; ++j) {
+        const int n = wn * 32 * NT1 + j * 32 + (lane & 31);
+        sc2[j] = a.scale2 ? a.scale2[n] : 1.f;
+        bi2[j] = a.bias2 ? a.bias2[n] : 0.f;
+    }
+    constexpr int NP = MID / 32;                       // 128-channel output pieces (COUT = 4 MID)
+    [[maybe_unused]] float sc3[NP][2], bi3[NP][2];
+    if constexpr (FAST) {
+#pragma unroll
+        for (int nc = 0; nc < NP; ++nc)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = nc * 128 + wn * 64 + j * 32 + (lane & 31);
+                sc3[nc][j] = a.scale3 ? a.scale3[n] : 1.f;
+                bi3[nc][j] = a.bias3 ? a.bias3[n] : 0.f;
+            }
+    }
+
     f32x16 acc2[MT][NT1];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -143,10 +177,19 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
 
+#if defined(TD_TAIL_DIAG) && (TD_TAIL_DIAG & 1)      // timing builds only (tools/tail_probe.py): no phase 1 (the 3x3)
+    if (false)
+#endif
+    {
     stage(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    }
+#if defined(TD_TAIL_DIAG) && (TD_TAIL_DIAG & 1)
+    for (int it = 0; it < 0; ++it) {
+#else
     for (int it = 0; it < nit; ++it) {
+#endif
         const int cur = it & 1;
         if (it + 1 < nit) stage(cur ^ 1);
         const char* Ab = &As[(cur * BM + wm * 32 * MT) * CHUNK_BYTES];
@@ -182,12 +225,41 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
     };
     stage_w3(0);                                       // the phase-1 stages are free (barrier above); lands under phase 2
 
+    // FAST: the shortcut rows this lane finishes (8 channels = 16 B of 4 rows per 128-channel piece) are requested here, two
+    // pieces ahead of their use — behind the filters in the queue, so that the counted wait below does not include them.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NDMA3 = KC * BROWS3;                 // DMA instructions of one stage_w3 per wave
+    const int er = lane >> 3, ec = (lane & 7) * 8;     // FAST epilogue: row within a pass of 8, first of the lane's 8 channels
+    [[maybe_unused]] u32x4 rb[2][4];
+    [[maybe_unused]] unsigned eoff[4];
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rrsrc, yrsrc;
+    [[maybe_unused]] auto load_res = [&](int nc, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            rb[slot][k] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, eoff[k] == OOB ? OOB : eoff[k] + (unsigned)nc * 256u, 0, 0);
+    };
+    if constexpr (FAST) {
+        const int bytes = (int)((size_t)M * a.COUT * ES);
+        rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.y), 0, bytes, 0x00020000);
+        yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, bytes, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = m0 + wm * 32 + 8 * k + er;
+            eoff[k] = m < M ? ((unsigned)m * (unsigned)a.COUT + (unsigned)(wn * 64 + ec)) * ES : OOB;
+        }
+#if !(defined(TD_TAIL_DIAG) && (TD_TAIL_DIAG & 4))
+        if (a.res) {
+            load_res(0, 0);
+            load_res(1, 1);
+        }
+#endif
+    }
+
     // ---- phase 2: mid tile = ReLU(acc2 * scale2 + bias2) → LDS, in the image the DMA builds from a [row][MID] tensor --------
 #pragma unroll
     for (int j = 0; j < NT1; ++j) {
         const int n = wn * 32 * NT1 + j * 32 + (lane & 31);            // mid channel of this lane's accumulator column
-        const float sc = a.scale2 ? a.scale2[n] : 1.f;
-        const float bi = a.bias2 ? a.bias2[n] : 0.f;
+        const float sc = sc2[j], bi = bi2[j];
         const unsigned c = (unsigned)n / KE, e = (unsigned)n % KE;
         const unsigned piece = (e * ES) >> 4, inb = (e * ES) & 15;
 #pragma unroll
@@ -227,12 +299,122 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if constexpr (FAST) {
+        if (a.res) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");        // the filters; the 8 shortcut loads stay in flight
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                      // mid tile visible to every wave, filters of piece 0 landed
 
+#if defined(TD_TAIL_DIAG) && (TD_TAIL_DIAG & 2)      // timing builds only: stop after phase 2 (no 1x1, no epilogue)
+    if (tid == 0 && m0 == 0x7fffff00) static_cast<T*>(a.y)[0] = *reinterpret_cast<const T*>(T2s);
+    return;
+#endif
     // ---- phase 3: the 1x1, 128 output channels per piece -------------------------------------------------------------------------
+    if constexpr (FAST) {
+        // Wave-private wide epilogue. A wave owns 32 rows x 64 channels of a piece; it transposes them 16 rows at a time through
+        // its OWN 4 KB of LDS (no block barrier; scale and bias applied on the way in), finishes 8 channels of a row per lane in
+        // fp32 with the same single IEEE operations as conv_epilogue (+ shortcut, ReLU, one rounding to fp16) and stores 16 B per
+        // lane: 128-B row segments per 8 lanes. The shortcut was requested before phase 2 (and two pieces ahead after that), so that no load
+        // is issued and awaited inside the epilogue; the only block barriers left are the two around the filter restaging.
+        float* Ew = reinterpret_cast<float*>(Epi) + (wave * 16 * 64);
+        auto piece = [&](auto nc_c) __attribute__((always_inline)) {
+            constexpr int nc = decltype(nc_c)::value;
+            f32x16 acc3[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc3[j][r] = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const char* Ab = T2s + (kc * BM + wm * 32) * CHUNK_BYTES;
+                const char* Bb = W3s + (kc * 128 + wn * 64) * CHUNK_BYTES;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const f32x4 fa = *reinterpret_cast<const f32x4*>(Ab + frag_off[kk]);
+                    f32x4 fb[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * CHUNK_BYTES + frag_off[kk]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) Elem<T>::mma(fa, fb[j], acc3[j]);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();              // every wave has read this piece's filters
+            if constexpr (nc + 1 < NP) stage_w3(nc + 1);
+            u32x4 out[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                // rows 16 h .. 16 h + 15 of the wave's tile: accumulator registers 8 h .. 8 h + 7 of both column blocks. Bank
+                // picture: a row is 64 floats = all 64 banks; rows 4-7 / 12-15 (the upper half-wave's) are flipped by 32
+                // columns and odd rows by one float4, so that both the 4-B writes and the 16-B reads are conflict-free.
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int lr = e + 8 * g + 4 * (lane >> 5);
+                        const int flip = (((lr >> 2) & 1) << 5) ^ ((lr & 1) << 2);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            float t = acc3[j][4 * (2 * h + g) + e];        // scale and bias here: one channel per lane and block
+                            if (a.scale3) t = __fmul_rn(t, sc3[nc][j]);
+                            if (a.bias3) t = __fadd_rn(t, bi3[nc][j]);
+                            Ew[lr * 64 + ((j * 32 + (lane & 31)) ^ flip)] = t;
+                        }
+                    }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int lr = 8 * p + er;
+                    const int flip = (((lr >> 2) & 1) << 5) ^ ((lr & 1) << 2);
+                    f32x4 v[2];
+                    v[0] = *reinterpret_cast<const f32x4*>(&Ew[lr * 64 + (ec ^ flip)]);
+                    v[1] = *reinterpret_cast<const f32x4*>(&Ew[lr * 64 + ((ec + 4) ^ flip)]);
+                    if constexpr (nc == 0) {
+                        // queue: [shortcut piece 0][shortcut piece 1][filters of piece 1]: piece 0's rows have landed when at most
+                        // the later ones are outstanding (loads return in order); later pieces were awaited by the vmcnt(0) below
+                        if (h == 0 && p == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + (NP > 1 ? NDMA3 : 0)) : "memory");
+                    }
+                    typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+                    const f16x8v rs = __builtin_bit_cast(f16x8v, rb[nc & 1][2 * h + p]);
+                    f16x8v o;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        float t = v[q >> 2][q & 3];
+#if !(defined(TD_TAIL_DIAG) && (TD_TAIL_DIAG & 4))
+                        if (a.res) t = __fadd_rn(t, (float)rs[q]);
+#endif
+                        t = t > 0.f ? t : 0.f;
+                        o[q] = (_Float16)t;
+                    }
+                    out[2 * h + p] = __builtin_bit_cast(u32x4, o);
+                }
+            }
+            if constexpr (nc + 1 < NP) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next piece's filters (and its shortcut rows)
+                __builtin_amdgcn_s_barrier();
+            }
+#if !(defined(TD_TAIL_DIAG) && (TD_TAIL_DIAG & 8))
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                __builtin_amdgcn_raw_buffer_store_b128(out[k], yrsrc, eoff[k] == OOB ? OOB : eoff[k] + (unsigned)nc * 256u, 0, 0);
+#else
+            if (m0 == 0x7fffff00) __builtin_amdgcn_raw_buffer_store_b128(out[0] + out[1] + out[2] + out[3], yrsrc, 0, 0, 0);
+#endif
+            if constexpr (nc + 2 < NP) {
+#if !(defined(TD_TAIL_DIAG) && (TD_TAIL_DIAG & 4))
+                if (a.res) load_res(nc + 2, nc & 1);
+#endif
+            }
+        };
+        static_for<NP>(piece);
+        return;
+    }
     ConvArgs e{};
     e.y = a.y; e.res = a.res; e.scale = a.scale3; e.bias = a.bias3;
+#if defined(TD_TAIL_DIAG) && (TD_TAIL_DIAG & 4)      // timing builds only: no shortcut read
+    e.res = nullptr;
+#endif
     e.Cout = a.COUT; e.relu = 1; e.out_mode = 0; e.res_shift = 0; e.Ho = a.H; e.Wo = a.W;
     const int npieces = (a.COUT + 127) / 128;
     for (int nc = 0; nc < npieces; ++nc) {
@@ -277,19 +459,19 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
 }
 
 // BPC = blocks per CU the LDS footprint allows (__launch_bounds__' second argument is waves per SIMD = BPC for 4-wave blocks)
-template <typename T, int MID, bool OVERLAP, int MT, int BPC>
+template <typename T, int MID, bool OVERLAP, int MT, bool FAST, int BPC>
 __global__ __launch_bounds__(256, BPC)
 void bottleneck_tail_kernel(const TailArgs a) {
-    static_assert(BPC >= 1 && BPC * TailGeom<T, MID, OVERLAP, MT>::LDS_BYTES <= 160 * 1024, "LDS footprint does not allow that many blocks per CU");
-    __shared__ __attribute__((aligned(16))) char lds[TailGeom<T, MID, OVERLAP, MT>::LDS_BYTES];
-    bottleneck_tail_body<T, MID, OVERLAP, MT>(a, lds);
+    static_assert(BPC >= 1 && BPC * TailGeom<T, MID, OVERLAP, MT, FAST>::LDS_BYTES <= 160 * 1024, "LDS footprint does not allow that many blocks per CU");
+    __shared__ __attribute__((aligned(16))) char lds[TailGeom<T, MID, OVERLAP, MT, FAST>::LDS_BYTES];
+    bottleneck_tail_body<T, MID, OVERLAP, MT, FAST>(a, lds);
 }
 
-template <typename T, int MID, bool OVERLAP, int MT>
+template <typename T, int MID, bool OVERLAP, int MT, bool FAST = false>
 td_status launch_tail(const TailArgs& a, hipStream_t stream) {
-    typedef TailGeom<T, MID, OVERLAP, MT> G;
+    typedef TailGeom<T, MID, OVERLAP, MT, FAST> G;
     const int tiles = td_cdiv(a.M, G::BM);
-    hipLaunchKernelGGL((bottleneck_tail_kernel<T, MID, OVERLAP, MT, G::BPC>), dim3(tiles), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((bottleneck_tail_kernel<T, MID, OVERLAP, MT, FAST, G::BPC>), dim3(tiles), dim3(256), 0, stream, a);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
@@ -312,6 +494,13 @@ td_status bottleneck_tail_launch(const TailArgs& a, int precision, hipStream_t s
     static const int forced = getenv("TD_TAIL_BM") ? atoi(getenv("TD_TAIL_BM")) : 0;
     const int bm = forced == 64 || forced == 128 ? forced : 64;
     if (precision == TD_PRECISION_FP32) return bm == 64 ? launch_tail<float, 64, false, 1>(a, stream) : launch_tail<float, 64, false, 2>(a, stream);
-    if (a.MID == 64) return bm == 64 ? launch_tail<_Float16, 64, false, 1>(a, stream) : launch_tail<_Float16, 64, true, 2>(a, stream);
-    return bm == 64 ? launch_tail<_Float16, 128, false, 1>(a, stream) : launch_tail<_Float16, 128, true, 2>(a, stream);
+    // fp16, 64 rows: the wave-private wide epilogue (32-bit buffer offsets into the shortcut / output: below 4 GB)
+    static const int fast_env = getenv("TD_TAIL_FAST") ? atoi(getenv("TD_TAIL_FAST")) : 1;
+    const bool fast = fast_env && (size_t)a.M * a.COUT * es < 0xfffffff0ull - (1u << 20);
+    if (a.MID == 64) {
+        if (bm == 64) return fast ? launch_tail<_Float16, 64, false, 1, true>(a, stream) : launch_tail<_Float16, 64, false, 1>(a, stream);
+        return launch_tail<_Float16, 64, true, 2>(a, stream);
+    }
+    if (bm == 64) return fast ? launch_tail<_Float16, 128, false, 1, true>(a, stream) : launch_tail<_Float16, 128, false, 1>(a, stream);
+    return launch_tail<_Float16, 128, true, 2>(a, stream);
 }
