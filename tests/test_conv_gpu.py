@@ -449,7 +449,10 @@ def test_retired_tile_ids_are_refused():
 @pytest.mark.parametrize("prec", [1, 0])
 @pytest.mark.parametrize("cfg", [23, 24, 25, 26, 27, 29, 30])
 @pytest.mark.parametrize("case", PP8_CASES + [(8, 256, 50, 50, 256, 3, 1, 1, 0, True), (8, 2048, 25, 25, 512, 1, 1, 0, 0, True),
-                                              (2, 256, 13, 13, 15, 1, 1, 0, 0, False)])
+                                              (2, 256, 13, 13, 15, 1, 1, 0, 0, False),
+                                              (1, 64, 24, 24, 128, 1, 1, 0, 1, True),       # shortcut prefetch with a single fp16 k-step
+                                              (2, 128, 9, 9, 20, 1, 1, 0, 1, False),        # shortcut, 20 channels (not a multiple of 8): the general epilogue
+                                              (2, 256, 31, 17, 512, 1, 1, 0, 1, True)])     # shortcut, ragged last row tile, four column tiles
 def test_conv_filter_direct_equals_the_reference_tile_bit_for_bit(case, cfg, prec):
     """conv_bd_kernel keeps the k order, the MFMA and the epilogue of conv_igemm_kernel: on the same inputs (fp16 and fp32) its
     output is IDENTICAL to the 128 x 128 tile's (cfg 0) — which is what lets the engine's tuner choose it per layer by measurement."""

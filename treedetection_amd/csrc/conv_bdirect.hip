@@ -34,7 +34,9 @@ namespace {
 // what the filter-direct layout buys: the stages are small), DEEP + 1 register sets for the filter fragments, ONE barrier per
 // k-step (the stage a DMA overwrites was consumed two barriers ago), and COUNTED s_waitcnt vmcnt: the filter loads are inline
 // asm so that hipcc, which waits vmcnt(0) for any VGPR load it knows of next to an LDS-DMA, does not drain the pipeline.
-template <typename T, typename TO, int MT, int NT, int WN, int KS, int DEEP>
+// RES = the shortcut-prefetch form of the deep pipeline (its own instantiation: the extra live registers and the wider waits cost
+// the layers without a shortcut 5-20 % when compiled into the same kernel)
+template <typename T, typename TO, int MT, int NT, int WN, int KS, int DEEP, bool RES = false>
 __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
     constexpr int THREADS = 64 * WN;
     constexpr int BM = 32 * MT, BN = 32 * NT * WN;
@@ -187,18 +189,64 @@ __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
                 }
             stage_a(it % NS);
         };
-        auto wait_for = [&](int younger) {            // all but the `younger` newest k-steps' operations have completed
+        // Shortcut prefetch (fp16 64 x 128 tiles): the residual rows a thread will finish in the epilogue
+        // — 16 B of NRES rows — are requested right behind the LAST k-step's operands, so that they travel under the final DEEP
+        // k-steps instead of being issued and awaited inside the epilogue (these layers have 2 - 8 k-steps: the epilogue's load
+        // round trip was a third of a block's life). They sit at the tail of the in-order queue: every counted wait below allows
+        // NRES more outstanding operations once they are out.
+        // fp16 only: measured on the fp32 engine the same layers (MFMA-bound there, 168 registers with the 8 extra rows) lose 1-2 %.
+        constexpr bool RESPRE_OK = RES;
+        static_assert(!RES || (sizeof(T) == 2 && sizeof(TO) == 2 && MT == 2 && NT == 1 && WN == 4), "shortcut prefetch: fp16 64 x 128 tiles");
+        constexpr int CPL = 16 / (int)sizeof(TO), CHUNKS = BN / CPL, RPP = THREADS / CHUNKS, NRES = RESPRE_OK ? BM / RPP : 1;
+        const size_t res_bytes = (a.res_shift ? (size_t)a.B * (a.Ho >> 1) * (a.Wo >> 1) : (size_t)a.M) * a.Cout * sizeof(T);
+        constexpr bool respre = RES;                  // conv_bd_launch checked: shortcut present, Cout % 8 == 0, shortcut below 4 GB
+        [[maybe_unused]] f32x4 rb[NRES];
+        [[maybe_unused]] const int ec = (tid % CHUNKS) * CPL, er = tid / CHUNKS;
+        [[maybe_unused]] auto issue_res = [&]() {
+            const unsigned long long rbase = (unsigned long long)a.res;
+            i32x4 rdesc;
+            rdesc[0] = __builtin_amdgcn_readfirstlane((int)(rbase & 0xffffffffu));
+            rdesc[1] = __builtin_amdgcn_readfirstlane((int)((rbase >> 32) & 0xffffu));
+            rdesc[2] = __builtin_amdgcn_readfirstlane((int)res_bytes);
+            rdesc[3] = 0x00020000;
+            const int hw = a.Ho * a.Wo;
+#pragma unroll
+            for (int k = 0; k < NRES; ++k) {
+                const int m = m0 + er + RPP * k, n = n0 + ec;
+                unsigned off = OOB;
+                if (m < M && n < a.Cout) {
+                    size_t e = (size_t)m * a.Cout + n;
+                    if (a.res_shift) {
+                        const int b = m / hw;
+                        const int rem = m - b * hw;
+                        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+                        e = ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout + n;
+                    }
+                    off = (unsigned)(e * sizeof(T));
+                }
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb[k]) : "v"(off), "s"(rdesc) : "memory");
+            }
+        };
+        auto wait_for = [&](int younger, bool res_out) {      // all but the `younger` newest k-steps' operations (and the shortcut rows behind them) have completed
+            if (RESPRE_OK && res_out) {
+                if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * OPS + NRES) : "memory");
+                else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS + NRES) : "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS + NRES) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES) : "memory");
+                return;
+            }
             if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * OPS) : "memory");
             else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
-        static_assert(DEEP <= 3 && 3 * OPS < 64, "vmcnt immediates");
+        static_assert(DEEP <= 3 && 3 * OPS + NRES < 64, "vmcnt immediates");
         auto step = [&](auto set_c, int it) {
             constexpr int S = decltype(set_c)::value;
             if (it + DEEP < nit) issue(std::integral_constant<int, (S + DEEP) % NR>{}, it + DEEP);
+            if constexpr (RESPRE_OK) { if (respre && it + DEEP == nit - 1) issue_res(); }
             const int younger = nit - 1 - it < DEEP ? nit - 1 - it : DEEP;
-            wait_for(younger);
+            wait_for(younger, respre && it + DEEP >= nit - 1);
             __builtin_amdgcn_s_barrier();             // every wave's A rows of step `it` have landed; stage (it - 1) % NS is free
 #pragma unroll
             for (int j = 0; j < NT; ++j)
@@ -211,6 +259,7 @@ __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
         if (0 < nit) issue(std::integral_constant<int, 0>{}, 0);
         if constexpr (DEEP >= 2) { if (1 < nit) issue(std::integral_constant<int, 1 % NR>{}, 1); }
         if constexpr (DEEP >= 3) { if (2 < nit) issue(std::integral_constant<int, 2 % NR>{}, 2); }
+        if constexpr (RESPRE_OK) { if (respre && nit <= DEEP) issue_res(); }      // every k-step is already in flight
         for (int it = 0; it < nit; it += NR) {
             step(std::integral_constant<int, 0>{}, it);
             if constexpr (NR > 1) { if (it + 1 < nit) step(std::integral_constant<int, 1 % NR>{}, it + 1); }
@@ -218,6 +267,59 @@ __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
             if constexpr (NR > 3) { if (it + 3 < nit) step(std::integral_constant<int, 3 % NR>{}, it + 3); }
         }
         __builtin_amdgcn_s_barrier();                 // all fragment reads are done: LDS is the epilogue's
+        if constexpr (RESPRE_OK) {
+            if (respre) {
+                // conv_epilogue's general path with the loads already done: scale and bias in the accumulator layout (one channel
+                // per lane), the fp32 tile through LDS once, then 16 B of NRES rows per thread: + shortcut, ReLU, one rounding —
+                // the same single IEEE operations in the same order, bit-identical to conv_epilogue
+                constexpr int CS = BN + 4;
+                float* Cs = reinterpret_cast<float*>(lds);
+                const int col = wave * 32 + (lane & 31);
+                float sc = 1.f, bi = 0.f;
+                if (n0 + col < a.Cout) {
+                    if (a.scale) sc = a.scale[n0 + col];
+                    if (a.bias) bi = a.bias[n0 + col];
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float t = acc[i][0][r];
+                        if (a.scale) t = __fmul_rn(t, sc);
+                        if (a.bias) t = __fadd_rn(t, bi);
+                        Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + col] = t;
+                    }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < NRES; ++k) asm volatile("" : "+v"(rb[k]));
+                __syncthreads();
+                TO* __restrict__ Y = static_cast<TO*>(a.y);
+                const int n = n0 + ec;
+#pragma unroll
+                for (int k = 0; k < NRES; ++k) {
+                    const int row = er + RPP * k, m = m0 + row;
+                    if (m >= M || n >= a.Cout) continue;
+                    float v[CPL];
+#pragma unroll
+                    for (int g = 0; g < CPL / 4; ++g) {
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(&Cs[row * CS + ec + 4 * g]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * g + e] = t[e];
+                    }
+                    typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+                    const f16x8v rs = __builtin_bit_cast(f16x8v, rb[k]);
+                    f16x8v h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float t = __fadd_rn(v[e], (float)rs[e]);
+                        if (a.relu) t = t > 0.f ? t : 0.f;
+                        h[e] = (_Float16)t;
+                    }
+                    *reinterpret_cast<f16x8v*>(Y + (size_t)m * a.Cout + n) = h;
+                }
+                return;
+            }
+        }
         conv_epilogue<T, TO, MT, NT, 1, WN, 1>(a, acc, lds, M, m0, n0, tid, lane, 0, wave);
         return;
     }
@@ -257,7 +359,7 @@ __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
     conv_epilogue<T, TO, MT, NT, 1, WN, 1>(a, acc, lds, M, m0, n0, tid, lane, 0, wave);
 }
 
-template <typename T, typename TO, int MT, int NT, int WN, int BPC, int KS, int DEEP>
+template <typename T, typename TO, int MT, int NT, int WN, int BPC, int KS, int DEEP, bool RES>
 __global__ __launch_bounds__(64 * WN, (BPC * WN + 3) / 4)
 void conv_bd_kernel(const ConvArgs a) {
     constexpr int BM = 32 * MT;
@@ -266,13 +368,13 @@ void conv_bd_kernel(const ConvArgs a) {
     constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
     static_assert(BPC * LDS_BYTES <= 160 * 1024, "LDS footprint does not allow that many blocks per CU");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-    conv_bd_body<T, TO, MT, NT, WN, KS, DEEP>(a, lds);
+    conv_bd_body<T, TO, MT, NT, WN, KS, DEEP, RES>(a, lds);
 }
 
-template <typename T, typename TO, int MT, int NT, int WN, int BPC, int KS, int DEEP = 0>
+template <typename T, typename TO, int MT, int NT, int WN, int BPC, int KS, int DEEP = 0, bool RES = false>
 td_status launch_bd(const ConvArgs& a, hipStream_t stream) {
     const int tiles = td_cdiv(a.M, 32 * MT) * td_cdiv(a.Cout, 32 * NT * WN);
-    hipLaunchKernelGGL((conv_bd_kernel<T, TO, MT, NT, WN, BPC, KS, DEEP>), dim3(tiles), dim3(64 * WN), 0, stream, a);
+    hipLaunchKernelGGL((conv_bd_kernel<T, TO, MT, NT, WN, BPC, KS, DEEP, RES>), dim3(tiles), dim3(64 * WN), 0, stream, a);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
@@ -316,7 +418,13 @@ td_status bd_variant(const ConvArgs& a, int variant, hipStream_t stream) {
     switch (variant) {
         case 6: return launch_bd<T, TO, 4, 1, 4, 2, 1, 3>(a, stream);   // 128 x 128 (4 waves of 128 x 32), three k-steps in flight: half the filter re-reads of the 64-row tiles
         case 5: return launch_bd<T, TO, 4, 2, 4, 1, 1, 3>(a, stream);   // 128 x 256 (4 waves of 128 x 64, one per SIMD: ~300 registers), three k-steps in flight: long-K layers with few row tiles (fc1)
-        case 3: return launch_bd<T, TO, 2, 1, 4, 3, 1, 3>(a, stream);   // 64 x 128, three k-steps of loads in flight (five 8-KB LDS stages, four filter register sets)
+        case 3:                                                         // 64 x 128, three k-steps of loads in flight (five 8-KB LDS stages, four filter register sets)
+            if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
+                const size_t res_bytes = (a.res_shift ? (size_t)a.B * (a.Ho >> 1) * (a.Wo >> 1) : (size_t)a.M) * a.Cout * sizeof(T);
+                if (a.res && (a.Cout & 7) == 0 && !a.out_f32 && res_bytes < 0xfffffff0ull - (1u << 20))
+                    return launch_bd<T, TO, 2, 1, 4, 3, 1, 3, true>(a, stream);       // + the shortcut rows prefetched behind the last k-step
+            }
+            return launch_bd<T, TO, 2, 1, 4, 3, 1, 3>(a, stream);
         case 4: return launch_bd<T, TO, 2, 2, 4, 2, 1, 2>(a, stream);   // 64 x 256, two k-steps in flight
         case 2: return launch_bd<T, TO, 2, 1, 4, 3, 2>(a, stream);      // 64 x 128, two k-chunks per barrier interval
         case 1: return launch_bd<T, TO, 2, 1, 4, 4, 1>(a, stream);      // 64 x 128 (4 waves of 64 x 32: narrow layers, more blocks)
