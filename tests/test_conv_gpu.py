@@ -447,12 +447,16 @@ def test_retired_tile_ids_are_refused():
 # ---- filter-direct tiles (conv_bdirect.hip): tile_cfg 23 = 64 x 256, 24 = 64 x 128; A through LDS-DMA, filter fragments from a
 # fragment-ordered copy of the bank straight into registers ----
 @pytest.mark.parametrize("prec", [1, 0])
-@pytest.mark.parametrize("cfg", [23, 24, 25, 26, 27, 29, 30])
+@pytest.mark.parametrize("cfg", [23, 24, 25, 26, 27, 29, 30, 33])
 @pytest.mark.parametrize("case", PP8_CASES + [(8, 256, 50, 50, 256, 3, 1, 1, 0, True), (8, 2048, 25, 25, 512, 1, 1, 0, 0, True),
                                               (2, 256, 13, 13, 15, 1, 1, 0, 0, False),
                                               (1, 64, 24, 24, 128, 1, 1, 0, 1, True),       # shortcut prefetch with a single fp16 k-step
                                               (2, 128, 9, 9, 20, 1, 1, 0, 1, False),        # shortcut, 20 channels (not a multiple of 8): the general epilogue
-                                              (2, 256, 31, 17, 512, 1, 1, 0, 1, True)])     # shortcut, ragged last row tile, four column tiles
+                                              (2, 256, 31, 17, 512, 1, 1, 0, 1, True),      # shortcut, ragged last row tile, four column tiles
+                                              (1, 256, 16, 16, 256, 1, 1, 0, 2, False),     # filter-stationary tile (33): half-resolution shortcut
+                                              (2, 128, 23, 19, 384, 1, 1, 0, 0, False),     # 33: no shortcut, a half-empty second column tile
+                                              (8, 128, 100, 100, 512, 1, 1, 0, 1, True),    # 33: res3 conv3 at BASELINE size (10 row tiles per block)
+                                              (1, 64, 9, 7, 256, 1, 1, 0, 1, True)])        # 33: one row tile in all (most blocks idle)
 def test_conv_filter_direct_equals_the_reference_tile_bit_for_bit(case, cfg, prec):
     """conv_bd_kernel keeps the k order, the MFMA and the epilogue of conv_igemm_kernel: on the same inputs (fp16 and fp32) its
     output is IDENTICAL to the 128 x 128 tile's (cfg 0) — which is what lets the engine's tuner choose it per layer by measurement."""

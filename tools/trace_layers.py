@@ -76,7 +76,7 @@ def launches_of(name, M, N, K, fp32, B=8, min43=12):
 def main(path, depth=50, fp32=False):
     import os
     min43 = int(os.environ.get("TD_WINO43_MIN", "12"))
-    fam = ("conv_igemm", "conv_pp8", "plane_gemm", "wino_gemm", "wino_output", "wino_input", "wino43_input", "wino43_output", "wino43_fused", "bottleneck_tail", "conv_sk", "conv_bd")
+    fam = ("conv_igemm", "conv_pp8", "plane_gemm", "wino_gemm", "wino_output", "wino_input", "wino43_input", "wino43_output", "wino43_fused", "bottleneck_tail", "conv_sk", "conv_bd", "conv_bs")
     # launch order = start order on the one stream of the plain loop (the CSV itself is not written in that order)
     rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
     rows = [r for r in rows if any(f in r["Kernel_Name"] for f in fam)]
@@ -118,7 +118,7 @@ def main(path, depth=50, fp32=False):
         if "conv2+3" in name:
             assert "bottleneck_tail" in kn, (name, kn)
         kern = label if label else ("pp8 grouped" if "grouped" in name else "pp8" if "conv_pp8" in kn else "bottleneck_tail" if "bottleneck_tail" in kn else
-                                    "conv_sk" if "conv_sk" in kn else ("conv_bd 64x256" if "Li2ELi2ELi4" in kn or "2, 2, 4" in kn else "conv_bd 128x256" if "Li4ELi2ELi4" in kn or "4, 2, 4" in kn else
+                                    "conv_sk" if "conv_sk" in kn else "conv_bs (filter-stationary)" if "conv_bs" in kn else ("conv_bd 64x256" if "Li2ELi2ELi4" in kn or "2, 2, 4" in kn else "conv_bd 128x256" if "Li4ELi2ELi4" in kn or "4, 2, 4" in kn else
                                                  "conv_bd 128x128" if "Li4ELi1ELi4" in kn or "4, 1, 4" in kn else "conv_bd 64x128") if "conv_bd" in kn else
                                     "plane_gemm" + kn.split("plane_gemm_kernel")[1].split("(")[0][:12] if "plane_gemm" in kn else
                                     kn.split("conv_igemm_")[1].split("(")[0][:28])

@@ -99,9 +99,10 @@ static inline bool conv_head_capable(int cfg, int precision) {
 // straight from a fragment-ordered copy of the filters into registers (conv_bdirect.hip)
 // 29 / 30 = conv_bd_kernel 128x256 / 128x128, three k-steps of loads in flight: taller tiles, half the filter re-reads (round 4)
 // 31 / 32 = conv_igemm_kernel 256x32 / 128x32 (4 x 1 waves): layers with at most 32 output channels (round 4)
-#define TD_CONV_TILE_CFG_MAX 32
-static inline bool conv_cfg_is_bd(int cfg) { return (cfg >= 23 && cfg <= 27) || cfg == 29 || cfg == 30; }
-static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17, 18, 19, 20, 23, 24, 25, 26, 27, 29, 30, 31, 32};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16, 18-20 only for plane contractions, 23-27 / 29 / 30 only with packed filters, 31 / 32 only for <= 32 output channels
+// 33 = conv_bs_kernel (conv_bstat.hip, round 4): filter-stationary 1x1 for the thin-K layers (<= 4 k-chunks), one block per CU
+#define TD_CONV_TILE_CFG_MAX 33
+static inline bool conv_cfg_is_bd(int cfg) { return (cfg >= 23 && cfg <= 27) || cfg == 29 || cfg == 30 || cfg == 33; }      // tiles that read the fragment-ordered filter copy
+static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17, 18, 19, 20, 23, 24, 25, 26, 27, 29, 30, 31, 32, 33};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16, 18-20 only for plane contractions, 23-27 / 29 / 30 / 33 only with packed filters, 31 / 32 only for <= 32 output channels, 33 only where conv_bs_ok
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
 // a.nlev levels (x / w / bias / y / head_y / H / W filled in; M, tile0, ntiles are computed here) in one conv_pp8_kernel grid;
 // everything else (B, Cin, Cout = 256, KH = KW = 3, relu, head_w / head_b / head_n) from the common fields. Bit-identical to one
@@ -111,6 +112,9 @@ td_status conv_pp8_grouped_launch(ConvArgs a, hipStream_t stream);
 void conv_bd_pack(const void* w_ohwi, int elem_bytes, int cout, int kh, int kw, int cin, std::vector<unsigned char>& out);
 bool conv_bd_ok(const ConvArgs& a, int precision);
 td_status conv_bd_launch(const ConvArgs& a, int precision, int variant, hipStream_t stream);
+// filter-stationary form (conv_bstat.hip, tile id 33)
+bool conv_bs_ok(const ConvArgs& a, int precision);
+td_status conv_bs_launch(const ConvArgs& a, int precision, hipStream_t stream);
 bool conv_plane_ok(const ConvArgs& a, int precision);       // tile ids 18-20 apply to this launch
 td_status wino_gemm_launch(const ConvArgs& a, hipStream_t stream);     // Winograd plane contractions, input transform fused (fp32)
 

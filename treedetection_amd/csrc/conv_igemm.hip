@@ -1106,11 +1106,13 @@ td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream) {
     if (cfg == 17 && no_fp16_tile) cfg = -1;                       // fp16-only variant
     if (cfg == 28 && (no_fp16_tile || a.m_dyn)) cfg = -1;          // fp16-only, static row counts only
     if (cfg >= 18 && cfg <= 20 && !conv_plane_ok(a, precision)) cfg = -1;                                       // plane contractions only
+    if (cfg == 33 && !conv_bs_ok(a, precision)) cfg = -1;                                                       // thin 1x1 layers with packed filters only
     if (conv_cfg_is_bd(cfg) && !conv_bd_ok(a, precision)) cfg = -1;                                             // needs the fragment-ordered filters
     // a fused head (ConvArgs::head_w) exists only in the tiles that stage all 256 output channels as one fp16 tile: any other
     // resolution of the tile id would silently write y and leave head_y untouched
     TD_REQUIRE(!a.head_w || (conv_head_capable(cfg, precision) && a.Cout == 256 && !a.res && a.out_mode == 0 && a.head_y && a.head_n >= 1 && a.head_n <= 32),
                "conv2d: a fused head needs a 256-channel fp16 layer on a tile that owns all its channels (tile id %d)", cfg);
+    if (cfg == 33) return conv_bs_launch(a, precision, stream);
     if (conv_cfg_is_bd(cfg)) return conv_bd_launch(a, precision, cfg <= 27 ? cfg - 23 : cfg - 24, stream);
     TD_REQUIRE(a.batch_count <= 1 || (a.KH == 1 && a.KW == 1 && !a.res), "conv2d: batched launches are 1x1 contractions");
     if (cfg < 0) {

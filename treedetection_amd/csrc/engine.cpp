@@ -897,6 +897,7 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
             if (c == 17 && !pp8_ok) continue;                    // fp16 256x256 ping-pong tile
             if (c >= 18 && c <= 20 && !plane_ok) continue;       // persistent tile walk: Winograd plane contractions only
             if (conv_cfg_is_bd(c) && !bd_ok) continue;          // filter-direct tiles: layers with a fragment-ordered filter copy
+            if (c == 33 && !(std::get<2>(key) == 17 && (std::get<4>(key) & ~1) == 4 && std::get<0>(key) >= 128 && ksteps <= 4 && ksteps != 3)) continue;      // filter-stationary: 1x1, stride 1, plain output, <= 4 k-chunks
             if ((c == 31 || c == 32) && std::get<0>(key) > 32) continue;      // 32-column tiles: the thin heads only
             float ms = 1e30f;
             td_status st2 = time_launch(s_, ea, eb, [&]() { return launch_cfg(c); }, &ms);
