@@ -29,9 +29,9 @@ def _asm(src, tmp_path, extra=()):
 
 
 def _kernels(text):
-    """name → body (lines) of every kernel in the assembly, plus its metadata record."""
+    """name → body (lines, the whole function: early exits included) of every kernel in the assembly, plus its metadata record."""
     bodies = {}
-    for m in re.finditer(r"^(_Z\w+):\s*;\s*@\1\n(.*?)^\s*s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(_Z\w+):\s*;\s*@\1\n(.*?)^\.Lfunc_end\d+:", text, re.S | re.M):
         bodies[m.group(1)] = m.group(2).splitlines()
     meta = {}
     for m in re.finditer(r"\.name:\s+(_Z\w+)\n(.*?)(?=\n\s+- \.agpr_count|\namdhsa.target|\Z)", text, re.S):
@@ -62,8 +62,8 @@ def _operands(line):
 def test_conv_bd_deep_pipelines_keep_their_fragment_registers_untouched(tmp_path):
     text = _asm("conv_bdirect.hip", tmp_path)
     bodies, meta = _kernels(text)
-    deep = {n: b for n, b in bodies.items() if "conv_bd_kernel" in n and re.search(r"ELi[123]EEEv8ConvArgs$", n)}
-    assert len(deep) >= 9, sorted(bodies)          # 3 element-type pairs x the deep variants
+    deep = {n: b for n, b in bodies.items() if "conv_bd_kernel" in n and re.search(r"ELi[123]ELb0EEEv8ConvArgs$", n)}
+    assert len(deep) >= 9, sorted(bodies)          # 3 element-type pairs x the deep variants (the shortcut-prefetch form: next test)
     for name, body in deep.items():
         md = meta[name]
         assert re.search(r"\.vgpr_spill_count:\s+0\b", md) and re.search(r"\.private_segment_fixed_size:\s+0\b", md), name
@@ -106,6 +106,67 @@ def test_conv_bd_deep_pipelines_keep_their_fragment_registers_untouched(tmp_path
                 bad.append(ln.strip())
         assert seen_load and checked > 100, name
         assert not bad, (name, bad[:5])
+
+
+def _audit_asm_load_sites(name, body, md, min_sites):
+    """Kernels whose control flow is not one straight unrolled loop (runtime-selected waits, producer / consumer roles): the local
+    form of the audit. No scratch; and from every asm buffer_load_dwordx4 on, along the fall-through text until the next asm
+    s_waitcnt vmcnt / branch / label, no instruction outside the asm statements reads or writes the registers the load is filling
+    (what hipcc would do if it took the asm output for a finished value: a copy or a re-use right behind the statement)."""
+    assert re.search(r"\.vgpr_spill_count:\s+0\b", md) and re.search(r"\.private_segment_fixed_size:\s+0\b", md), name
+    assert not [ln for ln in body if ln.strip().startswith("scratch_")], name
+    sites, bad = 0, []
+    n = len(body)
+    i = 0
+    while i < n:
+        if "#ASMSTART" in body[i] and i + 1 < n:
+            op, ops = _operands(body[i + 1])
+            if op == "buffer_load_dwordx4" and ops:
+                sites += 1
+                dst = _regs(ops[0])
+                in_asm, j = True, i + 1
+                while j + 1 < n:
+                    j += 1
+                    ln = body[j]
+                    if "#ASMSTART" in ln:
+                        in_asm = True
+                        continue
+                    if "#ASMEND" in ln:
+                        in_asm = False
+                        continue
+                    st = ln.strip()
+                    if re.match(r"^\.LBB\d+_\d+:", st):
+                        break
+                    o2, p2 = _operands(ln)
+                    if o2 is None:
+                        continue
+                    if in_asm:
+                        if o2 == "s_waitcnt" and "vmcnt" in st:
+                            break
+                        continue
+                    if o2.startswith("s_cbranch") or o2 in ("s_branch", "s_endpgm", "s_barrier"):
+                        break
+                    touched = set().union(*[_regs(t) for t in p2]) if p2 else set()
+                    if touched & dst:
+                        bad.append(st)
+        i += 1
+    assert sites >= min_sites, (name, sites)
+    assert not bad, (name, bad[:5])
+
+
+def test_shortcut_prefetch_kernels_leave_their_in_flight_registers_alone(tmp_path):
+    """conv_bd_kernel<..., RES = true> (shortcut rows behind the prologue) and conv_bs_kernel (tile id 33: the consumers' two
+    shortcut register sets) load with inline asm and retire with counted waits chosen at run time."""
+    bodies, meta = _kernels(_asm("conv_bdirect.hip", tmp_path))
+    res = {n: b for n, b in bodies.items() if "conv_bd_kernel" in n and n.endswith("ELb1EEEv8ConvArgs")}
+    assert len(res) == 1, sorted(bodies)
+    for name, body in res.items():
+        _audit_asm_load_sites(name, body, meta[name], 4 + 4 * 4)     # the shortcut rows + four filter register sets
+    bodies, meta = _kernels(_asm("conv_bstat.hip", tmp_path))
+    ks = {n: b for n, b in bodies.items() if "conv_bs_kernel" in n}
+    assert len(ks) == 6, sorted(bodies)
+    for name, body in ks.items():
+        _audit_asm_load_sites(name, body, meta[name], 8)
 
 
 def test_wino43_fused_kernel_has_no_scratch_and_no_drain_in_its_loop(tmp_path):

@@ -30,6 +30,9 @@ SHAPES = {  # name: (B, H, W, Cin, Cout, k, stride, residual)
     "fpn_lateral3": (8, 100, 100, 512, 256, 1, 1, False),
     "fc2": (8000, 1, 1, 1024, 1024, 1, 1, False),
     "rpn_head_p2": (8, 200, 200, 256, 15, 1, 1, False),
+    "fpn_lateral2_up": (8, 200, 200, 256, 256, 1, 1, 2),        # as the engine runs it: + the half-resolution top-down map
+    "fpn_lateral2_res": (8, 200, 200, 256, 256, 1, 1, True),
+    "res2_shortcut": (8, 200, 200, 64, 256, 1, 1, False),
 }
 
 
@@ -47,12 +50,12 @@ def main():
         bias = torch.zeros(Cout, device="cuda")
         Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
         y = torch.empty(B, Ho, Wo, Cout, device="cuda", dtype=dt)
-        r = torch.randn(B, Ho, Wo, Cout, device="cuda").to(dt) if res else None
+        r = (torch.randn(B, Ho // 2, Wo // 2, Cout, device="cuda") if res == 2 else torch.randn(B, Ho, Wo, Cout, device="cuda")).to(dt) if res else None
         torch.cuda.synchronize()
         for cfg in cfgs:
             ok = 0
             for _ in range(3):
-                st = lib.td_conv2d_nhwc(x.data_ptr(), w.data_ptr(), None, bias.data_ptr(), r.data_ptr() if res else None, 0, y.data_ptr(), B, H, W, Cin, Cout,
+                st = lib.td_conv2d_nhwc(x.data_ptr(), w.data_ptr(), None, bias.data_ptr(), r.data_ptr() if res else None, 1 if res == 2 else 0, y.data_ptr(), B, H, W, Cin, Cout,
                                         k, k, stride, k // 2, 1, prec | ((cfg + 1) << 8), _lib.stream_ptr())
                 ok += st == 0
             torch.cuda.synchronize()

@@ -8,7 +8,7 @@ timeout -k 10 500 rocprofv3 --kernel-trace -d $O/trace -o t --output-format csv 
 python3 - "$(find $O/trace -name '*kernel_trace.csv' | head -1)" $O/plan.txt <<'PY' | tee $O/summary.txt
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-rows = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm_kernel", "conv_pp8_kernel", "conv_bd_kernel", "plane_gemm_kernel"))]
+rows = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm_kernel", "conv_pp8_kernel", "conv_bd_kernel", "plane_gemm_kernel", "conv_bs_kernel"))]
 plan = [ln.split() for ln in open(sys.argv[2])]
 i = 0
 table = {}
@@ -17,7 +17,7 @@ for name, cfg, ok in plan:
     d = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows[i:i + n])
     kn = rows[i]["Kernel_Name"] if n else ""
     i += n
-    short = "pp8" if "conv_pp8" in kn else ("bd" if "conv_bd" in kn else ("plane" if "plane_gemm" in kn else "igemm"))
+    short = "pp8" if "conv_pp8" in kn else "bs" if "conv_bs" in kn else ("bd" if "conv_bd" in kn else ("plane" if "plane_gemm" in kn else "igemm"))
     table.setdefault(name, []).append((int(cfg), d[0] if d else float("nan"), short))
 for name, lst in table.items():
     best = min(v for _, v, _ in lst)

@@ -190,10 +190,10 @@ __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
             stage_a(it % NS);
         };
         // Shortcut prefetch (fp16 64 x 128 tiles): the residual rows a thread will finish in the epilogue
-        // — 16 B of NRES rows — are requested right behind the LAST k-step's operands, so that they travel under the final DEEP
+        // — 16 B of NRES rows — are requested right behind the prologue's k-steps, so that they travel under the first DEEP
         // k-steps instead of being issued and awaited inside the epilogue (these layers have 2 - 8 k-steps: the epilogue's load
-        // round trip was a third of a block's life). They sit at the tail of the in-order queue: every counted wait below allows
-        // NRES more outstanding operations once they are out.
+        // round trip was a third of a block's life). In the in-order queue they are younger than k-steps 0 .. DEEP - 1 only:
+        // the counted waits of those steps allow NRES more outstanding operations, later steps retire them on the way.
         // fp16 only: measured on the fp32 engine the same layers (MFMA-bound there, 168 registers with the 8 extra rows) lose 1-2 %.
         constexpr bool RESPRE_OK = RES;
         static_assert(!RES || (sizeof(T) == 2 && sizeof(TO) == 2 && MT == 2 && NT == 1 && WN == 4), "shortcut prefetch: fp16 64 x 128 tiles");
@@ -244,9 +244,8 @@ __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
         auto step = [&](auto set_c, int it) {
             constexpr int S = decltype(set_c)::value;
             if (it + DEEP < nit) issue(std::integral_constant<int, (S + DEEP) % NR>{}, it + DEEP);
-            if constexpr (RESPRE_OK) { if (respre && it + DEEP == nit - 1) issue_res(); }
             const int younger = nit - 1 - it < DEEP ? nit - 1 - it : DEEP;
-            wait_for(younger, respre && it + DEEP >= nit - 1);
+            wait_for(younger, respre && it < DEEP);   // the shortcut rows sit behind the prologue's k-steps 0 .. DEEP - 1: younger than those only
             __builtin_amdgcn_s_barrier();             // every wave's A rows of step `it` have landed; stage (it - 1) % NS is free
 #pragma unroll
             for (int j = 0; j < NT; ++j)
@@ -259,7 +258,7 @@ __device__ __forceinline__ void conv_bd_body(const ConvArgs& a, char* lds) {
         if (0 < nit) issue(std::integral_constant<int, 0>{}, 0);
         if constexpr (DEEP >= 2) { if (1 < nit) issue(std::integral_constant<int, 1 % NR>{}, 1); }
         if constexpr (DEEP >= 3) { if (2 < nit) issue(std::integral_constant<int, 2 % NR>{}, 2); }
-        if constexpr (RESPRE_OK) { if (respre && nit <= DEEP) issue_res(); }      // every k-step is already in flight
+        if constexpr (RESPRE_OK) { if (respre) issue_res(); }      // ONE issue site, right behind the prologue: in flight under the first DEEP k-steps
         for (int it = 0; it < nit; it += NR) {
             step(std::integral_constant<int, 0>{}, it);
             if constexpr (NR > 1) { if (it + 1 < nit) step(std::integral_constant<int, 1 % NR>{}, it + 1); }

@@ -96,7 +96,11 @@ __global__ __launch_bounds__(640, 3) void conv_bs_kernel(const ConvArgs a, const
                     const int row = r0 + lr, m = m0 + row;
                     const unsigned piece = (unsigned)(lc ^ ((row >> 1) & 7));
                     const unsigned off = m < M ? (unsigned)m * pix_bytes + (unsigned)c * CHUNK_BYTES + piece * 16u : OOB;
+#if !(defined(TD_BS_DIAG) && (TD_BS_DIAG & 8))       // timing builds (tools/bs_probe.py): 8 = no activation loads
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(base + (c * BM + r0) * CHUNK_BYTES), 16, off, 0, 0, 0);
+#else
+                    if (off == 0x12345u) lds[0] = 1;
+#endif
                 }
         };
         for (int k = 0; k < D && k < nk; ++k) issue_tile(k);
@@ -221,8 +225,13 @@ __global__ __launch_bounds__(640, 3) void conv_bs_kernel(const ConvArgs a, const
                 f32x4 fa[MT];
 #pragma unroll
                 for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + (c * BM + i * 32) * CHUNK_BYTES + frag_off[kk]);
+#if !(defined(TD_BS_DIAG) && (TD_BS_DIAG & 2))       // 2 = no MFMAs
 #pragma unroll
                 for (int i = 0; i < MT; ++i) Elem<T>::mma(fa[i], fb[c][kk], acc[i]);
+#else
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][kk] += fa[i][0] * fb[c][kk][0];
+#endif
             }
         // the shortcut rows of THIS tile were requested one tile ago; younger in this wave's queue: the next tile's rows only
         // (stores are older or not issued yet: an allowance that counts younger LOADS only is safe whatever order stores retire in)
@@ -244,18 +253,27 @@ __global__ __launch_bounds__(640, 3) void conv_bs_kernel(const ConvArgs a, const
                     float t = acc[i][4 * (2 * hq + gg) + e];
                     if (a.scale) t = __fmul_rn(t, sc);
                     if (a.bias) t = __fadd_rn(t, bi);
+#if !(defined(TD_BS_DIAG) && (TD_BS_DIAG & 4))       // 4 = no transposition through LDS (wrong layout)
                     Ew[(e + 8 * gg + 4 * hi) * 40 + (lane & 31)] = t;
+#else
+                    acc[i][4 * (2 * hq + gg) + e] = t;
+#endif
                 }
 #pragma unroll
             for (int p = 0; p < Gm::PASSES; ++p) {
                 const int lrow = Gm::RPP * p + er;
                 float v[CPL];
+#if !(defined(TD_BS_DIAG) && (TD_BS_DIAG & 4))
 #pragma unroll
                 for (int h = 0; h < CPL / 4; ++h) {
                     const f32x4 t = *reinterpret_cast<const f32x4*>(&Ew[lrow * 40 + ec + 4 * h]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[4 * h + e] = t[e];
                 }
+#else
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) v[e] = acc[i][(8 * hq + 4 * p + e) & 15];
+#endif
                 const int q = qq * Gm::PASSES + p;
                 const unsigned yoff = row_off[q] == OOB ? OOB : row_off[q] + tile_off;
                 if constexpr (sizeof(T) == 4) {
@@ -267,7 +285,11 @@ __global__ __launch_bounds__(640, 3) void conv_bs_kernel(const ConvArgs a, const
                         v[e] = t;
                     }
                     const f32x4 o = {v[0], v[1], v[2], v[3]};
+#if !(defined(TD_BS_DIAG) && (TD_BS_DIAG & 1))       // 1 = no output stores
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrsrc, yoff, 0, 0);
+#else
+                    if (yoff == 0x12345u) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrsrc, yoff, 0, 0);
+#endif
                 } else {
                     typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
                     const f16x8v rs = __builtin_bit_cast(f16x8v, rb[SET][q]);
@@ -279,7 +301,11 @@ __global__ __launch_bounds__(640, 3) void conv_bs_kernel(const ConvArgs a, const
                         if (a.relu) t = t > 0.f ? t : 0.f;
                         o[e] = (_Float16)t;
                     }
+#if !(defined(TD_BS_DIAG) && (TD_BS_DIAG & 1))       // 1 = no output stores
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrsrc, yoff, 0, 0);
+#else
+                    if (yoff == 0x12345u) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrsrc, yoff, 0, 0);
+#endif
                 }
             }
         }
