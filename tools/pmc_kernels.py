@@ -16,7 +16,7 @@ def load(path):
 
 
 def short(n):
-    for k in ("conv_pp8", "conv_bd", "conv_sk", "bottleneck_tail", "plane_gemm", "wino_gemm", "wino43_input", "wino43_output", "wino_output"):
+    for k in ("conv_pp8", "conv_bd", "conv_bs", "conv_sk", "bottleneck_tail", "plane_gemm", "wino_gemm", "wino43_input", "wino43_output", "wino_output"):
         if k in n:
             return k
     if "conv_igemm" in n:

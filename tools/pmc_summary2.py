@@ -18,6 +18,8 @@ def family(name):
         return "conv_pp8_kernel"
     if "conv_bd" in name:
         return "conv_bd_kernel"
+    if "conv_bs" in name:
+        return "conv_bs_kernel"
     if "conv_sk" in name:
         return "conv_sk_kernel"
     if "bottleneck_tail" in name:
@@ -81,13 +83,13 @@ def main():
                "mfma_util": f["SQ_VALU_MFMA_BUSY_CYCLES"] / simd if simd else 0.0,
                "hbm_tb_per_s": hbm / (f["us"] * 1e-6) / 1e12 if f["us"] else 0.0}
         out["families"][name] = rec
-        if name in ("conv_igemm_kernel", "conv_pp8_kernel", "conv_bd_kernel", "conv_sk_kernel", "bottleneck_tail_kernel", "plane_gemm_kernel", "wino_gemm_kernel", "wino_input_kernel", "wino_output_kernel",
+        if name in ("conv_igemm_kernel", "conv_pp8_kernel", "conv_bd_kernel", "conv_bs_kernel", "conv_sk_kernel", "bottleneck_tail_kernel", "plane_gemm_kernel", "wino_gemm_kernel", "wino_input_kernel", "wino_output_kernel",
                     "wino43_input_kernel", "wino43_output_kernel", "wino43_fused_kernel"):
             for k in ("launches", "us", "SQ_VALU_MFMA_BUSY_CYCLES"):
                 conv[k] += f[k]
             conv["hbm"] += hbm
             conv["simd"] += simd
-    out["conv_family"] = {"members": "conv_igemm_kernel + conv_pp8_kernel + conv_bd_kernel + conv_sk_kernel + bottleneck_tail_kernel + plane_gemm_kernel + "
+    out["conv_family"] = {"members": "conv_igemm_kernel + conv_pp8_kernel + conv_bd_kernel + conv_bs_kernel + conv_sk_kernel + bottleneck_tail_kernel + plane_gemm_kernel + "
                                      "wino_gemm_kernel + wino_input_kernel + wino_output_kernel + wino43_input_kernel + wino43_output_kernel + wino43_fused_kernel",
                           "launches": conv["launches"] / steps, "ms_per_step": conv["us"] / steps / 1e3,
                           "hbm_traffic_gb_per_step": conv["hbm"] / steps / 1e9,
