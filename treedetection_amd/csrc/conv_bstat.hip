@@ -72,11 +72,16 @@ __global__ __launch_bounds__(640, 3) void conv_bs_kernel(const ConvArgs a, const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = a.M;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (a.Cout + Gm::BN - 1) / Gm::BN;
-    // block → (column tile, row group): the tiles_n blocks that read the same rows sit on one XCD (blockIdx round-robins over 8)
+    // block → (column tile, row group). blockIdx round-robins over the 8 XCDs; an XCD owns the CONTIGUOUS range of row tiles
+    // xcd_remap gives it in every other conv kernel (the layer before wrote those rows through this XCD's L2, the layer after reads
+    // them through it), its G / 8 row groups interleave inside that range, and the tiles_n blocks of a group sit on the same XCD
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int tn = slot % tiles_n, g = (slot / tiles_n) * 8 + xcd;
-    const int nk = g < tiles_m ? (tiles_m - 1 - g) / G + 1 : 0;       // row tiles g, g + G, ... of this block
+    const int tn = slot % tiles_n, gl = slot / tiles_n, tstep = G >> 3;
+    const int xq = tiles_m >> 3, xr = tiles_m & 7;
+    const int xcnt = xq + (xcd < xr ? 1 : 0), xstart = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+    const int nk = gl < xcnt ? (xcnt - 1 - gl) / tstep + 1 : 0;       // row tiles t0, t0 + tstep, ... of this block
     if (nk == 0) return;
+    const int t0 = xstart + gl;
     const int n0 = tn * Gm::BN;
 
     if (wave >= Gm::CONS) {
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(640, 3) void conv_bs_kernel(const ConvArgs a, const
         const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)((size_t)M * pix_bytes), 0x00020000);
         const int lr = lane >> 3, lc = lane & 7;
         auto issue_tile = [&](int k) __attribute__((always_inline)) {
-            const int m0 = (g + k * G) * BM;
+            const int m0 = (t0 + k * tstep) * BM;
             char* base = lds + (k % S) * Gm::STAGE;
 #pragma unroll
             for (int c = 0; c < NIT; ++c)
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(640, 3) void conv_bs_kernel(const ConvArgs a, const
         constexpr int SET = decltype(set_c)::value;
         auto& rb_ = rb;                                               // (asm operands alone do not capture in a generic lambda)
         const i32x4& rdesc_ = rdesc;
-        const int m0 = __builtin_amdgcn_readfirstlane((g + k * G) * BM);
+        const int m0 = __builtin_amdgcn_readfirstlane((t0 + k * tstep) * BM);
         const unsigned tile_off = (unsigned)m0 * (unsigned)a.Cout * ES;
         int b0 = 0, oy0 = 0, ox0 = 0;
         if (a.res_shift) {
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(640, 3) void conv_bs_kernel(const ConvArgs a, const
 #pragma unroll
             for (int q = 0; q < NRES; ++q) asm volatile("" : "+v"(rb_[SET][q]));
         }
-        const unsigned tile_off = (unsigned)__builtin_amdgcn_readfirstlane((g + k * G) * BM) * (unsigned)a.Cout * ES;
+        const unsigned tile_off = (unsigned)__builtin_amdgcn_readfirstlane((t0 + k * tstep) * BM) * (unsigned)a.Cout * ES;
 #pragma unroll
         for (int qq = 0; qq < Gm::NQ; ++qq) {
             // rows 16 qq .. 16 qq + 15 of the wave's tile = accumulator registers 8 (qq & 1) .. + 7 of row block qq >> 1
