@@ -23,18 +23,9 @@
 // as conv_epilogue: BIT-IDENTICAL to every other tile (tests/test_conv_gpu.py), so the tuner may choose it by measurement.
 #include "common.h"
 #include "conv_tiles.h"
-#include <utility>
+#include <type_traits>
 
 namespace {
-
-template <typename F, int... I>
-__device__ __forceinline__ void bs_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void bs_static_for(F&& f) {
-    bs_static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
 
 template <typename T, int MT, int NIT>
 struct BsGeom {
@@ -326,7 +317,14 @@ template <typename T, int MT, int NIT>
 td_status launch_bs(const ConvArgs& a, hipStream_t stream) {
     typedef BsGeom<T, MT, NIT> Gm;
     const int tiles_n = td_cdiv(a.Cout, Gm::BN);
-    const int G = (256 / tiles_n) & ~7;
+    // one block per CU: G row groups per column tile, a multiple of 8 (the XCD count) — 256 CUs on MI355X
+    static const int num_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 64) n = 256;
+        return n;
+    }();
+    int G = (num_cu / tiles_n) & ~7;
+    if (G < 8) G = 8;
     hipLaunchKernelGGL((conv_bs_kernel<T, MT, NIT>), dim3(tiles_n * G), dim3(Gm::THREADS), 0, stream, a, G);
     TD_KERNEL_CHECK();
     return TD_OK;
