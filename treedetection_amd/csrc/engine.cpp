@@ -834,8 +834,14 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
             // one launch per timed interval, L2 emptied before it; the fastest of five
             if (!e->tune_evict) {
                 e->tune_evict_bytes = (size_t)64 << 20;
-                TD_HIP_CHECK(hipMalloc(&e->tune_evict, e->tune_evict_bytes));
+                if (hipMalloc(&e->tune_evict, e->tune_evict_bytes) != hipSuccess) {      // no room for the scratch: time the hot loop instead
+                    (void)hipGetLastError();
+                    e->tune_evict = nullptr;
+                    e->tune_evict_bytes = 0;
+                }
             }
+        }
+        if (evict && e->tune_evict) {
             float ms = 1e30f;
             for (int rep = 0; rep < 5; ++rep) {
                 TD_HIP_CHECK(hipMemsetAsync(e->tune_evict, rep, e->tune_evict_bytes, s_));
