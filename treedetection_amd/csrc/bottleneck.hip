@@ -44,9 +44,11 @@ struct TailGeom {
     static constexpr int NT1 = MID / 64;                     // phase 1: wave tile 64 x (32 NT1), block tile 128 x MID
     static constexpr int STAGE1 = 2 * (BM + MID) * CHUNK_BYTES;
     static constexpr int W3_BYTES = KC * 128 * CHUNK_BYTES;  // the 1x1 filters of one 128-channel output piece: [KC][128][128 B]
-    static_assert(!FAST || (ES == 2 && MT == 1), "the wave-private epilogue is written for fp16 and 64-row blocks");
+    static_assert(!FAST || MT == 1, "the wave-private epilogue is written for 64-row blocks");
     static constexpr int EPI_BYTES = FAST ? 4 * 16 * 64 * 4 : conv_epilogue_lds_bytes<T, MT, 2, 2, 2, 1, false>();    // FAST: 16 rows x 64 floats per wave
-    static constexpr int EPI_OFF = OVERLAP || FAST ? W3_BYTES : 0;   // OVERLAP / FAST: the next piece's filters arrive while this piece is finished
+    // OVERLAP / fp16 FAST: the next piece's filters arrive while this piece is finished; fp32 FAST stages on top of the filters it
+    // has just read (with both regions the block would cost the third block per CU) and restages them behind a barrier
+    static constexpr int EPI_OFF = OVERLAP || (FAST && ES == 2) ? W3_BYTES : 0;
     // region 0 = the phase-1 stages, later the filters of a piece and the epilogue's staging tile (side by side or aliased)
     static constexpr int R0 = cmax(STAGE1, cmax(W3_BYTES, EPI_OFF + EPI_BYTES));
     static constexpr int T2_BYTES = KC * BM * CHUNK_BYTES;   // the mid tile as the 1x1's A image: [KC][128][128 B]
@@ -238,7 +240,30 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
         for (int k = 0; k < 4; ++k)
             rb[slot][k] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, eoff[k] == OOB ? OOB : eoff[k] + (unsigned)nc * 256u, 0, 0);
     };
-    if constexpr (FAST) {
+    // fp32 FAST: one register set of 8 rows x 4 channels per 128-channel piece, requested one piece ahead (the fp32 MFMAs of a
+    // piece take ~2 us: cover enough), with two sets the kernel would leave the 170-register budget of three blocks per CU
+    const int er4 = lane >> 4, ec4 = (lane & 15) * 4;
+    [[maybe_unused]] u32x4 rbf[8];
+    [[maybe_unused]] unsigned eoff8[8];
+    [[maybe_unused]] auto load_res4 = [&](int nc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            rbf[k] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, eoff8[k] == OOB ? OOB : eoff8[k] + (unsigned)nc * 512u, 0, 0);
+    };
+    if constexpr (FAST && sizeof(T) == 4) {
+        const int bytes = (int)((size_t)M * a.COUT * ES);
+        rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.y), 0, bytes, 0x00020000);
+        yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, bytes, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int m = m0 + wm * 32 + 4 * k + er4;
+            eoff8[k] = m < M ? ((unsigned)m * (unsigned)a.COUT + (unsigned)(wn * 64 + ec4)) * ES : OOB;
+        }
+#if !(defined(TD_TAIL_DIAG) && (TD_TAIL_DIAG & 4))
+        if (a.res) load_res4(0);
+#endif
+    }
+    if constexpr (FAST && sizeof(T) == 2) {
         const int bytes = (int)((size_t)M * a.COUT * ES);
         rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.y), 0, bytes, 0x00020000);
         yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, bytes, 0x00020000);
@@ -312,7 +337,96 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
     return;
 #endif
     // ---- phase 3: the 1x1, 128 output channels per piece -------------------------------------------------------------------------
-    if constexpr (FAST) {
+    if constexpr (FAST && sizeof(T) == 4) {
+        // fp32 form of the wave-private epilogue below: 4 channels (16 B) of 8 rows per lane and piece; the staging tiles lie on
+        // the filters the piece has just read (block barrier before and after), the next piece's filters and shortcut rows are
+        // requested behind it and awaited BEFORE this piece's stores are issued — so the counted wait never has a store to sit out.
+        float* Ew = reinterpret_cast<float*>(Epi) + (wave * 16 * 64);
+        auto piece4 = [&](auto nc_c) __attribute__((always_inline)) {
+            constexpr int nc = decltype(nc_c)::value;
+            f32x16 acc3[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc3[j][r] = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const char* Ab = T2s + (kc * BM + wm * 32) * CHUNK_BYTES;
+                const char* Bb = W3s + (kc * 128 + wn * 64) * CHUNK_BYTES;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const f32x4 fa = *reinterpret_cast<const f32x4*>(Ab + frag_off[kk]);
+                    f32x4 fb[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * CHUNK_BYTES + frag_off[kk]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) Elem<T>::mma(fa, fb[j], acc3[j]);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();              // every wave has read this piece's filters: the region is the staging tiles' now
+            f32x4 out[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int lr = e + 8 * g + 4 * (lane >> 5);
+                        const int flip = (((lr >> 2) & 1) << 5) ^ ((lr & 1) << 2);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            float t = acc3[j][4 * (2 * h + g) + e];
+                            if (a.scale3) t = __fmul_rn(t, sc3[nc][j]);
+                            if (a.bias3) t = __fadd_rn(t, bi3[nc][j]);
+                            Ew[lr * 64 + ((j * 32 + (lane & 31)) ^ flip)] = t;
+                        }
+                    }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int lr = 4 * p + er4;
+                    const int flip = (((lr >> 2) & 1) << 5) ^ ((lr & 1) << 2);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&Ew[lr * 64 + (ec4 ^ flip)]);
+                    const f32x4 rs = __builtin_bit_cast(f32x4, rbf[4 * h + p]);
+                    f32x4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float t = v[q];
+#if !(defined(TD_TAIL_DIAG) && (TD_TAIL_DIAG & 4))
+                        if (a.res) t = __fadd_rn(t, rs[q]);
+#endif
+                        o[q] = t > 0.f ? t : 0.f;
+                    }
+                    out[4 * h + p] = o;
+                }
+            }
+            if constexpr (nc + 1 < NP) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();          // every wave is done with its staging tile: the next filters may land on it
+                stage_w3(nc + 1);
+#if !(defined(TD_TAIL_DIAG) && (TD_TAIL_DIAG & 4))
+                if (a.res) {
+                    load_res4(nc + 1);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // the filters; the 8 shortcut loads behind them stay in flight
+                } else
+#endif
+                {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+            }
+#if !(defined(TD_TAIL_DIAG) && (TD_TAIL_DIAG & 8))
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out[k]), yrsrc, eoff8[k] == OOB ? OOB : eoff8[k] + (unsigned)nc * 512u, 0, 0);
+#else
+            if (m0 == 0x7fffff00) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out[0] + out[7]), yrsrc, 0, 0, 0);
+#endif
+        };
+        static_for<NP>(piece4);
+        return;
+    }
+    if constexpr (FAST && sizeof(T) == 2) {
         // Wave-private wide epilogue. A wave owns 32 rows x 64 channels of a piece; it transposes them 16 rows at a time through
         // its OWN 4 KB of LDS (no block barrier; scale and bias applied on the way in), finishes 8 channels of a row per lane in
         // fp32 with the same single IEEE operations as conv_epilogue (+ shortcut, ReLU, one rounding to fp16) and stores 16 B per
@@ -493,7 +607,12 @@ td_status bottleneck_tail_launch(const TailArgs& a, int precision, hipStream_t s
     // re-reads); TD_TAIL_BM picks for experiments, the default is what measured faster per shape (profiles/)
     static const int forced = getenv("TD_TAIL_BM") ? atoi(getenv("TD_TAIL_BM")) : 0;
     const int bm = forced == 64 || forced == 128 ? forced : 64;
-    if (precision == TD_PRECISION_FP32) return bm == 64 ? launch_tail<float, 64, false, 1>(a, stream) : launch_tail<float, 64, false, 2>(a, stream);
+    static const int fast_env32 = getenv("TD_TAIL_FAST") ? atoi(getenv("TD_TAIL_FAST")) : 1;
+    const bool fast32 = fast_env32 && (size_t)a.M * a.COUT * es < 0xfffffff0ull - (1u << 20);
+    if (precision == TD_PRECISION_FP32) {
+        if (bm == 64) return fast32 ? launch_tail<float, 64, false, 1, true>(a, stream) : launch_tail<float, 64, false, 1>(a, stream);
+        return launch_tail<float, 64, false, 2>(a, stream);
+    }
     // fp16, 64 rows: the wave-private wide epilogue (32-bit buffer offsets into the shortcut / output: below 4 GB)
     static const int fast_env = getenv("TD_TAIL_FAST") ? atoi(getenv("TD_TAIL_FAST")) : 1;
     const bool fast = fast_env && (size_t)a.M * a.COUT * es < 0xfffffff0ull - (1u << 20);
