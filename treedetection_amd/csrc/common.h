@@ -102,7 +102,13 @@ static inline bool conv_head_capable(int cfg, int precision) {
 // 33 = conv_bs_kernel (conv_bstat.hip, round 4): filter-stationary 1x1 for the thin-K layers (<= 4 k-chunks), one block per CU
 #define TD_CONV_TILE_CFG_MAX 33
 static inline bool conv_cfg_is_bd(int cfg) { return (cfg >= 23 && cfg <= 27) || cfg == 29 || cfg == 30 || cfg == 33; }      // tiles that read the fragment-ordered filter copy
-static const int TD_CONV_TUNE_CANDIDATES[] = {0, 1, 2, 3, 10, 15, 16, 17, 18, 19, 20, 23, 24, 25, 26, 27, 29, 30, 31, 32, 33};   // 15 / 16 only for <= 4 k-steps, 17 only for fp16, 18-20 only for plane contractions, 23-27 / 29 / 30 / 33 only with packed filters, 31 / 32 only for <= 32 output channels, 33 only where conv_bs_ok
+// Tried in this order — from the tile that moves the fewest bytes per FLOP to the one that moves the most — and a later candidate
+// replaces the best so far only when it is more than TD_TUNE_HYST percent faster (default 2): among tiles that tie within the
+// measurement noise the one with the larger footprint wins, which keeps the choice (and with it the HBM / L2 traffic the PMC
+// passes report) from flipping between runs — fc1 was seen on the 128 x 128 tile in one run and on a 64 x 128 tile (+2 GB of filter
+// re-reads per step, same time) in the next.
+// 15 / 16 only for <= 4 k-steps, 17 only for fp16, 18-20 only for plane contractions, 23-27 / 29 / 30 / 33 only with packed filters, 31 / 32 only for <= 32 output channels, 33 only where conv_bs_ok
+static const int TD_CONV_TUNE_CANDIDATES[] = {33, 10, 17, 29, 16, 0, 15, 30, 23, 27, 1, 2, 24, 25, 26, 31, 3, 32, 18, 19, 20};
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
 // a.nlev levels (x / w / bias / y / head_y / H / W filled in; M, tile0, ntiles are computed here) in one conv_pp8_kernel grid;
 // everything else (B, Cin, Cout = 256, KH = KW = 3, relu, head_w / head_b / head_n) from the common fields. Bit-identical to one

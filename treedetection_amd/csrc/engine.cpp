@@ -912,7 +912,8 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                 (void)hipEventDestroy(eb);
                 return st2;
             }
-            if (ms < best) { best = ms; best_cfg = c; }
+            static const float hyst = 1.f - 0.01f * (getenv("TD_TUNE_HYST") ? (float)atof(getenv("TD_TUNE_HYST")) : 2.f);
+            if (best_cfg < 0 || ms < best * hyst) { best = ms; best_cfg = c; }
         }
         (void)hipEventDestroy(ea);
         (void)hipEventDestroy(eb);
