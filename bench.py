@@ -230,6 +230,7 @@ def compact_line(full):
             "e2e_f16": val("e2e", "f16", "value"), "e2e_f16_ratio": val("e2e", "f16", "ratio_to_model_stage"),
             "e2e_chained_f32": val("e2e", "f32", "chained", "value"), "e2e_chained_f32_ratio": val("e2e", "f32", "chained", "ratio_to_model_stage"),
             "e2e_chained_f16": val("e2e", "f16", "chained", "value"), "e2e_chained_f16_ratio": val("e2e", "f16", "chained", "ratio_to_model_stage"),
+            "e2e_crowns_model_f32": val("e2e_crowns", "f32", "model_stage_same_weights"), "e2e_crowns_model_f16": val("e2e_crowns", "f16", "model_stage_same_weights"),
             "e2e_crowns_f32": val("e2e_crowns", "f32", "value"), "e2e_crowns_f32_ratio": val("e2e_crowns", "f32", "ratio_to_model_stage"),
             "e2e_crowns_f16": val("e2e_crowns", "f16", "value"), "e2e_crowns_f16_ratio": val("e2e_crowns", "f16", "ratio_to_model_stage"),
             "e2e_crowns_chained_f32_ratio": val("e2e_crowns", "f32", "chained", "ratio_to_model_stage"),
@@ -378,11 +379,12 @@ def main():
                             prof[k][f] += p1[k][f]
         return prof
 
-    def run(precision, ns, profile, name=None):
+    def run(precision, ns, profile, name=None, weights=None):
         """Warm-up + timed region for one engine precision over `ns` engines / HIP streams → (seconds max over
-        ranks, profile dict or None, detections)."""
+        ranks, profile dict or None, detections). `weights`: another state dict of the same architecture (the compact-crown
+        mask head of the e2e fixture) instead of the run's own."""
         log(f"creating engine ({precision}, {ns} stream(s))")
-        engs = [Engine(sd, device=local_rank, precision=precision) for _ in range(ns)]
+        engs = [Engine(weights if weights is not None else sd, device=local_rank, precision=precision) for _ in range(ns)]
         outs = [e.alloc_outputs(B, S, S, paste=True) for e in engs]
         streams = [torch.cuda.Stream() for _ in range(ns)] if ns > 1 else [torch.cuda.current_stream()]
         eng, out = engs[0], outs[0]
@@ -726,6 +728,10 @@ def main():
             for pk in precs:
                 e2e.update(run_e2e([pk], args.e2e_side, sd, "noise-like masks"))
                 e2e_c.update(run_e2e([pk], args.e2e_side, sd_c, "compact crowns"))
+                # the crowns fixture's OWN model stage (same stream, same schedule, its weights): the blob mask head changes what the
+                # mask-head contractions and the paste see, so the e2e ratio of that fixture is taken against this rate
+                dtc, _, _ = run(pk, args.streams, False, name=f"crowns_model_{pk}", weights=sd_c)
+                e2e_c[pk]["model_stage_same_weights"] = args.steps * B * world / dtc
 
     # what the collective layer saw (for the reader of an N > 1 line: did RCCL really run N ranks on N different GPUs?)
     props = torch.cuda.get_device_properties(local_rank)
@@ -961,9 +967,11 @@ def main():
                 continue
             o = {"note": "predict_tiles' model stage files to files: warm Predictor.__call__ over a synthetic GeoTIFF (window reads, H2D, resize, "
                          "forward, paste, D2H, contours, Prediction_*.json written); ratio = e2e rate / the model-stage rate of the same precision "
-                         "in this line (inputs resident in HBM, results left in HBM)", "fixture": what}
+                         "in this line (inputs resident in HBM, results left in HBM); the crowns fixture divides by ITS model-stage rate "
+                         "(`model_stage_same_weights`: the same timed region with the blob mask head)", "fixture": what}
             for pk, r in res.items():
                 ref_rate = line["value"] if pk == args.precision else (line.get("fp16") or {}).get("value")
+                ref_rate = r.get("model_stage_same_weights") or ref_rate
                 r["ratio_to_model_stage"] = r["value"] / ref_rate if ref_rate else None
                 if "chained" in r:
                     r["chained"]["ratio_to_model_stage"] = r["chained"]["value"] / ref_rate if ref_rate else None
