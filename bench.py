@@ -230,6 +230,7 @@ def compact_line(full):
             "e2e_f16": val("e2e", "f16", "value"), "e2e_f16_ratio": val("e2e", "f16", "ratio_to_model_stage"),
             "e2e_chained_f32": val("e2e", "f32", "chained", "value"), "e2e_chained_f32_ratio": val("e2e", "f32", "chained", "ratio_to_model_stage"),
             "e2e_chained_f16": val("e2e", "f16", "chained", "value"), "e2e_chained_f16_ratio": val("e2e", "f16", "chained", "ratio_to_model_stage"),
+            "e2e_model_f32": val("e2e", "f32", "model_stage_same_weights"), "e2e_model_f16": val("e2e", "f16", "model_stage_same_weights"),
             "e2e_crowns_model_f32": val("e2e_crowns", "f32", "model_stage_same_weights"), "e2e_crowns_model_f16": val("e2e_crowns", "f16", "model_stage_same_weights"),
             "e2e_crowns_f32": val("e2e_crowns", "f32", "value"), "e2e_crowns_f32_ratio": val("e2e_crowns", "f32", "ratio_to_model_stage"),
             "e2e_crowns_f16": val("e2e_crowns", "f16", "value"), "e2e_crowns_f16_ratio": val("e2e_crowns", "f16", "ratio_to_model_stage"),
@@ -726,10 +727,13 @@ def main():
             # the crowns fp32 rate read 5 % low when it ran right after the fp16 noise region)
             e2e, e2e_c, sd_c = {}, {}, blob_mask_head(sd, seed=0)
             for pk in precs:
+                # each fixture's e2e rate is followed by ITS model stage (same stream, same schedule, its weights) in the same part of
+                # the run: late regions run on a hotter chip (5-9 % below the first region of the line), and the blob mask head changes
+                # what the mask-head contractions and the paste see — the e2e ratio is taken against this rate
                 e2e.update(run_e2e([pk], args.e2e_side, sd, "noise-like masks"))
+                dtn, _, _ = run(pk, args.streams, False, name=f"e2e_model_{pk}")
+                e2e[pk]["model_stage_same_weights"] = args.steps * B * world / dtn
                 e2e_c.update(run_e2e([pk], args.e2e_side, sd_c, "compact crowns"))
-                # the crowns fixture's OWN model stage (same stream, same schedule, its weights): the blob mask head changes what the
-                # mask-head contractions and the paste see, so the e2e ratio of that fixture is taken against this rate
                 dtc, _, _ = run(pk, args.streams, False, name=f"crowns_model_{pk}", weights=sd_c)
                 e2e_c[pk]["model_stage_same_weights"] = args.steps * B * world / dtc
 
@@ -967,11 +971,13 @@ def main():
                 continue
             o = {"note": "predict_tiles' model stage files to files: warm Predictor.__call__ over a synthetic GeoTIFF (window reads, H2D, resize, "
                          "forward, paste, D2H, contours, Prediction_*.json written); ratio = e2e rate / the model-stage rate of the same precision "
-                         "in this line (inputs resident in HBM, results left in HBM); the crowns fixture divides by ITS model-stage rate "
-                         "(`model_stage_same_weights`: the same timed region with the blob mask head)", "fixture": what}
+                         "(inputs resident in HBM, results left in HBM): the LARGER of this line's value for that precision "
+                         "and `model_stage_same_weights`, the same timed region with the fixture's weights right after the e2e calls", "fixture": what}
             for pk, r in res.items():
                 ref_rate = line["value"] if pk == args.precision else (line.get("fp16") or {}).get("value")
-                ref_rate = r.get("model_stage_same_weights") or ref_rate
+                # the larger of the line's model-stage rate (first region, cool chip) and the fixture's own rate measured right after it
+                # (late regions drift by +-4 %): the ratio never flatters the pipeline
+                ref_rate = max(ref_rate or 0.0, r.get("model_stage_same_weights") or 0.0) or None
                 r["ratio_to_model_stage"] = r["value"] / ref_rate if ref_rate else None
                 if "chained" in r:
                     r["chained"]["ratio_to_model_stage"] = r["chained"]["value"] / ref_rate if ref_rate else None
