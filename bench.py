@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MATRIX_TFLOPS = 2500.0
 _PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-PMC_TAG = next((t for t in ("r04", "r03", "r02") if os.path.exists(os.path.join(_PROFILES, f"{t}_pmc_conv_fp32.json"))), "r02")
+PMC_TAG = next((t for t in ("r05", "r04", "r03", "r02") if os.path.exists(os.path.join(_PROFILES, f"{t}_pmc_conv_fp32.json"))), "r02")
 HBM_ACHIEVABLE_TBS = 6.3            # MI355X_MICROARCH.md: measured streaming rate (8.0 TB/s spec)
 MASK_HEAD_GFLOP_PER_DET = 1.028
 SCHED = {"streams": "{n} engines, each a whole forward on its own HIP stream, batches round-robin (HBM-bound kernels and kernel tails of one "
@@ -185,14 +185,17 @@ def compact_line(full):
     c = {k: (_r(full[k], 6) if isinstance(full.get(k), float) else full.get(k)) for k in keep}
     cfg = full["config"]
     c["config"] = {k: cfg.get(k) for k in ("workload", "depth", "batch_per_gpu", "tile", "net_input", "parallelism", "schedule",
-                                          "concurrent_forwards") if k in cfg}
+                                          "concurrent_forwards", "stream_tiles", "distinct_tiles", "detections_per_tile") if k in cfg}
     c["timed_steps"] = full.get("timed_steps")
     c["timed_seconds"] = _r(full.get("timed_seconds"))
     rf = full.get("roofline")
     if rf:
         o = {k: (_r(rf.get(k), 5) if isinstance(rf.get(k), float) else rf.get(k)) for k in
-             ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch",
+             ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch",
               "executed_flops_per_launch", "kernel", "launches_per_step", "method")}
+        if o.get("traffic_source"):
+            o["traffic_source"] = str(o["traffic_source"]).split(" ")[0]        # the file; the detail file keeps the sentence
+        o["algorithmic_gflop_per_tile"] = {k: _r(v, 5) for k, v in (rf.get("algorithmic_gflop_per_tile") or {}).items()}
         o["avg_launch_us"] = _r(rf.get("span", {}).get("avg_launch_us"))
         o["effective_tflops"] = _r(rf.get("effective_tflops"))
         o["hbm_gbytes_per_step"] = _r(rf.get("hbm_gbytes_per_step"))
@@ -236,11 +239,14 @@ def compact_line(full):
             "e2e_crowns_f16": val("e2e_crowns", "f16", "value"), "e2e_crowns_f16_ratio": val("e2e_crowns", "f16", "ratio_to_model_stage"),
             "e2e_crowns_chained_f32_ratio": val("e2e_crowns", "f32", "chained", "ratio_to_model_stage"),
             "e2e_crowns_chained_f16_ratio": val("e2e_crowns", "f16", "chained", "ratio_to_model_stage"),
+            "predict_tiles_f32": val("predict_tiles", "f32", "value"), "predict_tiles_f16": val("predict_tiles", "f16", "value"),
+            "predict_tiles_f32_ratio": val("predict_tiles", "f32", "ratio_to_model_stage"), "predict_tiles_f16_ratio": val("predict_tiles", "f16", "ratio_to_model_stage"),
+            "predict_tiles_noise_f32": val("predict_tiles_noise", "f32", "value"), "predict_tiles_noise_f16": val("predict_tiles_noise", "f16", "value"),
             "e2e_contours_per_tile": val("e2e", "f32", "contours_per_tile"), "e2e_crowns_contours_per_tile": val("e2e_crowns", "f32", "contours_per_tile"),
             "e2e_json_kb_per_tile": _r((full.get("e2e", {}).get("f32", {}).get("json_bytes_per_tile") or 0) / 1e3) or None,
             "e2e_crowns_json_kb_per_tile": _r((full.get("e2e_crowns", {}).get("f32", {}).get("json_bytes_per_tile") or 0) / 1e3) or None}
     c["regions"] = {k: v for k, v in scal.items() if v is not None}
-    c["regions_unit"] = "tiles/s (two_model: tile visits/s; *_frac: executed FLOPs / MFMA peak; *_ratio: e2e / model stage; *_per_tile: counts / kB)"
+    c["regions_unit"] = "tiles/s (two_model: tile visits/s; *_frac: executed FLOPs / MFMA peak; *_ratio: e2e / model stage; predict_tiles_*: files to GeoPackage layers = predict + stitch, image-sharded at N > 1; *_per_tile: counts / kB)"
     c["detail"] = full.get("detail_file")
     return c
 
@@ -579,24 +585,17 @@ def main():
         log(f"two-model region done: {dtm * R:.3f} s for {R} x (urban pass + forest pass)")
         return dtm, len(visit["urban"]), len(visit["forest"]), n_tiles, dets
 
-    def run_e2e(precisions, side, sd_e2e, tag):
-        """predict_tiles' model stage end to end, files to files (reference prediction.py:47-77,197-265): a warm
-        Predictor.__call__ over ONE synthetic GeoTIFF on tmpfs — side x side tiles of S x S pixels (default 20 x 20: the 400 tiles
-        the reference cuts from one 1 km² image, example/config.yml:26-28), 4-band RGBI uint8, tile metadata from the package's
-        own tile producer — window reads into pinned memory, H2D, resize, forward, paste, D2H of the rows the paste wrote,
-        contours → polygons → Prediction_<tile>.json written and counted. Per precision: first call = warm-up (weights, tile
-        choices, buffers), then three timed calls (value = the fastest). `sd_e2e` = the weights: the seeded random set (noise-like
-        masks: thousands of contours and ~1 MB of JSON per tile — a stress fixture for the host epilogue) or the same set with
-        weights.blob_mask_head (compact crowns, tens of contours per tile: what a trained segmenter hands the epilogue)."""
-        import shutil
+    def make_fixture(side):
+        """The e2e raster on tmpfs, built by rank 0 and seen by every rank of the node: side x side tiles of S x S pixels (default
+        20 x 20: the 400 tiles the reference cuts from one 1 km² image, example/config.yml:26-28), 4-band RGBI uint8, tile
+        metadata from the package's own tile producer. → {"root", "tif", "tjson", "ntiles", "tmpfs"}."""
         import tempfile
-        import treedetection_amd as T
         from treedetection_amd.geotiff import write_geotiff
         from treedetection_amd.preprocessing import tile_data
         base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
-        root = tempfile.mkdtemp(prefix="td_e2e_", dir=base)
-        out = {}
-        try:
+        fx = None
+        if rank == 0:
+            root = tempfile.mkdtemp(prefix="td_e2e_", dir=base)
             os.makedirs(f"{root}/rgb")
             img = np.zeros((4, side * S, side * S), np.uint8)
             for r in range(side):
@@ -610,7 +609,106 @@ def main():
             del img
             tile_data([tif], f"{root}/tiles", buffer=0, tile_width=int(S * gsd), tile_height=int(S * gsd))
             tjson = f"{root}/tiles/324125317.json"
-            ntiles = len(json.load(open(tjson)))
+            fx = {"root": root, "tif": tif, "tjson": tjson, "ntiles": len(json.load(open(tjson))), "tmpfs": bool(base), "side": side}
+        if world > 1:
+            box = [fx]
+            dist.broadcast_object_list(box, src=0, device=dev if backend == "nccl" else None)
+            fx = box[0]
+        return fx
+
+    def run_predict_tiles(precision, fx, sd_w, tag, per_rank):
+        """``predict_tiles`` as the reference defines it — predict AND stitch (detection.py:228-243) — files to GeoPackage layers,
+        through the package's own walk (detection.walk_images: chained Predictor.submit, every finished image stitched on host
+        threads while the GPU predicts the next one, then the leftover stitching pass + resume files exactly as
+        predict_on_model / predict_tiles run them). ``per_rank`` images per rank = the fixture raster under per_rank x world
+        names (hard links); at N > 1 the images are sharded whole over the ranks (detection.assign_images) with NO collective
+        inside the walk: one manifest gather + one all-reduce after it, as predict_on_model does. Warm predictor (weights
+        resident, tile choices measured, buffers allocated): one untimed image first. → dict (value = tiles/s, all ranks)."""
+        import logging
+        import shutil
+        import treedetection_amd as T
+        from treedetection_amd import detection as DT
+        from treedetection_amd import distributed as TD
+        from treedetection_amd.recoveries import load_stitching_recovery, save_stitching_recovery
+        from treedetection_amd.stitching import process_and_stitch_predictions
+        root, n_img = fx["root"], per_rank * world
+        work = f"{root}/pt_{tag}_{precision}"
+        tiles_pt, out_pred, out_gpkg = f"{work}/tiles", f"{work}/predictions", f"{work}/geojson_predictions"
+        names = [str(324125400 + k) for k in range(n_img)]
+        if rank == 0:
+            os.makedirs(tiles_pt)
+            os.makedirs(f"{work}/rgb")
+            for nm in names:
+                os.link(fx["tif"], f"{work}/rgb/{nm}.tif")
+                os.link(fx["tjson"], f"{tiles_pt}/{nm}.json")
+        if world > 1:
+            dist.barrier()
+        paths = [f"{work}/rgb/{nm}.tif" for nm in names]
+        cfg = T.setup_model_cfg(update_model="synthetic", device=str(local_rank))
+        pred = T.Predictor(cfg, device_type=str(local_rank), max_batch_size=B, output_dir=out_pred, precision=precision,
+                           state_dict=sd_w, return_predictions=False, sharded_epilogue="local")
+        logger = logging.getLogger("td-bench")
+        logger.setLevel(logging.ERROR)
+        config = {"logger": logger, "simplify_tolerance": 0.2}
+        try:
+            pred.submit(fx["tif"], fx["tjson"], whole_image=True).result()          # warm-up image (not in the timed set)
+            shutil.rmtree(f"{out_pred}/324125317", ignore_errors=True)
+            owner = DT.assign_images(paths, world)
+            mine = [paths[i] for i in range(n_img) if owner[i] == rank]
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rep = DT.walk_images(config, pred, mine, tiles_pt, out_pred, chain=True, stitch_to=out_gpkg)
+            t_walk = time.perf_counter() - t0
+            reports = TD.gather_objects(rep) if world > 1 else [rep]
+            ok = True
+            if rank == 0:
+                stitched = [f for r in reports for f in r["stitched"]]
+                ok = sorted(p_ for r in reports for p_ in r["done"]) == sorted(paths)
+                save_stitching_recovery(out_gpkg, sorted(load_stitching_recovery(out_gpkg, None)) + stitched, None)
+                process_and_stitch_predictions(tiles_pt, out_pred, out_gpkg, max_workers=4, shift=1, simplify_tolerance=0.2, logger=logger)
+            ok = TD.all_ok(ok)
+            if world > 1:
+                dist.barrier()
+            dt_pt = time.perf_counter() - t0
+        finally:
+            pred.close()
+        tm = torch.tensor([dt_pt, t_walk, rep["stitch_seconds"]], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        res = None
+        if rank == 0:
+            layers = [f for f in os.listdir(out_gpkg) if f.endswith(".gpkg")]
+            nbytes = sum(os.path.getsize(f"{out_gpkg}/{f}") for f in layers)
+            assert ok and len(layers) == n_img, f"predict_tiles region: {len(layers)} layers for {n_img} images (ok={ok})"
+            files = sum(len(os.listdir(f"{out_pred}/{nm}")) for nm in names)
+            res = {"value": n_img * fx["ntiles"] / float(tm[0]), "unit": "tiles/s", "images": n_img, "images_per_rank": per_rank,
+                   "tiles_per_image": fx["ntiles"], "seconds": float(tm[0]), "walk_seconds_max": float(tm[1]),
+                   "stitch_thread_seconds_max": float(tm[2]), "prediction_files": files, "layers": len(layers), "layer_bytes": nbytes,
+                   "sharding": "single process" if world == 1 else f"whole images over {world} ranks (detection.assign_images), no collective in the walk",
+                   "note": "files to GeoPackage layers: window reads, H2D, resize, forward, paste, contours, Prediction_*.json, then per image "
+                           "simplify + edge filter + <image>.gpkg on host threads while the next image predicts; + the resume files"}
+            log(f"predict_tiles region ({tag}, {precision}): {n_img} images x {fx['ntiles']} tiles in {float(tm[0]):.3f} s "
+                f"(walk {float(tm[1]):.3f} s, stitch threads {float(tm[2]):.3f} s)")
+            shutil.rmtree(work, ignore_errors=True)
+        if world > 1:
+            dist.barrier()
+        return res
+
+    def run_e2e(precisions, fx, sd_e2e, tag):
+        """predict_tiles' model stage end to end, files to files (reference prediction.py:47-77,197-265): a warm
+        Predictor.__call__ over ONE synthetic GeoTIFF on tmpfs (``make_fixture``) — window reads into pinned memory, H2D, resize,
+        forward, paste, D2H of the rows the paste wrote,
+        contours → polygons → Prediction_<tile>.json written and counted. Per precision: first call = warm-up (weights, tile
+        choices, buffers), then three timed calls (value = the fastest). `sd_e2e` = the weights: the seeded random set (noise-like
+        masks: thousands of contours and ~1 MB of JSON per tile — a stress fixture for the host epilogue) or the same set with
+        weights.blob_mask_head (compact crowns, tens of contours per tile: what a trained segmenter hands the epilogue)."""
+        import shutil
+        import treedetection_amd as T
+        root, tif, tjson, ntiles, side, base = fx["root"], fx["tif"], fx["tjson"], fx["ntiles"], fx["side"], fx["tmpfs"]
+        out = {}
+        if True:
             cfg = T.setup_model_cfg(update_model="synthetic", device=str(local_rank))
             for precision in precisions:
                 pred = T.Predictor(cfg, device_type=str(local_rank), max_batch_size=B, output_dir=f"{root}/out_{precision}",
@@ -625,8 +723,8 @@ def main():
                 # the stage as predict_on_model runs it over MANY images: the next image is submitted while the previous one
                 # drains (Predictor.submit). Three images = the same raster under three names (hard links), one timed pass.
                 chain = []
-                for k in (1, 2, 3):
-                    name = f"32412531{7 + k}"
+                for k in range(1, (3 if precision == "fp32" else 6) + 1):       # >= 1 s of chained work at either precision's rate
+                    name = str(324125317 + k)
                     for src, dst in ((tif, f"{root}/rgb/{name}.tif"), (tjson, f"{root}/tiles/{name}.json")):
                         if not os.path.exists(dst):
                             os.link(src, dst)
@@ -659,10 +757,8 @@ def main():
                                   "host_stage_seconds_last_call": stats,
                                   "chained": {"value": len(chain) * ntiles / dt_chain, "unit": "tiles/s", "images": len(chain), "seconds": dt_chain,
                                               "files_written": chained_files,
-                                              "note": "three images back to back as detection.predict_on_model walks them: image i+1 submitted while image i drains"}}
+                                              "note": "images back to back as detection.predict_on_model walks them: image i+1 submitted while image i drains"}}
             return out
-        finally:
-            shutil.rmtree(root, ignore_errors=True)
 
     if "TD_TUNE_CACHE" not in os.environ:     # engines of one run share their measured block-tile choices
         import tempfile
@@ -715,27 +811,52 @@ def main():
             b32 = go("fp16", not args.no_profile, "fp16_batch32") + (nsteps,)
             B, nsteps = args.batch, args.steps
     two = e2e = e2e_c = None
-    if args.depth == 50 and world == 1 and args.schedule == "streams":
-        if not args.no_two_model:
-            two = {args.precision: run_two_model(args.precision)}
-            if args.precision == "fp32" and not args.no_fp16:
-                two["fp16"] = run_two_model("fp16")
-        if not args.no_e2e:
-            from treedetection_amd.weights import blob_mask_head
-            precs = [args.precision] + (["fp16"] if args.precision == "fp32" and not args.no_fp16 else [])
-            # both fixtures of one precision back to back (an fp32 region that follows an fp16 one starts on a hotter, slower chip:
-            # the crowns fp32 rate read 5 % low when it ran right after the fp16 noise region)
-            e2e, e2e_c, sd_c = {}, {}, blob_mask_head(sd, seed=0)
-            for pk in precs:
-                # each fixture's e2e rate is followed by ITS model stage (same stream, same schedule, its weights) in the same part of
-                # the run: late regions run on a hotter chip (5-9 % below the first region of the line), and the blob mask head changes
-                # what the mask-head contractions and the paste see — the e2e ratio is taken against this rate
-                e2e.update(run_e2e([pk], args.e2e_side, sd, "noise-like masks"))
-                dtn, _, _ = run(pk, args.streams, False, name=f"e2e_model_{pk}")
-                e2e[pk]["model_stage_same_weights"] = args.steps * B * world / dtn
-                e2e_c.update(run_e2e([pk], args.e2e_side, sd_c, "compact crowns"))
-                dtc, _, _ = run(pk, args.streams, False, name=f"crowns_model_{pk}", weights=sd_c)
-                e2e_c[pk]["model_stage_same_weights"] = args.steps * B * world / dtc
+    pt = pt_n = None
+    if args.depth == 50 and args.schedule == "streams" and not args.no_e2e:
+        import shutil
+        from treedetection_amd.weights import blob_mask_head
+        precs = [args.precision] + (["fp16"] if args.precision == "fp32" and not args.no_fp16 else [])
+        fx = make_fixture(args.e2e_side)
+        try:
+            sd_c = blob_mask_head(sd, seed=0)
+            per_rank = {"fp32": 3, "fp16": 6}        # images per rank in the predict_tiles regions: >= 1 s of work at either rate
+            if world == 1:
+                if not args.no_two_model:
+                    two = {args.precision: run_two_model(args.precision)}
+                    if args.precision == "fp32" and not args.no_fp16:
+                        two["fp16"] = run_two_model("fp16")
+                # both fixtures of one precision back to back (an fp32 region that follows an fp16 one starts on a hotter, slower chip:
+                # the crowns fp32 rate read 5 % low when it ran right after the fp16 noise region)
+                e2e, e2e_c, pt, pt_n = {}, {}, {}, {}
+                for pk in precs:
+                    # each fixture's e2e rate is followed by ITS model stage (same stream, same schedule, its weights) in the same part of
+                    # the run: late regions run on a hotter chip (5-9 % below the first region of the line), and the blob mask head changes
+                    # what the mask-head contractions and the paste see — the e2e ratio is taken against this rate
+                    e2e.update(run_e2e([pk], fx, sd, "noise-like masks"))
+                    pt_n[pk] = run_predict_tiles(pk, fx, sd, "noise", per_rank[pk])
+                    dtn, _, _ = run(pk, args.streams, False, name=f"e2e_model_{pk}")
+                    e2e[pk]["model_stage_same_weights"] = pt_n[pk]["model_stage_same_weights"] = args.steps * B * world / dtn
+                    e2e_c.update(run_e2e([pk], fx, sd_c, "compact crowns"))
+                    pt[pk] = run_predict_tiles(pk, fx, sd_c, "crowns", per_rank[pk])
+                    dtc, _, _ = run(pk, args.streams, False, name=f"crowns_model_{pk}", weights=sd_c)
+                    e2e_c[pk]["model_stage_same_weights"] = pt[pk]["model_stage_same_weights"] = args.steps * B * world / dtc
+            else:
+                # N > 1: predict_tiles files to GeoPackage layers with WHOLE IMAGES sharded over the ranks (the structure
+                # detection.predict_on_model runs), compact-crown fixture
+                pt = {}
+                for pk in precs:
+                    r = run_predict_tiles(pk, fx, sd_c, "crowns", per_rank[pk])
+                    dtc, _, _ = run(pk, args.streams, False, name=f"crowns_model_{pk}", weights=sd_c)
+                    if rank == 0:
+                        r["model_stage_same_weights"] = args.steps * B * world / dtc
+                        pt[pk] = r
+        finally:
+            if rank == 0:
+                shutil.rmtree(fx["root"], ignore_errors=True)
+    elif args.depth == 50 and world == 1 and args.schedule == "streams" and not args.no_two_model:
+        two = {args.precision: run_two_model(args.precision)}
+        if args.precision == "fp32" and not args.no_fp16:
+            two["fp16"] = run_two_model("fp16")
 
     # what the collective layer saw (for the reader of an N > 1 line: did RCCL really run N ranks on N different GPUs?)
     props = torch.cuda.get_device_properties(local_rank)
@@ -764,8 +885,10 @@ def main():
             "dtype": "f32" if args.precision == "fp32" else "f16",
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: single model ResNet{args.depth}-FPN Mask R-CNN, "
-                                   f"{args.stream_tiles}-tile synthetic {S}x{S} RGB(+nDSM side band) stream, batch={B} per GPU, "
+                                   f"{n_local}-tile synthetic {S}x{S} RGB(+nDSM side band) stream per GPU ({min(args.distinct, n_local)} distinct "
+                                   f"seeds cycled; re-walked R times for the >= 1 s region), batch={B} per GPU, "
                                    f"resize 800x800 + forward + paste on device, inputs resident in HBM",
+                       "stream_tiles": n_local, "distinct_tiles": min(args.distinct, n_local), "detections_per_tile": ndet / B,
                        "depth": args.depth, "batch_per_gpu": B, "tile": S, "net_input": "3x800x800",
                        "parallelism": f"tile-shard x{world} (replicated weights, RCCL gather of detections to rank 0)",
                        "schedule": f"{args.schedule} x{args.streams}", "schedule_note": SCHED[args.schedule].format(n=args.streams),
@@ -803,7 +926,7 @@ def main():
                 out[name] = o
             return out
 
-        def roofline(profx, dtx, k, peak, pmc_name=None, detail=None, kd=1):
+        def roofline(profx, dtx, k, peak, pmc_name=None, detail=None, kd=1, ndet_tile=None, depth=None):
             """`roofline` object of one timed region of k steps (conv family = every MFMA contraction + the Winograd transform
             kernels of the layers on that path).
 
@@ -876,6 +999,13 @@ def main():
                          "times the tile padding, F(2x2,3x3) layers 4/9) over the time; effective_tflops = algorithmic FLOPs (2 x MACs of "
                          "the direct convolution, SURVEY.md §8d) over the same time")
             o["winograd_layers_per_step"] = ex["launches"] / k
+            # 261.9 (R50) / 356.6 (R101) GFLOP + 1.028 GFLOP per detection — at the stream's measured detections per
+            # tile and at the 30 the survey quotes (the family's FLOPs above are the static layers: trunk, FPN, RPN, box head)
+            base = 356.6 if (depth or args.depth) == 101 else 261.9
+            o["algorithmic_gflop_per_tile"] = {"static": base, "at_30_detections": base + 30 * MASK_HEAD_GFLOP_PER_DET}
+            if ndet_tile is not None:
+                o["algorithmic_gflop_per_tile"]["detections_per_tile"] = ndet_tile
+                o["algorithmic_gflop_per_tile"]["at_measured_detections"] = base + ndet_tile * MASK_HEAD_GFLOP_PER_DET
             for key in ("frac",):
                 assert o[key] <= 1.0 + 1e-9, f"roofline.{key} = {o[key]} is not a fraction"
             assert o["sol"]["frac_chip"] <= 1.0 + 1e-9 and o["span"]["frac"] <= 1.0 + 1e-9, "speed-of-light fraction above 1"
@@ -902,7 +1032,7 @@ def main():
         if prof is not None:
             line["roofline"] = roofline(prof, dt, args.steps, peak_main,
                                         (f"{PMC_TAG}_pmc_conv_fp32.json" if args.precision == "fp32" else f"{PMC_TAG}_pmc_conv_fp16.json") if std else None,
-                                        detail[1] if detail else None, kd)
+                                        detail[1] if detail else None, kd, ndet_tile=ndet / B)
             line["breakdown_ms_per_step"] = breakdown(prof, args.steps)
         if extra is not None:
             dt16, prof16, ndet16 = extra
@@ -912,7 +1042,7 @@ def main():
                  "detections_last_batch": ndet16}
             if prof16 is not None:
                 o["roofline"] = roofline(prof16, dt16, args.steps, PEAK_F16_MATRIX_TFLOPS, f"{PMC_TAG}_pmc_conv_fp16.json" if std else None,
-                                         detail16[1] if detail16 else None, kd)
+                                         detail16[1] if detail16 else None, kd, ndet_tile=ndet16 / B)
                 o["breakdown_ms_per_step"] = breakdown(prof16, args.steps)
                 if piped16 is not None and piped16[1] is not None:
                     o["roofline"]["exclusive"] = exclusive(piped16[1], args.steps, PEAK_F16_MATRIX_TFLOPS)
@@ -925,7 +1055,7 @@ def main():
             o = {"value": k * batch * world / dtx, "unit": "tiles/s", "ms_per_step": 1000.0 * dtx / k, "steps": k,
                  "batch_per_gpu": batch, "depth": depth, "detections_last_batch": ndetx}
             if profx is not None:
-                o["roofline"] = roofline(profx, dtx, k, peak)
+                o["roofline"] = roofline(profx, dtx, k, peak, ndet_tile=ndetx / batch, depth=depth)
                 o["breakdown_ms_per_step"] = breakdown(profx, k)
             return o
         if r101 is not None:
@@ -981,6 +1111,17 @@ def main():
                 r["ratio_to_model_stage"] = r["value"] / ref_rate if ref_rate else None
                 if "chained" in r:
                     r["chained"]["ratio_to_model_stage"] = r["chained"]["value"] / ref_rate if ref_rate else None
+                o["f32" if pk == "fp32" else "f16"] = r
+            line[key] = o
+        for key, res, what in (("predict_tiles", pt, "weights.blob_mask_head: compact crowns"), ("predict_tiles_noise", pt_n, "seeded random mask head: noise-like masks")):
+            if not res:
+                continue
+            o = {"note": "predict_tiles as the reference defines it (predict + stitch, detection.py:228-243), files to GeoPackage layers, warm "
+                         "predictor; ratio = rate / model-stage rate of the same precision and weights (inputs resident in HBM)", "fixture": what}
+            for pk, r in res.items():
+                ref_rate = line["value"] if pk == args.precision else (line.get("fp16") or {}).get("value")
+                ref_rate = max(ref_rate or 0.0, r.get("model_stage_same_weights") or 0.0) or None
+                r["ratio_to_model_stage"] = r["value"] / ref_rate if ref_rate else None
                 o["f32" if pk == "fp32" else "f16"] = r
             line[key] = o
         if world == 1 and not args.no_cpu_baseline:

@@ -63,6 +63,14 @@ def test_compact_line_worst_case_with_eight_ranks_and_every_region(tmp_path):
     full["cpu_baseline"]["sample"] = "z" * 1000
     full["e2e_crowns"] = json.loads(json.dumps(full["e2e"]))
     full["timed_steps"], full["timed_seconds"], full["detail_file"] = 160, 2.0123456, "bench_detail.json"
+    # round 5: the line says what ran and carries the predict + stitch rate
+    full["config"].update(stream_tiles=200, distinct_tiles=16, detections_per_tile=18.5)
+    full["roofline"]["traffic_source"] = "profiles/r05_pmc_conv_fp32.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; conv family: 27.05 GB per step)"
+    full["roofline"]["algorithmic_gflop_per_tile"] = {"static": 261.9, "at_30_detections": 292.74, "detections_per_tile": 18.5,
+                                                      "at_measured_detections": 280.918}
+    for key in ("predict_tiles", "predict_tiles_noise"):
+        full[key] = {"note": "n" * 300, "f32": {"value": 612.3456, "ratio_to_model_stage": 0.93123, "images": 24},
+                     "f16": {"value": 1912.3456, "ratio_to_model_stage": 0.90123, "images": 48}}
     out, err = io.StringIO(), io.StringIO()
     with redirect_stdout(out), redirect_stderr(err):
         s = bench.emit(full, str(tmp_path / "bench_detail.json"))
@@ -74,6 +82,12 @@ def test_compact_line_worst_case_with_eight_ranks_and_every_region(tmp_path):
     assert c["cpu_baseline"]["extra"]["r101_b8"] == 0.9 and len(c["cpu_baseline"]["sample"]) <= 200
     assert c["timed_steps"] == 160 and c["detail"] == "bench_detail.json"
     assert "e2e_crowns_f16_ratio" in c["regions"]
+    assert c["config"]["stream_tiles"] == 200 and c["config"]["distinct_tiles"] == 16 and c["config"]["detections_per_tile"] == 18.5
+    assert c["roofline"]["traffic_source"] == "profiles/r05_pmc_conv_fp32.json"
+    assert c["roofline"]["algorithmic_gflop_per_tile"]["at_measured_detections"] == pytest.approx(280.92, rel=1e-4)
+    assert c["roofline"]["algorithmic_gflop_per_tile"]["at_30_detections"] == pytest.approx(292.74, rel=1e-4)
+    assert c["regions"]["predict_tiles_f32"] == pytest.approx(612.3, rel=1e-3) and c["regions"]["predict_tiles_f16_ratio"] == pytest.approx(0.9012, rel=1e-3)
+    assert c["regions"]["predict_tiles_noise_f16"] == pytest.approx(1912, rel=1e-3)
     assert json.load(open(tmp_path / "bench_detail.json"))["roofline"]["sol"]          # everything else lives in the detail file
     assert "full result" in err.getvalue()
 

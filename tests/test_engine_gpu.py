@@ -255,3 +255,24 @@ def test_resnet101_layout(setup):
     assert abs(len(got[0]["scores"]) - len(ref[0]["scores"])) <= 1
     m = min(len(got[0]["scores"]), len(ref[0]["scores"]))
     assert m > 0 and np.abs(np.sort(got[0]["scores"])[-m:] - np.sort(ref[0]["scores"])[-m:]).max() <= 1e-3
+
+
+def test_mask_head_beyond_the_fold_kernels_plane_limit(setup):
+    """the mask head launches all B x detections_per_image reserved RoIs as ONE group; the folded F(4x4) kernel's
+    32-bit plane offsets hold 36 * tiles * C * 4 < 4 GB (about 14 500 RoIs of 14 x 14 at this fixture's 128 channels, 7 279 at
+    256). A configuration past that (8 x 2000 RoIs) must take the three-launch form instead of failing the forward — and give
+    the detections of the default configuration (same boxes and scores bit for bit; mask probabilities within the fp32
+    tolerance: the two Winograd forms associate their sums differently)."""
+    from treedetection_amd.engine import Engine
+    inputs = [setup["inputs"][k % 2] for k in range(8)]
+    big = Engine(setup["sd"], detections_per_image=2000)
+    try:
+        got = big(inputs, paste=False)
+    finally:
+        big.close()
+    ref = setup["eng"](inputs, paste=False)
+    for g, r in zip(got, ref):
+        assert len(r["scores"]) < 100                       # (else the two top-D limits would cut different sets)
+        assert len(g["scores"]) == len(r["scores"]) > 0
+        assert (g["pred_boxes"] == r["pred_boxes"]).all() and (g["scores"] == r["scores"]).all()
+        assert np.abs(g["mask_probs"] - r["mask_probs"]).max() <= TOL_MASKP

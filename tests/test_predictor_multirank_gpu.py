@@ -174,3 +174,88 @@ def test_config3_mosaic_10k_tiles_sharded(tmp_path):
             assert e["image_id"] == tif and 0.3 < e["score"] <= 1.0 and len(e["polygon_coords"][0]) >= 4
         nonempty += bool(entries)
     assert nonempty > 0
+
+
+PREDICT_TILES_WORKER = r"""
+import logging, os, sys
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+import treedetection_amd as T
+world = int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    dist.init_process_group("gloo")
+rank = dist.get_rank() if world > 1 else 0
+log = logging.getLogger("td")
+log.setLevel(logging.INFO)
+log.addHandler(logging.FileHandler(os.path.join({out!r}, f"log_rank{{rank}}.txt")))
+config = dict({cfg!r}, logger=log)
+T.predict_tiles(config)
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+"""
+
+
+def _layer_rows(path):
+    import sqlite3
+    con = sqlite3.connect(path)
+    try:
+        table = con.execute("SELECT table_name FROM gpkg_contents").fetchone()[0]
+        return con.execute(f'SELECT * FROM "{table}" ORDER BY fid').fetchall()
+    finally:
+        con.close()
+
+
+def test_image_level_sharding_two_ranks_equals_one_process(tmp_path):
+    """with at least as many images as ranks every rank owns WHOLE images (detection.assign_images), runs
+    them through the chained single-process pipeline, writes their tile files and stitches them while it predicts the next
+    one; no collective per image. A 6-image folder, one of them unreadable (logged by its owner, the walk goes on on every
+    rank, reference detection.py:117-120): the 2-rank run's Prediction_*.json are byte-identical to the single process's
+    and the stitched layers hold the same rows."""
+    from treedetection_amd.preprocessing import tile_single_file
+    np.savez(tmp_path / "model_combined.npz", **make_synthetic_state_dict(50, seed=3, width_div=2))
+    rgb_dir, tiles = tmp_path / "rgb", tmp_path / "tiles"
+    rgb_dir.mkdir()
+    names = ["3241", "3242", "3243", "3244", "3245", "3246"]
+    for k, name in enumerate(names):
+        tif = str(rgb_dir / f"{name}.tif")
+        if name == "3244":
+            continue
+        rgb, _ = make_tile(300 + k, 400)
+        write_geotiff(tif, np.ascontiguousarray(rgb.transpose(2, 0, 1)), (0.2, 0.0, 412000.0 + 80 * k, 0.0, -0.2, 5318080.0), 25832)
+        tile_single_file(tif, str(tiles), buffer=10, tile_width=40, tile_height=40)
+    (rgb_dir / "3244.tif").write_bytes(b"II*\x00 not a raster")                      # listed, tiled once, unreadable now
+    (tiles / "3244.json").write_text((tiles / "3243.json").read_text().replace("3243", "3244"))
+    outs = {}
+    for world in (1, 2):
+        out = tmp_path / f"out{world}"
+        out.mkdir()
+        cfg = {"image_directory": str(rgb_dir), "merged_path": "merged", "tiles_path": str(tiles), "output_directory": str(out),
+               "device": "0", "simplify_tolerance": 0.2, "num_workers": 2, "batch_size": 3, "precision": "fp32",
+               "combined_model": str(tmp_path / "model_combined.npz")}
+        script = tmp_path / f"pt{world}.py"
+        script.write_text(PREDICT_TILES_WORKER.format(root=ROOT, out=str(out), cfg=cfg))
+        _run(script, world)
+        outs[world] = out
+    logs = "".join((outs[2] / f"log_rank{r}.txt").read_text() for r in (0, 1))
+    assert "sharding by image" in logs and "3244.tif" in logs and "Error processing" in logs
+    # the unreadable image belongs to ONE rank; the other rank's log never mentions it
+    assert sum("3244.tif" in (outs[2] / f"log_rank{r}.txt").read_text() for r in (0, 1)) == 1
+    total = 0
+    for name in names:
+        d1, d2 = outs[1] / "predictions" / name, outs[2] / "predictions" / name
+        if name == "3244":
+            assert not d1.exists() or not os.listdir(d1)
+            assert not d2.exists() or not os.listdir(d2)
+        else:
+            f1, f2 = sorted(os.listdir(d1)), sorted(os.listdir(d2))
+            assert f1 == f2 and len(f1) == 4, (name, f1, f2)
+            for f in f1:
+                assert (d1 / f).read_bytes() == (d2 / f).read_bytes(), (name, f)          # byte for byte
+                total += len(json.loads((d1 / f).read_bytes()))
+        r1 = _layer_rows(str(outs[1] / "geojson_predictions" / f"{name}.gpkg"))
+        r2 = _layer_rows(str(outs[2] / "geojson_predictions" / f"{name}.gpkg"))
+        assert r1 == r2, name
+    assert total > 20
+    s1, s2 = (yaml.safe_load(open(o / "geojson_predictions" / "stitching_recovery.yaml")) for o in (outs[1], outs[2]))
+    assert s1 == s2 and len(s1["completed_files"]) == 6

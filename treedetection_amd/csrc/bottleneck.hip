@@ -382,6 +382,7 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
                             Ew[lr * 64 + ((j * 32 + (lane & 31)) ^ flip)] = t;
                         }
                     }
+                __builtin_amdgcn_wave_barrier();       // staged in one lane layout, read back in another (same wave): pin the order
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const int lr = 4 * p + er4;
@@ -399,6 +400,7 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
                     }
                     out[4 * h + p] = o;
                 }
+                __builtin_amdgcn_wave_barrier();       // the next half's staging writes stay behind these reads
             }
             if constexpr (nc + 1 < NP) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -477,6 +479,7 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
                             Ew[lr * 64 + ((j * 32 + (lane & 31)) ^ flip)] = t;
                         }
                     }
+                __builtin_amdgcn_wave_barrier();       // staged in one lane layout, read back in another (same wave): pin the order
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const int lr = 8 * p + er;
@@ -503,6 +506,7 @@ __device__ __forceinline__ void bottleneck_tail_body(const TailArgs& a, char* ld
                     }
                     out[2 * h + p] = __builtin_bit_cast(u32x4, o);
                 }
+                __builtin_amdgcn_wave_barrier();       // the next half's staging writes stay behind these reads
             }
             if constexpr (nc + 1 < NP) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next piece's filters (and its shortcut rows)

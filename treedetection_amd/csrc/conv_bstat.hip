@@ -255,6 +255,10 @@ __global__ __launch_bounds__(640, 3) void conv_bs_kernel(const ConvArgs a, const
                     acc[i][4 * (2 * hq + gg) + e] = t;
 #endif
                 }
+            // wave-private staging: written in the accumulator lane layout, read back transposed by OTHER lanes of the same wave.
+            // DS operations of a wave retire in order; the wave barrier (no instruction) keeps the compiler from moving the
+            // reads above the writes, or the next quarter's writes above these reads
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int p = 0; p < Gm::PASSES; ++p) {
                 const int lrow = Gm::RPP * p + er;
@@ -304,6 +308,7 @@ __global__ __launch_bounds__(640, 3) void conv_bs_kernel(const ConvArgs a, const
 #endif
                 }
             }
+            __builtin_amdgcn_wave_barrier();       // the next quarter's staging writes stay behind these reads
         }
     };
     if (has_res) issue_res(std::integral_constant<int, 0>{}, 0);

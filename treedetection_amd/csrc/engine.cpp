@@ -1073,7 +1073,9 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
                 // (a layer with a 1x1 head — the RPN conv — folds only on the 160 x 160+ maps, bit 32: its head then runs as a launch
                 // of its own on the stored map, 1 000 + ~70 us against 1 280 us for the three-launch form with the head in its
                 // output transform; on the smaller maps that form wins)
-                use_fold = use_43 && wf_ > 0 && wino43_fused_ok(1, H_, W_, L.cin, L.cout) &&
+                // (device-side RoI count: ALL B_ reserved RoIs are one group below, so its 32-bit plane offsets must hold them — about
+                // 7 279 RoIs of 14 x 14 x 256; past that the layer keeps the three-launch form. Still a rule on reserved shapes only.)
+                use_fold = use_43 && wf_ > 0 && wino43_fused_ok(m_dyn ? B_ : 1, H_, W_, L.cin, L.cout) &&
                            (((wf_ & 1) && !m_dyn && (!head || (wf_ & 32)) && ((L.cin == 256 && hw_ >= 160 * 160) || (L.cin == 128 && hw_ >= 80 * 80))) ||
                             ((wf_ & 2) && m_dyn && !head) || ((wf_ & 4) && !m_dyn && !head && L.cin == 256 && hw_ >= 80 * 80) ||
                             ((wf_ & 8) && !m_dyn && !head && hw_ >= 40 * 40) || ((wf_ & 16) && !m_dyn && !head));

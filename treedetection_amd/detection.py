@@ -27,9 +27,108 @@ from .postprocessing import process_files_in_directory
 from .stitching import process_and_stitch_predictions
 
 
-def predict_on_model(config, model_path, tiles_path, output_path, batch_size=10, exclude_vars=None):
-    """Reference detection.py:62-132: build the predictor once, walk the images (+ ``merged/``) sequentially, swallow
-    and log per-image errors, write the resume file."""
+def assign_images(paths, world: int):
+    """Image-level sharding: → owner rank of every image. Longest-processing-time first on the raster's file size (a proxy for
+    its tile count: the seam strips under ``merged/`` are a fraction of a full image), ties and equal sizes fall back to
+    round-robin in list order — with equal images this IS ``i mod world``. Deterministic in (paths, sizes, world)."""
+    sizes = []
+    for p in paths:
+        try:
+            sizes.append(os.path.getsize(p))
+        except OSError:
+            sizes.append(0)
+    order = sorted(range(len(paths)), key=lambda i: (-sizes[i], i))
+    load = [0] * world
+    owner = [0] * len(paths)
+    for n, i in enumerate(order):
+        r = min(range(world), key=lambda k: (load[k], (k - n) % world))
+        owner[i] = r
+        load[r] += max(sizes[i], 1)
+    return owner
+
+
+def resolve_shard_by(config, world: int, epilogue: str, n_images: int) -> str:
+    """How a multi-rank ``predict_on_model`` cuts its work (config key ``shard_by``: "auto" | "image" | "tile").
+
+    "image": rank r predicts WHOLE images (``assign_images``) through the chained single-process pipeline, writes their tile
+    files and stitches them; no collective per image (one list broadcast before the walk, one manifest gather + one all-reduce
+    after it). Needs the "local" epilogue (every rank writes into the shared output folder). "tile": every image is sharded
+    tile by tile over all ranks (``Predictor.__call__``: BASELINE configs[3]'s single 10k-tile mosaic, or the "rank0"
+    epilogue). "auto" = "image" when the epilogue is "local" and there are at least as many images as ranks."""
+    mode = str(config.get("shard_by", "auto"))
+    if mode not in ("auto", "image", "tile"):
+        raise ValueError(f"shard_by must be 'auto', 'image' or 'tile', got {mode!r}")
+    if world == 1:
+        return "single"
+    if epilogue != "local":
+        return "tile"
+    if mode == "auto":
+        return "image" if n_images >= world else "tile"
+    return mode
+
+
+def walk_images(config, predictor, paths, tiles_path, output_path, chain=True, stitch_to=None):
+    """The walk of ``predict_on_model`` over the images THIS process is responsible for (reference detection.py:112-129), with
+    no collective of its own. ``chain``: the images are this process's alone (single process, image-level sharding) — image
+    i+1 is started (read, launched) while image i's last forwards and tile files finish (``Predictor.submit``); the per-image
+    outcome (files written, or the error logged and the walk continuing, reference detection.py:117-120) is the same as
+    calling the predictor image by image. Otherwise every image is one collective structure all ranks enter together
+    (``Predictor.__call__``). ``stitch_to``: every image whose tile files are complete is stitched at once on host threads
+    (stitching.EagerStitcher) while the GPU goes on. → {"done", "failed", "stitched", "stitch_seconds"}."""
+    logger = config.get("logger", None)
+    stitcher = None
+    if stitch_to is not None:
+        from .prediction import host_core_share
+        from .stitching import EagerStitcher
+        stitcher = EagerStitcher(tiles_path, output_path, stitch_to, shift=1, simplify_tolerance=config["simplify_tolerance"],
+                                 logger=logger, workers=max(1, min(4, host_core_share() // 4)))
+    total = len(paths)
+    pending = None
+    done, failed = [], []
+
+    def finish(item):
+        path, handle = item
+        try:
+            if handle is not None:
+                handle.result()
+            done.append(path)
+            if stitcher is not None:
+                stitcher.submit(os.path.basename(path).replace(".tif", ".json"))
+        except Exception as e:
+            failed.append(path)
+            logger.error(f"Error processing {path}: {e}")
+
+    try:
+        for n, fp in enumerate(paths):
+            cur, prev = int(100 * (n + 1) / total), int(100 * n / total)
+            if logger and ((cur // 5) != (prev // 5) or cur == 100 or n == 0):
+                logger.info(f"Predicting file {n + 1}/{total} ({cur}%)")
+            tile_json = os.path.join(tiles_path, os.path.basename(fp).replace(".tif", ".json"))
+            handle = None
+            try:
+                if chain:
+                    handle = predictor.submit(fp, tile_json, whole_image=True)
+                else:
+                    predictor(fp, tile_json)
+                    finish((fp, None))
+            except Exception as e:
+                failed.append(fp)
+                logger.error(f"Error processing {fp}: {e}")
+            if pending is not None:
+                finish(pending)
+            pending = (fp, handle) if handle is not None else None
+        if pending is not None:
+            finish(pending)
+    finally:
+        stitched = stitcher.close() if stitcher is not None else []
+    return {"done": done, "failed": failed, "stitched": stitched, "stitch_seconds": stitcher.seconds if stitcher is not None else 0.0}
+
+
+def predict_on_model(config, model_path, tiles_path, output_path, batch_size=10, exclude_vars=None, stitch_to=None):
+    """Reference detection.py:62-132: build the predictor once, walk the images (+ ``merged/``), swallow and log per-image
+    errors, write the resume file. ``stitch_to`` (not in the reference's signature; ``predict_tiles`` passes it): the folder
+    of the stitched layers — every image whose tile files are complete is stitched right away on host threads while the GPU
+    predicts the next one (stitching.EagerStitcher), by the rank that completed it."""
     logger = config.get("logger", None)
     for path, name in [(model_path, "Model file"), (tiles_path, "Tiles directory")]:
         if not os.path.exists(path):
@@ -38,68 +137,83 @@ def predict_on_model(config, model_path, tiles_path, output_path, batch_size=10,
             raise NotADirectoryError(f"{name} is not a directory: {path}")
     os.makedirs(output_path, exist_ok=True)
     D.bind_device(config["device"])      # before the first collective of this stage (nccl picks the current device)
+    W, me = D.world(), D.rank()
+    # the image list first: how a multi-rank run cuts its work depends on it
+    images_directory = Path(config["image_directory"])
+    images_paths = sorted(str(f) for f in images_directory.glob("*.tif"))
+    merged_directory = Path(f"{images_directory}/{config['merged_path']}")
+    images_paths.extend(sorted(str(f) for f in merged_directory.glob("*.tif")))
+    found = len(images_paths)
+    processed_files = set()
+    if images_paths:
+        file_list, processed_files = load_prediction_recovery_data(output_path, tiles_path, model_path, logger, exclude_vars)
+        if not file_list:
+            images_paths = [f for f in images_paths if f not in processed_files]
+    owner = None
+    if W > 1:
+        # ONE list for everybody (rank 0's view of the folders, of the resume file and of the raster sizes): the ranks' walks
+        # must agree on the images and — image-level sharding — on who owns which. The only collective before the walk.
+        images_paths, processed_files, found, owner = D.broadcast_object((images_paths, processed_files, found, assign_images(images_paths, W)))
+    if not images_paths:
+        if logger and not found:
+            logger.warning("No TIF files found for prediction.")
+        elif logger:
+            logger.info("All files have already been predicted. Exiting Prediction.")
+        D.barrier()
+        return
+    epilogue = config.get("sharded_epilogue", "auto")
+    if W > 1 and epilogue == "auto":
+        # "local" (every rank pastes, traces and writes its own tiles) needs an output folder rank 0 can read; with at least
+        # as many images as ranks it is also what lets a rank own whole images — no data-path collective at all. Otherwise
+        # the rule of prediction.resolve_sharded_epilogue: "rank0" below 4 ranks.
+        from .prediction import resolve_sharded_epilogue
+        shared = D.single_node() or D.output_is_shared(output_path)
+        by_image = str(config.get("shard_by", "auto")) in ("auto", "image") and len(images_paths) >= W
+        epilogue = "local" if shared and by_image else resolve_sharded_epilogue(W, config.get("precision", "fp32"), shared)
     cfg = setup_model_cfg(update_model=model_path, device=config["device"])
     # one process per GPU under torch.distributed: the shared config names one device, each rank takes its own
     # (LOCAL_RANK), see distributed.local_device
-    device = config["device"] if D.world() == 1 else str(D.local_device(config["device"]))
+    device = config["device"] if W == 1 else str(D.local_device(config["device"]))
     predictor = Predictor(cfg, device_type=device, max_batch_size=batch_size, output_dir=output_path,
                           exclude_vars=exclude_vars, precision=config.get("precision", "fp32"),
                           return_predictions=False,       # the files are the product; the list is unused here
                           pipeline=config.get("pipeline", True), device_contours=config.get("device_contours", False),
-                          sharded_epilogue=config.get("sharded_epilogue", "auto"))     # rank0 below 4 ranks, local from 4 (prediction.py)
+                          sharded_epilogue=epilogue)
     try:
-        images_directory = Path(config["image_directory"])
-        images_paths = sorted(str(f) for f in images_directory.glob("*.tif"))
-        merged_directory = Path(f"{images_directory}/{config['merged_path']}")
-        images_paths.extend(sorted(str(f) for f in merged_directory.glob("*.tif")))
-        if not images_paths:
-            logger.warning("No TIF files found for prediction.")
-            return
-        file_list, processed_files = load_prediction_recovery_data(output_path, tiles_path, model_path, logger, exclude_vars)
-        if not file_list:
-            images_paths = [f for f in images_paths if f not in processed_files]
-        if not images_paths:
-            logger.info("All files have already been predicted. Exiting Prediction.")
-            return
-        total = len(images_paths)
-        # Single process: image i+1 is started (read, launched) while image i's last forwards and tile files finish —
-        # Predictor.submit; the per-image outcome (files written, or the error logged and the walk continuing, reference
-        # detection.py:117-120) is the same as calling the predictor image by image. Sharded runs keep the image-by-image walk:
-        # every image is one collective structure all ranks enter together.
-        chain = D.world() == 1
-        pending = None
-
-        def finish(item):
-            path, handle = item
-            try:
-                handle.result()
-            except Exception as e:
-                logger.error(f"Error processing {path}: {e}")
-
-        for i, fp in enumerate(images_paths):
-            cur, prev = int(100 * (i + 1) / total), int(100 * i / total)
-            if logger and ((cur // 5) != (prev // 5) or cur == 100 or i == 0):
-                logger.info(f"Predicting file {i + 1}/{total} ({cur}%)")
-            tile_json = os.path.join(tiles_path, os.path.basename(fp).replace(".tif", ".json"))
-            handle = None
-            try:
-                if chain:
-                    handle = predictor.submit(fp, tile_json)
-                else:
-                    predictor(fp, tile_json)
-            except Exception as e:
-                logger.error(f"Error processing {fp}: {e}")
-            if pending is not None:
-                finish(pending)
-            pending = (fp, handle) if handle is not None else None
-        if pending is not None:
-            finish(pending)
-        logger.info(f"Completed prediction for {len(images_paths)} images.")
-        if D.rank() == 0:
+        shard_by = resolve_shard_by(config, W, predictor.sharded_epilogue, len(images_paths))
+        if shard_by != "image":
+            owner = None
+        mine = [i for i in range(len(images_paths)) if owner is None or owner[i] == me]
+        if logger and W > 1:
+            logger.info(f"rank {me}/{W}: sharding by {shard_by}; {len(mine)} of {len(images_paths)} images to walk")
+        # who stitches an image as soon as its tile files are complete: the rank that owns it (image-level sharding, single
+        # process), else rank 0 (tile-level sharding: every image's files are complete when its collective call returns)
+        stitch_here = stitch_to if (config.get("eager_stitch", True) and (shard_by in ("single", "image") or me == 0)) else None
+        report = walk_images(config, predictor, [images_paths[i] for i in mine], tiles_path, output_path,
+                             chain=shard_by in ("single", "image"), stitch_to=stitch_here)
+        # the ONLY collectives of the walk under image-level sharding: one manifest gather, one all-reduce
+        reports = D.gather_objects(report) if (W > 1 and shard_by == "image") else [report]
+        ok = True
+        if me == 0:
+            all_done = [p for r in reports for p in r["done"]]
+            all_failed = [p for r in reports for p in r["failed"]]
+            all_stitched = [p for r in reports for p in r["stitched"]]
+            if shard_by == "image":
+                seen = sorted(all_done + all_failed)
+                ok = seen == sorted(images_paths)
+                if not ok:
+                    logger.error(f"image-level sharding: {len(images_paths)} images assigned, {len(seen)} reported "
+                                 f"({len(set(images_paths) - set(seen))} missing, {len(seen) - len(set(seen))} twice)")
+            logger.info(f"Completed prediction for {len(images_paths)} images.")
             save_prediction_recovery_data(output_path, tiles_path, model_path, processed_files, images_paths)
+            if stitch_to is not None and all_stitched:
+                from .recoveries import load_stitching_recovery, save_stitching_recovery
+                save_stitching_recovery(stitch_to, sorted(load_stitching_recovery(stitch_to, None)) + all_stitched, logger)
+        if W > 1 and shard_by == "image" and not D.all_ok(ok):
+            raise RuntimeError("image-level sharding: the ranks' manifests do not cover the image list exactly once")
     finally:
         predictor.close()
-        D.barrier()      # rank 0 has written every Prediction_*.json and the resume file before anyone moves on
+        D.barrier()      # every Prediction_*.json, every eagerly stitched layer and the resume files are written before anyone moves on
 
 
 def _stitch(config, pred_dir, out_dir):
@@ -122,10 +236,10 @@ def predict_tiles(config):
         logger.info("Urban, forrest models and forrest outline are available. Starting prediction...")
         t0 = time.time()
         predict_on_model(config, config["urban_model"], config["tiles_path"], os.path.join(out, "urban_predictions"),
-                         batch_size=config["batch_size"], exclude_vars=["only_forest"])
+                         batch_size=config["batch_size"], exclude_vars=["only_forest"], stitch_to=os.path.join(out, "urban_geojson"))
         t1 = time.time()
         predict_on_model(config, config["forrest_model"], config["tiles_path"], os.path.join(out, "forrest_predictions"),
-                         batch_size=config["batch_size"], exclude_vars=["only_urban"])
+                         batch_size=config["batch_size"], exclude_vars=["only_urban"], stitch_to=os.path.join(out, "forrest_geojson"))
         t2 = time.time()
         _stitch(config, os.path.join(out, "urban_predictions"), os.path.join(out, "urban_geojson"))
         _stitch(config, os.path.join(out, "forrest_predictions"), os.path.join(out, "forrest_geojson"))
@@ -142,7 +256,7 @@ def predict_tiles(config):
         logger.info("Only Combined Model is given. Starting prediction...")
         t0 = time.time()
         predict_on_model(config, config["combined_model"], config["tiles_path"], os.path.join(out, "predictions"),
-                         batch_size=config["batch_size"])
+                         batch_size=config["batch_size"], stitch_to=os.path.join(out, "geojson_predictions"))
         t1 = time.time()
         _stitch(config, os.path.join(out, "predictions"), os.path.join(out, "geojson_predictions"))
         logger.debug(f"Prediction took {t1 - t0} seconds")

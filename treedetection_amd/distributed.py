@@ -60,30 +60,40 @@ def local_world() -> int:
 
 
 def output_is_shared(folder: str) -> bool:
-    """Proof that rank 0 can read what any rank writes into ``folder``: rank 0 drops a token file, broadcasts its name,
-    every rank looks for it (collective: all ranks call it). True only if ALL ranks see the token."""
+    """Proof that rank 0 — which alone stitches after a "local" run — can read what EVERY other rank writes into ``folder``:
+    each rank drops its own token file ``<nonce>.<rank>`` (the nonce comes from rank 0), all meet, rank 0 looks for every
+    token and broadcasts the verdict. Collective: all ranks call it, each on its own GPU under nccl (the caller binds the
+    device first: :func:`bind_device`). The decision is only as good as this probe — a folder that is shared but slow to
+    publish new entries (some NFS settings) reads as "not shared" and the run falls back to the "rank0" epilogue."""
     import os
     import uuid
     if world() == 1:
         return True
-    name = None
-    if rank() == 0:
-        name = f".td_shared_{uuid.uuid4().hex}"
+    me = rank()
+    nonce = broadcast_object(f".td_shared_{uuid.uuid4().hex}" if me == 0 else None, 0)
+    wrote = True
+    try:
+        os.makedirs(folder, exist_ok=True)
+        with open(os.path.join(folder, f"{nonce}.{me}"), "w") as f:
+            f.write("x")
+            f.flush()
+            os.fsync(f.fileno())
+    except OSError:
+        wrote = False
+    wrote = all_ok(wrote)          # an all-reduce: returns only after EVERY rank has written (or failed to)
+    seen = False
+    if me == 0 and wrote:
         try:
-            os.makedirs(folder, exist_ok=True)
-            with open(os.path.join(folder, name), "w") as f:
-                f.write("x")
+            names = set(os.listdir(folder))
         except OSError:
-            name = ""
-    name = broadcast_object(name, 0)
-    seen = bool(name) and os.path.exists(os.path.join(folder, name))
-    ok = all_ok(seen)              # an all-reduce: returns only after EVERY rank has looked
-    if rank() == 0 and name:
-        try:
-            os.remove(os.path.join(folder, name))
-        except OSError:
-            pass
-    barrier()                      # nobody goes on to list the folder before the token is gone
+            names = set()
+        seen = all(f"{nonce}.{r}" in names for r in range(world()))
+    ok = bool(broadcast_object(seen if me == 0 else None, 0))
+    try:
+        os.remove(os.path.join(folder, f"{nonce}.{me}"))
+    except OSError:
+        pass
+    barrier()                      # nobody goes on to list the folder before the tokens are gone
     return ok
 
 

@@ -27,7 +27,8 @@ from .geotiff import GeoTiff
 from .weights import load_checkpoint
 
 
-TILE_TABLE_VERSION = 11      # bump when the tile ids of csrc/conv_igemm.hip:dispatch() change meaning
+TILE_TABLE_VERSION = 12      # bump when the tile ids of csrc/conv_igemm.hip:dispatch() change meaning, the candidate set grows or the
+                             # tuner's timing method changes (12: ids 29-33, id 28 retired, cold-L2 timing + hysteresis)
 
 
 def _tune_cache_path(device_index: int) -> str:
@@ -123,7 +124,7 @@ class _Slot:
             p["scores"] = torch.empty((B, Dn), dtype=torch.float32, pin_memory=True)
             cur = sets[src] = {"key": key, "dev": d, "pin": p, "np": {k: v.numpy() for k, v in p.items()}}
         n = len(hw)
-        engine.paste_masks_batch(g["mask_probs"], g["boxes"], g["count"], hw, cur["dev"])
+        engine.paste_masks_batch(g["mask_probs"], g["boxes"], g["count"].clamp(min=0), hw, cur["dev"])     # (-1 = dropped tile)
         for k in ("mask_region", "mask_offset"):       # the bit rows: fetched per tile by the epilogue worker (used words only)
             cur["pin"][k][:n].copy_(cur["dev"][k][:n], non_blocking=True)
         cur["pin"]["count"][:n].copy_(g["count"][:n], non_blocking=True)
@@ -204,6 +205,10 @@ class Predictor:
         os.makedirs(self.output_dir, exist_ok=True)
         if sharded_epilogue not in ("rank0", "local", "auto"):
             raise ValueError(f"sharded_epilogue must be 'rank0', 'local' or 'auto', got {sharded_epilogue!r}")
+        if D.world() > 1:
+            # the collectives below (and every later one of this rank) run on torch.cuda.current_device() under nccl: a
+            # Predictor built without a prior distributed.bind_device must not leave every rank on cuda:0
+            torch.cuda.set_device(self.device_index)
         if sharded_epilogue == "auto":
             # (collective when world >= 4 and the launcher did not say that all ranks share a node: every rank builds its
             # Predictor with the same arguments, predict_on_model does)
@@ -344,10 +349,12 @@ class Predictor:
         return x, INPUT_F32_CHW, shapes, [(b["orig_height"], b["orig_width"]) for b in batch]
 
     # -- single process: reader thread → launcher (this thread) → epilogue workers --------------------------------
-    def _read_batch(self, tiles, indices, img: GeoTiff, slot: _Slot, keep_failed: bool = False):
-        """Crops the tiles of one batch into the slot's pinned staging buffer (uint8 rasters) — reader thread.
-        ``keep_failed`` (sharded runs, where every rank must see the same batch structure): a tile whose read fails
-        unexpectedly stays in the batch as a black tile instead of being dropped."""
+    def _read_batch(self, tiles, indices, img: GeoTiff, slot: _Slot, keep_failed: bool = False, dropped: Optional[list] = None):
+        """Crops the tiles of one batch into the slot's pinned staging buffer (uint8 rasters) — reader thread. A tile whose
+        crop fails is dropped (reference prediction.py:174-176; its index is appended to ``dropped``). ``keep_failed``
+        (tile-sharded "rank0" runs, where rank 0 derives every rank's batch structure from the raster's geometry alone): the
+        tile stays in the batch as a black stand-in marked ``failed`` — the gather then carries count = -1 for it and rank 0
+        writes no file, so the outcome is the reference's there too."""
         staging = None
         if img.dtype == np.uint8:
             need = 0
@@ -387,8 +394,10 @@ class Predictor:
                     staging[off:off + black.size] = 0
                     data = {"staged": (off, black.shape)}
                 info = {"orig_height": h, "orig_width": w, "height": h, "width": w, "json_name": tiles[idx]["json_name"],
-                        "tile_id": tiles[idx]["tile_id"], "meta": tiles[idx]["meta"]}
+                        "tile_id": tiles[idx]["tile_id"], "meta": tiles[idx]["meta"], "failed": True}
             if data is None:
+                if dropped is not None:
+                    dropped.append(idx)
                 continue
             batch.append({"data": data, **info})
         return batch
@@ -543,7 +552,17 @@ class Predictor:
                 item["phase"] = phase + 2
             # batches finish in arrival order (a failed or empty one may be "ready" early: it waits for its elders)
             while window and window[0]["phase"] >= 6:
-                finish(window.pop(0))
+                item = window.pop(0)
+                try:
+                    finish(item)
+                except BaseException:
+                    # finish() hands back its OWN slot when it fails (_finish_local); the batches still in the window hold
+                    # slots no epilogue task will ever return — single process: give them back before the image fails
+                    if total_rounds is None:
+                        for it in window:
+                            self._give_back(it["slot"], self._free)
+                        del window[:]
+                    raise
             self.stats["launch"] += time.perf_counter() - t0
 
     def _launch_streams(self, ready, prepare, finish, total_rounds: Optional[int] = None) -> None:
@@ -654,6 +673,7 @@ class Predictor:
         self.stats = dict.fromkeys(self.stats, 0.0)
         ready: "queue.Queue" = queue.Queue(maxsize=2)
         stop = threading.Event()
+        dropped: List[int] = []
 
         def reader():
             try:
@@ -666,7 +686,7 @@ class Predictor:
                     self._mark("read", k)
                     t0 = time.perf_counter()
                     try:
-                        batch = self._read_batch(tiles, indices, img, slot)
+                        batch = self._read_batch(tiles, indices, img, slot, dropped=dropped)
                     except BaseException:
                         self._give_back(slot, self._free)
                         raise
@@ -703,7 +723,7 @@ class Predictor:
                 self._launch_pipelined(ready, prepare,
                                        lambda item: self._finish_local(item, pred_subdir, tifpath, futures, item["slot"].side))
             t.join()
-            return _PendingImage(self, futures)
+            return _PendingImage(self, futures, dropped)
         except BaseException:
             self._drain(t, ready, futures, stop)
             raise
@@ -790,6 +810,9 @@ class Predictor:
                 send = slot.gather_buffers(B, Dn, dev)
                 if n < B:
                     send["count"][n:].zero_()
+                for j in range(n):
+                    if item["batch"][j].get("failed"):          # a black stand-in for a tile whose crop failed: no file for it
+                        send["count"][j:j + 1].fill_(-1)
                 recv = slot.recv_buffers(W, B, Dn, dev, host_backend) if me == 0 else None
                 for key in D.GATHER_KEYS:
                     t = send[key].cpu() if host_backend else send[key]
@@ -865,9 +888,11 @@ class Predictor:
         one PCIe link moves them)."""
         me, W = D.rank(), D.world()
         mine = D.shard_indices(len(tiles), me, W)
-        err, preds = None, []
+        err, preds, dropped = None, [], []
         try:
-            preds = self._run_single([tiles[i] for i in mine], img, pred_subdir, tifpath)
+            handle = self._start_single([tiles[i] for i in mine], img, pred_subdir, tifpath)
+            dropped = [mine[k] for k in handle.dropped]        # crops that failed: no file, as in the reference (174-176)
+            preds = handle.result()
         except Exception as e:
             err = e
         written = []
@@ -875,10 +900,11 @@ class Predictor:
             fn = os.path.join(pred_subdir, f"Prediction_{os.path.basename(tiles[i]['tile_id'])}.json")
             if os.path.exists(fn):
                 written.append(i)
-        manifests = D.gather_objects(written)
+        manifests = D.gather_objects((written, dropped))
         if me == 0 and err is None:
-            seen = sorted(i for m in manifests for i in m)
-            expect = [i for i in range(len(tiles)) if self._tile_ok(tiles[i], img)]
+            seen = sorted(i for m, _ in manifests for i in m)
+            gone = set(i for _, d in manifests for i in d)
+            expect = [i for i in range(len(tiles)) if self._tile_ok(tiles[i], img) and i not in gone]
             if len(seen) != len(set(seen)) or not set(expect) <= set(seen):
                 err = RuntimeError(f"sharded prediction of {tifpath}: {len(set(expect) - set(seen))} tiles missing, "
                                    f"{len(seen) - len(set(seen))} written twice")
@@ -902,6 +928,8 @@ class Predictor:
         try:
             slot.event.synchronize()
             n = int(pin["count"][j])
+            if n < 0:           # the owning rank could not crop this tile: dropped, as the reference drops it (prediction.py:174-176)
+                return []
             path = os.path.join(pred_subdir, f"Prediction_{os.path.basename(tile['tile_id'])}.json")
             tile_prediction_file(self.device_index, pin["mask_region"][j], pin["mask_offset"][j],
                                  pin["bits_base"] + j * pin["bits_stride"], pin["mask_bits"][j], pin["scores"][j][:n],
@@ -916,13 +944,18 @@ class Predictor:
                 if slot.pending == 0:
                     self._give_back(slot, free)
 
-    def submit(self, tifpath, tilepath) -> "_PendingImage":
-        """Single-process runs: starts an image and returns once its last batch is enqueued; ``.result()`` of the handle waits
-        for its tile files (and returns the predictions list). Between the two the caller may submit the next image, so one
-        image's drain (its last forwards and epilogues, ≈ 20 ms) overlaps the next image's fill — what
-        ``detection.predict_on_model`` does. ``predictor(tif, tiles)`` = ``predictor.submit(tif, tiles).result()``."""
-        if D.world() != 1:
-            raise RuntimeError("Predictor.submit is for single-process runs; sharded runs go image by image (one collective structure per image)")
+    def submit(self, tifpath, tilepath, whole_image: bool = False) -> "_PendingImage":
+        """Starts an image THIS process predicts alone and returns once its last batch is enqueued; ``.result()`` of the handle
+        waits for its tile files (and returns the predictions list). Between the two the caller may submit the next image, so
+        one image's drain (its last forwards and epilogues, ≈ 20 ms) overlaps the next image's fill — what
+        ``detection.predict_on_model`` does. ``predictor(tif, tiles)`` = ``predictor.submit(tif, tiles).result()`` in a single
+        process. Under ``torch.distributed`` an image is by default one collective structure all ranks enter together
+        (``__call__``); ``whole_image=True`` says this rank owns the image whole (image-level sharding, detection.py): no
+        collective is issued, every tile is read, predicted, traced and written here, and a tile whose crop fails is dropped
+        as the reference drops it (prediction.py:174-176)."""
+        if D.world() != 1 and not whole_image:
+            raise RuntimeError("Predictor.submit under torch.distributed needs whole_image=True (this rank owns the image); "
+                               "tile-sharded images go through __call__ (one collective structure per image)")
         pred_subdir = os.path.join(self.output_dir, os.path.basename(tifpath).replace(".tif", "").replace(".json", ""))
         os.makedirs(pred_subdir, exist_ok=True)
         if self._trace is not None:
@@ -970,8 +1003,9 @@ class _PendingImage:
     ``return_predictions=False``). The first failed tile task is re-raised after ALL tasks have finished, so no worker of this
     image is still reading its slot when the caller moves on."""
 
-    def __init__(self, predictor: "Predictor", futures):
+    def __init__(self, predictor: "Predictor", futures, dropped=None):
         self._predictor, self._futures, self._done = predictor, futures, None
+        self.dropped = dropped if dropped is not None else []      # indices (into the image's tile list) whose crop failed
 
     def result(self):
         if self._done is None:

@@ -133,8 +133,10 @@ def process_prediction_file_sync(file, tiles_path, tif_lookup, shift, simplify_t
         return None
 
 
-def process_folder_sync(folder, tiles_path, pred_fold, output_path, shift, simplify_tolerance, logger=None):
-    """All tile files of one image → ``<output_path>/<image>.gpkg`` (empty layer, EPSG:4326, when nothing survives)."""
+def process_folder_sync(folder, tiles_path, pred_fold, output_path, shift, simplify_tolerance, logger=None, file_pool=None):
+    """All tile files of one image → ``<output_path>/<image>.gpkg`` (empty layer, EPSG:4326, when nothing survives).
+    ``file_pool``: an executor the tile files are spread over (td_stitch_tile_json releases the GIL); the layer keeps the
+    sorted-file order either way, so the bytes written do not depend on it."""
     try:
         image_meta_path = os.path.join(tiles_path, f"{folder}")
         folder = folder.replace(".json", "")
@@ -142,8 +144,9 @@ def process_folder_sync(folder, tiles_path, pred_fold, output_path, shift, simpl
             metadata = json.load(f)
         tif_lookup = {Path(t).stem: Path(t) for t in metadata}
         pred_files = sorted(Path(os.path.join(pred_fold, folder)).rglob("*.json"))
-        parts = [r for r in (process_prediction_file_sync(file, tiles_path, tif_lookup, shift, simplify_tolerance, logger, metadata)
-                             for file in pred_files) if r is not None and len(r)]
+        one = lambda file: process_prediction_file_sync(file, tiles_path, tif_lookup, shift, simplify_tolerance, logger, metadata)  # noqa: E731
+        results = list(file_pool.map(one, pred_files)) if file_pool is not None and len(pred_files) > 1 else [one(f) for f in pred_files]
+        parts = [r for r in results if r is not None and len(r)]
         output_file = os.path.join(output_path, f"{folder}.gpkg")
         if not parts:
             if logger:
@@ -194,3 +197,52 @@ def process_and_stitch_predictions(tiles_path, pred_fold, output_path, max_worke
                 logger.info(f"Stitching file {i + 1}/{total} ({cur}%)")
     save_stitching_recovery(output_path, list(completed) + results, logger)
     return output_path
+
+
+class EagerStitcher:
+    """Stitches images as their prediction files become complete, while the predictor goes on with the next image
+    (detection.predict_on_model): ``submit("<image>.json")`` queues ``process_folder_sync`` for one image, ``close()``
+    waits and returns the folders whose layer was written. The reference stitches after ALL images are predicted
+    (detection.py:170-195, 235-243) and on one process; the layers are the same files — ``process_and_stitch_predictions``
+    afterwards finds them in the resume file and only handles what is left (images whose prediction failed). Folders the
+    resume file already lists are skipped here as the reference would skip them."""
+
+    def __init__(self, tiles_path, pred_fold, output_path, shift=1, simplify_tolerance=0.2, logger=None, workers=2):
+        os.makedirs(output_path, exist_ok=True)
+        self.args = (tiles_path, pred_fold, output_path, shift, simplify_tolerance, logger)
+        self.completed_before = set(load_stitching_recovery(output_path, None))
+        # two images may be stitched side by side (one finishing its GeoPackage while the next one parses tile files);
+        # the tile files of an image are spread over ``workers`` threads
+        self._images = ThreadPoolExecutor(max_workers=2, thread_name_prefix="td-stitch")
+        self._files = ThreadPoolExecutor(max_workers=max(1, int(workers)), thread_name_prefix="td-stitch-file")
+        self._futures = {}
+        self.seconds = 0.0
+
+    def submit(self, folder_json: str) -> None:
+        name = os.path.splitext(folder_json)[0]
+        if name in self.completed_before or folder_json in self._futures:
+            return
+        if not os.path.isfile(os.path.join(self.args[0], folder_json)):
+            return
+        self._futures[folder_json] = self._images.submit(self._one, folder_json)
+
+    def _one(self, folder_json):
+        import time
+        t0 = time.perf_counter()
+        tiles_path, pred_fold, output_path, shift, tol, logger = self.args
+        out = process_folder_sync(folder_json, tiles_path, pred_fold, output_path, shift, tol, logger, file_pool=self._files)
+        self.seconds += time.perf_counter() - t0
+        return out
+
+    def close(self) -> List[str]:
+        """→ folder names ("<image>.json", the resume file's spelling) whose layer exists now."""
+        done = []
+        for folder_json, fut in self._futures.items():
+            try:
+                if fut.result() is not None:
+                    done.append(folder_json)
+            except Exception:
+                pass
+        self._images.shutdown(wait=True)
+        self._files.shutdown(wait=True)
+        return done
