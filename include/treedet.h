@@ -326,6 +326,17 @@ int td_stitch_tile_json(const char* json, int64_t len, const double* box, double
                         uint8_t* blobs, int64_t blob_cap, int64_t* blob_offsets, double* scores, int max_features,
                         int64_t* needed_bytes, int* needed_features);
 
+/* The same for a whole image in ONE call (reference helpers.py:524-554 process_folder_sync: every tile file of the image's
+ * prediction folder): file i = the NUL-terminated path at paths + path_offsets[i] with its own box (boxes[4 i ..]) and
+ * srs_ids[i]; the files are read, parsed, simplified, filtered and encoded on `threads` host threads and the features come
+ * back concatenated in FILE order (feature numbering as in td_stitch_tile_json, blob_offsets has total + 1 entries).
+ * file_status[i] = features of file i, or the negative status that file failed with — such a file is left out, as the
+ * reference's per-file try / except leaves it out (helpers.py:419-476). Returns the total feature count; TD_ERR_CAPACITY
+ * (needed_bytes / needed_features) when a buffer is too small. Host code only. */
+int td_stitch_tile_files(const char* paths, const int64_t* path_offsets, int n_files, const double* boxes, double tolerance,
+                         const int32_t* srs_ids, int threads, uint8_t* blobs, int64_t blob_cap, int64_t* blob_offsets,
+                         double* scores, int max_features, int32_t* file_status, int64_t* needed_bytes, int* needed_features);
+
 /* ---- outline predicates (reference helpers.py:703-834 fuse_predictions; preprocessing.py:70-95 tile flags) ---- */
 /* Relates query rings to a region given as polygons with holes (the outline file's geometries, NOT unioned):
  * ring r = ring_xy[ring_start[r] .. ring_start[r+1]) (x,y pairs, closed), ring_poly[r] = polygon it belongs to,

@@ -26,6 +26,11 @@ def _launch(nproc, env_extra, port, detail=None):
     if detail:
         cmd += ["--detail", detail]
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    if r.returncode != 0:       # the launcher's summary names only the first rank that died: keep every rank's stderr where a reader finds it
+        log_dir = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(log_dir):
+            with open(os.path.join(log_dir, f"bench_launch_{nproc}ranks_{port}.stderr"), "w") as f:
+                f.write(r.stderr)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]

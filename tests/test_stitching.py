@@ -241,3 +241,59 @@ def test_stitch_tile_json_equals_per_polygon_path(tmp_path):
     assert len(Log.msgs) == 6 and "polygon_coords" in Log.msgs[0] and "at least 4" in Log.msgs[1]
     f.write_text("[]")
     assert len(process_prediction_file_sync(f, str(tmp_path), {tid: Path(tid)}, 1, 0.2, None, meta)) == 0
+
+
+def test_stitch_tile_files_equals_the_per_file_calls(tmp_path):
+    """td_stitch_tile_files (a whole image in one library call, tile files spread over host threads) = the per-file
+    td_stitch_tile_json results concatenated in file order, whatever the thread count; a malformed, an unknown and an
+    unreadable file are left out with a warning each."""
+    from pathlib import Path
+    from treedetection_amd.stitching import process_prediction_file_sync, stitch_tile_files
+    rng = np.random.default_rng(9)
+    os.makedirs(tmp_path / "img")
+    tids, meta, files = [], {}, []
+    for k in range(24):
+        tid = f"img_{412000 + 10 * (k % 6)}_{5319000 + 10 * (k // 6)}_10_2_25832"
+        tids.append(tid)
+        meta[tid] = {"crs": "EPSG:25832"}
+        entries = []
+        for _ in range(int(rng.integers(0, 9))):
+            ring = _blob_ring(rng, size=40, gsd=0.2, x0=411996.0 + 10 * (k % 6) + rng.uniform(0, 6), y0=5319013.0 + 10 * (k // 6) - rng.uniform(0, 5))
+            entries.append({"image_id": "a.tif", "category_id": 0, "score": float(rng.random()), "polygon_coords": [ring.tolist()]})
+        f = tmp_path / "img" / f"Prediction_{tid}.json"
+        f.write_text(json.dumps(entries))
+        files.append(f)
+    lookup = {t: Path(t) for t in tids}
+    want = [process_prediction_file_sync(f, str(tmp_path), lookup, 1, 0.2, None, meta) for f in files]
+    want_blobs = [bytes(w.blobs[w.offsets[i]:w.offsets[i + 1]]) for w in want for i in range(len(w))]
+    want_scores = [s for w in want for s in w.scores.tolist()]
+    assert len(want_blobs) > 20
+    # three files that must be left out
+    bad = tmp_path / "img" / f"Prediction_{tids[3]}.json"
+    kept = [f for f in files if f != bad]
+    want_kept = [process_prediction_file_sync(f, str(tmp_path), lookup, 1, 0.2, None, meta) for f in kept]
+    kept_blobs = [bytes(w.blobs[w.offsets[i]:w.offsets[i + 1]]) for w in want_kept for i in range(len(w))]
+
+    class Log:
+        def __init__(self):
+            self.msgs = []
+
+        def warning(self, m):
+            self.msgs.append(m)
+
+    for threads in (1, 3, 16):
+        got = stitch_tile_files(files, lookup, meta, 1, 0.2, threads)
+        assert len(got) == len(want_blobs) and got.scores.tolist() == want_scores and got.epsg == "EPSG:25832"
+        assert [bytes(got.blobs[got.offsets[i]:got.offsets[i + 1]]) for i in range(len(got))] == want_blobs
+    bad.write_text('[{"score": 0.5, "polygon_coords": [[[0,0],[1,0],[1,1]]]}]')
+    extra = [tmp_path / "img" / "Prediction_img_1_1_10_2_25832.json", tmp_path / "img" / "Prediction_gone.json"]
+    extra[0].write_text("[]")
+    lookup["gone"] = Path(tids[0])                         # known tile, file does not exist
+    log = Log()
+    got = stitch_tile_files(files + extra, lookup, meta, 1, 0.2, 4, log)
+    assert [bytes(got.blobs[got.offsets[i]:got.offsets[i + 1]]) for i in range(len(got))] == kept_blobs
+    assert len(log.msgs) == 3 and all("Error processing file" in m for m in log.msgs)
+    assert stitch_tile_files([], lookup, meta, 1, 0.2, 4) is None
+    empty = tmp_path / "img" / f"Prediction_{tids[5]}.json"
+    empty.write_text("[]")
+    assert stitch_tile_files([empty], lookup, meta, 1, 0.2, 2) is None

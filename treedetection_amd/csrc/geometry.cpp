@@ -16,7 +16,11 @@
 #include "common.h"
 #include "geom_predicates.h"
 
+#include <algorithm>
+#include <atomic>
 #include <charconv>
+#include <cstdio>
+#include <thread>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -307,19 +311,17 @@ inline void put(std::vector<uint8_t>& b, const void* src, size_t n) {
 
 extern "C" int td_simplify_ring(const double* xy, int n, double tolerance, double* out_xy, int out_cap);
 
-extern "C" int td_stitch_tile_json(const char* json, int64_t len, const double* box, double tolerance, int32_t srs_id,
-                                   uint8_t* blobs, int64_t blob_cap, int64_t* blob_offsets, double* scores, int max_features,
-                                   int64_t* needed_bytes, int* needed_features) {
-    if (!json || len < 0 || !box || !needed_bytes || !needed_features || std::isnan(tolerance)) {
-        td_set_error("td_stitch_tile_json: bad argument");
-        return TD_ERR_INVALID;
-    }
+namespace {
+
+// One prediction file's text → geometry blobs / offsets / scores appended to the vectors (the body of td_stitch_tile_json).
+// `what` names the entry point in error messages.
+int stitch_text(const char* what_fn, const char* json, int64_t len, const double* box, double tolerance, int32_t srs_id,
+                std::vector<uint8_t>& out, std::vector<int64_t>& offs, std::vector<double>& sc) {
     JsonCursor c{json, json + len};
-    std::vector<uint8_t> out;
-    std::vector<int64_t> offs{0};
-    std::vector<double> sc, coords, simp;
+    std::vector<double> coords, simp;
+    if (offs.empty()) offs.push_back(0);
     auto bad = [&](const char* what) {
-        td_set_error("td_stitch_tile_json: %s at byte %lld", what, (long long)(c.p - json));
+        td_set_error("%s: %s at byte %lld", what_fn, what, (long long)(c.p - json));
         return TD_ERR_INVALID;
     };
     c.ws();
@@ -412,6 +414,23 @@ extern "C" int td_stitch_tile_json(const char* json, int64_t len, const double* 
     ++c.p;
     c.ws();
     if (c.p != c.end) return bad("trailing data");
+    return TD_OK;
+}
+
+}  // namespace
+
+extern "C" int td_stitch_tile_json(const char* json, int64_t len, const double* box, double tolerance, int32_t srs_id,
+                                   uint8_t* blobs, int64_t blob_cap, int64_t* blob_offsets, double* scores, int max_features,
+                                   int64_t* needed_bytes, int* needed_features) {
+    if (!json || len < 0 || !box || !needed_bytes || !needed_features || std::isnan(tolerance)) {
+        td_set_error("td_stitch_tile_json: bad argument");
+        return TD_ERR_INVALID;
+    }
+    std::vector<uint8_t> out;
+    std::vector<int64_t> offs{0};
+    std::vector<double> sc;
+    const int st = stitch_text("td_stitch_tile_json", json, len, box, tolerance, srs_id, out, offs, sc);
+    if (st < 0) return st;
     *needed_bytes = (int64_t)out.size();
     *needed_features = (int)sc.size();
     if ((int64_t)out.size() > blob_cap || (int)sc.size() > max_features) {
@@ -423,4 +442,85 @@ extern "C" int td_stitch_tile_json(const char* json, int64_t len, const double* 
     std::memcpy(blob_offsets, offs.data(), offs.size() * sizeof(int64_t));
     if (!sc.empty()) std::memcpy(scores, sc.data(), sc.size() * sizeof(double));
     return (int)sc.size();
+}
+
+
+// Whole image in one call: every tile file read, parsed, simplified, edge-filtered and encoded on `threads` host threads;
+// the features come back concatenated in FILE order (the order process_folder_sync gives the layer).
+extern "C" int td_stitch_tile_files(const char* paths, const int64_t* path_offsets, int n_files, const double* boxes, double tolerance,
+                                    const int32_t* srs_ids, int threads, uint8_t* blobs, int64_t blob_cap, int64_t* blob_offsets,
+                                    double* scores, int max_features, int32_t* file_status, int64_t* needed_bytes, int* needed_features) {
+    if (!paths || !path_offsets || n_files < 0 || !boxes || !srs_ids || !file_status || !needed_bytes || !needed_features || std::isnan(tolerance) ||
+        (n_files > 0 && (!blob_offsets || blob_cap < 0 || max_features < 0))) {
+        td_set_error("td_stitch_tile_files: bad argument");
+        return TD_ERR_INVALID;
+    }
+    struct Part {
+        std::vector<uint8_t> out;
+        std::vector<int64_t> offs;
+        std::vector<double> sc;
+    };
+    std::vector<Part> parts((size_t)n_files);
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        std::vector<char> text;
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n_files) return;
+            Part& pt = parts[(size_t)i];
+            pt.offs.assign(1, 0);
+            const char* path = paths + path_offsets[i];
+            FILE* f = std::fopen(path, "rb");
+            if (!f) { file_status[i] = TD_ERR_INVALID; continue; }
+            text.clear();
+            char buf[1 << 16];
+            size_t got;
+            while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) text.insert(text.end(), buf, buf + got);
+            const bool rerr = std::ferror(f) != 0;
+            std::fclose(f);
+            if (rerr) { file_status[i] = TD_ERR_INVALID; continue; }
+            const int st = stitch_text("td_stitch_tile_files", text.data(), (int64_t)text.size(), boxes + 4 * (size_t)i, tolerance, srs_ids[i],
+                                       pt.out, pt.offs, pt.sc);
+            if (st < 0) {           // the file is left out (the reference's try / except around each tile file, helpers.py:419-476)
+                pt.out.clear();
+                pt.offs.assign(1, 0);
+                pt.sc.clear();
+                file_status[i] = st;
+            } else {
+                file_status[i] = (int32_t)pt.sc.size();
+            }
+        }
+    };
+    const int nt = std::max(1, std::min(threads, std::max(n_files, 1)));
+    if (nt == 1) {
+        work();
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; ++t) pool.emplace_back(work);
+        for (auto& t : pool) t.join();
+    }
+    int64_t bytes = 0, feats = 0;
+    for (const Part& pt : parts) {
+        bytes += (int64_t)pt.out.size();
+        feats += (int64_t)pt.sc.size();
+    }
+    *needed_bytes = bytes;
+    *needed_features = (int)feats;
+    if (bytes > blob_cap || feats > max_features) {
+        td_set_error("td_stitch_tile_files: %lld bytes / %lld features needed, capacity %lld / %d", (long long)bytes, (long long)feats,
+                     (long long)blob_cap, max_features);
+        return TD_ERR_CAPACITY;
+    }
+    int64_t bo = 0, fo = 0;
+    if (n_files > 0 || blob_offsets) blob_offsets[0] = 0;
+    for (const Part& pt : parts) {
+        if (!pt.out.empty()) std::memcpy(blobs + bo, pt.out.data(), pt.out.size());
+        for (size_t k = 0; k < pt.sc.size(); ++k) {
+            blob_offsets[fo + (int64_t)k + 1] = bo + pt.offs[k + 1];
+            scores[fo + (int64_t)k] = pt.sc[k];
+        }
+        bo += (int64_t)pt.out.size();
+        fo += (int64_t)pt.sc.size();
+    }
+    return (int)feats;
 }

@@ -133,10 +133,72 @@ def process_prediction_file_sync(file, tiles_path, tif_lookup, shift, simplify_t
         return None
 
 
-def process_folder_sync(folder, tiles_path, pred_fold, output_path, shift, simplify_tolerance, logger=None, file_pool=None):
+def stitch_tile_files(files, tif_lookup, metadata, shift, simplify_tolerance, threads=1, logger=None):
+    """All tile files of one image through ONE library call (td_stitch_tile_files: read, parse, simplify, edge filter and
+    encode on ``threads`` host threads, no Python per file) → :class:`TileFeatures` of the whole image in file order, or None
+    when nothing survives. A file that cannot be matched to a tile, read or parsed is left out with a warning — what the
+    reference's try / except around each file does (helpers.py:419-476)."""
+    paths, boxes, srs, epsg_first = [], [], [], None
+    for file in files:
+        try:
+            tifpath = tif_lookup.get(Path(file).stem.replace("Prediction_", ""))
+            if not tifpath:
+                raise FileNotFoundError(f"No matching TIFF file for {file}")
+            if str(tifpath) not in metadata:
+                raise FileNotFoundError(f"No matching metadata for {tifpath}")
+            epsg = metadata[str(tifpath)]["crs"]
+            box = box_filter(str(tifpath), shift)
+            code = _epsg_code(epsg)
+        except Exception as e:
+            if logger:
+                logger.warning(f"Error processing file {file}: {e}")
+            continue
+        paths.append(os.fsencode(str(file)))
+        boxes.append(box)
+        srs.append(code)
+        epsg_first = epsg if epsg_first is None else epsg_first
+    if not paths:
+        return None
+    n = len(paths)
+    offs = np.zeros(n + 1, np.int64)
+    np.cumsum([len(p) + 1 for p in paths], out=offs[1:])
+    blob_paths = b"\0".join(paths) + b"\0"
+    boxes_a = np.ascontiguousarray(boxes, dtype=np.float64)
+    srs_a = np.ascontiguousarray(srs, dtype=np.int32)
+    status = np.zeros(n, np.int32)
+    total = 0
+    for p in paths:
+        try:
+            total += os.path.getsize(p)
+        except OSError:         # reported per file by the library call (status < 0)
+            pass
+    cap_b, cap_f = max(total, 1024), max(total // 64, 16)          # a blob is smaller than its JSON text
+    lib = _lib.load()
+    need_b, need_f = C.c_int64(0), C.c_int(0)
+    while True:
+        blobs = np.empty(cap_b, dtype=np.uint8)
+        offsets = np.empty(cap_f + 1, dtype=np.int64)
+        scores = np.empty(cap_f, dtype=np.float64)
+        m = lib.td_stitch_tile_files(blob_paths, offs.ctypes.data, n, boxes_a.ctypes.data, float(simplify_tolerance), srs_a.ctypes.data,
+                                     int(max(1, threads)), blobs.ctypes.data, cap_b, offsets.ctypes.data, scores.ctypes.data, cap_f,
+                                     status.ctypes.data, C.byref(need_b), C.byref(need_f))
+        if m == _lib.ERR_CAPACITY:
+            cap_b, cap_f = max(cap_b, int(need_b.value)), max(cap_f, int(need_f.value))
+            continue
+        _lib.check(m, "td_stitch_tile_files")
+        break
+    if logger:
+        for i in np.nonzero(status < 0)[0]:
+            logger.warning(f"Error processing file {os.fsdecode(paths[i])}: status {int(status[i])} (unreadable or malformed prediction file)")
+    if m == 0:
+        return None
+    return TileFeatures(blobs[: int(need_b.value)].tobytes(), offsets[: m + 1].copy(), scores[:m].copy(), epsg_first)
+
+
+def process_folder_sync(folder, tiles_path, pred_fold, output_path, shift, simplify_tolerance, logger=None, threads=1):
     """All tile files of one image → ``<output_path>/<image>.gpkg`` (empty layer, EPSG:4326, when nothing survives).
-    ``file_pool``: an executor the tile files are spread over (td_stitch_tile_json releases the GIL); the layer keeps the
-    sorted-file order either way, so the bytes written do not depend on it."""
+    ``threads``: host threads the tile files are spread over inside the library call; the layer keeps the sorted-file order
+    either way, so the bytes written do not depend on it."""
     try:
         image_meta_path = os.path.join(tiles_path, f"{folder}")
         folder = folder.replace(".json", "")
@@ -144,21 +206,21 @@ def process_folder_sync(folder, tiles_path, pred_fold, output_path, shift, simpl
             metadata = json.load(f)
         tif_lookup = {Path(t).stem: Path(t) for t in metadata}
         pred_files = sorted(Path(os.path.join(pred_fold, folder)).rglob("*.json"))
-        one = lambda file: process_prediction_file_sync(file, tiles_path, tif_lookup, shift, simplify_tolerance, logger, metadata)  # noqa: E731
-        results = list(file_pool.map(one, pred_files)) if file_pool is not None and len(pred_files) > 1 else [one(f) for f in pred_files]
-        parts = [r for r in results if r is not None and len(r)]
+        feats = stitch_tile_files(pred_files, tif_lookup, metadata, shift, simplify_tolerance, threads, logger)
         output_file = os.path.join(output_path, f"{folder}.gpkg")
-        if not parts:
+        if feats is None:
             if logger:
                 logger.debug(f"No valid results for folder {folder}. Creating empty output.")
             write_blobs(output_file, [], {}, None, None)
         else:
-            env = np.concatenate([t.envelopes() for t in parts])
+            env = feats.envelopes()
             extent = (float(env[:, 0].min()), float(env[:, 2].min()), float(env[:, 1].max()), float(env[:, 3].max()))
-            blobs = (memoryview(t.blobs)[t.offsets[i]:t.offsets[i + 1]] for t in parts for i in range(len(t)))
-            scores = np.concatenate([t.scores for t in parts]).tolist()
+            view = memoryview(feats.blobs)
+            o = feats.offsets.tolist()
+            blobs = (view[o[i]:o[i + 1]] for i in range(len(feats)))
+            scores = feats.scores.tolist()
             write_blobs(output_file, blobs, {"Confidence_score": scores, "filter_index_right": [0] * len(scores)},
-                        _epsg_code(parts[0].epsg), extent)
+                        _epsg_code(feats.epsg), extent)
         return output_file
     except Exception as e:
         if logger:
@@ -185,9 +247,11 @@ def process_and_stitch_predictions(tiles_path, pred_fold, output_path, max_worke
     if logger and len(folders) - len(todo) > 0:
         logger.info(f"Skipping stiching {len(folders) - len(todo)} of {len(folders)} folders that have already been processed.")
     results = []
-    workers = max(1, min(int(max_workers or 1), len(todo) or 1, len(os.sched_getaffinity(0))))
+    cores = len(os.sched_getaffinity(0))
+    workers = max(1, min(int(max_workers or 1), len(todo) or 1, cores))
+    per_folder = max(1, min(8, cores // workers))       # few folders: the tile files of each are spread over the idle cores
     with ThreadPoolExecutor(max_workers=workers) as ex:
-        futures = {ex.submit(process_folder_sync, f, tiles_path, pred_fold, output_path, shift, simplify_tolerance, logger): f
+        futures = {ex.submit(process_folder_sync, f, tiles_path, pred_fold, output_path, shift, simplify_tolerance, logger, per_folder): f
                    for f in todo}
         total = len(todo)
         for i, fut in enumerate(as_completed(futures)):
@@ -212,9 +276,10 @@ class EagerStitcher:
         self.args = (tiles_path, pred_fold, output_path, shift, simplify_tolerance, logger)
         self.completed_before = set(load_stitching_recovery(output_path, None))
         # two images may be stitched side by side (one finishing its GeoPackage while the next one parses tile files);
-        # the tile files of an image are spread over ``workers`` threads
+        # the tile files of an image are spread over ``workers`` threads inside td_stitch_tile_files (no Python per file: the
+        # epilogue workers of the running prediction hold the GIL most of the time)
         self._images = ThreadPoolExecutor(max_workers=2, thread_name_prefix="td-stitch")
-        self._files = ThreadPoolExecutor(max_workers=max(1, int(workers)), thread_name_prefix="td-stitch-file")
+        self._threads = max(1, int(workers))
         self._futures = {}
         self.seconds = 0.0
 
@@ -230,7 +295,7 @@ class EagerStitcher:
         import time
         t0 = time.perf_counter()
         tiles_path, pred_fold, output_path, shift, tol, logger = self.args
-        out = process_folder_sync(folder_json, tiles_path, pred_fold, output_path, shift, tol, logger, file_pool=self._files)
+        out = process_folder_sync(folder_json, tiles_path, pred_fold, output_path, shift, tol, logger, threads=self._threads)
         self.seconds += time.perf_counter() - t0
         return out
 
@@ -244,5 +309,4 @@ class EagerStitcher:
             except Exception:
                 pass
         self._images.shutdown(wait=True)
-        self._files.shutdown(wait=True)
         return done
