@@ -641,6 +641,10 @@ def main():
             for nm in names:
                 os.link(fx["tif"], f"{work}/rgb/{nm}.tif")
                 os.link(fx["tjson"], f"{tiles_pt}/{nm}.json")
+            os.makedirs(f"{work}/warm")
+            for r in range(world):          # one warm-up image per rank (its own output folder: nobody deletes under a writer)
+                os.link(fx["tif"], f"{work}/warm/{324125300 + r}.tif")
+                os.link(fx["tjson"], f"{work}/warm/{324125300 + r}.json")
         if world > 1:
             dist.barrier()
         paths = [f"{work}/rgb/{nm}.tif" for nm in names]
@@ -651,8 +655,7 @@ def main():
         logger.setLevel(logging.ERROR)
         config = {"logger": logger, "simplify_tolerance": 0.2}
         try:
-            pred.submit(fx["tif"], fx["tjson"], whole_image=True).result()          # warm-up image (not in the timed set)
-            shutil.rmtree(f"{out_pred}/324125317", ignore_errors=True)
+            pred.submit(f"{work}/warm/{324125300 + rank}.tif", f"{work}/warm/{324125300 + rank}.json", whole_image=True).result()   # warm-up image (not in the timed set)
             owner = DT.assign_images(paths, world)
             mine = [paths[i] for i in range(n_img) if owner[i] == rank]
             if world > 1:

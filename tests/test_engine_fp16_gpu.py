@@ -67,18 +67,19 @@ def test_fp16_trunk_close_to_fp32(setup16):
 SCORE_THRESH = 0.3            # cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST (reference config.py:60)
 
 
-def check_fp16_detections(got, ref, label="", depth_factor=1.0):
+def check_fp16_detections(got, ref, label=""):
     """Shared by the full-size / batch-32 / R101 / two-model tests. → per-detection statistics.
     A detection may exist on one side only where its score sits within the fp16 score tolerance of the 0.3 cut (the
     tolerance at s = 0.3 is 5e-3 * 4 s (1 - s) / 0.36 = 1.2e-2: a score that close to the threshold may land on either
     side of it); beyond those, at most max(2, 10 %) unmatched detections per image on either side: the seeded random heads put
     CLUSTERS of heavily overlapping proposals with near-tied scores on a tile, fp16 noise in the RPN logits reorders them, and
     the box that survives NMS in a cluster may descend from another proposal (IoU 0.5 - 0.7 with the oracle's survivor —
-    tools/fp16_set_diag.py lists them; the fp32 engine reproduces the oracle's set exactly on the same tiles).
-    ``depth_factor`` scales the score / probability / box bounds for deeper trunks: every layer adds one fp16 rounding of its
-    output, so the feature error grows with depth (R50 p5: 4e-3 relative RMS; R101 has 33 bottleneck blocks against 16 — its
-    test passes 2.5 and prints what it measured)."""
-    f = float(depth_factor)
+    tools/fp16_set_diag.py lists them; the fp32 engine reproduces the oracle's set exactly on the same tiles). This is the
+    STRESS rule of the random-head fixtures; how often such a flip happens is measured and bounded over 64 tiles by
+    test_fp16_flip_rate_is_bounded_over_64_tiles, and on heads that behave like a trained detector's the detected OBJECTS are
+    identical (test_fp16_detection_set_on_fitted_heads). One set of bounds for every depth (R101's trunk drift is measured where
+    it arises: test_fp16_r101_trunk_close_to_fp32)."""
+    f = 1.0
     rows = []
     band = f * 5e-3 * 4.0 * SCORE_THRESH * (1.0 - SCORE_THRESH) / 0.36
     worst = {"score": 0.0, "box": 0.0, "prob": 0.0}
@@ -243,3 +244,154 @@ def test_fp16_stated_tolerances_on_heads_with_trained_like_margins():
     assert (rows[~big, 4] <= 16).all(), rows[~big]
     assert np.median(ious) >= 0.99
     eng.close()
+
+
+def test_fp16_r101_trunk_close_to_fp32():
+    """Depth drift measured where it arises: the reference's depth (R101: 23 res4 blocks, one fp16 rounding
+    per layer) at full width through the fp16 engine against the fp32 oracle — per stage max |err| / max |ref| AND relative RMS,
+    printed; the same 8e-3 bound as R50's trunk test for every tensor (measured on R50: 3.5e-4 stem … 4.3e-3 p5)."""
+    from treedetection_amd.engine import Engine
+    torch.set_num_threads(8)
+    sd = make_synthetic_state_dict(101, seed=0)
+    rng = np.random.default_rng(23)
+    inputs = [{"image": smooth_image(rng, 256, 320), "height": 320, "width": 400},
+              {"image": smooth_image(rng, 224, 256), "height": 224, "width": 256}]
+    oracle = MaskRCNNOracle(sd)
+    assert oracle.blocks == [3, 4, 23, 3]
+    _, taps = oracle.forward(inputs, paste=False, return_taps=True)
+    eng = Engine(sd, precision="fp16")
+    eng(inputs, paste=False)
+    report = []
+    for name, ref in [(k, taps["res"][k]) for k in ("stem", "res2", "res3", "res4", "res5")] + \
+                     [(k, taps["feats"][k]) for k in ("p2", "p3", "p4", "p5", "p6")]:
+        r = ref.numpy()
+        g = nchw(eng.tensor(name).float())
+        assert g.shape == r.shape and eng.tensor(name).dtype == torch.float16
+        rel_max = float(np.abs(g - r).max() / np.abs(r).max())
+        rel_rms = float(np.sqrt(((g - r) ** 2).mean() / (r ** 2).mean()))
+        report.append(f"{name} {rel_max:.1e}/{rel_rms:.1e}")
+        assert rel_max < 8e-3 and rel_rms < 8e-3, (name, rel_max, rel_rms)
+    print("\n[fp16 R101 trunk] max|err|/max|ref| / relative RMS per stage: " + ", ".join(report))
+    eng.close()
+
+
+def match_detection_sets(g, r, band):
+    """One-to-one matching of two detection lists, greedy by IoU: → (strict pairs at IoU >= 0.9, cluster pairs at 0.5 <= IoU < 0.9
+    — the same object, another member of its duplicate cluster survived NMS —, oracle-only scores, engine-only scores); the
+    unpaired lists hold only detections clear of the score cut's band."""
+    ng, nr = len(g["scores"]), len(r["scores"])
+    m = np.array([[iou(r["pred_boxes"][i], g["pred_boxes"][j]) for j in range(ng)] for i in range(nr)]).reshape(nr, ng)
+    strict, cluster, used_r, used_g = [], [], set(), set()
+    for thr, out in ((0.9, strict), (0.5, cluster)):
+        order = np.dstack(np.unravel_index(np.argsort(-m, axis=None), m.shape))[0] if m.size else []
+        for i, j in order:
+            if m[i, j] < thr:
+                break
+            if i in used_r or j in used_g:
+                continue
+            used_r.add(int(i))
+            used_g.add(int(j))
+            out.append((int(i), int(j), float(m[i, j])))
+    lost = [float(r["scores"][i]) for i in range(nr) if i not in used_r and r["scores"][i] > SCORE_THRESH + band]
+    extra = [float(g["scores"][j]) for j in range(ng) if j not in used_g and g["scores"][j] > SCORE_THRESH + band]
+    return strict, cluster, lost, extra
+
+
+@pytest.mark.parametrize("depth", [50, 101])
+def test_fp16_detection_set_on_fitted_heads(depth):
+    """the detection-SET statement on heads that behave like a trained detector's (tests/trained_heads.py:
+    the RPN's output layers and the box predictor FITTED on the oracle's features of these very tiles — every crown is
+    found, class scores saturate, every proposal near a crown is regressed onto it; blob mask head), full width, two full-size
+    1000 x 1000 tiles, R50 and the reference's R101. Asserted:
+      * the detected OBJECTS are identical: outside the score cut's band |delta len| = 0 and every detection of either side
+        pairs one-to-one with a detection of the other at IoU >= 0.5 — no crown is lost or invented by fp16;
+      * at least 90 % of the pairs meet the strict rule (IoU >= 0.9) with the per-detection fp16 bounds (score <= 5e-3 rule,
+        box <= 0.5 px, mask probability <= 3e-2, pasted IoU >= 0.97 on compact masks); the rest are duplicate-cluster flips
+        (another proposal of the SAME crown survived the final NMS: IoU 0.5 - 0.9 with the oracle's survivor), counted and
+        printed. What keeps this from being 100 %: fitted linear layers on random features regress the duplicates of a crown to
+        within IoU ~0.9 of each other, not onto the same box as a trained regressor does (measured on the oracle alone:
+        tools / DESIGN.md §2)."""
+    from tests.trained_heads import fit_trained_like_heads, tile_inputs
+    from treedetection_amd.engine import Engine
+    from treedetection_amd.weights import blob_mask_head, boundary_over_area
+    torch.set_num_threads(16)
+    tiles = [0, 1]
+    sd = fit_trained_like_heads(blob_mask_head(make_synthetic_state_dict(depth, seed=5)), tiles)
+    inputs = tile_inputs(tiles, 1000)
+    ref = MaskRCNNOracle(sd).forward(inputs)
+    eng = Engine(sd, precision="fp16")
+    got = eng(inputs)
+    eng.close()
+    band = 5e-3 * 4.0 * SCORE_THRESH * (1.0 - SCORE_THRESH) / 0.36
+    n_strict = n_cluster = n_total = 0
+    worst = {"score": 0.0, "box": 0.0, "prob": 0.0, "iou": 1.0}
+    for n, (g, r) in enumerate(zip(got, ref)):
+        assert 25 <= len(r["scores"]) <= 80, len(r["scores"])             # ~ one detection per crown (38 whole crowns per tile)
+        strict, cluster, lost, extra = match_detection_sets(g, r, band)
+        assert not lost and not extra, (depth, n, "objects on one side only, clear of the score cut", lost, extra)
+        for i, j, v in strict:
+            s = float(r["scores"][i])
+            es = abs(float(g["scores"][j]) - s)
+            eb = float(np.abs(g["pred_boxes"][j] - r["pred_boxes"][i]).max())
+            ep = float(np.abs(g["mask_probs"][j] - r["mask_probs"][i]).max())
+            assert es <= 5e-3 * max(1.0, 4.0 * s * (1.0 - s) / 0.36), (depth, n, i, s, es)
+            assert eb <= 0.5 and ep <= 3e-2, (depth, n, i, eb, ep)
+            a, b = g["pred_masks"][j], r["pred_masks"][i]
+            u = (a | b).sum()
+            m_iou = (a & b).sum() / u if u else 1.0
+            if b.sum() and boundary_over_area(b) <= 0.2:
+                assert m_iou >= 0.97, (depth, n, i, m_iou)
+                worst["iou"] = min(worst["iou"], m_iou)
+            worst.update(score=max(worst["score"], es), box=max(worst["box"], eb), prob=max(worst["prob"], ep))
+        n_strict += len(strict)
+        n_cluster += len(cluster)
+        n_total += len(r["scores"])
+        print(f"\n[fp16 fitted heads R{depth}] tile {tiles[n]}: {len(r['scores'])} oracle / {len(g['scores'])} engine detections, "
+              f"{len(strict)} strict pairs (IoU >= 0.9), {len(cluster)} duplicate-cluster pairs {[round(v, 2) for _, _, v in cluster]}")
+    print(f"[fp16 fitted heads R{depth}] strict {n_strict} / {n_total}; worst strict pair: score {worst['score']:.2e}, box {worst['box']:.3f} px, "
+          f"mask probability {worst['prob']:.2e}, compact-mask IoU {worst['iou']:.4f}")
+    assert n_strict >= 0.9 * n_total
+
+
+def test_fp16_flip_rate_is_bounded_over_64_tiles():
+    """the random-head stress rule ("at most max(2, 10 %) detections per image on one side only, clear of the
+    cut") put on a measured footing. 64 full-size tiles of the bench's own stream (R50, the bench's weights) through the fp32
+    engine — which reproduces the oracle's detection set exactly, tests/test_fullsize_gpu.py — and the fp16 engine; a FLIP = a
+    detection clear of the score cut's band without an IoU >= 0.9 partner on the other side. Printed: flips per tile (mean,
+    max), the rate per detection, how many flips still have an IoU >= 0.5 partner (duplicate-cluster flips) and how many are
+    objects on one side only. Asserted: rate <= 6 % of the detections (measured 2.9 % on this build), no tile above max(2, 10 %)
+    + 1, and at least 85 % of the flips are cluster flips."""
+    from treedetection_amd.engine import Engine, INPUT_U8_HWC, unpack_outputs
+    from treedetection_amd.synth import make_tile
+    sd = make_synthetic_state_dict(50, seed=0)
+    band = 5e-3 * 4.0 * SCORE_THRESH * (1.0 - SCORE_THRESH) / 0.36
+    res = {}
+    for prec in ("fp32", "fp16"):
+        eng = Engine(sd, precision=prec)
+        outs = []
+        for b0 in range(0, 64, 8):
+            tiles = [torch.from_numpy(make_tile(100 + b0 + k, 1000)[0]).cuda() for k in range(8)]
+            batch, hw_valid, hw_out = eng.preprocess_tiles_u8(tiles)
+            out = eng.alloc_outputs(8, 1000, 1000, paste=False)
+            eng.forward_raw(batch, INPUT_U8_HWC, hw_valid, hw_out, out)
+            torch.cuda.synchronize()
+            outs.extend(unpack_outputs(out, hw_out, False))
+        eng.close()
+        res[prec] = outs
+    flips, clusters, dets, per_tile = 0, 0, 0, []
+    for g, r in zip(res["fp16"], res["fp32"]):
+        strict, cluster, lost, extra = match_detection_sets(g, r, band)
+        far = lambda d, idx: d["scores"][idx] > SCORE_THRESH + band      # noqa: E731
+        c = sum(1 for i, j, _ in cluster if far(r, i)) + sum(1 for i, j, _ in cluster if far(g, j))
+        f = c + len(lost) + len(extra)
+        flips += f
+        clusters += c
+        dets += len(r["scores"]) + len(g["scores"])
+        per_tile.append(f / 2.0)
+        assert len(lost) + sum(1 for i, j, _ in cluster if far(r, i)) <= max(2, int(np.ceil(0.1 * len(r["scores"])))) + 1
+    rate = flips / max(dets, 1)
+    print(f"\n[fp16 flip rate, 64 tiles, random heads] {dets // 2} detections per side, {flips / 2:.0f} flips per side "
+          f"({100 * rate:.2f} % of the detections; per tile mean {np.mean(per_tile):.2f}, max {max(per_tile):.1f}); "
+          f"{100 * clusters / max(flips, 1):.0f} % of them duplicate-cluster flips (IoU >= 0.5 partner)")
+    assert rate <= 0.06
+    assert clusters >= 0.85 * flips

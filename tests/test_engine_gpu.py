@@ -260,12 +260,12 @@ def test_resnet101_layout(setup):
 def test_mask_head_beyond_the_fold_kernels_plane_limit(setup):
     """the mask head launches all B x detections_per_image reserved RoIs as ONE group; the folded F(4x4) kernel's
     32-bit plane offsets hold 36 * tiles * C * 4 < 4 GB (about 14 500 RoIs of 14 x 14 at this fixture's 128 channels, 7 279 at
-    256). A configuration past that (8 x 2000 RoIs) must take the three-launch form instead of failing the forward — and give
+    256). A configuration past that (16 x 1024 RoIs) must take the three-launch form instead of failing the forward — and give
     the detections of the default configuration (same boxes and scores bit for bit; mask probabilities within the fp32
     tolerance: the two Winograd forms associate their sums differently)."""
     from treedetection_amd.engine import Engine
-    inputs = [setup["inputs"][k % 2] for k in range(8)]
-    big = Engine(setup["sd"], detections_per_image=2000)
+    inputs = [setup["inputs"][k % 2] for k in range(16)]
+    big = Engine(setup["sd"], detections_per_image=1024)
     try:
         got = big(inputs, paste=False)
     finally:

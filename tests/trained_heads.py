@@ -1,0 +1,222 @@
+"""A detector whose LAST layers are fitted — test fixture, not product code.
+
+The seeded random heads of ``make_synthetic_state_dict`` behave unlike any trained detector in one respect that matters for the
+fp16 detection-set statement (SURVEY.md §8d "set match by IoU >= 0.9 & score"): their objectness varies smoothly over the
+map, so a crown is covered by a cluster of heavily overlapping, near-tied proposals, and their box regression is random, so
+the boxes of such a cluster differ (IoU 0.5 - 0.7). fp16 noise reorders the near-ties and the NMS survivor of a cluster may
+descend from another proposal with ANOTHER box. A trained detector also produces near-tied duplicates — but its box head has
+learnt to move every proposal of an object onto the object, so whichever duplicate survives carries the same box and score.
+
+This module gives the synthetic model that property by fitting, in closed form (ridge regression, float64), the four LINEAR
+output layers of the detector on the oracle's own fp32 features of a few synthetic tiles whose crowns are known
+(treedetection_amd.synth.tile_crowns):
+  * ``rpn_head.objectness_logits`` / ``anchor_deltas`` (1x1 convs on the shared 256-channel RPN feature): objectness +-L
+    for anchors that do / do not cover a crown (IoU >= 0.5 / < 0.3), deltas (weights 1,1,1,1) onto the crown's box;
+  * ``box_predictor.cls_score`` / ``bbox_pred`` (FCs on the 1024-vector of the box head): class margin +-M for proposals
+    that do / do not cover a crown, deltas (weights 10,10,5,5) onto the crown's box.
+Everything upstream (trunk, FPN, RPN conv, fc1, fc2) keeps its seeded random weights, the mask head is
+``weights.blob_mask_head``; every kernel of the forward runs exactly as before. Nothing of the reference is involved: the
+fit needs only the oracle (test infrastructure) and the tile generator, is deterministic, and takes a few CPU seconds per
+tile. The fixture is conditioned ON the tiles it is tested with (the tests pass the same tile indices): it is a numerical
+conditioning device, not a claim about generalisation.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from oracle import ops_ref as R
+from oracle.maskrcnn_ref import MaskRCNNOracle
+from treedetection_amd.synth import make_tile, tile_crowns
+
+CROWN_HALF_SIGMAS = 1.6        # a crown's box: centre +- 1.6 sigma (where the Gaussian has fallen to 28 % of its peak)
+RPN_LOGIT = 4.0                # objectness targets +-L
+CLS_MARGIN = 5.0               # class margin targets (fg logit - bg logit) +-M: scores 0.993 / 0.007
+
+
+def crown_boxes(tile: int, size: int, net_hw: Tuple[int, int]) -> np.ndarray:
+    """Boxes (x1, y1, x2, y2) of tile ``tile``'s crowns in NETWORK pixels, clipped to the image; crowns whose centre is
+    closer than half a sigma to the border are left out (half of the blob is outside)."""
+    sy, sx = net_hw[0] / size, net_hw[1] / size
+    out = []
+    for cx, cy, sg in tile_crowns(tile, size):
+        if not (0.5 * sg <= cx <= size - 0.5 * sg and 0.5 * sg <= cy <= size - 0.5 * sg):
+            continue
+        h = CROWN_HALF_SIGMAS * sg
+        out.append([max(cx - h, 0) * sx, max(cy - h, 0) * sy, min(cx + h, size) * sx, min(cy + h, size) * sy])
+    return np.asarray(out, dtype=np.float64).reshape(-1, 4)
+
+
+def iou_matrix(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    if len(a) == 0 or len(b) == 0:
+        return np.zeros((len(a), len(b)))
+    x1 = np.maximum(a[:, None, 0], b[None, :, 0])
+    y1 = np.maximum(a[:, None, 1], b[None, :, 1])
+    x2 = np.minimum(a[:, None, 2], b[None, :, 2])
+    y2 = np.minimum(a[:, None, 3], b[None, :, 3])
+    inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+    aa = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    ab = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return inter / (aa[:, None] + ab[None, :] - inter)
+
+
+def box_deltas(src: np.ndarray, dst: np.ndarray, weights) -> np.ndarray:
+    """Inverse of ops_ref.apply_deltas: the (dx, dy, dw, dh) that move ``src`` boxes onto ``dst``."""
+    sw, sh = src[:, 2] - src[:, 0], src[:, 3] - src[:, 1]
+    sx, sy = src[:, 0] + 0.5 * sw, src[:, 1] + 0.5 * sh
+    dw, dh = dst[:, 2] - dst[:, 0], dst[:, 3] - dst[:, 1]
+    dx, dy = dst[:, 0] + 0.5 * dw, dst[:, 1] + 0.5 * dh
+    wx, wy, ww, wh = weights
+    return np.stack([wx * (dx - sx) / sw, wy * (dy - sy) / sh, ww * np.log(dw / sw), wh * np.log(dh / sh)], axis=1)
+
+
+class _Ridge:
+    """Weighted ridge regression accumulated in normal-equation form (float64): rows = samples [n, f] (+ bias column)."""
+
+    def __init__(self, nfeat: int, nout: int):
+        self.A = np.zeros((nfeat + 1, nfeat + 1))
+        self.B = np.zeros((nfeat + 1, nout))
+
+    def add(self, X: np.ndarray, Y: np.ndarray, w: np.ndarray) -> None:
+        X1 = np.concatenate([X.astype(np.float64), np.ones((X.shape[0], 1))], axis=1)
+        Xw = X1 * w[:, None]
+        self.A += Xw.T @ X1
+        self.B += Xw.T @ Y
+
+    def solve(self, lam: float) -> Tuple[np.ndarray, np.ndarray]:
+        n = self.A.shape[0]
+        reg = lam * np.trace(self.A[:-1, :-1]) / (n - 1) * np.eye(n)
+        reg[-1, -1] = 0.0                      # the bias is not penalised
+        W = np.linalg.solve(self.A + reg, self.B)
+        return W[:-1].T.astype(np.float32), W[-1].astype(np.float32)       # [nout, nfeat], [nout]
+
+
+def tile_inputs(tiles: Sequence[int], size: int) -> List[dict]:
+    """The model inputs of synthetic tiles exactly as the predictor builds them (Pillow-exact resize to 800 on the short side)."""
+    out = []
+    for t in tiles:
+        rgb, _ = make_tile(t, size)
+        img, h, w = R.preprocess_tile_u8(rgb.transpose(2, 0, 1))
+        out.append({"image": img, "height": h, "width": w})
+    return out
+
+
+@torch.no_grad()
+def fit_trained_like_heads(sd: Dict[str, np.ndarray], tiles: Sequence[int], size: int = 1000, lam_rpn: float = 1e-3,
+                           lam_box: float = 1e-3, verbose: bool = False) -> Dict[str, np.ndarray]:
+    """→ a copy of ``sd`` whose RPN output layers and box predictor are fitted on ``tiles`` (see the module docstring)."""
+    sd = dict(sd)
+    inputs = tile_inputs(tiles, size)
+    oracle = MaskRCNNOracle(sd)
+    pfx = "proposal_generator.rpn_head."
+    feats_all, gts = [], []
+    rpn = None
+    for k, inp in enumerate(inputs):
+        x, sizes = oracle.batch_images([inp["image"]])
+        feats = oracle.fpn(oracle.backbone(x))
+        feats_all.append(feats)
+        gt = crown_boxes(tiles[k], size, sizes[0])
+        gts.append(gt)
+        for li, lvl in enumerate((2, 3, 4, 5, 6)):
+            t = oracle._conv(feats[f"p{lvl}"], pfx + "conv", pad=1, relu=True)[0]             # [C, H, W]
+            C, H, W = t.shape
+            if rpn is None:
+                rpn = [_SplitRidge(C, 1, 4) for _ in range(3)]                                # per anchor shape: logit | 4 deltas
+            X = t.permute(1, 2, 0).reshape(-1, C).numpy()
+            anchors = R.grid_anchors(H, W, R.FPN_STRIDES[li], R.ANCHOR_SIZES[li]).astype(np.float64)   # (y, x, a) order
+            iou = iou_matrix(anchors, gt)
+            best = iou.max(axis=1) if gt.size else np.zeros(len(anchors))
+            arg = iou.argmax(axis=1) if gt.size else np.zeros(len(anchors), int)
+            pos = best >= 0.5
+            if gt.size:                       # every crown's best anchor of this level counts as positive if it overlaps decently
+                top = iou.argmax(axis=0)
+                ok = iou[top, np.arange(gt.shape[0])] >= 0.35
+                pos[top[ok]] = True
+                arg[top[ok]] = np.arange(gt.shape[0])[ok]
+            neg = (best < 0.3) & ~pos
+            for a in range(3):
+                sel = np.arange(a, len(anchors), 3)
+                Y = np.zeros((len(sel), 5))
+                w = np.zeros((len(sel), 5))
+                p, n = pos[sel], neg[sel]
+                Y[p, 0], Y[n, 0] = RPN_LOGIT, -RPN_LOGIT
+                if p.any():
+                    Y[p, 1:] = box_deltas(anchors[sel][p], gt[arg[sel][p]], (1.0, 1.0, 1.0, 1.0))
+                # objectness: positives are rare — weigh them up to a tenth of the negatives' mass; deltas: positives only
+                wp = max(1.0, 0.1 * n.sum() / max(p.sum(), 1))
+                wl = np.where(p, wp, np.where(n, 1.0, 0.0))
+                rpn[a].add(X, Y, wl, p.astype(np.float64))          # anchor a of every position: one row per position
+    obj_w, obj_b, del_w, del_b = [], [], [], []
+    for a in range(3):
+        Wl, bl, Wd, bd = rpn[a].solve(lam_rpn)
+        obj_w.append(Wl)
+        obj_b.append(bl)
+        del_w.append(Wd)
+        del_b.append(bd)
+    C = obj_w[0].shape[1]
+    sd[pfx + "objectness_logits.weight"] = np.stack([w[0] for w in obj_w]).reshape(3, C, 1, 1).astype(np.float32)
+    sd[pfx + "objectness_logits.bias"] = np.array([b[0] for b in obj_b], np.float32)
+    sd[pfx + "anchor_deltas.weight"] = np.concatenate(del_w).reshape(12, C, 1, 1).astype(np.float32)      # per anchor (dx, dy, dw, dh)
+    sd[pfx + "anchor_deltas.bias"] = np.concatenate(del_b).astype(np.float32)
+
+    # ---- second stage: the fitted RPN's proposals through the (random) box head; fit the predictor on its 1024-vector
+    oracle = MaskRCNNOracle(sd)
+    box = None
+    for k, inp in enumerate(inputs):
+        feats, gt = feats_all[k], gts[k]
+        x, sizes = oracle.batch_images([inp["image"]])
+        logits, deltas = oracle.rpn_head(feats)
+        feat_hw = [tuple(feats[f"p{l}"].shape[-2:]) for l in (2, 3, 4, 5, 6)]
+        props, _ = oracle.rpn_proposals(logits, deltas, feat_hw, sizes)
+        boxes = props[0][0].astype(np.float64)
+        pooled, _ = oracle.roi_pool(feats, [props[0][0]], 7)
+        v = torch.as_tensor(pooled[0]).flatten(1)
+        s = oracle.sd
+        v = torch.relu(torch.nn.functional.linear(v, s["roi_heads.box_head.fc1.weight"], s["roi_heads.box_head.fc1.bias"]))
+        v = torch.relu(torch.nn.functional.linear(v, s["roi_heads.box_head.fc2.weight"], s["roi_heads.box_head.fc2.bias"])).numpy()
+        if box is None:
+            box = _SplitRidge(v.shape[1], 1, 4)
+        iou = iou_matrix(boxes, gt)
+        best = iou.max(axis=1) if gt.size else np.zeros(len(boxes))
+        arg = iou.argmax(axis=1) if gt.size else np.zeros(len(boxes), int)
+        p, n = best >= 0.5, best < 0.4
+        # the regression is fitted on every proposal that overlaps a crown at all (IoU >= 0.2): whatever the classifier lets
+        # through near a crown has been taught where the crown is
+        q = best >= 0.2
+        Y = np.zeros((len(boxes), 5))
+        Y[p, 0], Y[n, 0] = CLS_MARGIN, -CLS_MARGIN
+        if q.any():
+            Y[q, 1:] = box_deltas(boxes[q], gt[arg[q]], (10.0, 10.0, 5.0, 5.0))
+        wl = np.where(p, max(1.0, 0.5 * n.sum() / max(p.sum(), 1)), np.where(n, 1.0, 0.0))
+        box.add(v, Y, wl, q.astype(np.float64))
+        if verbose:
+            print(f"[trained_heads] tile {tiles[k]}: {len(gt)} crowns, {len(boxes)} proposals, {int(p.sum())} on a crown, "
+                  f"{int((iou.max(axis=0) >= 0.5).sum()) if gt.size else 0} crowns covered")
+    Wm, bm, Wd, bd = box.solve(lam_box)
+    # cls_score rows: (foreground, background); margin = fg - bg
+    sd["roi_heads.box_predictor.cls_score.weight"] = np.concatenate([0.5 * Wm, -0.5 * Wm]).astype(np.float32)
+    sd["roi_heads.box_predictor.cls_score.bias"] = np.array([0.5 * bm[0], -0.5 * bm[0]], np.float32)
+    sd["roi_heads.box_predictor.bbox_pred.weight"] = Wd.astype(np.float32)
+    sd["roi_heads.box_predictor.bbox_pred.bias"] = bd.astype(np.float32)
+    return sd
+
+
+class _SplitRidge:
+    """Two ridge systems on the same features: the first ``na`` outputs weighted by ``wa`` (classification: positives and
+    negatives), the other ``nb`` by ``wb`` (regression: positives only)."""
+
+    def __init__(self, nfeat: int, na: int, nb: int):
+        self.a, self.b, self.na = _Ridge(nfeat, na), _Ridge(nfeat, nb), na
+
+    def add(self, X, Y, wa, wb):
+        if (wa > 0).any():
+            self.a.add(X[wa > 0], Y[wa > 0, :self.na], wa[wa > 0])
+        if (wb > 0).any():
+            self.b.add(X[wb > 0], Y[wb > 0, self.na:], wb[wb > 0])
+
+    def solve(self, lam):
+        Wa, ba = self.a.solve(lam)
+        Wb, bb = self.b.solve(lam)
+        return Wa, ba, Wb, bb

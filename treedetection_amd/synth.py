@@ -43,6 +43,27 @@ def make_tile(i: int, size: int = 1000) -> Tuple[np.ndarray, np.ndarray]:
     return rgb, ndsm
 
 
+def tile_crowns(i: int, size: int = 1000):
+    """(cx, cy, sigma) of tile i's crowns in tile pixels, in generation order — the same random draws as :func:`make_tile`
+    (test fixtures that need to know where the crowns are: tests/trained_heads.py)."""
+    rng = np.random.default_rng(SEED0 + i)
+    for _ in range(6):
+        rng.uniform(-0.02, 0.02, 2)
+        rng.uniform(0, 2 * np.pi)
+        rng.uniform(-10, 10, 3)
+    out = []
+    for _ in range(40):
+        cy, cx = rng.uniform(0, size, 2)
+        sg = rng.uniform(8, 40)
+        r = int(3 * sg) + 1
+        if max(int(cy) - r, 0) >= min(int(cy) + r + 1, size) or max(int(cx) - r, 0) >= min(int(cx) + r + 1, size):
+            continue
+        rng.uniform(-40, 10), rng.uniform(20, 70), rng.uniform(-50, 0)
+        rng.uniform(3, 30)
+        out.append((float(cx), float(cy), float(sg)))
+    return out
+
+
 def make_stream(n: int, size: int = 1000, distinct: int | None = None):
     """n tiles (RGB uint8 [n,S,S,3], nDSM float32 [n,S,S]); only ``distinct`` different seeds are generated and
     cycled when given (start-up time of the bench)."""
