@@ -649,7 +649,7 @@ def main():
             dist.barrier()
         paths = [f"{work}/rgb/{nm}.tif" for nm in names]
         cfg = T.setup_model_cfg(update_model="synthetic", device=str(local_rank))
-        Bp = DT.engine_batch_size({"precision": precision}, B)       # fp16: the engine's operating point is batch 32 (detection.engine_batch_size)
+        Bp = DT.engine_batch_size({"precision": precision}, B)       # what predict_on_model would run (fp16_min_batch off by default: B)
         pred = T.Predictor(cfg, device_type=str(local_rank), max_batch_size=Bp, output_dir=out_pred, precision=precision,
                            state_dict=sd_w, return_predictions=False, sharded_epilogue="local")
         logger = logging.getLogger("td-bench")
@@ -716,7 +716,7 @@ def main():
             cfg = T.setup_model_cfg(update_model="synthetic", device=str(local_rank))
             for precision in precisions:
                 from treedetection_amd.detection import engine_batch_size
-                Bp = engine_batch_size({"precision": precision}, B)    # what predict_on_model runs: batch 32 for the fp16 engine
+                Bp = engine_batch_size({"precision": precision}, B)    # what predict_on_model runs (fp16_min_batch off by default: B)
                 pred = T.Predictor(cfg, device_type=str(local_rank), max_batch_size=Bp, output_dir=f"{root}/out_{precision}",
                                    precision=precision, state_dict=sd_e2e, return_predictions=False)
                 pred(tif, tjson)                        # warm-up call

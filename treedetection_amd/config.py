@@ -8,7 +8,7 @@ Optional extra keys (defaults preserve the reference's behaviour): ``precision``
 (101 — the reference hard-codes mask_rcnn_R_101_FPN_3x, config.py:25; a checkpoint's own depth wins); multi-rank runs:
 ``sharded_epilogue`` ("auto" | "rank0" | "local"), ``shard_by`` ("auto" | "image" | "tile": whole images per rank when there
 are at least as many images as ranks, detection.resolve_shard_by), ``eager_stitch`` (true: every image is stitched as soon as
-its tile files are complete, while the next one predicts), ``fp16_min_batch`` (32: the fp16 engine's operating point,
+its tile files are complete, while the next one predicts), ``fp16_min_batch`` (0 = off: a larger batch for the fp16 engine only,
 detection.engine_batch_size).
 """
 from __future__ import annotations
@@ -160,7 +160,7 @@ def get_config(config_path: str):
         "timestamped_output_directory": False, "simplify_tolerance": 0.2, "building_shapes": None,
         # extensions of this package (defaults = the reference's behaviour)
         "precision": "fp32", "resnet_depth": 101, "sharded_epilogue": "auto", "shard_by": "auto", "eager_stitch": True,
-        "fp16_min_batch": 32,
+        "fp16_min_batch": 0,
     }
     for k, v in defaults.items():
         config[k] = config.get(k, v)

@@ -124,16 +124,18 @@ def walk_images(config, predictor, paths, tiles_path, output_path, chain=True, s
     return {"done": done, "failed": failed, "stitched": stitched, "stitch_seconds": stitcher.seconds if stitcher is not None else 0.0}
 
 
-FP16_MIN_BATCH = 32
+FP16_MIN_BATCH = 0
 
 
 def engine_batch_size(config, batch_size: int) -> int:
     """Tiles per forward. ``batch_size`` is the reference's key ("1 per GB on GPU", default 10: example/config.yml:29) and is
-    what the fp32 engine runs. With ``precision: fp16`` the engine's operating point is BASELINE configs[4]'s batch 32 unless
-    the config asks for more (``fp16_min_batch``, 0 = keep ``batch_size``): the fp16 forward is 5-7 % faster per tile there
-    (2 375 vs 2 248 tiles/s, BENCH_r04) — four times the rows per launch fill the last wave of the small-map layers — the
-    288 GB of HBM hold it with room to spare, and a batch of 32 equals the same tiles forwarded in smaller batches bit for
-    bit (tests/test_fullsize_gpu.py), so the files do not depend on it."""
+    what both engines run by default. ``fp16_min_batch`` (default 0 = off) raises it for ``precision: fp16``: at the ENGINE
+    level BASELINE configs[4]'s batch 32 is 5 % faster per tile than batch 8 (2 381 vs 2 266 tiles/s, inputs resident in HBM:
+    four times the rows per launch fill the last wave of the small-map layers) and gives the same files bit for bit
+    (tests/test_fullsize_gpu.py) — but files to files it is SLOWER on a 16-core host (round 5, same box: e2e 1 737 vs 2 122
+    tiles/s, chained 1 797 vs 2 210): a 400-tile image is 13 batches of 32 over three engines, the reader, the H2D copy and
+    the epilogue workers hand over 128 MB / 32 files at a time and overlap worse than with 8-tile batches. So the default
+    stays the configured batch size; the key is for hosts with more cores per GPU."""
     if str(config.get("precision", "fp32")) != "fp16":
         return batch_size
     return max(int(batch_size), int(config.get("fp16_min_batch", FP16_MIN_BATCH)))
