@@ -3,6 +3,9 @@ the call's marks (TD_E2E_TRACE) → fixed part (call start → first launch; las
 how long the reader waited for a slot and the launcher for the reader.
 
     python tools/e2e_timeline.py [fp16|fp32] [side ...]      # side x side tiles of 1000 px; default 12
+    python tools/e2e_timeline.py [fp16|fp32] chain=3 [side]  # the chained walk of detection.walk_images over 3 images of side x side
+                                                             # tiles (predict + eager stitching): launches of ALL images on one time axis —
+                                                             # the largest gap between consecutive launches against the steady batch period
 """
 import json, os, shutil, sys, tempfile, time
 sys.path.insert(0, ".")
@@ -53,8 +56,67 @@ def summarize(trace, ntiles, dt):
     return {k: (round(v, 2) if isinstance(v, float) else v) for k, v in out.items()}
 
 
+def chained(precision, n_images, side, sd):
+    """detection.walk_images over n_images copies (hard links) of one raster: where the launcher's time axis has gaps."""
+    import logging
+    from treedetection_amd import detection as DT
+    os.environ["TD_E2E_TRACE"] = "keep"
+    tiles = [make_tile(i, S)[0] for i in range(16)]
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    root = tempfile.mkdtemp(prefix="td_e2e_", dir=base)
+    try:
+        tif, tjson = raster(root, side, tiles)
+        n = len(json.load(open(tjson)))
+        names = [str(324125400 + k) for k in range(n_images)]
+        os.makedirs(f"{root}/w/rgb"), os.makedirs(f"{root}/w/tiles")
+        for nm in names:
+            os.link(tif, f"{root}/w/rgb/{nm}.tif")
+            os.link(tjson, f"{root}/w/tiles/{nm}.json")
+        cfg = T.setup_model_cfg(update_model="synthetic", device="0")
+        pred = T.Predictor(cfg, device_type="0", max_batch_size=B, output_dir=f"{root}/w/pred", precision=precision, state_dict=sd,
+                           return_predictions=False)
+        pred(tif, tjson)                                   # warm-up
+        log = logging.getLogger("tl")
+        log.setLevel(logging.ERROR)
+        best = None
+        for rep in range(2):                               # first pass creates the files, second is the one reported
+            del pred._trace[:]
+            shutil.rmtree(f"{root}/w/gpkg", ignore_errors=True)
+            t0 = time.perf_counter()
+            rep_ = DT.walk_images({"logger": log, "simplify_tolerance": 0.2}, pred, [f"{root}/w/rgb/{nm}.tif" for nm in names],
+                                  f"{root}/w/tiles", f"{root}/w/pred", chain=True, stitch_to=f"{root}/w/gpkg")
+            dt = time.perf_counter() - t0
+            best = (dt, list(pred._trace), rep_)
+        pred.close()
+        dt, trace, rep_ = best
+        t0 = trace[0][2]
+        launches = [t - t0 for what, k, t in trace if what == "launch"]
+        per_image = (n + B - 1) // B
+        gaps = np.diff(launches)
+        steady = float(np.median(gaps))
+        # gaps that straddle an image boundary: launch index per_image * i - 1 → per_image * i
+        bound = [float(gaps[per_image * i - 1]) for i in range(1, n_images) if per_image * i - 1 < len(gaps)]
+        calls = [t - t0 for what, k, t in trace if what == "call"]
+        print(json.dumps({"precision": precision, "fixture": os.environ.get("E2E_FIXTURE", "noise"), "images": n_images, "tiles_per_image": n,
+                          "walk_s": round(dt, 4), "tiles_per_s": round(n_images * n / dt, 1), "launches": len(launches),
+                          "steady_batch_period_ms": round(steady * 1e3, 2), "largest_gap_ms": round(float(gaps.max()) * 1e3, 2),
+                          "gaps_across_image_boundaries_ms": [round(g * 1e3, 2) for g in bound],
+                          "submit_calls_at_ms": [round(c * 1e3, 1) for c in calls], "last_launch_ms": round(launches[-1] * 1e3, 1),
+                          "stitched": len(rep_["stitched"]), "stitch_thread_s": round(rep_["stitch_seconds"], 3)}), flush=True)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def main():
     precision = sys.argv[1] if len(sys.argv) > 1 else "fp16"
+    chain = [a for a in sys.argv[2:] if a.startswith("chain=")]
+    if chain:
+        sd = make_synthetic_state_dict(50, seed=0)
+        if os.environ.get("E2E_FIXTURE") == "crowns":
+            from treedetection_amd.weights import blob_mask_head
+            sd = blob_mask_head(sd, seed=0)
+        rest = [int(a) for a in sys.argv[2:] if not a.startswith("chain=")]
+        return chained(precision, int(chain[0].split("=")[1]), rest[0] if rest else 20, sd)
     sides = [int(a) for a in sys.argv[2:]] or [12]
     sd = make_synthetic_state_dict(50, seed=0)
     if os.environ.get("E2E_FIXTURE") == "crowns":        # the compact-crown mask head of bench.py's e2e_crowns region

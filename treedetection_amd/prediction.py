@@ -958,7 +958,7 @@ class Predictor:
                                "tile-sharded images go through __call__ (one collective structure per image)")
         pred_subdir = os.path.join(self.output_dir, os.path.basename(tifpath).replace(".tif", "").replace(".json", ""))
         os.makedirs(pred_subdir, exist_ok=True)
-        if self._trace is not None:
+        if self._trace is not None and os.environ.get("TD_E2E_TRACE") != "keep":      # "keep": one trace over a chained walk of images
             del self._trace[:]
         self._mark("call")
         tiles = self._load_tiles(tilepath)
