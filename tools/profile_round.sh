@@ -1,7 +1,7 @@
 # Regenerates the judged artefacts of profiles/ on the GPU box: bash tools/profile_round.sh [round tag, default r02]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
 export TD_TUNE_CACHE=$O/tune.txt
