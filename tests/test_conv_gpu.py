@@ -277,7 +277,7 @@ def test_winograd_f4x4_conv_matches_torch(case):
 
 
 WINO_FOLD_CASES = [
-    # B, Cin, H, W, Cout, scale, bias, relu — Cin = 128 or 256, Cout % 64 == 0 (wino43_fused_ok)
+    # B, Cin, H, W, Cout, scale, bias, relu — Cin = 128, 256 or 512, Cout % 64 == 0 (wino43_fused_ok)
     (1, 128, 100, 100, 128, True, True, True),        # res3 conv2: 4 k-chunks per plane (the 4-stage pipeline), whole tiles
     (2, 256, 50, 50, 256, False, True, True),         # res4 conv2 / FPN output 4: a half tile per row / column
     (1, 256, 200, 200, 256, False, True, False),      # FPN output 2 / RPN conv p2: 2 500 tiles = 39 blocks + 4 tiles
@@ -285,6 +285,8 @@ WINO_FOLD_CASES = [
     (3, 256, 25, 25, 512, True, True, True),          # 147 tiles (a partial block of 19), eight channel blocks
     (5, 256, 14, 14, 256, False, True, True),         # mask-head RoIs: 16 tiles per image
     (1, 128, 9, 5, 64, False, False, False),          # 6 tiles: one block, mostly dead rows
+    (2, 512, 25, 25, 512, True, False, True),         # res5 conv2 (round 5): 512 input channels = 16 chunks per plane, four ring passes
+    (1, 512, 13, 19, 128, False, True, False),        # 512 channels, partial tiles on both axes
 ]
 
 
@@ -318,9 +320,11 @@ def test_winograd_f4x4_folded_conv_matches_torch(case):
     bd = dev(bias) if use_bias else None
     p = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
 
-    def run(fold):
+    def run(fold, nwt=None):
         os.environ["TD_WINO_TILE"] = "4"
         os.environ["TD_WINO_FOLD"] = "1" if fold else "0"
+        if nwt:
+            os.environ["TD_WF_NWT"] = str(nwt)
         try:
             y = torch.full((B, H, W, Cout), float("nan"), dtype=torch.float32, device="cuda")
             _lib.check(lib.td_conv2d_winograd_nhwc(p(xd), p(wd), p(sd), p(bd), y.data_ptr(), B, H, W, Cin, Cout, int(relu), _lib.stream_ptr()),
@@ -328,8 +332,16 @@ def test_winograd_f4x4_folded_conv_matches_torch(case):
             return y
         finally:
             del os.environ["TD_WINO_TILE"], os.environ["TD_WINO_FOLD"]
+            os.environ.pop("TD_WF_NWT", None)
     ys = [run(True) for _ in range(3)]
     assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])          # a racy pipeline would not repeat
+    # round 5: the block geometries (64-tile blocks of 512 threads / 32-tile blocks of 256 threads on a 4-stage ring, whatever the
+    # launcher picked by the launch's size) give the SAME BITS: every output sees the same chunks in the same order
+    for nwt in (2, 4):
+        if nwt == 4 and Cin == 512:
+            continue                                   # 512 channels run on the 32-tile geometry only
+        yv = run(True, nwt)
+        assert torch.equal(yv, ys[0]), f"block geometry NWT = {nwt} differs from the launcher's choice"
     got = ys[0].cpu().numpy().transpose(0, 3, 1, 2)
     assert np.isfinite(got).all()
     scale_ref = max(1.0, np.abs(ref).max())

@@ -98,10 +98,19 @@ def chained(precision, n_images, side, sd):
         # gaps that straddle an image boundary: launch index per_image * i - 1 → per_image * i
         bound = [float(gaps[per_image * i - 1]) for i in range(1, n_images) if per_image * i - 1 < len(gaps)]
         calls = [t - t0 for what, k, t in trace if what == "call"]
+        # GPU side: when each batch's results were seen by the first epilogue worker (its event had fired), in completion order.
+        # The launcher runs up to nine batches ahead of the GPU, so gaps between LAUNCHES are waits for a free slot; gaps between
+        # COMPLETIONS are what the GPU did: across an image boundary they should look like any other batch period.
+        done = sorted(t - t0 for what, k, t in trace if what == "batch_done")
+        dgap = np.diff(done)
+        dbound = [float(dgap[per_image * i - 1]) for i in range(1, n_images) if per_image * i - 1 < len(dgap)]
         print(json.dumps({"precision": precision, "fixture": os.environ.get("E2E_FIXTURE", "noise"), "images": n_images, "tiles_per_image": n,
                           "walk_s": round(dt, 4), "passes_s (first creates the files)": passes, "tiles_per_s": round(n_images * n / dt, 1), "launches": len(launches),
                           "steady_batch_period_ms": round(steady * 1e3, 2), "largest_gap_ms": round(float(gaps.max()) * 1e3, 2),
-                          "gaps_across_image_boundaries_ms": [round(g * 1e3, 2) for g in bound],
+                          "launch_gaps_across_image_boundaries_ms": [round(g * 1e3, 2) for g in bound],
+                          "batch_completion_period_ms": {"median": round(float(np.median(dgap)) * 1e3, 2), "p90": round(float(np.quantile(dgap, 0.9)) * 1e3, 2),
+                                                         "max": round(float(dgap.max()) * 1e3, 2)},
+                          "completion_gaps_across_image_boundaries_ms": [round(g * 1e3, 2) for g in dbound],
                           "submit_calls_at_ms": [round(c * 1e3, 1) for c in calls], "last_launch_ms": round(launches[-1] * 1e3, 1),
                           "stitched": len(rep_["stitched"]), "stitch_thread_s": round(rep_["stitch_seconds"], 3)}), flush=True)
     finally:

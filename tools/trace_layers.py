@@ -67,7 +67,7 @@ def launches_of(name, M, N, K, fp32, B=8, min43=12):
         rpn_fold = "rpn_conv p" in name and (wf & 1) and (wf & 32) and cin == 256 and side >= 160      # head as a launch of its own
         fold = rpn_fold or "rpn" not in name and (((wf & 1) and M and ((cin == 256 and side >= 160) or (cin == 128 and side >= 80))) or ((wf & 2) and not M) or
                                       ((wf & 4) and M and cin == 256 and side >= 80) or ((wf & 8) and M and side >= 40) or ((wf & 16) and M))
-        if fold and cin in (128, 256) and N % 64 == 0:
+        if fold and cin in (128, 256, 512) and N % 64 == 0:
             return 2, "winograd F(4x4) folded"
         return 3, "winograd F(4x4)"
     return 2, "winograd F(2x2)"

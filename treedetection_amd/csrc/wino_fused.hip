@@ -24,6 +24,15 @@
 // constants 2, 4, 8) instead of column by column: |error| vs float64 stays at the F(4x4) level (tests/test_conv_gpu.py keeps
 // the 5e-5 * max|y| bound), every engine-level fp32 tolerance unchanged. Which layers take this form is a FIXED rule on the
 // layer shape (engine.cpp), never a timing decision: it rounds differently from the three-launch form.
+//
+// Round 5 — the same kernel for grids that cannot fill the chip and for 512 channels. NWT = tile-waves per block: 4 (the geometry
+// above: 64 tiles, 512 threads) or 2 (32 tiles x 64 channels, 256 threads = 2 tile halves x 2 channel halves; per WAVE nothing
+// changes — 16 tiles x 32 channels, the same fragments, MFMAs, fold and stores — a block just has half the rows: a layer of
+// 1 352 tiles x 256 channels (res4 conv2, FPN output 4 at batch 8) is 172 blocks instead of 88 on 256 CUs). KREP = ring passes
+// per plane: a plane of C / 32 chunks no longer has to equal the NS LDS stages — C = 256 on a 4-stage ring (48 KB: two 256-thread
+// blocks per CU) is two passes, C = 512 four; the fold slices ride in the first pass only. Every output element sees the same
+// chunks in the same order through the same instruction in every variant: NWT / NS / KREP are bit-identical to each other
+// (tests/test_conv_gpu.py), so the launcher may pick them by the launch's size.
 #include "common.h"
 #include "conv_tiles.h"
 #include <utility>
@@ -41,8 +50,7 @@ struct WinoFusedArgs {
     long long T;           // tiles of the full batch = plane stride in rows
 };
 
-constexpr int WF_BT = 64, WF_BN = 64;            // tiles x output channels per block
-constexpr int WF_STAGE = (WF_BT + WF_BN) * CHUNK_BYTES;      // 16 KB: V rows then U rows
+constexpr int WF_BN = 64;                        // output channels per block; tiles per block = 16 NWT
 
 // A^T of F(4x4,3x3), [i][component]: the fold's coefficients, looked up per plane (wave-uniform scalar loads)
 __constant__ float WF_AT[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -2.f, 0.f}, {0.f, 1.f, 1.f, 4.f, 4.f, 0.f}, {0.f, 1.f, -1.f, 8.f, -8.f, 1.f}};
@@ -58,10 +66,15 @@ __device__ __forceinline__ void wf_static_for(F&& f) {
 
 // VAR (TD_WF_VAR) = timing diagnostics with WRONG results: bit 3 = no DMA inside the loop, bit 4 = no MFMAs, bit 5 = no fragment
 // reads, bit 6 = no barriers
-template <int NS, int VAR>
-__global__ __launch_bounds__(512, 2) void wino43_fused_kernel(const WinoFusedArgs a) {
+template <int NS, int KREP, int NWT, int VAR>
+__global__ __launch_bounds__(NWT * 128, 2) void wino43_fused_kernel(const WinoFusedArgs a) {
     constexpr int AHEAD = NS - 1;                     // chunks of DMA in flight; NS LDS stages (see the WAR argument at the barrier)
-    static_assert((NS == 4 || NS == 8) && NS * WF_STAGE <= 160 * 1024, "pipeline depth");
+    constexpr int WF_BT = 16 * NWT, THREADS = 128 * NWT;
+    constexpr int DROWS = THREADS / 8;                // rows one block-wide DMA instruction moves (= WF_BT)
+    constexpr int NU = WF_BN / DROWS;                 // DMA instructions per chunk for the 64 U rows: 1 (NWT = 4) or 2 (NWT = 2)
+    constexpr int NDMA = 1 + NU;                      // per wave and chunk: what the counted waits count in
+    constexpr int WF_STAGE = (WF_BT + WF_BN) * CHUNK_BYTES;      // V rows then U rows: 16 KB (NWT = 4) / 12 KB (NWT = 2)
+    static_assert((NWT == 2 || NWT == 4) && (NS == 4 || NS == 8) && KREP >= 1 && NS * WF_STAGE <= 160 * 1024 && DROWS == WF_BT, "geometry");
     __shared__ __attribute__((aligned(16))) char lds[NS * WF_STAGE];
 
     const int TH = (a.H + 3) >> 2, TW = (a.W + 3) >> 2;
@@ -80,8 +93,8 @@ __global__ __launch_bounds__(512, 2) void wino43_fused_kernel(const WinoFusedArg
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wt = wave & 3, wc = wave >> 2;
-    const int KC = NS;                                // k-chunks of 32 floats per plane: C = 32 NS (launcher)
+    const int wt = wave & (NWT - 1), wc = wave / NWT;
+    constexpr int KC = NS * KREP;                     // k-chunks of 32 floats per plane: C = 32 NS KREP (launcher)
 
     // ---- LDS-DMA source offsets (bytes into V / U; rows past the live tiles read beyond num_records → zeros) ----
     constexpr unsigned OOB = 0xfffffff0u;
@@ -89,11 +102,11 @@ __global__ __launch_bounds__(512, 2) void wino43_fused_kernel(const WinoFusedArg
     const unsigned planeV = (unsigned)((unsigned long long)a.T * row_bytes), planeU = (unsigned)a.N * row_bytes;
     const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.V), 0, (int)(36u * planeV), 0x00020000);
     const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.U), 0, (int)(36u * planeU), 0x00020000);
-    const int ld_c = tid & 7, ld_r = tid >> 3;       // 16-B piece, row 0..63 (a wave instruction = 8 rows x 128 B)
+    const int ld_c = tid & 7, ld_r = tid >> 3;       // 16-B piece, row 0..DROWS-1 (a wave instruction = 8 rows x 128 B)
     const unsigned src_piece = (unsigned)(ld_c ^ ((ld_r >> 1) & 7)) * 16u;
     const bool v_ok = t0 + ld_r < live;
     const unsigned v_off = (unsigned)(t0 + ld_r) * row_bytes + src_piece;
-    const unsigned u_off = (unsigned)(n0 + ld_r) * row_bytes + src_piece;
+    const unsigned u_off = (unsigned)(n0 + ld_r) * row_bytes + src_piece;       // (+ DROWS rows for the second U instruction: same swizzle, DROWS % 16 == 0)
     typedef __attribute__((address_space(3))) void lds_void;
     char* const dstV = lds + wave * 8 * CHUNK_BYTES;
     char* const dstU = lds + WF_BT * CHUNK_BYTES + wave * 8 * CHUNK_BYTES;
@@ -103,6 +116,8 @@ __global__ __launch_bounds__(512, 2) void wino43_fused_kernel(const WinoFusedArg
         constexpr int ST = decltype(st_c)::value;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(dstV + ST * WF_STAGE), 16, v_ok ? v_off + ld_v : OOB, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(dstU + ST * WF_STAGE), 16, u_off + ld_u, 0, 0, 0);
+        if constexpr (NU == 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(dstU + ST * WF_STAGE + DROWS * CHUNK_BYTES), 16, u_off + (unsigned)DROWS * row_bytes + ld_u, 0, 0, 0);
         ld_v += CHUNK_BYTES;
         ld_u += CHUNK_BYTES;
         if (++ld_kc == KC) {                          // next plane
@@ -203,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void wino43_fused_kernel(const WinoFusedArg
 
     // ---- prologue: chunks 0 .. AHEAD-1 in flight (stages 0 .. AHEAD-1); chunk 0 landed and its first half-fragment read ----
     wf_static_for<AHEAD>([&](auto i_c) __attribute__((always_inline)) { issue(i_c); });          // KC % NS == 0 (launcher): the stream is longer than the pipeline
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AHEAD - 1)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (AHEAD - 1)) : "memory");
     __builtin_amdgcn_s_barrier();
     Frag f0, f1;
     if constexpr (VAR & 32) {
@@ -222,24 +237,34 @@ __global__ __launch_bounds__(512, 2) void wino43_fused_kernel(const WinoFusedArg
     // writes zeros into stages nobody reads again — no tail variant of the loop; the wave drains its DMAs before it ends.
     // XC = this plane's component (its accumulators: set XC & 1). Its first two steps carry the fold of the plane before it
     // (component (XC + 5) % 6, set (XC + 1) & 1): step 0 the S slices, step 1 — when that plane closed a row — the row's Y slices.
-    auto plane = [&](auto xc_c) __attribute__((always_inline)) {
+    // FOLD = the plane's first ring pass (it carries the fold slices of the plane before it); the KREP - 1 further passes of a
+    // plane longer than the ring run the same steps with empty fillers.
+    auto ring_pass = [&](auto xc_c, auto fold_c) __attribute__((always_inline)) {
         constexpr int XC = decltype(xc_c)::value, SET = XC & 1, PXC = (XC + 5) % 6;
+        constexpr bool FOLD = decltype(fold_c)::value;
         wf_static_for<NS>([&](auto st_c) __attribute__((always_inline)) {
             constexpr int ST = decltype(st_c)::value, NEXT = (ST + 1) % NS;
             auto filler = [&](auto slot_c) __attribute__((always_inline)) {
-                if constexpr (ST == 0) fold_s(std::integral_constant<int, PXC>{}, std::integral_constant<int, 1 - SET>{}, slot_c);
-                if constexpr (ST == 1 && PXC == 5) fold_y(slot_c);
+                if constexpr (FOLD && ST == 0) fold_s(std::integral_constant<int, PXC>{}, std::integral_constant<int, 1 - SET>{}, slot_c);
+                if constexpr (FOLD && ST == 1 && PXC == 5) fold_y(slot_c);
             };
             if constexpr (!(VAR & 8)) issue(std::integral_constant<int, (ST + AHEAD) % NS>{});
             read_frag(f1, st_c, pc1);
             mma(f0, std::integral_constant<int, SET>{}, filler, std::integral_constant<int, 0>{});
-            if constexpr (!(VAR & 8)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AHEAD - 1)) : "memory");
+            if constexpr (!(VAR & 8)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (AHEAD - 1)) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(VAR & 64)) __builtin_amdgcn_s_barrier();
             read_frag(f0, std::integral_constant<int, NEXT>{}, pc0);
             mma(f1, std::integral_constant<int, SET>{}, filler, std::integral_constant<int, 4>{});
         });
+    };
+    auto plane = [&](auto xc_c) __attribute__((always_inline)) {
+        ring_pass(xc_c, std::true_type{});
+        if constexpr (KREP > 1) {
+#pragma unroll 1
+            for (int rep = 1; rep < KREP; ++rep) ring_pass(xc_c, std::false_type{});
+        }
     };
     for (int xr = 0; xr < 6; ++xr) {
         // coefficients of the row that closed before this one (none before row 0: S is zero and so are they)
@@ -300,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void wino43_fused_kernel(const WinoFusedArg
 
 bool wino43_fused_ok(int B, int H, int W, int C, int N) {
     const long long T = (long long)B * ((H + 3) / 4) * ((W + 3) / 4);
-    return (C == 128 || C == 256) && N >= WF_BN && N % WF_BN == 0 && 36ull * (unsigned long long)T * C * 4 < 0xfffffff0ull - (1u << 20) &&
+    return (C == 128 || C == 256 || C == 512) && N >= WF_BN && N % WF_BN == 0 && 36ull * (unsigned long long)T * C * 4 < 0xfffffff0ull - (1u << 20) &&
            36ull * (unsigned long long)N * C * 4 < 0xfffffff0ull - (1u << 20) && (unsigned long long)B * H * W * N * 4 < 0xfffffff0ull - (1u << 20);
 }
 
@@ -308,30 +333,53 @@ bool wino43_fused_ok(int B, int H, int W, int C, int N) {
 td_status wino43_fused_launch(const float* V, const float* U, int B, int H, int W, int C, int N, const float* scale, const float* bias,
                               int relu, float* y, const int* m_dyn, hipStream_t s) {
     TD_REQUIRE(V && U && y && B >= 1 && H >= 1 && W >= 1, "winograd F(4x4) fused contraction: bad arguments");
-    TD_REQUIRE(wino43_fused_ok(B, H, W, C, N), "winograd F(4x4) fused contraction: needs C = 128 or 256, N %% 64 == 0 and planes below 4 GB (C %d, N %d)", C, N);
+    TD_REQUIRE(wino43_fused_ok(B, H, W, C, N), "winograd F(4x4) fused contraction: needs C = 128, 256 or 512, N %% 64 == 0 and planes below 4 GB (C %d, N %d)", C, N);
     WinoFusedArgs a{};
     a.V = V; a.U = U; a.scale = scale; a.bias = bias; a.y = y; a.m_dyn = m_dyn;
     a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.relu = relu;
     a.T = (long long)B * ((H + 3) / 4) * ((W + 3) / 4);
-    const long long blocks = ((a.T + WF_BT - 1) / WF_BT) * (N / WF_BN);
+    // Block geometry by the launch's size (every variant gives the same bits): 64-tile blocks where they fill the chip — at
+    // least one block per CU —, else 32-tile blocks (res4 / res5 conv2, FPN output 4 / 5 at batch 8: 88 - 104 blocks of 64 tiles
+    // on 256 CUs). C = 512 always takes them (a 4-stage ring, four passes per plane). TD_WF_NWT = 2 / 4 forces one (tests, probes).
+    static const int num_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 64) n = 256;
+        return n;
+    }();
+    const long long blocks64 = ((a.T + 63) / 64) * (N / WF_BN);
+    int nwt = (C == 512 || (blocks64 < num_cu && !m_dyn)) ? 2 : 4;
+    if (const char* f = getenv("TD_WF_NWT")) {
+        const int v = atoi(f);
+        if ((v == 2 || v == 4) && !(v == 4 && C == 512)) nwt = v;
+    }
+    const long long blocks = ((a.T + 16 * nwt - 1) / (16 * nwt)) * (N / WF_BN);
     TD_REQUIRE(blocks < (1ll << 31), "winograd F(4x4) fused contraction: grid too large");
-    // a plane = C / 32 chunk-steps = the LDS stages of the unrolled loop: 8 (C = 256: seven chunks of DMA in flight, 128 KB) or 4 (C = 128)
-    const bool s8 = C == 256;
-#define TD_WF_LAUNCH(NSV, VARV) hipLaunchKernelGGL((wino43_fused_kernel<NSV, VARV>), dim3((unsigned)blocks), dim3(512), 0, s, a)
+#define TD_WF_LAUNCH(NSV, KREPV, NWTV, VARV) hipLaunchKernelGGL((wino43_fused_kernel<NSV, KREPV, NWTV, VARV>), dim3((unsigned)blocks), dim3(128 * NWTV), 0, s, a)
 #if defined(TD_WF_DIAG)     // timing builds only (tools/wino_fold_probe.py builds this file with -DTD_WF_DIAG into /tmp; never shipped): TD_WF_VAR picks an ablation
     const int var = getenv("TD_WF_VAR") ? atoi(getenv("TD_WF_VAR")) : 0;
-    switch (var) {
-        case 8: TD_WF_LAUNCH(8, 8); break;        // wrong results: no DMA in the loop
-        case 16: TD_WF_LAUNCH(8, 16); break;      // no MFMAs
-        case 32: TD_WF_LAUNCH(8, 32); break;      // no fragment reads
-        case 40: TD_WF_LAUNCH(8, 40); break;      // MFMAs + barriers (+ fold) only
-        case 104: TD_WF_LAUNCH(8, 104); break;    // MFMAs (+ fold) only
-        default: if (s8) TD_WF_LAUNCH(8, 0); else TD_WF_LAUNCH(4, 0); break;
+    if (var && C == 256 && nwt == 4) {
+        switch (var) {
+            case 8: TD_WF_LAUNCH(8, 1, 4, 8); break;        // wrong results: no DMA in the loop
+            case 16: TD_WF_LAUNCH(8, 1, 4, 16); break;      // no MFMAs
+            case 32: TD_WF_LAUNCH(8, 1, 4, 32); break;      // no fragment reads
+            case 40: TD_WF_LAUNCH(8, 1, 4, 40); break;      // MFMAs + barriers (+ fold) only
+            case 104: TD_WF_LAUNCH(8, 1, 4, 104); break;    // MFMAs (+ fold) only
+            default: TD_WF_LAUNCH(8, 1, 4, 0); break;
+        }
+        TD_KERNEL_CHECK();
+        return TD_OK;
     }
-#else
-    if (s8) TD_WF_LAUNCH(8, 0);
-    else TD_WF_LAUNCH(4, 0);
 #endif
+    // a plane = C / 32 chunk-steps = NS LDS stages x KREP ring passes. 64-tile blocks: 8 stages at C = 256 (seven chunks of DMA in
+    // flight, 128 KB, one block per CU), 4 at C = 128; 32-tile blocks: 4 stages of 12 KB (two blocks per CU)
+    if (nwt == 4) {
+        if (C == 256) TD_WF_LAUNCH(8, 1, 4, 0);
+        else TD_WF_LAUNCH(4, 1, 4, 0);
+    } else {
+        if (C == 512) TD_WF_LAUNCH(4, 4, 2, 0);
+        else if (C == 256) TD_WF_LAUNCH(4, 2, 2, 0);
+        else TD_WF_LAUNCH(4, 1, 2, 0);
+    }
 #undef TD_WF_LAUNCH
     TD_KERNEL_CHECK();
     return TD_OK;

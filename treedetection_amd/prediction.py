@@ -430,6 +430,8 @@ class Predictor:
             slot.event.synchronize()
             t1 = time.perf_counter()
             self._mark("epi", i)
+            if i == 0:
+                self._mark("batch_done", getattr(slot, "mark_id", -1))      # the batch's results have left the GPU (first worker to see it)
             host = slot.host
             output_file = os.path.join(pred_subdir, f"Prediction_{os.path.basename(b['tile_id'])}.json")
             n = int(host["count"][i])
@@ -590,6 +592,7 @@ class Predictor:
             if isinstance(batch, BaseException):
                 item["failed"], item["batch"] = batch, []
             launched += 1
+            slot.mark_id = launched - 1
             self._mark("launch", launched - 1)
             t0 = time.perf_counter()
             slot.side = stream               # where finish() enqueues this batch's copies / gather
