@@ -676,9 +676,18 @@ def main():
             if world > 1:
                 dist.barrier()
             dt_pt = time.perf_counter() - t0
+            # the same walk once more WITHOUT stitching (same predictor, same images, files rewritten): what the stitching costs
+            # the walk it runs beside
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            DT.walk_images(config, pred, mine, tiles_pt, out_pred, chain=True, stitch_to=None)
+            if world > 1:
+                dist.barrier()
+            dt_plain = time.perf_counter() - t0
         finally:
             pred.close()
-        tm = torch.tensor([dt_pt, t_walk, rep["stitch_seconds"]], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        tm = torch.tensor([dt_pt, t_walk, rep["stitch_seconds"], dt_plain], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         if world > 1:
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         res = None
@@ -689,7 +698,8 @@ def main():
             files = sum(len(os.listdir(f"{out_pred}/{nm}")) for nm in names)
             res = {"value": n_img * fx["ntiles"] / float(tm[0]), "unit": "tiles/s", "images": n_img, "images_per_rank": per_rank,
                    "tiles_per_image": fx["ntiles"], "batch": Bp, "seconds": float(tm[0]), "walk_seconds_max": float(tm[1]),
-                   "stitch_thread_seconds_max": float(tm[2]), "prediction_files": files, "layers": len(layers), "layer_bytes": nbytes,
+                   "stitch_thread_seconds_max": float(tm[2]), "same_walk_without_stitching_seconds": float(tm[3]),
+                   "predict_only_value": n_img * fx["ntiles"] / float(tm[3]), "prediction_files": files, "layers": len(layers), "layer_bytes": nbytes,
                    "sharding": "single process" if world == 1 else f"whole images over {world} ranks (detection.assign_images), no collective in the walk",
                    "note": "files to GeoPackage layers: window reads, H2D, resize, forward, paste, contours, Prediction_*.json, then per image "
                            "simplify + edge filter + <image>.gpkg on host threads while the next image predicts; + the resume files"}
