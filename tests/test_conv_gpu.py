@@ -137,7 +137,7 @@ def test_conv_pp8_equals_the_reference_tile_bit_for_bit(case, cfg256):
     assert np.abs(ref).max() > 0.5
 
 
-@pytest.mark.parametrize("cfg", [4, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 31, 32, 34, 35, 36])
+@pytest.mark.parametrize("cfg", [4, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 31, 32])
 def test_conv_every_block_tile_variant(cfg):
     """The engine picks a block tile per layer by measurement; every variant must compute the same convolution.
     TD_CONV_CFG forces one variant for a whole process (diagnostic hook), so the cases above re-run in a child."""
@@ -151,30 +151,6 @@ def test_conv_every_block_tile_variant(cfg):
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert f"{len(CASES) + len(FP16_CASES)} passed" in r.stdout
-
-
-@pytest.mark.parametrize("cfg", [34, 35, 36])
-def test_odd_row_tiles_equal_the_reference_tile_bit_for_bit(cfg):
-    """Tile ids 34 - 36 (96- and 160-row conv_igemm tiles, fp32, round 5) against tile id 0 (128 x 128) on the layer shapes they are
-    for and on ragged ones: the same k order through the same MFMA — bit for bit, so the tuner may pick them per launch shape
-    without touching the engine's batch invariance."""
-    cases = [(8, 1024, 50, 50, 256, 1, 1, 0, True, False),        # res4 conv1 (B, Cin, H, W, Cout, k, stride, pad, relu, residual)
-             (8, 2048, 25, 25, 512, 1, 1, 0, True, False),        # res5 conv1
-             (2, 96, 23, 17, 200, 1, 1, 0, False, True),          # ragged rows / columns, same-size residual
-             (1, 64, 31, 29, 136, 3, 1, 1, True, False),          # a 3x3 with padding
-             (3, 512, 13, 13, 256, 1, 2, 0, True, False)]         # stride 2
-    for (B, Cin, H, W, Cout, k, stride, pad, relu, use_res) in cases:
-        rng = np.random.default_rng(Cin + H)
-        x = rng.standard_normal((B, Cin, H, W), dtype=np.float32)
-        w = rng.standard_normal((Cout, Cin, k, k), dtype=np.float32) / np.float32(np.sqrt(Cin * k * k))
-        scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
-        bias = rng.standard_normal(Cout).astype(np.float32)
-        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-        res = rng.standard_normal((B, Cout, Ho, Wo), dtype=np.float32) if use_res else None
-        outs = []
-        for c in (0, cfg):
-            outs.append(conv2d_hip(x, w, scale, bias, res, stride=stride, pad=pad, relu=relu, tile_cfg=c))
-        assert np.isfinite(outs[1]).all() and (outs[0] == outs[1]).all(), (cfg, B, Cin, H, W, Cout)
 
 
 WINO_CASES = [

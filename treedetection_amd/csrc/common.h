@@ -100,9 +100,7 @@ static inline bool conv_head_capable(int cfg, int precision) {
 // 29 / 30 = conv_bd_kernel 128x256 / 128x128, three k-steps of loads in flight: taller tiles, half the filter re-reads (round 4)
 // 31 / 32 = conv_igemm_kernel 256x32 / 128x32 (4 x 1 waves): layers with at most 32 output channels (round 4)
 // 33 = conv_bs_kernel (conv_bstat.hip, round 4): filter-stationary 1x1 for the thin-K layers (<= 4 k-chunks), one block per CU
-// 34 / 35 / 36 = conv_igemm_kernel 96x128 / 160x128 (1 x 4 waves) / 96x128 (1 x 2 waves), fp32 (round 5): row counts that put M = 5 000 /
-// 20 000 rows on 256 CUs in ONE round (res5 conv1, res4 conv1, FPN lateral 4 / 5) where 128-row tiles leave 58 CUs with two blocks
-#define TD_CONV_TILE_CFG_MAX 36
+#define TD_CONV_TILE_CFG_MAX 33
 static inline bool conv_cfg_is_bd(int cfg) { return (cfg >= 23 && cfg <= 27) || cfg == 29 || cfg == 30 || cfg == 33; }      // tiles that read the fragment-ordered filter copy
 // Tried in this order — from the tile that moves the fewest bytes per FLOP to the one that moves the most — and a later candidate
 // replaces the best so far only when it is more than TD_TUNE_HYST percent faster (default 2): among tiles that tie within the
@@ -110,8 +108,7 @@ static inline bool conv_cfg_is_bd(int cfg) { return (cfg >= 23 && cfg <= 27) || 
 // passes report) from flipping between runs — fc1 was seen on the 128 x 128 tile in one run and on a 64 x 128 tile (+2 GB of filter
 // re-reads per step, same time) in the next.
 // 15 / 16 only for <= 4 k-steps, 17 only for fp16, 18-20 only for plane contractions, 23-27 / 29 / 30 / 33 only with packed filters, 31 / 32 only for <= 32 output channels, 33 only where conv_bs_ok
-// 34-36 only for fp32
-static const int TD_CONV_TUNE_CANDIDATES[] = {33, 10, 17, 29, 16, 0, 35, 15, 30, 34, 36, 23, 27, 1, 2, 24, 25, 26, 31, 3, 32, 18, 19, 20};
+static const int TD_CONV_TUNE_CANDIDATES[] = {33, 10, 17, 29, 16, 0, 15, 30, 23, 27, 1, 2, 24, 25, 26, 31, 3, 32, 18, 19, 20};
 td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream);
 // a.nlev levels (x / w / bias / y / head_y / H / W filled in; M, tile0, ntiles are computed here) in one conv_pp8_kernel grid;
 // everything else (B, Cin, Cout = 256, KH = KW = 3, relu, head_w / head_b / head_n) from the common fields. Bit-identical to one

@@ -1005,21 +1005,6 @@ td_status dispatch(const ConvArgs& a, int cfg, hipStream_t stream) {
         // quarters of its MFMAs on padding — the RPN head at p2 (M = 320 000, K = 256) was MFMA-bound on it (round 4)
         case 31: return launch<T, TO, 2, 1, 2, 4, 1>(a, stream);    // 256 x 32, 4 waves of 64 x 32
         case 32: return launch<T, TO, 1, 1, 2, 4, 1>(a, stream);    // 128 x 32, 4 waves of 32 x 32
-        // row counts that are not a power of two (round 5, fp32): M = 20 000 rows x 256 channels (res4 conv1, FPN lateral 4) is 314 tiles
-        // of 128 x 128 on 256 CUs — the 58 CUs that hold two of them finish last — or 1 252 tiles of 64 x 64 that re-read operands; 125 x 2
-        // tiles of 160 x 128 are ONE round. Likewise 96-row tiles for M = 5 000 (res5 conv1: 53 x 4 = 212 blocks; lateral 5: 96 x 64).
-        // Waves side by side along N (1 x 4 / 1 x 2), each owning all rows of the tile x 32 columns.
-        case 34:
-        case 35:
-        case 36:
-            if constexpr (std::is_same<T, float>::value && std::is_same<TO, float>::value) {
-                if (cfg == 34) return launch<T, TO, 3, 1, 2, 1, 4>(a, stream);     // 96 x 128, 4 waves of 96 x 32
-                if (cfg == 35) return launch<T, TO, 5, 1, 2, 1, 4>(a, stream);     // 160 x 128, 4 waves of 160 x 32
-                return launch<T, TO, 3, 2, 2, 1, 2>(a, stream);                    // 96 x 128, 2 waves of 96 x 64
-            } else {
-                td_set_error("conv2d: tile_cfg 34-36 are fp32 kernels");
-                return TD_ERR_INVALID;
-            }
         case 17:                                                     // 256 x 256, 8 waves, ping-pong phases (fp16 only)
             if constexpr (std::is_same<T, _Float16>::value) {
                 const int tiles = td_cdiv(a.M, 256) * td_cdiv(a.Cout, 256);
@@ -1119,7 +1104,6 @@ td_status conv2d_launch(const ConvArgs& a, int precision, hipStream_t stream) {
     }
     const bool no_fp16_tile = precision != TD_PRECISION_FP16 || a.out_mode != 0 || a.batch_count > 1;
     if (cfg == 17 && no_fp16_tile) cfg = -1;                       // fp16-only variant
-    if (cfg >= 34 && cfg <= 36 && precision != TD_PRECISION_FP32) cfg = -1;     // fp32-only tiles
     if (cfg == 28 && (no_fp16_tile || a.m_dyn)) cfg = -1;          // fp16-only, static row counts only
     if (cfg >= 18 && cfg <= 20 && !conv_plane_ok(a, precision)) cfg = -1;                                       // plane contractions only
     if (cfg == 33 && !conv_bs_ok(a, precision)) cfg = -1;                                                       // thin 1x1 layers with packed filters only

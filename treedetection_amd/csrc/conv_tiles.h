@@ -238,8 +238,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
         constexpr int ITERS = (RWM * WROW) / ROWS_PER_PASS;
         static_assert((RWM * WROW) % ROWS_PER_PASS == 0 && ITERS >= 1, "epilogue rows must split evenly over the threads");
         constexpr int UMAX = CPL == 8 ? 4 : 8;         // 64 B per lane in flight either way
-        // (the 96- / 160-row tiles of round 5 give ITERS = 12 / 20 / 24 / 40: the batch is the largest divisor within the budget)
-        constexpr int U = ITERS < UMAX ? ITERS : (ITERS % UMAX == 0 ? UMAX : (ITERS % 5 == 0 && UMAX >= 5 ? 5 : (ITERS % 4 == 0 ? 4 : (ITERS % 3 == 0 ? 3 : (ITERS % 2 == 0 ? 2 : 1)))));
+        constexpr int U = ITERS < UMAX ? ITERS : UMAX;
         static_assert(ITERS % U == 0, "epilogue batch must divide the rows per thread");
         typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
         typedef typename std::conditional<sizeof(T) == 4, f32x4, typename std::conditional<CPL == 8, f16x8v, f16x4>::type>::type ResVec;

@@ -905,7 +905,6 @@ td_status forward_impl(td_engine* e, unsigned phase_mask, hipStream_t s) {
             if (conv_cfg_is_bd(c) && !bd_ok) continue;          // filter-direct tiles: layers with a fragment-ordered filter copy
             if (c == 33 && !(std::get<2>(key) == 17 && (std::get<4>(key) & ~1) == 4 && std::get<0>(key) >= 128 && ksteps <= 4 && ksteps != 3)) continue;      // filter-stationary: 1x1, stride 1, plain output, <= 4 k-chunks
             if ((c == 31 || c == 32) && std::get<0>(key) > 32) continue;      // 32-column tiles: the thin heads only
-            if (c >= 34 && c <= 36 && (prec_ != TD_PRECISION_FP32 || std::get<0>(key) < 128)) continue;      // 96- / 160-row tiles: fp32, >= 128 output channels
             float ms = 1e30f;
             td_status st2 = time_launch(s_, ea, eb, [&]() { return launch_cfg(c); }, &ms);
             if (st2 < 0) {

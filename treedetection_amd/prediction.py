@@ -27,8 +27,8 @@ from .geotiff import GeoTiff
 from .weights import load_checkpoint
 
 
-TILE_TABLE_VERSION = 13      # bump when the tile ids of csrc/conv_igemm.hip:dispatch() change meaning, the candidate set grows or the
-                             # tuner's timing method changes (12: ids 29-33, id 28 retired, cold-L2 timing + hysteresis; 13: ids 34-36)
+TILE_TABLE_VERSION = 12      # bump when the tile ids of csrc/conv_igemm.hip:dispatch() change meaning, the candidate set grows or the
+                             # tuner's timing method changes (12: ids 29-33, id 28 retired, cold-L2 timing + hysteresis)
 
 
 def _tune_cache_path(device_index: int) -> str:
