@@ -460,7 +460,13 @@ extern "C" int td_stitch_tile_files(const char* paths, const int64_t* path_offse
         std::vector<int64_t> offs;
         std::vector<double> sc;
     };
-    std::vector<Part> parts((size_t)n_files);
+    std::vector<Part> parts;
+    try {
+        parts.resize((size_t)n_files);
+    } catch (...) {
+        td_set_error("td_stitch_tile_files: out of memory for %d files", n_files);
+        return TD_ERR_INVALID;
+    }
     std::atomic<int> next{0};
     auto work = [&]() {
         std::vector<char> text;
@@ -475,12 +481,22 @@ extern "C" int td_stitch_tile_files(const char* paths, const int64_t* path_offse
             text.clear();
             char buf[1 << 16];
             size_t got;
-            while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) text.insert(text.end(), buf, buf + got);
-            const bool rerr = std::ferror(f) != 0;
+            bool rerr = false;
+            try {
+                while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) text.insert(text.end(), buf, buf + got);
+            } catch (...) {
+                rerr = true;
+            }
+            rerr = rerr || std::ferror(f) != 0;
             std::fclose(f);
             if (rerr) { file_status[i] = TD_ERR_INVALID; continue; }
-            const int st = stitch_text("td_stitch_tile_files", text.data(), (int64_t)text.size(), boxes + 4 * (size_t)i, tolerance, srs_ids[i],
-                                       pt.out, pt.offs, pt.sc);
+            int st;
+            try {       // no exception may leave a worker thread (std::terminate) or cross the C ABI: an allocation failure fails this file
+                st = stitch_text("td_stitch_tile_files", text.data(), (int64_t)text.size(), boxes + 4 * (size_t)i, tolerance, srs_ids[i],
+                                 pt.out, pt.offs, pt.sc);
+            } catch (...) {
+                st = TD_ERR_INVALID;
+            }
             if (st < 0) {           // the file is left out (the reference's try / except around each tile file, helpers.py:419-476)
                 pt.out.clear();
                 pt.offs.assign(1, 0);
@@ -492,11 +508,13 @@ extern "C" int td_stitch_tile_files(const char* paths, const int64_t* path_offse
         }
     };
     const int nt = std::max(1, std::min(threads, std::max(n_files, 1)));
-    if (nt == 1) {
-        work();
-    } else {
+    {
         std::vector<std::thread> pool;
-        for (int t = 0; t < nt; ++t) pool.emplace_back(work);
+        try {
+            for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+        } catch (...) {       // no more threads to be had: the calling thread (and those that did start) do all the files
+        }
+        work();
         for (auto& t : pool) t.join();
     }
     int64_t bytes = 0, feats = 0;

@@ -15,6 +15,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
+import threading
 from concurrent.futures import ThreadPoolExecutor, as_completed
 from pathlib import Path
 from typing import List, Tuple
@@ -282,6 +283,7 @@ class EagerStitcher:
         self._threads = max(1, int(workers))
         self._futures = {}
         self.seconds = 0.0
+        self._seconds_lock = threading.Lock()
 
     def submit(self, folder_json: str) -> None:
         name = os.path.splitext(folder_json)[0]
@@ -296,7 +298,8 @@ class EagerStitcher:
         t0 = time.perf_counter()
         tiles_path, pred_fold, output_path, shift, tol, logger = self.args
         out = process_folder_sync(folder_json, tiles_path, pred_fold, output_path, shift, tol, logger, threads=self._threads)
-        self.seconds += time.perf_counter() - t0
+        with self._seconds_lock:
+            self.seconds += time.perf_counter() - t0
         return out
 
     def close(self) -> List[str]:
