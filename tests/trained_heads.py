@@ -20,12 +20,14 @@ fit needs only the oracle (test infrastructure) and the tile generator, is deter
 tile. The fixture is conditioned ON the tiles it is evaluated with: a numerical conditioning device, not a claim about
 generalisation.
 
-What it showed (round 5, tools/fitted_heads_probe.py → profiles/r05_fitted_heads_probe.txt): the fitted detector finds every
-crown with ONE detection each and saturated scores, the fp32 engine reproduces the oracle's set exactly on it — and the fp16
-engine still changes the survivor of 2 - 10 % of the duplicate clusters, at every ridge strength: a linear fit on random
-features regresses a crown's duplicates to within IoU ~0.7 - 0.9 of each other, not onto one box, and saturated scores make
-every cluster a near-tie. It is therefore NOT the basis of a strict set assertion (none is made); the fp16 detection-set
-statement rests on the flip rate measured over 64 tiles (tests/test_engine_fp16_gpu.py).
+What it showed (round 5, tools/fitted_heads_probe.py → profiles/r05_fitted_heads_probe.txt): with the closed-form fits ALONE
+the detector finds every crown with one detection and saturated scores, the fp32 engine reproduces the oracle's set exactly —
+and the fp16 engine still changes the survivor of 2 - 10 % of the duplicate clusters, at every ridge strength: a linear fit on
+random features regresses a crown's duplicates to within IoU ~0.7 - 0.9 of each other, not onto one box, and saturated scores
+make every cluster a near-tie. What removes the flips is a box head that is TRAINED (``train_box_head`` below: fc1, fc2 and the
+predictor by gradient descent on the oracle's RoI features, the RPN's ridge fit kept): every proposal of a crown then lands on
+the crown's box, whichever duplicate survives carries the same box, and the strict set rule of SURVEY §8d holds — 79 of 79
+detections on R50, 78 of 79 on R101 (tests/test_engine_fp16_gpu.py::test_fp16_detection_set_on_a_trained_box_head).
 """
 from __future__ import annotations
 
@@ -227,3 +229,96 @@ class _SplitRidge:
         Wa, ba = self.a.solve(lam)
         Wb, bb = self.b.solve(lam)
         return Wa, ba, Wb, bb
+
+
+# ---- a TRAINED box head (round 5, second attempt at a fixture on which the strict fp16 set rule can hold) ----------------------
+# The closed-form fits above leave the duplicates of a crown within IoU 0.7 - 0.9 of each other. What makes near-tied duplicates
+# harmless in a real detector is a box head that has LEARNT to move every proposal of an object onto the object: then whichever
+# duplicate survives the final NMS carries the same box. So the box head (fc1, fc2, cls_score, bbox_pred: the layers detectron2
+# trains) is trained here by gradient descent — torch autograd on the GPU box's device where there is one (test infrastructure:
+# the product has no backward pass) — on the oracle's RoI features of the fixture's own tiles: the fitted RPN's proposals plus
+# jittered boxes around every crown, class labels by IoU with the crown, box deltas onto the crown. Deterministic (seeded), a
+# few hundred full-batch Adam steps, ~20 s per depth on an MI355X. The trunk, FPN and RPN conv stay seeded random weights.
+def _jittered_boxes(gt: np.ndarray, per_crown: int, rng, hw) -> np.ndarray:
+    out = []
+    for b in gt:
+        w, h = b[2] - b[0], b[3] - b[1]
+        for _ in range(per_crown):
+            s = np.exp(rng.uniform(-0.45, 0.45, 2))
+            dx, dy = rng.uniform(-0.3, 0.3, 2) * (w, h)
+            cx, cy = (b[0] + b[2]) / 2 + dx, (b[1] + b[3]) / 2 + dy
+            out.append([cx - s[0] * w / 2, cy - s[1] * h / 2, cx + s[0] * w / 2, cy + s[1] * h / 2])
+    o = np.asarray(out, dtype=np.float64).reshape(-1, 4)
+    o[:, 0::2] = np.clip(o[:, 0::2], 0, hw[1])
+    o[:, 1::2] = np.clip(o[:, 1::2], 0, hw[0])
+    keep = (o[:, 2] - o[:, 0] > 2) & (o[:, 3] - o[:, 1] > 2)
+    return o[keep]
+
+
+def train_box_head(sd: Dict[str, np.ndarray], tiles: Sequence[int], size: int = 1000, steps: int = 1500, lr: float = 2e-3,
+                   jitter_per_crown: int = 48, seed: int = 0, device=None, verbose: bool = False,
+                   predictor_init: Dict[str, np.ndarray] = None, label_smoothing: float = 0.0) -> Dict[str, np.ndarray]:
+    """→ a copy of ``sd`` (already carrying fitted RPN output layers: call fit_trained_like_heads first) whose box head is
+    trained on the oracle's RoI features of ``tiles`` (see the comment above). ``predictor_init``: a state dict whose
+    ``box_predictor`` tensors the training starts from (the seeded ones: the ridge-fitted predictor has 20 x their norm and
+    keeps amplifying fp16 feature noise through the whole training)."""
+    sd = dict(sd)
+    if predictor_init is not None:
+        for k in list(sd):
+            if k.startswith("roi_heads.box_predictor."):
+                sd[k] = predictor_init[k]
+    inputs = tile_inputs(tiles, size)
+    with torch.no_grad():
+        oracle = MaskRCNNOracle(sd)
+        rng = np.random.default_rng(seed)
+        X, Ycls, Ybox, W = [], [], [], []
+        for k, inp in enumerate(inputs):
+            x, sizes = oracle.batch_images([inp["image"]])
+            feats = oracle.fpn(oracle.backbone(x))
+            gt = crown_boxes(tiles[k], size, sizes[0])
+            logits, deltas = oracle.rpn_head(feats)
+            feat_hw = [tuple(feats[f"p{l}"].shape[-2:]) for l in (2, 3, 4, 5, 6)]
+            props, _ = oracle.rpn_proposals(logits, deltas, feat_hw, sizes)
+            boxes = np.concatenate([props[0][0].astype(np.float64), _jittered_boxes(gt, jitter_per_crown, rng, sizes[0])])
+            pooled, _ = oracle.roi_pool(feats, [boxes.astype(np.float32)], 7)
+            iou = iou_matrix(boxes, gt)
+            best, arg = iou.max(axis=1), iou.argmax(axis=1)
+            fg, bg = best >= 0.5, best < 0.4
+            keep = fg | bg
+            y = np.zeros((len(boxes), 4))
+            y[fg] = box_deltas(boxes[fg], gt[arg[fg]], (10.0, 10.0, 5.0, 5.0))
+            X.append(pooled[0][keep].reshape(int(keep.sum()), -1))
+            Ycls.append(np.where(fg[keep], 0, 1))            # class 0 = the one foreground class, last = background
+            Ybox.append(y[keep])
+            W.append(fg[keep].astype(np.float32))
+            if verbose:
+                print(f"[train_box_head] tile {tiles[k]}: {len(boxes)} boxes, {int(fg.sum())} on a crown, {int(bg.sum())} background")
+    dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+    torch.manual_seed(seed)
+    Xt = torch.from_numpy(np.concatenate(X)).to(dev)
+    yc = torch.from_numpy(np.concatenate(Ycls)).long().to(dev)
+    yb = torch.from_numpy(np.concatenate(Ybox)).float().to(dev)
+    wf = torch.from_numpy(np.concatenate(W)).to(dev)
+    names = ("roi_heads.box_head.fc1", "roi_heads.box_head.fc2", "roi_heads.box_predictor.cls_score", "roi_heads.box_predictor.bbox_pred")
+    P = {n + s: torch.tensor(sd[n + s], device=dev, requires_grad=True) for n in names for s in (".weight", ".bias")}
+    opt = torch.optim.Adam(P.values(), lr=lr, weight_decay=1e-5)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=steps, eta_min=lr * 0.01)
+    lin = torch.nn.functional.linear
+    for it in range(steps):
+        opt.zero_grad()
+        h = torch.relu(lin(Xt, P[names[0] + ".weight"], P[names[0] + ".bias"]))
+        h = torch.relu(lin(h, P[names[1] + ".weight"], P[names[1] + ".bias"]))
+        cls = lin(h, P[names[2] + ".weight"], P[names[2] + ".bias"])
+        reg = lin(h, P[names[3] + ".weight"], P[names[3] + ".bias"])
+        # (label smoothing was tried — 0.05: finite logits, but the regression then converges less far in the same steps and the
+        # fp16 exceptions go from 0 - 1 to 1 - 2 per depth: off)
+        l_cls = torch.nn.functional.cross_entropy(cls, yc, label_smoothing=label_smoothing)
+        l_box = (torch.nn.functional.smooth_l1_loss(reg, yb, beta=0.05, reduction="none").sum(dim=1) * wf).sum() / wf.sum().clamp(min=1)
+        (l_cls + l_box).backward()
+        opt.step()
+        sched.step()
+        if verbose and (it % 100 == 0 or it == steps - 1):
+            print(f"[train_box_head] step {it}: class loss {float(l_cls):.4f}, box loss {float(l_box):.4f}")
+    for k, v in P.items():
+        sd[k] = v.detach().float().cpu().numpy()
+    return sd
