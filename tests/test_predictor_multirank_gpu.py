@@ -64,8 +64,8 @@ def _free_port():
     return p
 
 
-def _run(script, world, timeout=600):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run(script, world, timeout=600, extra_env=None):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     if world == 1:
         subprocess.run([sys.executable, str(script)], check=True, env=env, timeout=timeout)
     else:
@@ -259,3 +259,35 @@ def test_image_level_sharding_two_ranks_equals_one_process(tmp_path):
     assert total > 20
     s1, s2 = (yaml.safe_load(open(o / "geojson_predictions" / "stitching_recovery.yaml")) for o in (outs[1], outs[2]))
     assert s1 == s2 and len(s1["completed_files"]) == 6
+
+
+def test_a_tile_whose_crop_fails_is_dropped_in_every_mode(tmp_path):
+    """Reference prediction.py:174-176: a tile whose crop raises is printed and DROPPED — no Prediction file, the image goes
+    on. Single process, 2 ranks with the "rank0" epilogue (plain and pipelined: the failed tile travels as a black stand-in so
+    that rank 0 can derive every rank's batch structure, with count = -1 in the gather) and 2 ranks with the "local" epilogue
+    (the manifest lists it as dropped): the same files everywhere, the failed tile's file nowhere, nobody raises."""
+    from treedetection_amd.preprocessing import tile_single_file
+    np.savez(tmp_path / "m.npz", **make_synthetic_state_dict(50, seed=3, width_div=2))
+    rgb, _ = make_tile(100, 600)
+    tif = str(tmp_path / "img.tif")
+    write_geotiff(tif, np.ascontiguousarray(rgb.transpose(2, 0, 1)), (0.2, 0, 0, 0, -0.2, 120.0), 25832)
+    tile_single_file(tif, str(tmp_path / "tiles"), buffer=20, tile_width=50, tile_height=50)
+    meta = str(tmp_path / "tiles" / "img.json")
+    ids = list(json.load(open(meta)))
+    bad = ids[4]                                           # rank 0's tile under i = r (mod 2); also try one of rank 1's below
+    outs = {}
+    runs = {"one": (1, {"pipeline": True}, bad), "two_rank0": (2, {"pipeline": False, "sharded_epilogue": "rank0"}, bad),
+            "two_rank0_pipelined": (2, {"pipeline": True, "sharded_epilogue": "rank0"}, bad),
+            "two_local": (2, {"pipeline": True, "sharded_epilogue": "local"}, bad),
+            "two_rank0_other_rank": (2, {"pipeline": True, "sharded_epilogue": "rank0"}, ids[3]), "one_other": (1, {"pipeline": True}, ids[3])}
+    for name, (world, kw, fault) in runs.items():
+        out = str(tmp_path / f"out_{name}")
+        script = tmp_path / f"w_{name}.py"
+        script.write_text(WORKER.format(root=ROOT, model=str(tmp_path / "m.npz"), out=out, tif=tif, meta=meta, batch=3, kw=kw))
+        _run(script, world, extra_env={"TD_FAULT_TILE": fault})
+        outs[name] = {f: open(os.path.join(out, "img", f), "rb").read() for f in sorted(os.listdir(os.path.join(out, "img")))}
+    assert len(outs["one"]) == 8 and f"Prediction_{bad}.json" not in outs["one"]
+    for name in ("two_rank0", "two_rank0_pipelined", "two_local"):
+        assert outs[name] == outs["one"], name                 # same names, same bytes
+    assert len(outs["one_other"]) == 8 and f"Prediction_{ids[3]}.json" not in outs["one_other"]
+    assert outs["two_rank0_other_rank"] == outs["one_other"]

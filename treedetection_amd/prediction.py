@@ -31,6 +31,9 @@ TILE_TABLE_VERSION = 12      # bump when the tile ids of csrc/conv_igemm.hip:dis
                              # tuner's timing method changes (12: ids 29-33, id 28 retired, cold-L2 timing + hysteresis)
 
 
+_FAULT_TILE = os.environ.get("TD_FAULT_TILE", "")      # tests only: the tile id whose crop raises (reference prediction.py:174-176 drops such a tile)
+
+
 def _tune_cache_path(device_index: int) -> str:
     try:
         name = torch.cuda.get_device_name(device_index).replace(" ", "_").replace("/", "_")
@@ -300,6 +303,8 @@ class Predictor:
         """Reference prediction.py:159-176. uint8 rasters: the window is copied (into the pinned ``staging`` buffer at
         ``staging_off`` when given) as it lies in the file, the BGR pick and resize happen on the device."""
         try:
+            if _FAULT_TILE and tile["tile_id"] == _FAULT_TILE:      # fault injection (tests): this tile's crop fails
+                raise OSError(f"injected read failure for tile {tile['tile_id']} (TD_FAULT_TILE)")
             if staging is not None and img.dtype == np.uint8:
                 hwc = img.read_bounds_hwc(tile["bounds"], out=staging, out_off=staging_off)
             else:
