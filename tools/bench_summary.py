@@ -28,3 +28,15 @@ if "r101" in j:
             show("r101 " + k, o)
 if "cpu_baseline" in j:
     print(" cpu_baseline", j["cpu_baseline"]["value"], j["cpu_baseline"]["unit"], j["cpu_baseline"]["cores"], "cores")
+for key in ("two_model", "e2e", "e2e_crowns", "predict_tiles", "predict_tiles_noise"):
+    for p in ("f32", "f16"):
+        o = (j.get(key) or {}).get(p)
+        if not isinstance(o, dict):
+            continue
+        extra = ""
+        if "chained" in o:
+            extra += f"  chained {o['chained']['value']:.0f} ({o['chained'].get('ratio_to_model_stage') or 0:.3f})"
+        if "same_walk_without_stitching_seconds" in o:
+            extra += f"  walk {o['walk_seconds_max']:.3f} s, without stitching {o['same_walk_without_stitching_seconds']:.3f} s, stitch threads {o['stitch_thread_seconds_max']:.3f} s"
+        ratio = o.get("ratio_to_model_stage")
+        print(f" {key + ' ' + p:24s} {o['value']:8.1f} {o.get('unit', 'tiles/s')}" + (f"  ratio {ratio:.3f}" if ratio else "") + extra)
