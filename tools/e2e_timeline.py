@@ -17,7 +17,7 @@ from treedetection_amd.preprocessing import tile_data
 from treedetection_amd.synth import make_tile
 from treedetection_amd.weights import make_synthetic_state_dict
 
-S, B = 1000, 8
+S, B = 1000, int(os.environ.get("TD_TL_BATCH", "8"))      # TD_TL_BATCH: tiles per forward (8 = the bench's batch)
 
 
 def raster(root, side, tiles):
