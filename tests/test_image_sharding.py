@@ -202,3 +202,42 @@ def test_two_ranks_own_whole_images_with_o1_collectives(tmp_path):
     assert s1 == s2 and len(s1["completed_files"]) == 6
     p1, p2 = (yaml.safe_load(open(os.path.join(r, "out", "predictions", "prediction_recovery.yaml"))) for r in (root1, root2))
     assert sorted(os.path.basename(k) for k in p1["files"]) == sorted(os.path.basename(k) for k in p2["files"])
+
+
+def test_walk_images_stitches_as_it_goes_and_respects_the_resume_file(tmp_path):
+    """detection.walk_images, single process: every finished image is handed to the eager stitcher (a failed one is not), the
+    layers exist when the walk returns, and a folder the stitching resume file already lists is neither rebuilt by the eager
+    stitcher nor by the pass afterwards (reference helpers.py:566-571 skips completed folders)."""
+    from treedetection_amd.recoveries import save_stitching_recovery
+    from treedetection_amd.stitching import process_and_stitch_predictions
+    root = str(tmp_path)
+    names = ["c1", "bad2", "c3"]
+    _make_folder(root, names)
+    cfg = _config(root, 0)
+    pred = FakePredictor(None, output_dir=os.path.join(root, "out", "predictions"), sharded_epilogue="rank0")
+    gp = os.path.join(root, "out", "gpkg")
+    os.makedirs(gp)
+    save_stitching_recovery(gp, ["c3.json"], None)                       # c3 counts as stitched already (no layer on disk)
+    paths = [os.path.join(root, "rgb", f"{n}.tif") for n in names]
+    rep = detection.walk_images(cfg, pred, paths, cfg["tiles_path"], pred.output_dir, chain=True, stitch_to=gp)
+    assert [os.path.basename(p) for p in rep["done"]] == ["c1.tif", "c3.tif"] and [os.path.basename(p) for p in rep["failed"]] == ["bad2.tif"]
+    assert rep["stitched"] == ["c1.json"]                                # bad2 failed, c3 was listed as complete
+    assert os.path.exists(os.path.join(gp, "c1.gpkg")) and not os.path.exists(os.path.join(gp, "c3.gpkg"))
+    assert len(_layer_rows(os.path.join(gp, "c1.gpkg"))) == 4
+    # what predict_on_model does next: merge the report into the resume file, then the leftover pass handles bad2 only
+    save_stitching_recovery(gp, ["c3", "c1.json"], None)
+    process_and_stitch_predictions(cfg["tiles_path"], pred.output_dir, gp, max_workers=2, shift=1, simplify_tolerance=0.2, logger=cfg["logger"])
+    assert os.path.exists(os.path.join(gp, "bad2.gpkg")) and _layer_rows(os.path.join(gp, "bad2.gpkg")) == []
+    assert not os.path.exists(os.path.join(gp, "c3.gpkg"))
+    assert yaml.safe_load(open(os.path.join(gp, "stitching_recovery.yaml")))["completed_files"] == ["bad2", "c1", "c3"]
+    # without stitch_to nothing is stitched; chain=False goes through __call__ (which this stand-in refuses: tile-sharded path)
+    rep2 = detection.walk_images(cfg, pred, paths[:1], cfg["tiles_path"], pred.output_dir, chain=True, stitch_to=None)
+    assert rep2["stitched"] == [] and rep2["stitch_seconds"] == 0.0
+    rep3 = detection.walk_images(cfg, pred, paths[:1], cfg["tiles_path"], pred.output_dir, chain=False)
+    assert rep3["done"] == [] and len(rep3["failed"]) == 1               # logged, walk continued
+    assert detection.resolve_shard_by({"shard_by": "image"}, 4, "local", 2) == "image"      # explicit: some ranks idle
+    assert detection.resolve_shard_by({"shard_by": "image"}, 4, "rank0", 9) == "tile"       # needs the local epilogue
+    with __import__("pytest").raises(ValueError):
+        detection.resolve_shard_by({"shard_by": "rows"}, 2, "local", 9)
+    assert detection.engine_batch_size({"precision": "fp16"}, 8) == 8 and detection.engine_batch_size({"precision": "fp16", "fp16_min_batch": 32}, 8) == 32
+    assert detection.engine_batch_size({"precision": "fp32", "fp16_min_batch": 32}, 8) == 8
