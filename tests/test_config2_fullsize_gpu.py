@@ -197,3 +197,78 @@ def test_one_tile_per_model_matches_the_oracle_fp16(two_model_fp16, model, flag,
     # the fp16 run visits exactly the tiles the fp32 run visits
     for f in ("urban_predictions", "forrest_predictions"):
         assert set(os.listdir(root / "output_fp16" / f / "1")) == set(os.listdir(root / "output" / f / "1"))
+
+
+@pytest.fixture(scope="module")
+def two_model_trained(two_model):
+    """The two-model flow once more with detectors whose box heads are TRAINED (tests/trained_heads.py: RPN output layers fitted,
+    fc1 / fc2 / predictor trained by gradient descent on the oracle's RoI features) — each model on the two tiles of the column
+    that ONLY it predicts (the raster is a 3 x 2 grid of generator tiles 300 … 305, so every tile's crowns are known) — through
+    `precision: fp16` into its own output folder."""
+    import treedetection_amd as T
+    from tests.trained_heads import fit_trained_like_heads, train_box_head
+    from treedetection_amd.weights import blob_mask_head
+    root, config, sds, meta = two_model
+    picks, trained = {}, {}
+    for model, flag in (("urban", "only_urban"), ("forest", "only_forest")):
+        tid = sorted(k for k, v in meta.items() if v[flag])[0]
+        minx, miny = (int(p) for p in tid.split("_")[1:3])
+        c, r = (minx - 412000) // 200, ROWS - 1 - (miny - 5318000) // 200
+        picks[model] = (tid, 300 + r * COLS + c)
+        column = [300 + rr * COLS + c for rr in range(ROWS)]                    # the tiles only this model sees
+        base = blob_mask_head(sds[model])
+        trained[model] = train_box_head(fit_trained_like_heads(base, column), column, steps=3000, jitter_per_crown=48, predictor_init=base)
+        np.savez(root / f"model_{model}_trained.npz", **trained[model])
+    cfg = yaml.safe_load((root / "config.yml").read_text())
+    cfg.update(precision="fp16", output_directory=str(root / "output_trained_fp16"),
+               urban_model=str(root / "model_urban_trained.npz"), forrest_model=str(root / "model_forest_trained.npz"))
+    (root / "config_trained_fp16.yml").write_text(yaml.safe_dump(cfg))
+    config16, _ = T.get_config(str(root / "config_trained_fp16.yml"))
+    T.predict_tiles(config16)
+    return root, trained, picks
+
+
+@pytest.mark.parametrize("model,folder", [("urban", "urban_predictions"), ("forest", "forrest_predictions")])
+def test_two_model_flow_fp16_set_rule_on_trained_box_heads(two_model_trained, model, folder):
+    """VERDICT r4 item 2a on the two-model flow (reference detection.py:154-164) at full size: per model, on a tile only THAT
+    model predicts, the fp16 engine against the fp32 oracle with the model's TRAINED box head — every detection clear of the score
+    cut pairs one-to-one at IoU >= 0.9 (at most 2 exceptions on the tile, at least 95 % strict pairs: the bounds of
+    tests/test_engine_fp16_gpu.py::test_fp16_detection_set_on_a_trained_box_head), scores <= 3e-2 / boxes <= 3 px / mask
+    probabilities <= 3e-2 on every pair — and the file `predict_tiles(precision: fp16)` wrote for the tile carries exactly the
+    fp16 engine's detections (scores bit for bit), the other model never wrote it."""
+    from tests.test_engine_fp16_gpu import SCORE_THRESH, match_detection_sets
+    from treedetection_amd.engine import Engine, INPUT_U8_HWC, unpack_outputs
+    root, trained, picks = two_model_trained
+    tile_id, _ = picks[model]
+    meta = json.load(open(root / "tiles" / "1.json"))
+    tif = str(root / "rgb" / "1.tif")
+    bands = GeoTiff(tif).read_bounds(meta[tile_id]["bounds"])
+    x, h, w = R.preprocess_tile_u8(bands)
+    ref = MaskRCNNOracle(trained[model]).forward([{"image": x, "height": h, "width": w}])[0]
+    eng = Engine(trained[model], precision="fp16")
+    tile = torch.from_numpy(np.ascontiguousarray(bands[:3].transpose(1, 2, 0))).cuda()
+    batch, hv, ho = eng.preprocess_tiles_u8([tile])
+    out = eng.alloc_outputs(1, 1000, 1000, paste=True)
+    eng.forward_raw(batch, INPUT_U8_HWC, hv, ho, out)
+    torch.cuda.synchronize()
+    g = unpack_outputs(out, ho, True)[0]
+    eng.close()
+    band = 5e-3 * 4.0 * SCORE_THRESH * (1.0 - SCORE_THRESH) / 0.36
+    strict, cluster, lost, extra = match_detection_sets(g, ref, band)
+    far = lambda d, idx: d["scores"][idx] > SCORE_THRESH + band      # noqa: E731
+    exceptions = sum(1 for i, j, _ in cluster if far(ref, i) or far(g, j)) + len(lost) + len(extra)
+    es = max(abs(float(g["scores"][j]) - float(ref["scores"][i])) for i, j, _ in strict)
+    eb = max(float(np.abs(g["pred_boxes"][j] - ref["pred_boxes"][i]).max()) for i, j, _ in strict)
+    ep = max(float(np.abs(g["mask_probs"][j] - ref["mask_probs"][i]).max()) for i, j, _ in strict)
+    print(f"\n[fp16 two-model, trained box head, {model}] tile {tile_id}: {len(ref['scores'])} oracle / {len(g['scores'])} engine detections, "
+          f"{len(strict)} strict pairs, cluster pairs {[round(v, 2) for _, _, v in cluster]}, unpaired oracle {np.round(lost, 3).tolist()} "
+          f"engine {np.round(extra, 3).tolist()}; worst pair: score {es:.2e}, box {eb:.3f} px, mask probability {ep:.2e}")
+    assert 20 <= len(ref["scores"]) <= 60
+    assert exceptions <= 2 and len(strict) >= 0.95 * len(ref["scores"])
+    assert es <= 3e-2 and eb <= 3.0 and ep <= 3e-2
+    got = json.load(open(root / "output_trained_fp16" / folder / "1" / f"Prediction_{tile_id}.json"))
+    eng_scores = {float(s) for s in g["scores"]}
+    assert len(got) >= len(g["scores"]) and {e["score"] for e in got} <= eng_scores
+    assert {e["score"] for e in got} == eng_scores                    # compact masks: every detection has a contour
+    other = "forrest_predictions" if folder == "urban_predictions" else "urban_predictions"
+    assert not os.path.exists(root / "output_trained_fp16" / other / "1" / f"Prediction_{tile_id}.json")
