@@ -1,7 +1,7 @@
 """How the fitted / trained head fixtures (tests/trained_heads.py) behave under the fp16 engine: strict pairs (IoU >= 0.9),
 duplicate-cluster pairs, unpaired detections, worst box / score error.
     python tools/fitted_heads_probe.py [depth]            # ridge-fitted output layers, four ridge strengths
-    python tools/fitted_heads_probe.py [depth] train      # + box head trained by gradient descent (train_box_head)"""
+    python tools/fitted_heads_probe.py [depth] train [weight seed] [tiles a,b] [steps s1,s2]     # + box head trained by gradient descent"""
 import sys
 sys.path.insert(0, ".")
 import numpy as np, torch
@@ -13,9 +13,11 @@ from treedetection_amd.weights import blob_mask_head, make_synthetic_state_dict
 
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 train = len(sys.argv) > 2 and sys.argv[2] == "train"
+wseed = int(sys.argv[3]) if len(sys.argv) > 3 else 5                       # weight seed of the synthetic model
+tiles = [int(t) for t in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0, 1]
+step_list = [int(t) for t in sys.argv[5].split(",")] if len(sys.argv) > 5 else [3000]
 torch.set_num_threads(16)
-tiles = [0, 1]
-base = blob_mask_head(make_synthetic_state_dict(depth, seed=5))
+base = blob_mask_head(make_synthetic_state_dict(depth, seed=wseed))
 inputs = tile_inputs(tiles, 1000)
 band = 5e-3 * 4.0 * SCORE_THRESH * (1.0 - SCORE_THRESH) / 0.36
 
@@ -43,7 +45,7 @@ def report(tag, sd):
 if train:
     import time
     rpn = fit_trained_like_heads(base, tiles)
-    for steps, jitter in ((3000, 48),):
+    for steps, jitter in [(st, 48) for st in step_list]:
         t0 = time.time()
         sd = train_box_head(rpn, tiles, steps=steps, jitter_per_crown=jitter, verbose=True, predictor_init=base)
         print(f"trained in {time.time() - t0:.1f} s")
