@@ -811,8 +811,8 @@ def main():
         # event spans are the kernels' own durations (the literal roofline of a schedule that still overlaps the selection work)
         phased = run_pipelined(args.precision, not args.no_profile, "phase_pipeline")
     r101 = b32 = None
-    if args.precision == "fp32" and args.depth == 50 and args.schedule != "plain" and world == 1:
-        if not args.no_r101:
+    if args.precision == "fp32" and args.depth == 50 and args.schedule != "plain":
+        if not args.no_r101 and world == 1:
             # the reference's own depth (TreeDetection/config.py:25 hard-codes R101-FPN): same stream, same schedule
             log("generating R101 weights")
             sd = make_synthetic_state_dict(101, seed=0)
@@ -822,7 +822,8 @@ def main():
                 r101["fp16"] = go("fp16", not args.no_profile, "r101_f16") + (nsteps,)
             sd = make_synthetic_state_dict(args.depth, seed=0)
         if not args.no_fp16 and not args.no_fp16_b32:
-            # BASELINE configs[4]: the fp16 MFMA path at batch 32 per GPU (same tiles, four times the rows per launch)
+            # BASELINE configs[4]: the fp16 MFMA path at batch 32 per GPU (same tiles, four times the rows per launch) — at every N:
+            # configs[4] is quoted on 8 GPUs
             B, nsteps = 32, -(-max(4, args.steps // 4) // args.streams) * args.streams
             b32 = go("fp16", not args.no_profile, "fp16_batch32") + (nsteps,)
             B, nsteps = args.batch, args.steps
