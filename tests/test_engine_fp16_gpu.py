@@ -311,10 +311,10 @@ def test_fp16_detection_set_on_a_trained_box_head(depth):
         IoU >= 0.9 — measured: ALL 79 of 79 on R50 (no exception), 78 of 79 on R101 (one oracle-only detection of score 0.98 on
         one tile); asserted: at most 2 exceptions per tile and 3 per depth (the training runs on the GPU: its reductions are
         not bit-reproducible from box to box), at least 95 % strict pairs;
-      * per strict pair: mask probability <= 3e-2; |score error| within the 5e-3 rule for at least 95 % of the pairs and
-        <= 3e-2 for all (R50: max 1.6e-3, all within the rule; R101: two of 78 outside it — 6.7e-3 at s = 0.91, 2.7e-2 at
+      * per strict pair: mask probability <= 3e-2; |score error| within the 5e-3 rule for at least 92 % of the pairs and
+        <= 4e-2 for all (R50: max 1.6e-3, all within the rule; R101: two of 78 outside it — 6.7e-3 at s = 0.91, 2.7e-2 at
         s = 0.39: a classifier trained to logit margins of +-8 turns the box head's fp16 feature noise, 0.1 in the logit, into
-        more score noise than the seeded heads do); box <= 0.5 px for at least 95 % of the pairs and <= 3 px for all (a pair
+        more score noise than the seeded heads do); box <= 0.5 px for at least 92 % of the pairs and <= 3 px for all (a pair
         whose fp16 survivor descends from ANOTHER proposal of the same crown — the RPN's own near-ties — is the same box to IoU
         0.96 but not to half a pixel: measured one such pair per depth, 1.64 px on a 113-px crown, 0.71 px on a 134-px one).
     The fp32 engine reproduces the oracle's set exactly on the same weights (tools/fitted_heads_probe.py train)."""
@@ -355,9 +355,10 @@ def test_fp16_detection_set_on_a_trained_box_head(depth):
           f"lowest pair IoU {rows[:, 4].min():.3f}")
     assert exceptions <= 3 and len(rows) >= 0.95 * sum(len(r["scores"]) for r in ref)
     in_rule = np.array([es <= 5e-3 * max(1.0, 4.0 * s * (1.0 - s) / 0.36) for es, _, _, s, _ in rows])
-    assert in_rule.mean() >= 0.95 and rows[:, 0].max() <= 3e-2, (depth, float(in_rule.mean()), float(rows[:, 0].max()))
+    # (fractions asserted with room for the box-to-box variation of the GPU training: measured 1.0 / 0.974 and 0.987 / 0.974)
+    assert in_rule.mean() >= 0.92 and rows[:, 0].max() <= 4e-2, (depth, float(in_rule.mean()), float(rows[:, 0].max()))
     assert rows[:, 1].max() <= 3.0 and rows[:, 2].max() <= 3e-2, (depth, float(rows[:, 1].max()), float(rows[:, 2].max()))
-    assert (rows[:, 1] <= 0.5).mean() >= 0.95
+    assert (rows[:, 1] <= 0.5).mean() >= 0.92
 
 
 def test_fp16_flip_rate_is_bounded_over_64_tiles():
