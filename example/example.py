@@ -13,7 +13,10 @@ if __name__ == "__main__":
     if world > 1:                       # launched by torch.distributed.run: RCCL over xGMI, each rank binds its GPU (LOCAL_RANK)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")
+        # no collective runs while a rank walks its images (treedetection_amd/detection.py shards by whole image), so the closing
+        # manifest gather must be allowed to wait for the slowest rank's walk: the 10-minute default would end a large job
+        import datetime
+        dist.init_process_group("nccl", timeout=datetime.timedelta(hours=6))
     config, _ = T.get_config(os.path.join(os.path.dirname(os.path.abspath(__file__)), "config.yml"))
     # the three stages can also be called one by one, in this order: T.preprocess_files(config), T.predict_tiles(config),
     # T.postprocess_files(config)

@@ -448,7 +448,7 @@ def test_engine_with_fused_tail_equals_engine_without_it():
 
 def test_retired_tile_ids_are_refused():
     """Stream-K (ids 21 / 22) and the 4-wave 256x256 tile (id 28) lost to the block tiles in round 3 and left the product library
-    (csrc/experimental/): the entry point says so instead of silently running another tile."""
+    (round 6: deleted from the tree, the findings are in DESIGN.md): the entry point says so instead of silently running another tile."""
     x = np.zeros((1, 64, 8, 8), np.float32)
     w = np.zeros((64, 64, 1, 1), np.float32)
     for cfg in (21, 22, 28):

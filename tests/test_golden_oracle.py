@@ -81,3 +81,37 @@ def test_known_values_in_the_fixture(pair):
     # duplicates 50..59 of boxes 40..49 never survive NMS together
     keep = set(gold["nms_keep_05"].tolist())
     assert all(not (i in keep and i + 10 in keep) for i in range(40, 50))
+
+
+def test_trained_head_fixtures_are_the_committed_data():
+    """tests/golden/trained_heads_*.npz (round 6): made ONCE by tests/golden/make_trained_heads.py on the CPU; the GPU tests load them
+    and train nothing. Here: every file matches the manifest's SHA-256, holds exactly the tensors the loader expects, and rebuilds
+    a state dict that differs from the seeded one ONLY in the RPN output layers, fc2 and the two predictors (fc1 stays frozen)."""
+    import os
+    from tests import trained_heads as TH
+    from treedetection_amd.weights import blob_mask_head, make_synthetic_state_dict
+    man = TH.manifest()
+    assert sorted(man) == sorted(f"trained_heads_{n}.npz" for n in TH.FIXTURES)
+    for name, (depth, seed, tiles) in TH.FIXTURES.items():
+        path = TH.fixture_path(name)
+        assert TH._sha256(path) == man[os.path.basename(path)], name
+        assert os.path.getsize(path) < 1 << 20
+    base = blob_mask_head(make_synthetic_state_dict(50, seed=5))
+    sd = TH.load_trained_heads("r50", base=base)
+    changed = sorted(k for k in base if not np.array_equal(base[k], sd[k]))
+    assert changed == sorted(["proposal_generator.rpn_head.objectness_logits.weight", "proposal_generator.rpn_head.objectness_logits.bias",
+                              "proposal_generator.rpn_head.anchor_deltas.weight", "proposal_generator.rpn_head.anchor_deltas.bias",
+                              "roi_heads.box_head.fc2.weight", "roi_heads.box_head.fc2.bias",
+                              "roi_heads.box_predictor.cls_score.weight", "roi_heads.box_predictor.cls_score.bias",
+                              "roi_heads.box_predictor.bbox_pred.weight", "roi_heads.box_predictor.bbox_pred.bias"]), changed
+    assert sorted(sd) == sorted(base) and all(sd[k].dtype == base[k].dtype and sd[k].shape == base[k].shape for k in base)
+    delta = sd["roi_heads.box_head.fc2.weight"].astype(np.float64) - base["roi_heads.box_head.fc2.weight"]
+    assert np.linalg.matrix_rank(delta, tol=1e-4) <= 64                      # fc2 = seeded + a rank-64 delta
+    # tampering is caught: a file that is not the manifest's is refused
+    with pytest.raises(AssertionError, match="sha256"):
+        real = TH.manifest
+        try:
+            TH.manifest = lambda: {k: "0" * 64 for k in real()}
+            TH.load_trained_heads("r50", base=base)
+        finally:
+            TH.manifest = real

@@ -64,6 +64,22 @@ def test_nms_dense_cluster_1000():
         assert np.array_equal(nms_hip(boxes, scores, thr), R.nms(boxes, scores, thr))
 
 
+@pytest.mark.parametrize("n,thr,seed,dense", [(1025, 0.5, 11, False), (4507, 0.7, 12, False), (4507, 0.5, 13, True), (9000, 0.3, 14, True)])
+def test_nms_beyond_1024_boxes_bit_exact(n, thr, seed, dense):
+    """td_nms above one block's capacity (counting sort + bit matrix + LDS-resident scan, rpn.hip): 4 507 = the candidates of one
+    image over the five RPN levels, the size torchvision's unbatched nms sees; index order bit-exact vs the
+    oracle, ties (scores rounded to 2 decimals) included."""
+    rng = np.random.default_rng(seed)
+    if dense:
+        base = random_boxes(rng, 300, span=800, size=90)
+        boxes = (base[rng.integers(0, 300, n)] + rng.normal(0, 2.0, (n, 4))).astype(np.float32)
+        scores = np.round(rng.uniform(0, 1, n), 2).astype(np.float32)
+    else:
+        boxes = random_boxes(rng, n, span=800.0)
+        scores = rng.standard_normal(n).astype(np.float32)
+    assert np.array_equal(nms_hip(boxes, scores, thr), R.nms(boxes, scores, thr))
+
+
 @pytest.mark.parametrize("pooled,scale,C,H,W", [(7, 0.25, 64, 40, 48), (14, 0.125, 32, 25, 25), (7, 1.0 / 32, 128, 7, 9)])
 def test_roi_align_matches_oracle(pooled, scale, C, H, W):
     lib = _lib.load()

@@ -176,6 +176,54 @@ def test_config3_mosaic_10k_tiles_sharded(tmp_path):
     assert nonempty > 0
 
 
+def test_config3_tile_shard_and_rank0_gather_at_full_tile_size(tmp_path):
+    """BASELINE configs[3]'s path — tiles of ONE mosaic sharded i = r (mod W), detections gathered to rank 0, rank 0 pastes,
+    traces and writes every file — at the WORKLOAD's size: full-width R50-FPN, 1000 x 1000-px tiles, the
+    400-tile raster of bench.py's e2e regions (20 x 20 tiles, 16 distinct generator tiles cycled), batch 8, three engines per
+    rank; 2 gloo ranks on this one GPU against ONE process: every Prediction_*.json byte for byte. (The RCCL transport on 8
+    GPUs is hardware-only; what runs here is everything around it: sharding, padded rounds, the fixed-shape gather, rank 0's
+    paste of other ranks' batches.)"""
+    import shutil
+    from treedetection_amd import distributed as D
+    from treedetection_amd.preprocessing import tile_single_file
+    from treedetection_amd.weights import blob_mask_head
+    np.savez(tmp_path / "m.npz", **blob_mask_head(make_synthetic_state_dict(50, seed=0)))          # full width, compact crowns
+    S, side = 1000, 20
+    distinct = [np.ascontiguousarray(make_tile(k, S)[0].transpose(2, 0, 1)) for k in range(16)]
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path)
+    shm = os.path.join(base, f"td_cfg3_{os.getpid()}")
+    os.makedirs(shm, exist_ok=True)
+    try:
+        tif = os.path.join(shm, "mosaic.tif")
+        mosaic = np.empty((3, side * S, side * S), np.uint8)                  # 1.2 GB, like the bench's raster
+        for r in range(side):
+            for c in range(side):
+                mosaic[:, r * S:(r + 1) * S, c * S:(c + 1) * S] = distinct[(r * side + c) % 16]
+        write_geotiff(tif, mosaic, (0.2, 0, 412000.0, 0, -0.2, 5318000.0 + side * S * 0.2), 25832)
+        del mosaic
+        tile_single_file(tif, str(tmp_path / "tiles"), buffer=0, tile_width=200, tile_height=200)
+        meta_path = str(tmp_path / "tiles" / "mosaic.json")
+        meta = json.load(open(meta_path))
+        assert len(meta) == 400
+        assert D.padded_rounds(400, 8, 2) == 25 and len(D.shard_indices(400, 1, 2)) == 200
+        outs = {}
+        for name, world in (("one", 1), ("two", 2)):
+            out = str(tmp_path / f"out_{name}")
+            script = tmp_path / f"w_{name}.py"
+            script.write_text(WORKER.format(root=ROOT, model=str(tmp_path / "m.npz"), out=out, tif=tif, meta=meta_path, batch=8,
+                                            kw={"pipeline": True, "sharded_epilogue": "rank0"}))
+            _run(script, world, timeout=900)
+            outs[name] = {f: open(os.path.join(out, "mosaic", f), "rb").read() for f in sorted(os.listdir(os.path.join(out, "mosaic")))}
+    finally:
+        shutil.rmtree(shm, ignore_errors=True)
+    assert sorted(outs["one"]) == sorted(f"Prediction_{k}.json" for k in meta)
+    assert sorted(outs["two"]) == sorted(outs["one"])
+    for f in outs["one"]:
+        assert outs["two"][f] == outs["one"][f], f                           # byte for byte
+    dets = sum(len(json.loads(v)) for v in outs["one"].values())
+    assert dets > 400 * 5, dets                                               # ~ 20 crowns per tile on this fixture
+
+
 PREDICT_TILES_WORKER = r"""
 import logging, os, sys
 sys.path.insert(0, {root!r})

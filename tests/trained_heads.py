@@ -24,10 +24,14 @@ What it showed (round 5, tools/fitted_heads_probe.py → profiles/r05_fitted_hea
 the detector finds every crown with one detection and saturated scores, the fp32 engine reproduces the oracle's set exactly —
 and the fp16 engine still changes the survivor of 2 - 10 % of the duplicate clusters, at every ridge strength: a linear fit on
 random features regresses a crown's duplicates to within IoU ~0.7 - 0.9 of each other, not onto one box, and saturated scores
-make every cluster a near-tie. What removes the flips is a box head that is TRAINED (``train_box_head`` below: fc1, fc2 and the
-predictor by gradient descent on the oracle's RoI features, the RPN's ridge fit kept): every proposal of a crown then lands on
-the crown's box, whichever duplicate survives carries the same box, and the strict set rule of SURVEY §8d holds — 79 of 79
-detections on R50, 78 of 79 on R101 (tests/test_engine_fp16_gpu.py::test_fp16_detection_set_on_a_trained_box_head).
+make every cluster a near-tie. What removes the flips is a box head that is TRAINED (gradient descent on the oracle's RoI features, the RPN's ridge fit
+kept): every proposal of a crown then lands on the crown's box and whichever duplicate survives carries the same box.
+
+Round 6: the trained heads are DATA. ``tests/golden/make_trained_heads.py`` (run once in the build container: CPU, fixed seed,
+deterministic algorithms, fc1 frozen at its seeded value, fc2 trained as a low-rank delta, the two predictors in full) writes
+``tests/golden/trained_heads_<name>.npz`` — the tensors that differ from the seeded state dict, < 1 MB each — and their SHA-256
+into ``tests/golden/trained_heads.sha256``. The parity tests LOAD them (``load_trained_heads``): nothing is trained on the GPU
+box, so the fixture is the same on every box and a failure is an engine regression, not a re-rolled fixture.
 """
 from __future__ import annotations
 
@@ -231,94 +235,81 @@ class _SplitRidge:
         return Wa, ba, Wb, bb
 
 
-# ---- a TRAINED box head (round 5, second attempt at a fixture on which the strict fp16 set rule can hold) ----------------------
-# The closed-form fits above leave the duplicates of a crown within IoU 0.7 - 0.9 of each other. What makes near-tied duplicates
-# harmless in a real detector is a box head that has LEARNT to move every proposal of an object onto the object: then whichever
-# duplicate survives the final NMS carries the same box. So the box head (fc1, fc2, cls_score, bbox_pred: the layers detectron2
-# trains) is trained here by gradient descent — torch autograd on the GPU box's device where there is one (test infrastructure:
-# the product has no backward pass) — on the oracle's RoI features of the fixture's own tiles: the fitted RPN's proposals plus
-# jittered boxes around every crown, class labels by IoU with the crown, box deltas onto the crown. Deterministic (seeded), a
-# few hundred full-batch Adam steps, ~20 s per depth on an MI355X. The trunk, FPN and RPN conv stay seeded random weights.
-def _jittered_boxes(gt: np.ndarray, per_crown: int, rng, hw) -> np.ndarray:
-    out = []
-    for b in gt:
-        w, h = b[2] - b[0], b[3] - b[1]
-        for _ in range(per_crown):
-            s = np.exp(rng.uniform(-0.45, 0.45, 2))
-            dx, dy = rng.uniform(-0.3, 0.3, 2) * (w, h)
-            cx, cy = (b[0] + b[2]) / 2 + dx, (b[1] + b[3]) / 2 + dy
-            out.append([cx - s[0] * w / 2, cy - s[1] * h / 2, cx + s[0] * w / 2, cy + s[1] * h / 2])
-    o = np.asarray(out, dtype=np.float64).reshape(-1, 4)
-    o[:, 0::2] = np.clip(o[:, 0::2], 0, hw[1])
-    o[:, 1::2] = np.clip(o[:, 1::2], 0, hw[0])
-    keep = (o[:, 2] - o[:, 0] > 2) & (o[:, 3] - o[:, 1] > 2)
-    return o[keep]
+# ---- the trained heads as committed data (round 6) -----------------------------------------------------------------------------
+import hashlib
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LOWRANK_U, LOWRANK_V = ".lowrank_u", ".lowrank_v"
+
+# name → (depth, weight seed, generator tiles the heads were fitted / trained on); tests/golden/make_trained_heads.py writes one
+# file per entry. The two-model fixtures are trained on the tiles of the raster column ONLY that model predicts
+# (tests/test_config2_fullsize_gpu.py: a 3 x 2 grid of generator tiles 300 … 305; column 2 = only_urban, column 0 = only_forest).
+FIXTURES = {
+    "r50": (50, 5, (0, 1)),
+    "r101": (101, 5, (0, 1)),
+    "urban": (50, 0, (302, 305)),
+    "forest": (50, 2, (300, 303)),
+}
 
 
-def train_box_head(sd: Dict[str, np.ndarray], tiles: Sequence[int], size: int = 1000, steps: int = 1500, lr: float = 2e-3,
-                   jitter_per_crown: int = 48, seed: int = 0, device=None, verbose: bool = False,
-                   predictor_init: Dict[str, np.ndarray] = None, label_smoothing: float = 0.0) -> Dict[str, np.ndarray]:
-    """→ a copy of ``sd`` (already carrying fitted RPN output layers: call fit_trained_like_heads first) whose box head is
-    trained on the oracle's RoI features of ``tiles`` (see the comment above). ``predictor_init``: a state dict whose
-    ``box_predictor`` tensors the training starts from (the seeded ones: the ridge-fitted predictor has 20 x their norm and
-    keeps amplifying fp16 feature noise through the whole training)."""
-    sd = dict(sd)
-    if predictor_init is not None:
-        for k in list(sd):
-            if k.startswith("roi_heads.box_predictor."):
-                sd[k] = predictor_init[k]
-    inputs = tile_inputs(tiles, size)
-    with torch.no_grad():
-        oracle = MaskRCNNOracle(sd)
-        rng = np.random.default_rng(seed)
-        X, Ycls, Ybox, W = [], [], [], []
-        for k, inp in enumerate(inputs):
-            x, sizes = oracle.batch_images([inp["image"]])
-            feats = oracle.fpn(oracle.backbone(x))
-            gt = crown_boxes(tiles[k], size, sizes[0])
-            logits, deltas = oracle.rpn_head(feats)
-            feat_hw = [tuple(feats[f"p{l}"].shape[-2:]) for l in (2, 3, 4, 5, 6)]
-            props, _ = oracle.rpn_proposals(logits, deltas, feat_hw, sizes)
-            boxes = np.concatenate([props[0][0].astype(np.float64), _jittered_boxes(gt, jitter_per_crown, rng, sizes[0])])
-            pooled, _ = oracle.roi_pool(feats, [boxes.astype(np.float32)], 7)
-            iou = iou_matrix(boxes, gt)
-            best, arg = iou.max(axis=1), iou.argmax(axis=1)
-            fg, bg = best >= 0.5, best < 0.4
-            keep = fg | bg
-            y = np.zeros((len(boxes), 4))
-            y[fg] = box_deltas(boxes[fg], gt[arg[fg]], (10.0, 10.0, 5.0, 5.0))
-            X.append(pooled[0][keep].reshape(int(keep.sum()), -1))
-            Ycls.append(np.where(fg[keep], 0, 1))            # class 0 = the one foreground class, last = background
-            Ybox.append(y[keep])
-            W.append(fg[keep].astype(np.float32))
-            if verbose:
-                print(f"[train_box_head] tile {tiles[k]}: {len(boxes)} boxes, {int(fg.sum())} on a crown, {int(bg.sum())} background")
-    dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
-    torch.manual_seed(seed)
-    Xt = torch.from_numpy(np.concatenate(X)).to(dev)
-    yc = torch.from_numpy(np.concatenate(Ycls)).long().to(dev)
-    yb = torch.from_numpy(np.concatenate(Ybox)).float().to(dev)
-    wf = torch.from_numpy(np.concatenate(W)).to(dev)
-    names = ("roi_heads.box_head.fc1", "roi_heads.box_head.fc2", "roi_heads.box_predictor.cls_score", "roi_heads.box_predictor.bbox_pred")
-    P = {n + s: torch.tensor(sd[n + s], device=dev, requires_grad=True) for n in names for s in (".weight", ".bias")}
-    opt = torch.optim.Adam(P.values(), lr=lr, weight_decay=1e-5)
-    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=steps, eta_min=lr * 0.01)
-    lin = torch.nn.functional.linear
-    for it in range(steps):
-        opt.zero_grad()
-        h = torch.relu(lin(Xt, P[names[0] + ".weight"], P[names[0] + ".bias"]))
-        h = torch.relu(lin(h, P[names[1] + ".weight"], P[names[1] + ".bias"]))
-        cls = lin(h, P[names[2] + ".weight"], P[names[2] + ".bias"])
-        reg = lin(h, P[names[3] + ".weight"], P[names[3] + ".bias"])
-        # (label smoothing was tried — 0.05: finite logits, but the regression then converges less far in the same steps and the
-        # fp16 exceptions go from 0 - 1 to 1 - 2 per depth: off)
-        l_cls = torch.nn.functional.cross_entropy(cls, yc, label_smoothing=label_smoothing)
-        l_box = (torch.nn.functional.smooth_l1_loss(reg, yb, beta=0.05, reduction="none").sum(dim=1) * wf).sum() / wf.sum().clamp(min=1)
-        (l_cls + l_box).backward()
-        opt.step()
-        sched.step()
-        if verbose and (it % 100 == 0 or it == steps - 1):
-            print(f"[train_box_head] step {it}: class loss {float(l_cls):.4f}, box loss {float(l_box):.4f}")
-    for k, v in P.items():
-        sd[k] = v.detach().float().cpu().numpy()
+def fixture_path(name: str) -> str:
+    return os.path.join(GOLDEN, f"trained_heads_{name}.npz")
+
+
+def _sha256(path: str) -> str:
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def manifest() -> Dict[str, str]:
+    out = {}
+    with open(os.path.join(GOLDEN, "trained_heads.sha256")) as f:
+        for line in f:
+            if line.strip():
+                digest, fname = line.split()
+                out[fname] = digest
+    return out
+
+
+def pack_heads(base: Dict[str, np.ndarray], tensors: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """What goes into a fixture file: every tensor of ``tensors`` as it is (float32); a key ending in ``.lowrank_u`` /
+    ``.lowrank_v`` is a factor of a delta onto the SEEDED tensor of that name (``apply_heads`` rebuilds it)."""
+    return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in tensors.items()}
+
+
+def apply_heads(base: Dict[str, np.ndarray], tensors: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """→ a copy of the seeded state dict ``base`` with the fixture's tensors put in. A low-rank pair (U [out, r], V [r, in])
+    becomes ``base[name] + U @ V``: the product is formed in float64 and rounded ONCE to float32, so every box rebuilds the
+    same weights (oracle and engine get the same array either way)."""
+    sd = dict(base)
+    for k in tensors:
+        if k.endswith(LOWRANK_V) or k == "meta":
+            continue
+        if k.endswith(LOWRANK_U):
+            name = k[:-len(LOWRANK_U)]
+            delta = tensors[k].astype(np.float64) @ tensors[name + LOWRANK_V].astype(np.float64)
+            sd[name] = (base[name].astype(np.float64) + delta).astype(np.float32)
+        else:
+            assert k in base and base[k].shape == tensors[k].shape, k
+            sd[k] = np.asarray(tensors[k], dtype=np.float32)
     return sd
+
+
+def load_trained_heads(name: str, base: Dict[str, np.ndarray] = None) -> Dict[str, np.ndarray]:
+    """The state dict of fixture ``name`` (see FIXTURES): the seeded weights of its depth / seed with the blob mask head, the
+    fitted RPN output layers and the trained box head of the committed file — hash-checked against the manifest."""
+    from treedetection_amd.weights import blob_mask_head, make_synthetic_state_dict
+    depth, seed, _ = FIXTURES[name]
+    path = fixture_path(name)
+    want = manifest()[os.path.basename(path)]
+    got = _sha256(path)
+    assert got == want, f"{path}: sha256 {got} != manifest {want} (regenerate with tests/golden/make_trained_heads.py)"
+    if base is None:
+        base = blob_mask_head(make_synthetic_state_dict(depth, seed=seed))
+    with np.load(path) as z:
+        tensors = {k: z[k] for k in z.files}
+    return apply_heads(base, tensors)

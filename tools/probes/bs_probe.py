@@ -1,13 +1,13 @@
 """Where does conv_bs_kernel (tile id 33) spend a row tile? Ablation builds of conv_bstat.hip (-DTD_BS_DIAG bit mask: 1 no stores,
 2 no MFMAs, 4 no LDS transposition, 8 no activation loads — WRONG results, timing only) on the engine's shapes, under rocprofv3
-(tools/bs_probe.sh). python tools/bs_probe.py fp16|fp32 <diag> [shape,...]"""
+(tools/probes/bs_probe.sh). python tools/probes/bs_probe.py fp16|fp32 <diag> [shape,...]"""
 import ctypes as C
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tools.conv_diag import build  # noqa: E402
 

@@ -1,5 +1,5 @@
 """Does the matrix pipe run at its nominal clock under the fp16 contractions? Runs one conv launch shape in a loop for a few seconds
-and samples `rocm-smi` (sclk, power) meanwhile: python tools/clock_probe.py [tile id, default 17] [fp16|fp32]."""
+and samples `rocm-smi` (sclk, power) meanwhile: python tools/probes/clock_probe.py [tile id, default 17] [fp16|fp32]."""
 import os, subprocess, sys, threading, time
 sys.path.insert(0, ".")
 import torch

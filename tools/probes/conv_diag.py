@@ -2,7 +2,7 @@
 of conv_igemm.hip — product, no global loads in the k-loop, no loads + no barrier — built into /tmp (never shipped)."""
 import ctypes as C, os, subprocess, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CS = os.path.join(ROOT, "treedetection_amd", "csrc")
 
 def build(tag, defs, src="conv_igemm"):

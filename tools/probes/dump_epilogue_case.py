@@ -1,5 +1,5 @@
 """Saves the packed masks of a few synthetic tiles (regions, offsets, used bit rows, scores) for host-epilogue profiling
-on a CPU-only machine: python tools/dump_epilogue_case.py out.npz [n_tiles] [precision]"""
+on a CPU-only machine: python tools/probes/dump_epilogue_case.py out.npz [n_tiles] [precision]"""
 import sys
 sys.path.insert(0, ".")
 import numpy as np, torch

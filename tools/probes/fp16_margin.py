@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, ".")
 from oracle.maskrcnn_ref import MaskRCNNOracle
 from tests.test_engine_gpu import smooth_image
 from tests.test_engine_fp16_gpu import iou

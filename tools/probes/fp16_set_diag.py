@@ -1,11 +1,11 @@
 """fp16 engine vs the fp32 oracle on full-size tiles: which detections exist on one side only (and why: score near the cut,
-NMS neighbours), and the error distribution of the matched ones. python tools/fp16_set_diag.py [depth] [seed] [tile ids ...]"""
+NMS neighbours), and the error distribution of the matched ones. python tools/probes/fp16_set_diag.py [depth] [seed] [tile ids ...]"""
 import sys
 
 import numpy as np
 import torch
 
-sys.path.insert(0, __file__.rsplit("/", 2)[0])
+sys.path.insert(0, __file__.rsplit("/", 3)[0])
 from oracle import ops_ref as R  # noqa: E402
 from oracle.maskrcnn_ref import MaskRCNNOracle  # noqa: E402
 from tests.test_engine_fp16_gpu import iou  # noqa: E402

@@ -1,5 +1,5 @@
 // Probe: does an out-of-range lane of buffer_load ... lds (LDS-DMA through a buffer descriptor) write ZERO to its
-// LDS slot, or leave the slot untouched?  hipcc --offload-arch=gfx950 tools/lds_dma_probe.hip -o /tmp/probe && /tmp/probe
+// LDS slot, or leave the slot untouched?  hipcc --offload-arch=gfx950 tools/probes/lds_dma_probe.hip -o /tmp/probe && /tmp/probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -1,11 +1,11 @@
 """Diagnostic: per-category device time of a plain-loop forward (one batch at a time, nothing overlapping), for the
-RoIAlign ring depth / blocks-per-RoI sweep:  TD_ROI_DEPTH=4 TD_ROI_PARTS=4 python tools/roi_bench.py fp16 [steps]"""
+RoIAlign ring depth / blocks-per-RoI sweep:  TD_ROI_DEPTH=4 TD_ROI_PARTS=4 python tools/probes/roi_bench.py fp16 [steps]"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from treedetection_amd.engine import Engine, INPUT_U8_HWC  # noqa: E402
 from treedetection_amd.synth import make_stream  # noqa: E402

@@ -1,12 +1,12 @@
 """Where does bottleneck_tail_kernel spend its time? Diagnostic builds of bottleneck.hip (-DTD_TAIL_DIAG=1: no 3x3 phase,
-=2: nothing after the mid tile — WRONG results, timing only) on the res2 shape, under rocprofv3 (tools/tail_probe.sh)."""
+=2: nothing after the mid tile — WRONG results, timing only) on the res2 shape, under rocprofv3 (tools/probes/tail_probe.sh)."""
 import ctypes as C
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tools.conv_diag import build  # noqa: E402
 

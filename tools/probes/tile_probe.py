@@ -1,5 +1,5 @@
 """Kernel duration of every block tile on the fp16 / fp32 engine's layer shapes (batch 8): run under rocprofv3 --kernel-trace
-(tools/tile_probe.sh); each (shape, tile id) launches td_conv2d_nhwc three times, the trace carries the kernel durations
+(tools/probes/tile_probe.sh); each (shape, tile id) launches td_conv2d_nhwc three times, the trace carries the kernel durations
 (the entry point's host-side filter packing and allocations are outside them)."""
 import ctypes as C
 import os
@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from treedetection_amd import _lib  # noqa: E402
 

@@ -1,10 +1,10 @@
-# bash tools/tile_probe.sh [fp16|fp32] [cfg,cfg,...] [shape,shape,...]: kernel us per (layer shape, block tile id)
+# bash tools/probes/tile_probe.sh [fp16|fp32] [cfg,cfg,...] [shape,shape,...]: kernel us per (layer shape, block tile id)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/tileprobe_${1:-fp16}
 rm -rf $O && mkdir -p $O
 export TILE_PROBE_PLAN=$O/plan.txt
-timeout -k 10 500 rocprofv3 --kernel-trace -d $O/trace -o t --output-format csv -- python3 $R/tools/tile_probe.py "$@" > $O/probe.log 2>&1 || { tail -5 $O/probe.log; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace -d $O/trace -o t --output-format csv -- python3 $R/tools/probes/tile_probe.py "$@" > $O/probe.log 2>&1 || { tail -5 $O/probe.log; exit 1; }
 python3 - "$(find $O/trace -name '*kernel_trace.csv' | head -1)" $O/plan.txt <<'PY' | tee $O/summary.txt
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))

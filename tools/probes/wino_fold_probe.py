@@ -1,5 +1,5 @@
 """Times the three-launch F(4x4,3x3) form against wino43_fused_kernel on the engine's layer shapes (fp32, batch 8). Run under
-rocprofv3 (tools/wino_fold_probe.sh): every shape runs each form a few times through td_conv2d_winograd_nhwc, whose host-side
+rocprofv3 (tools/probes/wino_fold_probe.sh): every shape runs each form a few times through td_conv2d_winograd_nhwc, whose host-side
 filter transform and allocations are outside the kernels; the kernel trace carries the durations."""
 import os
 import sys
@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from treedetection_amd import _lib  # noqa: E402
 

@@ -1,9 +1,9 @@
-# bash tools/wino_fold_probe.sh [shape ...]: kernel durations of the three-launch F(4x4) form vs wino43_fused_kernel per layer shape
+# bash tools/probes/wino_fold_probe.sh [shape ...]: kernel durations of the three-launch F(4x4) form vs wino43_fused_kernel per layer shape
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/wfold
 rm -rf $O && mkdir -p $O
-timeout -k 10 500 rocprofv3 --kernel-trace -d $O/trace -o t --output-format csv -- python3 $R/tools/wino_fold_probe.py "$@" > $O/probe.log 2>&1 || { tail -5 $O/probe.log; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace -d $O/trace -o t --output-format csv -- python3 $R/tools/probes/wino_fold_probe.py "$@" > $O/probe.log 2>&1 || { tail -5 $O/probe.log; exit 1; }
 python3 - "$(find $O/trace -name '*kernel_trace.csv' | head -1)" <<'PY' | tee $O/summary.txt
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))

@@ -225,7 +225,7 @@ void td_resize_shape(int h, int w, int short_edge, int max_size, int* out_h, int
 td_status td_nms(const float* boxes, const float* scores, int n, float iou_thresh, int32_t* keep_idx,
                  int32_t* keep_count, void* stream) {
     TD_REQUIRE(boxes && scores && keep_idx && keep_count, "td_nms: null pointer");
-    TD_REQUIRE(n >= 0 && n <= 1024, "td_nms: n=%d must be in [0, 1024]", n);
+    TD_REQUIRE(n >= 0 && n <= 32768, "td_nms: n=%d must be in [0, 32768]", n);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n == 0) {
         TD_HIP_CHECK(hipMemsetAsync(keep_count, 0, sizeof(int32_t), s));
@@ -239,8 +239,12 @@ td_status td_nms(const float* boxes, const float* scores, int n, float iou_thres
     if ((st = scratch(&sc, sizeof(int))) < 0) return st;
     if ((st = scratch(&mk, sizeof(unsigned long long) * n * td_cdiv(n, 64))) < 0) return st;
     if ((st = scratch(&kp, sizeof(int) * n)) < 0) return st;
-    st = sort_boxes_launch(boxes, scores, nullptr, nullptr, 1, n, (float*)sb, (float*)ss, (int*)si, (int*)sc, s);
-    if (st >= 0) st = nms_launch((float*)sb, (int*)sc, nullptr, 1, n, iou_thresh, (unsigned long long*)mk, (int*)kp, keep_count, n, s);
+    if (n > 1024) {      // beyond one block's LDS sort and 16-wave scan (the engine's own item sizes are bounded at td_engine_create)
+        st = nms_big_launch(boxes, scores, n, iou_thresh, (float*)sb, (float*)ss, (int*)si, (int*)sc, (unsigned long long*)mk, (int*)kp, keep_count, s);
+    } else {
+        st = sort_boxes_launch(boxes, scores, nullptr, nullptr, 1, n, (float*)sb, (float*)ss, (int*)si, (int*)sc, s);
+        if (st >= 0) st = nms_launch((float*)sb, (int*)sc, nullptr, 1, n, iou_thresh, (unsigned long long*)mk, (int*)kp, keep_count, n, s);
+    }
     if (st >= 0) st = gather_keep_launch((int*)si, (int*)kp, keep_count, n, keep_idx, s);
     hipError_t herr = hipStreamSynchronize(s);
     (void)hipFree(sb); (void)hipFree(ss); (void)hipFree(si); (void)hipFree(sc); (void)hipFree(mk); (void)hipFree(kp);

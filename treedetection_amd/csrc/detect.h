@@ -65,6 +65,9 @@ td_status rpn_topk_decode_launch(const RpnLevels& lv, const ImgSizes& valid, int
 td_status nms_launch(const float* sorted_boxes, const int* counts, const int* valid, int items, int stride_items,
                      float thr, unsigned long long* mask_ws, int* keep_idx, int* keep_count, int max_keep,
                      hipStream_t stream);
+// n > 1024 boxes of ONE item (td_nms): counting sort + bit matrix + LDS-resident scan; mask_ws: n * ceil(n / 64) words
+td_status nms_big_launch(const float* boxes, const float* scores, int n, float thr, float* sboxes, float* sscores, int* sidx,
+                         int* scount, unsigned long long* mask_ws, int* keep_pos, int* keep_count, hipStream_t stream);
 td_status rpn_merge_launch(const float* cand_boxes, const float* cand_scores, const int* keep_idx, const int* keep_count,
                            int B, int post_topk, float* props, float* prop_scores, int* prop_count, int prop_stride,
                            hipStream_t stream);

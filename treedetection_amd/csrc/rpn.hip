@@ -497,6 +497,107 @@ __global__ __launch_bounds__(1024) void sort_boxes_kernel(const float* __restric
     if (i == 0) scount[item] = m;
 }
 
+// one item, any number of 64-box chunks: row block = blockIdx.y + rb0
+__global__ __launch_bounds__(64) void nms_mask_rows_kernel(const float* __restrict__ boxes, int n, float thr,
+                                                           unsigned long long* __restrict__ mask, int words, int rb0) {
+    const int cb = blockIdx.x, rb = blockIdx.y + rb0;
+    if (rb * 64 >= n || cb * 64 >= n || cb < rb) return;
+    __shared__ float4 cbox[64];
+    const float4* bx = reinterpret_cast<const float4*>(boxes);
+    const int j0 = cb * 64;
+    if (j0 + (int)threadIdx.x < n) cbox[threadIdx.x] = bx[j0 + threadIdx.x];
+    __syncthreads();
+    const int i = rb * 64 + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = bx[i];
+    const float area_a = __fmul_rn(__fsub_rn(a.z, a.x), __fsub_rn(a.w, a.y));
+    unsigned long long bits = 0ull;
+    const int jn = (n - j0) < 64 ? (n - j0) : 64;
+    for (int jj = (cb == rb ? (int)threadIdx.x + 1 : 0); jj < jn; ++jj) {
+        const float4 c = cbox[jj];
+        if (iou_gt(a, area_a, c, thr)) bits |= 1ull << jj;
+    }
+    mask[(size_t)i * words + cb] = bits;
+}
+
+// ---- n > 1024 boxes per item (td_nms only: the engine's item sizes are bounded at td_engine_create) ---------------------
+// Sort by counting: rank(i) = #{j : key_j > key_i, or key_j == key_i and j < i} — the same total order as the bitonic
+// path (score descending, lower index first), O(n^2) compares staged through LDS, every CU takes part.
+__global__ __launch_bounds__(256) void rank_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, int n,
+                                                        float* __restrict__ sboxes, float* __restrict__ sscores,
+                                                        int* __restrict__ sidx, int* __restrict__ scount) {
+    __shared__ uint32_t tile[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t ki = i < n ? float_to_key(scores[i]) : 0u;
+    int rank = 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        tile[threadIdx.x] = j < n ? float_to_key(scores[j]) : 0u;
+        __syncthreads();
+        const int jn = (n - j0) < 256 ? (n - j0) : 256;
+        for (int jj = 0; jj < jn; ++jj) {
+            const uint32_t kj = tile[jj];
+            rank += (kj > ki || (kj == ki && j0 + jj < i)) ? 1 : 0;
+        }
+        __syncthreads();
+    }
+    if (i < n) {
+        *reinterpret_cast<float4*>(sboxes + (size_t)rank * 4) = *reinterpret_cast<const float4*>(boxes + (size_t)i * 4);
+        sscores[rank] = scores[i];
+        sidx[rank] = i;
+    }
+    if (i == 0) scount[0] = n;
+}
+
+// Greedy scan for any number of 64-box chunks: the removed bitmap lives in LDS (one word per chunk), wave 0 resolves chunk
+// c from the diagonal word exactly as nms_scan_kernel does, then the 16 waves share the words c+1 .. of the kept rows.
+constexpr int NMS_BIG_MAX = 32768;
+__global__ __launch_bounds__(1024) void nms_scan_big_kernel(int n, const unsigned long long* __restrict__ mask, int words,
+                                                            int* __restrict__ keep_idx, int* __restrict__ keep_count) {
+    __shared__ unsigned long long removed[NMS_BIG_MAX / 64];
+    __shared__ unsigned long long s_kept;
+    __shared__ int s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int w = threadIdx.x; w < words; w += 1024) {
+        const int left = n - w * 64;                         // boxes beyond n start out removed
+        removed[w] = left >= 64 ? 0ull : (left <= 0 ? ~0ull : (~0ull << left));
+    }
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int c = 0; c < words; ++c) {
+        if (wave == 0) {
+            const int i = c * 64 + lane;
+            const unsigned long long diag = (i < n) ? mask[(size_t)i * words + c] : 0ull;
+            unsigned long long rem = removed[c], kept = 0ull;
+            for (int j = 0; j < 64; ++j) {
+                const unsigned long long dj = __shfl(diag, j);
+                if (!((rem >> j) & 1ull)) {
+                    kept |= 1ull << j;
+                    rem |= dj;
+                }
+            }
+            const int base = s_base;
+            const int pos = base + __popcll(kept & ((1ull << lane) - 1ull));
+            if ((kept >> lane) & 1ull) keep_idx[pos] = i;
+            if (lane == 0) {
+                s_kept = kept;
+                s_base = base + __popcll(kept);
+            }
+        }
+        __syncthreads();
+        const unsigned long long kept = s_kept;
+        const int i = c * 64 + lane;
+        const bool mine = ((kept >> lane) & 1ull) && i < n;
+        for (int w = c + 1 + wave; w < words; w += 16) {
+            unsigned long long v = mine ? mask[(size_t)i * words + w] : 0ull;
+            for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off);
+            if (lane == 0) removed[w] |= v;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) keep_count[0] = s_base;
+}
+
 // map kept positions (in the sorted order) back to original indices
 __global__ void gather_keep_kernel(const int* __restrict__ sidx, const int* __restrict__ keep_pos,
                                    const int* __restrict__ keep_count, int n, int* __restrict__ out_idx) {
@@ -533,6 +634,23 @@ td_status nms_launch(const float* sorted_boxes, const int* counts, const int* va
     TD_KERNEL_CHECK();
     hipLaunchKernelGGL(nms_scan_kernel, dim3(items), dim3(1024), 0, stream, counts, stride_items, valid, mask_ws, words,
                        keep_idx, keep_count, max_keep);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
+td_status nms_big_launch(const float* boxes, const float* scores, int n, float thr, float* sboxes, float* sscores, int* sidx,
+                         int* scount, unsigned long long* mask_ws, int* keep_pos, int* keep_count, hipStream_t stream) {
+    TD_REQUIRE(n >= 1 && n <= NMS_BIG_MAX, "nms: at most %d boxes (got %d)", NMS_BIG_MAX, n);
+    const int words = td_cdiv(n, 64);
+    hipLaunchKernelGGL(rank_sort_kernel, dim3(td_cdiv(n, 256)), dim3(256), 0, stream, boxes, scores, n, sboxes, sscores, sidx, scount);
+    TD_KERNEL_CHECK();
+    // nms_mask_kernel only writes the words cb >= rb of a row: the scan reads exactly those (diagonal and later words)
+    for (int z0 = 0; z0 < words; z0 += 512) {      // grid.y slices (hip grid dims are generous; slices keep launches short)
+        const int zn = words - z0 < 512 ? words - z0 : 512;
+        hipLaunchKernelGGL(nms_mask_rows_kernel, dim3(words, zn), dim3(64), 0, stream, sboxes, n, thr, mask_ws, words, z0);
+        TD_KERNEL_CHECK();
+    }
+    hipLaunchKernelGGL(nms_scan_big_kernel, dim3(1), dim3(1024), 0, stream, n, mask_ws, words, keep_pos, keep_count);
     TD_KERNEL_CHECK();
     return TD_OK;
 }

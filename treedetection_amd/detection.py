@@ -27,16 +27,37 @@ from .postprocessing import process_files_in_directory
 from .stitching import process_and_stitch_predictions
 
 
-def assign_images(paths, world: int):
-    """Image-level sharding: → owner rank of every image. Longest-processing-time first on the raster's file size (a proxy for
-    its tile count: the seam strips under ``merged/`` are a fraction of a full image), ties and equal sizes fall back to
-    round-robin in list order — with equal images this IS ``i mod world``. Deterministic in (paths, sizes, world)."""
+def image_weights(paths, tiles_path=None):
+    """What an image costs its owner: its TILE COUNT — the number of entries of ``<tiles_path>/<image>.json``, the list the
+    predictor walks (reference prediction.py:127-157) — when every image's tile file can be read; else the raster's file size
+    for all of them (one unit for the whole list). File size alone misleads on DEFLATE / LZW rasters, whose bytes follow the
+    content and not the geometry: equal images would be split unevenly and the fast ranks would sit in the closing gather."""
+    import json
+    counts = []
+    if tiles_path is not None:
+        for p in paths:
+            try:
+                with open(os.path.join(tiles_path, os.path.basename(p).replace(".tif", ".json"))) as f:
+                    counts.append(len(json.load(f)))
+            except (OSError, ValueError):
+                counts = None
+                break
+        if counts is not None:
+            return counts
     sizes = []
     for p in paths:
         try:
             sizes.append(os.path.getsize(p))
         except OSError:
             sizes.append(0)
+    return sizes
+
+
+def assign_images(paths, world: int, tiles_path=None):
+    """Image-level sharding: → owner rank of every image. Longest-processing-time first on ``image_weights`` (tile counts; the
+    seam strips under ``merged/`` are a fraction of a full image), ties and equal weights fall back to round-robin in list
+    order — with equal images this IS ``i mod world``. Deterministic in (paths, weights, world)."""
+    sizes = image_weights(paths, tiles_path)
     order = sorted(range(len(paths)), key=lambda i: (-sizes[i], i))
     load = [0] * world
     owner = [0] * len(paths)
@@ -168,9 +189,9 @@ def predict_on_model(config, model_path, tiles_path, output_path, batch_size=10,
             images_paths = [f for f in images_paths if f not in processed_files]
     owner = None
     if W > 1:
-        # ONE list for everybody (rank 0's view of the folders, of the resume file and of the raster sizes): the ranks' walks
+        # ONE list for everybody (rank 0's view of the folders, of the resume file and of the images' tile counts): the ranks' walks
         # must agree on the images and — image-level sharding — on who owns which. The only collective before the walk.
-        images_paths, processed_files, found, owner = D.broadcast_object((images_paths, processed_files, found, assign_images(images_paths, W)))
+        images_paths, processed_files, found, owner = D.broadcast_object((images_paths, processed_files, found, assign_images(images_paths, W, tiles_path)))
     if not images_paths:
         if logger and not found:
             logger.warning("No TIF files found for prediction.")
@@ -207,28 +228,51 @@ def predict_on_model(config, model_path, tiles_path, output_path, batch_size=10,
         # who stitches an image as soon as its tile files are complete: the rank that owns it (image-level sharding, single
         # process), else rank 0 (tile-level sharding: every image's files are complete when its collective call returns)
         stitch_here = stitch_to if (config.get("eager_stitch", True) and (shard_by in ("single", "image") or me == 0)) else None
-        report = walk_images(config, predictor, [images_paths[i] for i in mine], tiles_path, output_path,
-                             chain=shard_by in ("single", "image"), stitch_to=stitch_here)
+        my_paths = [images_paths[i] for i in mine]
+        walk_error = None
+        try:
+            report = walk_images(config, predictor, my_paths, tiles_path, output_path,
+                                 chain=shard_by in ("single", "image"), stitch_to=stitch_here)
+        except Exception as e:
+            # outside the per-image try of the walk (the eager stitcher's folder on this rank's mount, say): under image-level
+            # sharding the peers are on their way into the manifest gather — this rank must enter the SAME collectives in the
+            # same order and raise afterwards, or they wait for it until the watchdog
+            if not (W > 1 and shard_by == "image"):
+                raise
+            walk_error = e
+            if logger:
+                logger.error(f"rank {me}: the image walk failed: {e}")
+            report = {"done": [], "failed": my_paths, "stitched": [], "stitch_seconds": 0.0, "error": repr(e)}
         # the ONLY collectives of the walk under image-level sharding: one manifest gather, one all-reduce
         reports = D.gather_objects(report) if (W > 1 and shard_by == "image") else [report]
-        ok = True
+        ok = walk_error is None
         if me == 0:
             all_done = [p for r in reports for p in r["done"]]
             all_failed = [p for r in reports for p in r["failed"]]
             all_stitched = [p for r in reports for p in r["stitched"]]
+            handled = images_paths
             if shard_by == "image":
                 seen = sorted(all_done + all_failed)
-                ok = seen == sorted(images_paths)
-                if not ok:
+                covered = seen == sorted(images_paths)
+                errors = [r["error"] for r in reports if r.get("error")]
+                if not covered:
                     logger.error(f"image-level sharding: {len(images_paths)} images assigned, {len(seen)} reported "
                                  f"({len(set(images_paths) - set(seen))} missing, {len(seen) - len(set(seen))} twice)")
-            logger.info(f"Completed prediction for {len(images_paths)} images.")
-            save_prediction_recovery_data(output_path, tiles_path, model_path, processed_files, images_paths)
+                if not covered or errors:
+                    # the resume file lists only what some rank really walked (predicted, or failed and logged like the reference's
+                    # log-and-continue): an image nobody reported, or one of a rank whose whole walk broke, is predicted by the next run
+                    ok = False
+                    broken = {p for r in reports if r.get("error") for p in r["failed"]}
+                    handled = [p for p in images_paths if p in set(seen) and p not in broken]
+            logger.info(f"Completed prediction for {len(handled)} of {len(images_paths)} images.")
+            save_prediction_recovery_data(output_path, tiles_path, model_path, processed_files, handled)
             if stitch_to is not None and all_stitched:
                 from .recoveries import load_stitching_recovery, save_stitching_recovery
                 save_stitching_recovery(stitch_to, sorted(load_stitching_recovery(stitch_to, None)) + all_stitched, logger)
         if W > 1 and shard_by == "image" and not D.all_ok(ok):
-            raise RuntimeError("image-level sharding: the ranks' manifests do not cover the image list exactly once")
+            if walk_error is not None:
+                raise walk_error
+            raise RuntimeError("image-level sharding: a rank's walk failed or the ranks' manifests do not cover the image list exactly once")
     finally:
         predictor.close()
         D.barrier()      # every Prediction_*.json, every eagerly stitched layer and the resume files are written before anyone moves on

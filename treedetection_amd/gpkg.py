@@ -108,12 +108,16 @@ def write_blobs(path: str, blobs: Iterable, columns: Dict[str, Sequence], epsg: 
     maxy) of the layer or None; ``epsg=None`` writes srs_id 4326 like the reference's empty frame (helpers.py:541-543)."""
     layer = layer or os.path.splitext(os.path.basename(path))[0]
     srs_id = int(epsg) if epsg else 4326
-    if os.path.exists(path):
-        os.remove(path)
+    final = path
+    path = final + ".tmp"          # written under a temporary name, fsynced once, then renamed: a layer that EXISTS is complete
+    for stale in (path, final):
+        if os.path.exists(stale):
+            os.remove(stale)
     con = sqlite3.connect(path)
     try:
-        # a file written once from scratch: no rollback journal, no fsync per transaction (a crash leaves a partial file that the
-        # resume logic rebuilds: stitching_recovery.yaml lists a folder only after its layer was written)
+        # a file written once from scratch: no rollback journal, no fsync per transaction; durability comes from the ONE fsync
+        # before the rename below — stitching_recovery.yaml lists a folder only after its layer was written, and after an OS
+        # crash the resume logic must not trust a layer whose pages never reached the disk
         con.execute("PRAGMA journal_mode = OFF")
         con.execute("PRAGMA synchronous = OFF")
         con.execute("PRAGMA application_id = 1196444487")      # 'GPKG'
@@ -156,8 +160,18 @@ def write_blobs(path: str, blobs: Iterable, columns: Dict[str, Sequence], epsg: 
             cols.append(vals)
         con.executemany(f'INSERT INTO "{layer}" (geom{", " + quoted if names else ""}) VALUES ({ph})', zip(blobs, *cols))
         con.commit()
-    finally:
+    except BaseException:
         con.close()
+        if os.path.exists(path):
+            os.remove(path)
+        raise
+    con.close()
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        os.fsync(fd)
+    finally:
+        os.close(fd)
+    os.replace(path, final)
 
 
 def _py(v):

@@ -67,71 +67,49 @@ def save_prediction_recovery_data(output_path, tiles_path, model_path, processed
         print(f"Failed to save prediction recovery file: {e}")
 
 
-# ---- stitching resume file (reference recoveries.py:111-144) -----------------------------------------------
+# ---- "which images are finished" lists of the stitching and the fusion stage ----------------------------------
+# On disk (the format is the contract: reference recoveries.py:111-144 and 251-284 write the same one-key mapping, and
+# tests/golden/recovery_fixture.json pins it against files the reference's own module wrote):
+#     <stage>_recovery.yaml = {completed_files: [<image stem>, ...]}      stems sorted, no folder, no extension
+# Both stages share one ledger class; the four module-level functions the rest of the package calls are its bound faces.
+class _CompletedLedger:
+    def __init__(self, file_name: str, label: str, failure_level: str):
+        self.file_name, self.label, self.failure_level = file_name, label, failure_level
+
+    @staticmethod
+    def _say(logger, level: str, text: str) -> None:
+        if logger is not None:
+            getattr(logger, level)(text)
+
+    def read(self, folder, logger=None) -> set:
+        """→ the set of finished stems; a missing, empty or unreadable ledger is an empty set (a read error is logged, never raised)."""
+        path = os.path.join(folder, self.file_name)
+        if not os.path.exists(path):
+            return set()
+        try:
+            with open(path) as f:
+                entries = (yaml.safe_load(f) or {}).get("completed_files") or []
+        except Exception as e:
+            self._say(logger, "warning", f"Failed to load {self.label} recovery: {e}")
+            return set()
+        self._say(logger, "info", f"Loaded {len(entries)} completed {self.label} files from recovery.")
+        return {os.path.basename(str(p)) for p in entries}
+
+    def write(self, folder, results, logger=None) -> None:
+        """``results``: paths or stems of finished images (None entries = failed ones, skipped). Errors are logged, never raised."""
+        stems = sorted({os.path.splitext(os.path.basename(str(r)))[0] for r in results if r is not None})
+        try:
+            with open(os.path.join(folder, self.file_name), "w") as f:
+                yaml.safe_dump({"completed_files": stems}, f, sort_keys=False)
+        except Exception as e:
+            self._say(logger, self.failure_level, f"Failed to save {self.label} recovery: {e}")
+            return
+        self._say(logger, "info", f"Saved {self.label} recovery with {len(stems)} files.")
+
+
 STITCHING_RECOVERY_NAME = "stitching_recovery.yaml"
-
-
-def load_stitching_recovery(output_path, logger=None):
-    """``stitching_recovery.yaml`` = ``{completed_files: [<image stem>, ...]}`` → set of stems (empty when the file is
-    missing or unreadable; a read error is logged, not raised)."""
-    recovery_file = os.path.join(output_path, STITCHING_RECOVERY_NAME)
-    completed = set()
-    if os.path.exists(recovery_file):
-        try:
-            with open(recovery_file) as f:
-                data = yaml.safe_load(f)
-            if data and "completed_files" in data:
-                completed = set(os.path.basename(p) for p in data["completed_files"])
-            if logger:
-                logger.info(f"Loaded {len(completed)} completed files from recovery.")
-        except Exception as e:
-            if logger:
-                logger.warning(f"Failed to load stitching recovery: {e}")
-    return completed
-
-
-def save_stitching_recovery(output_path, results, logger=None):
-    recovery_file = os.path.join(output_path, STITCHING_RECOVERY_NAME)
-    try:
-        stems = sorted({os.path.splitext(os.path.basename(r))[0] for r in results if r is not None})
-        with open(recovery_file, "w") as f:
-            yaml.safe_dump({"completed_files": stems}, f, sort_keys=False)
-        if logger:
-            logger.info(f"Saved recovery with {len(stems)} files.")
-    except Exception as e:
-        if logger:
-            logger.error(f"Failed to save stitching recovery: {e}")
-
-
-# ---- fusion resume file (reference recoveries.py:251-284) --------------------------------------------------
 FUSION_RECOVERY_NAME = "fusion_recovery.yaml"
-
-
-def load_fusion_recovery(output_dir, logger=None):
-    recovery_file = os.path.join(output_dir, FUSION_RECOVERY_NAME)
-    completed = set()
-    if os.path.exists(recovery_file):
-        try:
-            with open(recovery_file) as f:
-                data = yaml.safe_load(f)
-            if data and "completed_files" in data:
-                completed = set(os.path.basename(p) for p in data["completed_files"])
-            if logger:
-                logger.info(f"Loaded {len(completed)} completed fusion files from recovery.")
-        except Exception as e:
-            if logger:
-                logger.warning(f"Failed to load fusion recovery: {e}")
-    return completed
-
-
-def save_fusion_recovery(output_dir, results, logger=None):
-    recovery_file = os.path.join(output_dir, FUSION_RECOVERY_NAME)
-    try:
-        stems = sorted({os.path.splitext(os.path.basename(r))[0] for r in results if r is not None})
-        with open(recovery_file, "w") as f:
-            yaml.safe_dump({"completed_files": stems}, f, sort_keys=False)
-        if logger:
-            logger.info(f"Saved fusion recovery with {len(stems)} files.")
-    except Exception as e:
-        if logger:
-            logger.warning(f"Failed to save fusion recovery: {e}")
+_stitching = _CompletedLedger(STITCHING_RECOVERY_NAME, "stitching", "error")
+_fusion = _CompletedLedger(FUSION_RECOVERY_NAME, "fusion", "warning")
+load_stitching_recovery, save_stitching_recovery = _stitching.read, _stitching.write
+load_fusion_recovery, save_fusion_recovery = _fusion.read, _fusion.write

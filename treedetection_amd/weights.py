@@ -137,7 +137,7 @@ def make_synthetic_state_dict(depth: int = 50, seed: int = 0, num_classes: int =
                 # damp the residual branch so depth does not blow up: x + 0.5 f(x) grows the stream's variance by ~1.25 per
                 # block, fine for the <= 6 blocks of an R50 stage; R101's res4 has 23 — with the same gain its output was 13x
                 # the R50 amplitude, every head saturated (100 detections of score ~1 per tile, SURVEY §8d asks for ~30) and
-                # fp16 rounding was amplified 17x (tools/fp16_set_diag.py). Longer stages get 0.5 sqrt(6 / blocks): the same
+                # fp16 rounding was amplified 17x (tools/probes/fp16_set_diag.py). Longer stages get 0.5 sqrt(6 / blocks): the same
                 # total growth as six blocks. (R50 weights are unchanged: round 4.)
                 stage = int(name.split(".res")[1][0]) if ".res" in name else 0
                 nblk = RES_BLOCKS[depth][stage - 2] if 2 <= stage <= 5 else 1
