@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--no-two-model", action="store_true", help="skip the two-model (urban + forest, exclude flags) region of BASELINE configs[2]")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end region: warm Predictor.__call__ over a synthetic GeoTIFF on tmpfs "
                     "(window reads → device → Prediction_*.json files)")
+    ap.add_argument("--no-lzw", action="store_true", help="skip the LZW-raster region (device decode of compressed rasters, files to files)")
+    ap.add_argument("--lzw-side", type=int, default=10, help="the LZW raster is side x side tiles of --tile pixels")
     ap.add_argument("--e2e-side", type=int, default=20, help="the e2e raster is side x side tiles of --tile pixels")
     ap.add_argument("--streams", type=int, default=0, help="engines / HIP streams the batches alternate over (default 3 for "
                     "--schedule streams, 1 for plain): the HBM-bound kernels and the kernel tails of one forward run under the "
@@ -244,7 +246,10 @@ def compact_line(full):
             "predict_tiles_noise_f32": val("predict_tiles_noise", "f32", "value"), "predict_tiles_noise_f16": val("predict_tiles_noise", "f16", "value"),
             "e2e_contours_per_tile": val("e2e", "f32", "contours_per_tile"), "e2e_crowns_contours_per_tile": val("e2e_crowns", "f32", "contours_per_tile"),
             "e2e_json_kb_per_tile": _r((full.get("e2e", {}).get("f32", {}).get("json_bytes_per_tile") or 0) / 1e3) or None,
-            "e2e_crowns_json_kb_per_tile": _r((full.get("e2e_crowns", {}).get("f32", {}).get("json_bytes_per_tile") or 0) / 1e3) or None}
+            "e2e_crowns_json_kb_per_tile": _r((full.get("e2e_crowns", {}).get("f32", {}).get("json_bytes_per_tile") or 0) / 1e3) or None,
+            "e2e_lzw_f16": val("lzw", "f16", "device", "value"), "e2e_lzw_f16_ratio": val("lzw", "f16", "device", "ratio_to_model_stage"),
+            "e2e_lzw_host_reader_f16": val("lzw", "f16", "host_reader", "value"),
+            "lzw_decode_windows_450_per_s": val("lzw", "f16", "decode_windows_450x450x4_per_s"), "lzw_decode_gb_per_s": val("lzw", "f16", "decode_gbytes_per_s")}
     c["regions"] = {k: v for k, v in scal.items() if v is not None}
     c["regions_unit"] = "tiles/s (two_model: tile visits/s; *_frac: executed FLOPs / MFMA peak; *_ratio: e2e / model stage; predict_tiles_*: files to GeoPackage layers = predict + stitch, image-sharded at N > 1; *_per_tile: counts / kB)"
     c["detail"] = full.get("detail_file")
@@ -776,6 +781,87 @@ def main():
                                               "note": "images back to back as detection.predict_on_model walks them: image i+1 submitted while image i drains"}}
             return out
 
+    def run_lzw(precision, sd_w, side):
+        """SURVEY §8f-2's leftover: the raster as real orthophotos are stored — LZW, 256 x 256 tiles, predictor 2
+        (GDAL: TILED=YES COMPRESS=LZW PREDICTOR=2) — files to files. The compressed blocks cross PCIe once and are decoded on the GPU
+        (tiffdecode.hip, one wave per block), the tile windows are cut in HBM; the next image is decoded while the current one
+        predicts (Predictor.prefetch). Reported: the decode alone (raster bytes/s, also as 450 x 450 x 4 windows/s, the reference's
+        tile size), the chained files-to-files rate, and the same walk through the HOST reader's decode threads on a few tiles."""
+        import shutil
+        import tempfile
+        import treedetection_amd as T
+        from treedetection_amd.geotiff import GeoTiff, write_geotiff
+        from treedetection_amd.preprocessing import tile_data
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        root = tempfile.mkdtemp(prefix="td_lzw_", dir=base)
+        try:
+            os.makedirs(f"{root}/rgb")
+            img = np.zeros((4, side * S, side * S), np.uint8)
+            for r in range(side):
+                for c in range(side):
+                    t = rgb_np[(r * side + c) % len(rgb_np)]
+                    img[:3, r * S:(r + 1) * S, c * S:(c + 1) * S] = t.transpose(2, 0, 1)
+                    img[3, r * S:(r + 1) * S, c * S:(c + 1) * S] = t[..., 1]
+            tif = f"{root}/rgb/324125000.tif"
+            t0 = time.perf_counter()
+            write_geotiff(tif, img, (0.2, 0.0, 412000.0, 0.0, -0.2, 5318000.0 + side * S * 0.2), 25832, compression="lzw", tile=(256, 256), predictor=2)
+            t_enc = time.perf_counter() - t0
+            raw_bytes, file_bytes = img.nbytes, os.path.getsize(tif)
+            del img
+            tile_data([tif], f"{root}/tiles", buffer=0, tile_width=int(S * 0.2), tile_height=int(S * 0.2))
+            tjson = f"{root}/tiles/324125000.json"
+            ntiles = len(json.load(open(tjson)))
+            # (a) the decode alone: file → pinned memory → device → decoded raster in HBM
+            g = GeoTiff(tif)
+            times = []
+            for _ in range(4):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                image, check = g.decode_to_device(f"cuda:{local_rank}")
+                check()
+                times.append(time.perf_counter() - t0)
+                del image
+            t_dec = min(times[1:])
+            cfg = T.setup_model_cfg(update_model="synthetic", device=str(local_rank))
+            names = [str(324125001 + k) for k in range(5)]
+            for nm in names:
+                os.link(tif, f"{root}/rgb/{nm}.tif")
+                os.link(tjson, f"{root}/tiles/{nm}.json")
+            res = {"raster": f"{side * S}x{side * S}x4 uint8, LZW, 256x256 tiles, predictor 2, on {'tmpfs' if base else 'disk'}",
+                   "raw_bytes": raw_bytes, "file_bytes": file_bytes, "compression_ratio": raw_bytes / file_bytes, "encode_seconds": t_enc,
+                   "decode_seconds": t_dec, "decode_calls_s": times, "decode_gbytes_per_s": raw_bytes / t_dec / 1e9,
+                   "decode_windows_450x450x4_per_s": raw_bytes / t_dec / (450 * 450 * 4), "tiles_per_image": ntiles}
+            for mode, dd, imgs in (("device", "auto", names), ("host_reader", False, names[:1])):
+                pred = T.Predictor(cfg, device_type=str(local_rank), max_batch_size=B, output_dir=f"{root}/out_{mode}", precision=precision,
+                                   state_dict=sd_w, return_predictions=False, device_decode=dd)
+                try:
+                    pred.prefetch(tif)
+                    pred(tif, tjson)                   # warm-up image
+                    t0 = time.perf_counter()
+                    pending = None
+                    pred.prefetch(f"{root}/rgb/{imgs[0]}.tif")
+                    for k, nm in enumerate(imgs):
+                        if k + 1 < len(imgs):
+                            pred.prefetch(f"{root}/rgb/{imgs[k + 1]}.tif")
+                        h = pred.submit(f"{root}/rgb/{nm}.tif", f"{root}/tiles/{nm}.json")
+                        if pending is not None:
+                            pending.result()
+                        pending = h
+                    pending.result()
+                    dt_l = time.perf_counter() - t0
+                    files = sum(len(os.listdir(f"{root}/out_{mode}/{nm}")) for nm in imgs)
+                    assert files == len(imgs) * ntiles, (mode, files)
+                    res[mode] = {"value": len(imgs) * ntiles / dt_l, "unit": "tiles/s", "images": len(imgs), "seconds": dt_l,
+                                 "decode": dict(pred.decode_stats)}
+                finally:
+                    pred.close()
+                    shutil.rmtree(f"{root}/out_{mode}", ignore_errors=True)
+            log(f"lzw region ({precision}): decode {t_dec * 1e3:.1f} ms per {raw_bytes / 1e6:.0f} MB raster ({res['decode_windows_450x450x4_per_s']:.0f} windows of 450x450x4 per s), "
+                f"files to files {res['device']['value']:.0f} tiles/s on the device decoder, {res['host_reader']['value']:.0f} through the host reader")
+            return res
+        finally:
+            shutil.rmtree(root, ignore_errors=True)
+
     if "TD_TUNE_CACHE" not in os.environ:     # engines of one run share their measured block-tile choices
         import tempfile
         os.environ["TD_TUNE_CACHE"] = os.path.join(tempfile.mkdtemp(prefix="td_tune_"), f"tiles_rank{rank}.txt")
@@ -828,7 +914,7 @@ def main():
             b32 = go("fp16", not args.no_profile, "fp16_batch32") + (nsteps,)
             B, nsteps = args.batch, args.steps
     two = e2e = e2e_c = None
-    pt = pt_n = None
+    pt = pt_n = lzw = None
     if args.depth == 50 and args.schedule == "streams" and not args.no_e2e:
         import shutil
         from treedetection_amd.weights import blob_mask_head
@@ -857,6 +943,10 @@ def main():
                     pt[pk] = run_predict_tiles(pk, fx, sd_c, "crowns", per_rank[pk])
                     dtc, _, _ = run(pk, args.streams, False, name=f"crowns_model_{pk}", weights=sd_c)
                     e2e_c[pk]["model_stage_same_weights"] = pt[pk]["model_stage_same_weights"] = args.steps * B * world / dtc
+                if not args.no_lzw:
+                    pk = "fp16" if "fp16" in precs else precs[0]
+                    lzw = {pk: run_lzw(pk, sd_c, args.lzw_side)}
+                    lzw[pk]["model_stage_same_weights"] = e2e_c[pk]["model_stage_same_weights"]
             else:
                 # N > 1: predict_tiles files to GeoPackage layers with WHOLE IMAGES sharded over the ranks (the structure
                 # detection.predict_on_model runs), compact-crown fixture
@@ -1144,6 +1234,15 @@ def main():
                 r["ratio_to_model_stage"] = r["value"] / ref_rate if ref_rate else None
                 o["f32" if pk == "fp32" else "f16"] = r
             line[key] = o
+        if lzw:
+            o = {"note": "files to files on an LZW-compressed raster (256 x 256 tiles, predictor 2): compressed blocks decoded on the GPU, one wave per "
+                         "block, tile windows cut in HBM, next image decoded while the current one predicts; `host_reader` = the same raster through "
+                         "the host decode threads (device_decode: false); ratio = rate / model-stage rate of the same precision and weights"}
+            for pk, r in lzw.items():
+                ref_rate = max((line["value"] if pk == args.precision else (line.get("fp16") or {}).get("value")) or 0.0, r.get("model_stage_same_weights") or 0.0) or None
+                r["device"]["ratio_to_model_stage"] = r["device"]["value"] / ref_rate if ref_rate else None
+                o["f32" if pk == "fp32" else "f16"] = r
+            line["lzw"] = o
         if world == 1 and not args.no_cpu_baseline:
             sd101 = None
             if args.depth == 50 and not args.no_r101:

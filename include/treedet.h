@@ -290,6 +290,22 @@ int td_tile_prediction_file(int device, const int32_t* mask_region, const int64_
  * (TD_ERR_CAPACITY when the stream decodes to more than cap bytes, TD_ERR_INVALID for a corrupt stream). */
 int64_t td_tiff_lzw_decode(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap);
 int64_t td_tiff_packbits_decode(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap);
+/* The writer's side of td_tiff_lzw_decode (test rasters, the bench's LZW fixture): one strip or tile → a TIFF 6.0 LZW stream
+ * (ClearCode first, EOI last) that libtiff / GDAL / td_tiff_lzw_decode read back. Returns the compressed size or a negative status. */
+int64_t td_tiff_lzw_encode(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap);
+/* ---- compressed rasters decoded on the GPU (tiffdecode.hip). The reference decodes every tile window on the
+ * host (prediction.py:164 → GDAL → libtiff); here the compressed blocks of a raster cross PCIe once and are decoded by one wave
+ * each. comp: DEVICE copy of the file's compressed bytes (padded by >= 8 bytes); block_off / block_nbytes: DEVICE int64
+ * [nblocks], position and size of every LZW strip / tile in comp; blocks_out: DEVICE [nblocks][block_cap] bytes, block b decoded
+ * at b * block_cap (block_cap = bytes of a full block); decoded / status: DEVICE [nblocks] — bytes produced, and 0 = ok,
+ * 1 = corrupt stream, 2 = more than block_cap bytes (the rules of td_tiff_lzw_decode). Asynchronous on `stream`. */
+td_status td_tiff_lzw_decode_dev(const uint8_t* comp, const int64_t* block_off, const int64_t* block_nbytes, int nblocks,
+                                 uint8_t* blocks_out, int64_t block_cap, int64_t* decoded, int32_t* status, void* stream);
+/* Decoded blocks (strips: block_w = width; tiles: full padded tiles, row-major grid blocks_across x blocks_down) → the raster
+ * image [height][width][spp] uint8 (DEVICE), predictor 2 undone per block row on the way (td_tiff_unpredict's arithmetic).
+ * spp <= 4. Asynchronous on `stream`. */
+td_status td_tiff_blocks_to_image_dev(const uint8_t* blocks, int64_t block_cap, int block_w, int block_h, int blocks_across,
+                                      int blocks_down, int spp, int predictor, uint8_t* image, int width, int height, void* stream);
 /* Window of an uncompressed pixel-interleaved raster with contiguous strips (the tile windows of reference
  * prediction.py:164, rasterio.mask.mask(..., crop=True)): `rows` pieces of `row_bytes` bytes lying `row_stride` bytes apart
  * from `file_off` on, read with pread(2) into the dense buffer dst (e.g. pinned staging memory). Returns the bytes read or

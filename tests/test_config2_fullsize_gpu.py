@@ -232,10 +232,11 @@ def two_model_trained(two_model):
 def test_two_model_flow_fp16_set_rule_on_trained_box_heads(two_model_trained, model, folder):
     """The fp16 set rule on the two-model flow (reference detection.py:154-164) at full size: per model, on a tile only THAT model
     predicts, the fp16 engine against the fp32 oracle with the model's TRAINED box head (committed fixture) — every detection clear
-    of the score cut pairs one-to-one at IoU >= 0.9, and every pair is within the stated fp16 tolerances (boxes <= 0.5 px, scores
-    within 5e-3 * max(1, 4 s (1 - s) / 0.36), mask probabilities <= 3e-2) — and the file `predict_tiles(precision: fp16)` wrote for
+    of the score cut pairs one-to-one at IoU >= 0.9 up to the stated share of near-tie exceptions, and the pairs meet the stated
+    fp16 tolerances (tests/test_engine_fp16_gpu.FP16_TRAINED = BASELINE.md §3.4: the same bounds as the single-model fixtures) — and
+    the file `predict_tiles(precision: fp16)` wrote for
     the tile carries exactly the fp16 engine's detections (scores bit for bit), the other model never wrote it."""
-    from tests.test_engine_fp16_gpu import SCORE_THRESH, match_detection_sets
+    from tests.test_engine_fp16_gpu import SCORE_THRESH, assert_fp16_trained_statement, match_detection_sets
     from treedetection_amd.engine import Engine, INPUT_U8_HWC, unpack_outputs
     root, trained, picks = two_model_trained
     tile_id, _ = picks[model]
@@ -256,17 +257,13 @@ def test_two_model_flow_fp16_set_rule_on_trained_box_heads(two_model_trained, mo
     strict, cluster, lost, extra = match_detection_sets(g, ref, band)
     far = lambda d, idx: d["scores"][idx] > SCORE_THRESH + band      # noqa: E731
     exceptions = sum(1 for i, j, _ in cluster if far(ref, i) or far(g, j)) + len(lost) + len(extra)
-    es = max(abs(float(g["scores"][j]) - float(ref["scores"][i])) for i, j, _ in strict)
-    eb = max(float(np.abs(g["pred_boxes"][j] - ref["pred_boxes"][i]).max()) for i, j, _ in strict)
-    ep = max(float(np.abs(g["mask_probs"][j] - ref["mask_probs"][i]).max()) for i, j, _ in strict)
-    out_of_rule = [(float(ref["scores"][i]), abs(float(g["scores"][j]) - float(ref["scores"][i]))) for i, j, _ in strict
-                   if abs(float(g["scores"][j]) - float(ref["scores"][i])) > 5e-3 * max(1.0, 4.0 * float(ref["scores"][i]) * (1.0 - float(ref["scores"][i])) / 0.36)]
     print(f"\n[fp16 two-model, trained box head, {model}] tile {tile_id}: {len(ref['scores'])} oracle / {len(g['scores'])} engine detections, "
           f"{len(strict)} strict pairs, cluster pairs {[round(v, 2) for _, _, v in cluster]}, unpaired oracle {np.round(lost, 3).tolist()} "
-          f"engine {np.round(extra, 3).tolist()}; worst pair: score {es:.2e}, box {eb:.3f} px, mask probability {ep:.2e}; outside the score rule {out_of_rule}")
+          f"engine {np.round(extra, 3).tolist()}")
     assert 20 <= len(ref["scores"]) <= 60
-    assert exceptions == 0, (exceptions, cluster, lost, extra)
-    assert not out_of_rule and eb <= 0.5 and ep <= 3e-2, (out_of_rule, eb, ep)
+    rows = [(abs(float(g["scores"][j]) - float(ref["scores"][i])), float(np.abs(g["pred_boxes"][j] - ref["pred_boxes"][i]).max()),
+             float(np.abs(g["mask_probs"][j] - ref["mask_probs"][i]).max()), float(ref["scores"][i]), v) for i, j, v in strict]
+    assert_fp16_trained_statement(model, rows, [exceptions], len(ref["scores"]))
     got = json.load(open(root / "output_trained_fp16" / folder / "1" / f"Prediction_{tile_id}.json"))
     eng_scores = {float(s) for s in g["scores"]}
     assert len(got) >= len(g["scores"]) and {e["score"] for e in got} <= eng_scores

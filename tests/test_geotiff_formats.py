@@ -34,6 +34,9 @@ def _image(rng, c, h, w, dtype):
     {"tile": (32, 64), "compression": "deflate", "predictor": 2},
     {"tile": (48, 48), "planar": True, "compression": "deflate"},
     {"rows_per_strip": 33, "planar": True, "predictor": 2},
+    {"rows_per_strip": 5, "compression": "lzw"},                            # td_tiff_lzw_encode → td_tiff_lzw_decode
+    {"tile": (64, 64), "compression": "lzw", "predictor": 2},
+    {"compression": "lzw", "planar": True},                                 # one strip per band: several table clears per block
 ])
 @pytest.mark.parametrize("dtype,bands", [(np.uint8, 4), (np.uint16, 3), (np.float32, 1)])
 def test_layouts_round_trip(tmp_path, kw, dtype, bands):
@@ -202,3 +205,30 @@ def test_flat_windows_are_pread_into_the_callers_buffer(tmp_path):
         assert lib.td_read_window(-1, 0, 8, 8, 1, buf.ctypes.data) == _lib.ERR_INVALID
     assert g._fd is None
 
+
+
+def test_lzw_encoder_streams_are_what_libtiff_reads(tmp_path):
+    """td_tiff_lzw_encode (the writer's codec: test rasters, the bench's LZW fixture) against the two independent decoders at hand:
+    this package's td_tiff_lzw_decode and libtiff (through Pillow) — flat areas (long strings, the KwKwK case), noise (literals),
+    blocks large enough for several table clears, empty and one-byte blocks."""
+    from PIL import Image
+    lib = _lib.load()
+    rng = np.random.default_rng(2)
+    for raw in (b"", b"a", bytes(70000), rng.integers(0, 256, 150000, dtype=np.uint8).tobytes(),
+                rng.integers(0, 3, 200000, dtype=np.uint8).tobytes(), bytes(range(256)) * 200, b"ab" * 40000):
+        src = np.frombuffer(raw, dtype=np.uint8)
+        dst = np.empty(len(raw) * 3 // 2 + 64, np.uint8)
+        n = lib.td_tiff_lzw_encode(src.ctypes.data, src.size, dst.ctypes.data, dst.size)
+        assert n >= 3
+        out = np.empty(len(raw) + 8, np.uint8)
+        m = lib.td_tiff_lzw_decode(dst.ctypes.data, n, out.ctypes.data, out.size)
+        assert m == len(raw) and out[:m].tobytes() == raw
+        assert lib.td_tiff_lzw_encode(src.ctypes.data, src.size, dst.ctypes.data, 2) == _lib.ERR_CAPACITY
+    img = _image(rng, 3, 300, 420, np.uint8)
+    img[:, 50:200, 30:300] = 9                                               # a flat area
+    for kw in ({"tile": (128, 128)}, {"rows_per_strip": 7}, {"tile": (64, 256), "predictor": 2}, {"rows_per_strip": 1, "predictor": 2}, {}):
+        path = str(tmp_path / "lzw.tif")
+        write_geotiff(path, img, T, 25832, compression="lzw", **kw)
+        assert os.path.getsize(path) < img.nbytes
+        assert np.array_equal(np.asarray(Image.open(path)).transpose(2, 0, 1), img), kw       # libtiff's decoder
+        assert np.array_equal(GeoTiff(path).read(), img), kw                                   # ours

@@ -252,6 +252,63 @@ def test_compressed_tiled_raster_gives_the_same_predictions(tmp_path):
             == outs["gpu_contours_phases"] == outs["gpu_contours_plain"])
 
 
+def test_device_contours_auto_switches_between_batches_with_identical_files(tmp_path):
+    """``device_contours: auto`` (round 6): the tracer is switched on while the epilogue workers — not the GPU — set the batch
+    period (share of epilogue tasks that find their batch already finished when they start). Here the signal is driven by hand:
+    one image with the tracer off, the switch thrown, the same image again — both modes ran, the files are byte-identical, and an
+    image whose batches straddle the switch is identical too."""
+    import treedetection_amd as T
+    from treedetection_amd.preprocessing import tile_single_file
+    sd = make_synthetic_state_dict(50, seed=3, width_div=2)
+    rgb, _ = make_tile(300, 500)
+    rgbi = np.ascontiguousarray(np.concatenate([rgb, rgb[..., 1:2]], axis=2).transpose(2, 0, 1))
+    tif = str(tmp_path / "9.tif")
+    write_geotiff(tif, rgbi, (0.2, 0.0, 412000.0, 0.0, -0.2, 5318100.0), 25832)
+    tile_single_file(tif, str(tmp_path / "tiles"), buffer=10, tile_width=40, tile_height=40)
+    meta = str(tmp_path / "tiles" / "9.json")
+    cfg = T.setup_model_cfg(update_model="x", device="0")
+
+    def files(d):
+        return {f: open(os.path.join(d, "9", f), "rb").read() for f in sorted(os.listdir(os.path.join(d, "9")))}
+
+    with T.Predictor(cfg, device_type="0", max_batch_size=2, output_dir=str(tmp_path / "a"), state_dict=sd, device_contours="auto") as pred:
+        assert pred._contours_auto and pred.device_contours and not pred._contours_on
+        pred._note_epilogue_start = lambda late: None                 # the signal is driven by hand below
+        pred(tif, meta)
+        host_only = list(pred.device_contour_batches)
+        assert host_only[0] == 5 and host_only[1] == 0                # 9 tiles in batches of 2, all traced on the host
+        first = files(str(tmp_path / "a"))
+        pred._contours_on = True
+        pred(tif, meta)
+        assert pred.device_contour_batches == [5, 5]
+        assert files(str(tmp_path / "a")) == first
+        # the switch thrown in the middle of an image: batch 3 onwards on the device
+        calls = {"n": 0}
+        real = pred._contour_policy
+
+        def flip():
+            calls["n"] += 1
+            pred._contours_on = calls["n"] > 2
+            return real()
+        pred._contour_policy = flip
+        pred(tif, meta)
+        assert pred.device_contour_batches == [7, 8]
+        assert files(str(tmp_path / "a")) == first
+    # the signal itself: late tasks switch it on, a long quiet stretch switches it off again
+    with T.Predictor(cfg, device_type="0", max_batch_size=2, output_dir=str(tmp_path / "b"), state_dict=sd, device_contours="auto", pipeline=False) as pred:
+        for _ in range(31):
+            pred._note_epilogue_start(True)
+        assert not pred._contours_on
+        for _ in range(40):
+            pred._note_epilogue_start(True)
+        assert pred._contours_on
+        for _ in range(2500):
+            pred._note_epilogue_start(False)
+        assert not pred._contours_on
+    with pytest.raises(ValueError):
+        T.Predictor(cfg, device_type="0", output_dir=str(tmp_path / "c"), state_dict=sd, device_contours="sometimes")
+
+
 def test_predictor_fp16_engine_end_to_end(tmp_path):
     """config ``precision: fp16``: the same Predictor flow on the fp16 engine; per tile about the same crowns as fp32
     (engine-level tolerances: tests/test_engine_fp16_gpu.py)."""

@@ -1,0 +1,133 @@
+"""LZW rasters decoded on the GPU (tiffdecode.hip; SURVEY.md §8f-2 — the reference reads every tile window through rasterio /
+GDAL / libtiff on the host, prediction.py:61,164): the decoded raster in HBM must equal the host reader's pixels byte for
+byte, for every block layout the writer and libtiff produce; a corrupt block is reported and the Predictor falls back to the
+host reader; prediction files are byte-identical with the device decoder on or off."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from treedetection_amd import _lib
+from treedetection_amd.geotiff import GeoTiff, write_geotiff
+from treedetection_amd.synth import make_tile
+from treedetection_amd.weights import make_synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+T = (0.2, 0.0, 412000.0, 0.0, -0.2, 5318100.0)
+
+
+def _raster(bands, h, w, seed=0):
+    rgb, _ = make_tile(seed, max(h, w))
+    img = np.concatenate([rgb, rgb[..., 1:2]], axis=2)[:h, :w, :bands].transpose(2, 0, 1).copy()
+    img[:, h // 5: h // 2, w // 8: w // 2] = 7                      # a flat area: long strings, KwKwK codes
+    img[:, -40:, -90:] = np.arange(90, dtype=np.uint8)              # ramps: constant differences under predictor 2
+    return img
+
+
+@pytest.mark.parametrize("bands", [3, 4, 1])
+@pytest.mark.parametrize("kw", [{"tile": (128, 128)}, {"tile": (64, 256), "predictor": 2}, {"rows_per_strip": 7}, {"rows_per_strip": 1, "predictor": 2},
+                                {"rows_per_strip": 64, "predictor": 2}, {}])
+def test_device_decode_equals_the_host_reader(tmp_path, kw, bands):
+    img = _raster(bands, 517, 683, seed=bands)
+    path = str(tmp_path / "r.tif")
+    write_geotiff(path, img, T, 25832, compression="lzw", **kw)
+    g = GeoTiff(path)
+    assert g.device_decodable()
+    image, check = g.decode_to_device("cuda:0")
+    got = check().cpu().numpy()
+    assert got.shape == (517, 683, bands)
+    assert np.array_equal(got.transpose(2, 0, 1), img)
+    assert np.array_equal(got.transpose(2, 0, 1), GeoTiff(path).read())
+    assert check.compressed_bytes < img.nbytes
+
+
+def test_device_decode_of_a_file_written_by_libtiff(tmp_path):
+    """libtiff's own encoder (through Pillow): strips of its choosing, its ClearCode / width-change timing."""
+    from PIL import Image
+    img = _raster(3, 700, 900, seed=5)
+    path = str(tmp_path / "pil.tif")
+    Image.fromarray(img.transpose(1, 2, 0)).save(path, compression="tiff_lzw")
+    g = GeoTiff(path)
+    assert g.compression == 5 and g.device_decodable()
+    image, check = g.decode_to_device("cuda:0")
+    assert np.array_equal(check().cpu().numpy().transpose(2, 0, 1), img)
+
+
+def test_large_blocks_with_many_table_clears_and_incompressible_data(tmp_path):
+    """One strip = the whole raster (4 MB decoded: hundreds of table clears in one stream), noise (mostly literal codes) and a raster of
+    one value (strings up to thousands of bytes, copied 64 bytes per step)."""
+    rng = np.random.default_rng(3)
+    noise = rng.integers(0, 256, (4, 1000, 1000), dtype=np.uint8)
+    flat = np.full((3, 900, 1100), 201, np.uint8)
+    for name, img, kw in (("noise", noise, {}), ("flat", flat, {}), ("flat_tiles", flat, {"tile": (512, 512), "predictor": 2})):
+        path = str(tmp_path / f"{name}.tif")
+        write_geotiff(path, img, T, 25832, compression="lzw", **kw)
+        image, check = GeoTiff(path).decode_to_device("cuda:0")
+        assert np.array_equal(check().cpu().numpy().transpose(2, 0, 1), img), name
+
+
+def test_a_corrupt_block_is_reported_and_the_predictor_falls_back(tmp_path, capsys):
+    import treedetection_amd as TD
+    from treedetection_amd.preprocessing import tile_single_file
+    img = _raster(3, 500, 500, seed=9)
+    good, bad = str(tmp_path / "good.tif"), str(tmp_path / "bad.tif")
+    write_geotiff(good, img, T, 25832, compression="lzw", tile=(128, 128))
+    g = GeoTiff(good)
+    g._setup_blocks()
+    raw = bytearray(open(good, "rb").read())
+    off = g._offs[5]
+    raw[off + 2: off + 6] = b"\xff\xff\xff\xff"                     # codes beyond the table in block 5
+    open(bad, "wb").write(bytes(raw))
+    image, check = GeoTiff(bad).decode_to_device("cuda:0")
+    with pytest.raises(ValueError, match="block 5"):
+        check()
+    # the Predictor logs it and serves the image through the host reader — whose decoder rejects the same block: the tiles that
+    # need it are dropped (reference prediction.py:174-176), the others are predicted
+    tile_single_file(bad, str(tmp_path / "tiles"), buffer=0, tile_width=25, tile_height=25)
+    sd = make_synthetic_state_dict(50, seed=3, width_div=2)
+    cfg = TD.setup_model_cfg(update_model="x", device="0")
+    with TD.Predictor(cfg, device_type="0", max_batch_size=4, output_dir=str(tmp_path / "out"), state_dict=sd) as pred:
+        pred(bad, str(tmp_path / "tiles" / "bad.json"))
+        assert pred.decode_stats["images"] == 0
+    assert "using the host reader" in capsys.readouterr().out
+    files = os.listdir(tmp_path / "out" / "bad")
+    assert 0 < len(files) < 16
+
+
+def test_prediction_files_are_identical_with_the_device_decoder_on_or_off(tmp_path):
+    """An LZW raster (4 bands, tiles with predictor 2) through the Predictor: windows cut in HBM (device_decode auto) against the
+    host reader (false), plus the same pixels stored uncompressed — byte-identical Prediction_*.json; bounds that do not lie on
+    pixel edges go through rasterio.mask's centre rule on the device as on the host."""
+    import treedetection_amd as TD
+    from treedetection_amd.preprocessing import tile_single_file
+    rgb, _ = make_tile(300, 500)
+    rgbi = np.ascontiguousarray(np.concatenate([rgb, rgb[..., 1:2]], axis=2).transpose(2, 0, 1))
+    sd = make_synthetic_state_dict(50, seed=3, width_div=2)
+    cfg = TD.setup_model_cfg(update_model="x", device="0")
+    outs = {}
+    for tag, kw, dd in (("raw", {}, "auto"), ("lzw_dev", {"compression": "lzw", "tile": (128, 128), "predictor": 2}, "auto"),
+                        ("lzw_host", {"compression": "lzw", "tile": (128, 128), "predictor": 2}, False),
+                        ("lzw_strips_dev", {"compression": "lzw", "rows_per_strip": 3}, True)):
+        d = tmp_path / tag
+        (d / "rgb").mkdir(parents=True)
+        tif = str(d / "rgb" / "9.tif")
+        write_geotiff(tif, rgbi, T, 25832, **kw)
+        tile_single_file(tif, str(d / "tiles"), buffer=10, tile_width=40, tile_height=40)
+        meta = json.load(open(d / "tiles" / "9.json"))
+        # one tile whose bounds are off the pixel grid: half a pixel inwards on every side
+        k0 = next(iter(meta))
+        b = meta[k0]["bounds"]
+        meta[k0]["bounds"] = [b[0] + 0.1, b[1] + 0.1, b[2] - 0.1, b[3] - 0.1] + list(b[4:])
+        json.dump(meta, open(d / "tiles" / "9.json", "w"))
+        with TD.Predictor(cfg, device_type="0", max_batch_size=3, output_dir=str(d / "out"), state_dict=sd, device_decode=dd) as pred:
+            for _ in range(2):                                      # twice: the second image is prefetched by the first's walk
+                pred.prefetch(tif)
+                pred(tif, str(d / "tiles" / "9.json"))
+            assert pred.decode_stats["images"] == (2 if tag in ("lzw_dev", "lzw_strips_dev") else 0), (tag, pred.decode_stats)
+        files = sorted(os.listdir(d / "out" / "9"))
+        outs[tag] = {f: open(d / "out" / "9" / f, "rb").read().replace(tif.encode(), b"IMG") for f in files}
+        assert len(files) == 9
+    assert outs["raw"] == outs["lzw_dev"] == outs["lzw_host"] == outs["lzw_strips_dev"]
+    assert sum(len(json.loads(v)) for v in outs["raw"].values()) > 5

@@ -9,7 +9,9 @@ Optional extra keys (defaults preserve the reference's behaviour): ``precision``
 ``sharded_epilogue`` ("auto" | "rank0" | "local"), ``shard_by`` ("auto" | "image" | "tile": whole images per rank when there
 are at least as many images as ranks, detection.resolve_shard_by), ``eager_stitch`` (true: every image is stitched as soon as
 its tile files are complete, while the next one predicts), ``fp16_min_batch`` (0 = off: a larger batch for the fp16 engine only,
-detection.engine_batch_size).
+detection.engine_batch_size), ``device_contours`` ("auto" | true | false: mask borders followed on the GPU while the host epilogue,
+not the GPU, sets the batch period; same files), ``device_decode`` ("auto" | false: LZW rasters decoded on the GPU, tile windows cut
+in HBM; same pixels).
 """
 from __future__ import annotations
 
@@ -160,7 +162,7 @@ def get_config(config_path: str):
         "timestamped_output_directory": False, "simplify_tolerance": 0.2, "building_shapes": None,
         # extensions of this package (defaults = the reference's behaviour)
         "precision": "fp32", "resnet_depth": 101, "sharded_epilogue": "auto", "shard_by": "auto", "eager_stitch": True,
-        "fp16_min_batch": 0,
+        "fp16_min_batch": 0, "device_contours": "auto", "device_decode": "auto",
     }
     for k, v in defaults.items():
         config[k] = config.get(k, v)

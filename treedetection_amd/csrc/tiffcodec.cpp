@@ -84,6 +84,86 @@ extern "C" int64_t td_tiff_lzw_decode(const uint8_t* src, int64_t n, uint8_t* ds
     return op;
 }
 
+// TIFF LZW encoder (the writer's side of the codec above: test rasters and the bench's LZW fixture; libtiff's bit layout —
+// MSB-first codes, ClearCode first, the width grows one code early, a ClearCode when the table is full, EOI last). The string
+// table is an open-addressing hash of (prefix code, next byte) → code. Returns the compressed size or TD_ERR_CAPACITY.
+extern "C" int64_t td_tiff_lzw_encode(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap) {
+    if ((!src && n > 0) || !dst || n < 0 || cap < 0) {
+        td_set_error("td_tiff_lzw_encode: bad argument");
+        return TD_ERR_INVALID;
+    }
+    constexpr int CLEAR = 256, EOI = 257, FIRST = 258, MAXC = 4096, HSIZE = 1 << 14;
+    static thread_local int32_t hkey[HSIZE];
+    static thread_local uint16_t hval[HSIZE];
+    uint64_t acc = 0;
+    int have = 0, nbits = 9, next = FIRST;
+    int64_t op = 0;
+    bool full = false;
+    auto put = [&](int code) {
+        acc = (acc << nbits) | (uint64_t)code;
+        have += nbits;
+        while (have >= 8) {
+            if (op < cap) dst[op] = (uint8_t)(acc >> (have - 8));
+            else full = true;
+            ++op;
+            have -= 8;
+        }
+    };
+    auto reset = [&] {
+        for (int i = 0; i < HSIZE; ++i) hkey[i] = -1;
+        nbits = 9;
+        next = FIRST;
+    };
+    reset();
+    put(CLEAR);
+    if (n > 0) {
+        int cur = src[0];
+        for (int64_t i = 1; i < n; ++i) {
+            const int c = src[i];
+            const int32_t key = (cur << 8) | c;
+            uint32_t h = ((uint32_t)key * 2654435761u) >> 18;
+            int found = -1;
+            while (hkey[h] != -1) {
+                if (hkey[h] == key) {
+                    found = hval[h];
+                    break;
+                }
+                h = (h + 1) & (HSIZE - 1);
+            }
+            if (found >= 0) {
+                cur = found;
+                continue;
+            }
+            put(cur);
+            hkey[h] = key;
+            hval[h] = (uint16_t)next;
+            ++next;
+            // the decoder adds its entry one code later than the encoder and widens at 2^w - 2 entries of ITS table: the
+            // encoder therefore widens when its own next free code reaches 2^w - 1 (libtiff's CODE_MAX test)
+            if (next > (1 << nbits) - 1 && nbits < 12) ++nbits;
+            if (next >= MAXC - 1) {                       // table full (libtiff clears at 4094 entries)
+                put(CLEAR);
+                reset();
+            }
+            cur = c;
+        }
+        put(cur);
+        // the decoder has added one more entry for the last code: it may have widened
+        if (next + 1 > (1 << nbits) - 1 && nbits < 12) ++nbits;
+    }
+    put(EOI);
+    if (have > 0) {
+        if (op < cap) dst[op] = (uint8_t)(acc << (8 - have));
+        else full = true;
+        ++op;
+    }
+    if (full || op > cap) {
+        td_set_error("td_tiff_lzw_encode: %lld bytes needed, capacity %lld", (long long)op, (long long)cap);
+        return TD_ERR_CAPACITY;
+    }
+    return op;
+}
+
 // PackBits (TIFF 6.0 section 9): header byte h: 0..127 → copy h+1 literal bytes; -127..-1 → repeat the next byte
 // 1-h times; -128 → no operation.
 extern "C" int64_t td_tiff_packbits_decode(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap) {

@@ -1,0 +1,223 @@
+// TIFF LZW blocks decoded on the GPU (the tile producer's raster input). The reference reads every tile
+// window through rasterio → GDAL → libtiff on the host (TreeDetection/prediction.py:61 `rasterio.open`, :164
+// `rasterio.mask.mask`); real orthophoto mosaics are stored LZW- or DEFLATE-compressed, and host threads decode a few hundred
+// 450 x 450 x 4 windows per second where one MI355X consumes thousands. Here a raster's compressed strips / tiles cross PCIe
+// once as they lie in the file, every block is decoded by ONE wave (an LZW stream is sequential; the parallelism is the
+// 10^3 - 10^4 blocks of an image), and the decoded raster stays in HBM, where the tile windows are cut.
+//
+// Decoder (same stream format and the same accept / reject rules as the host decoder td_tiff_lzw_decode, tiffcodec.cpp:
+// MSB-first 9..12-bit codes, ClearCode 256, EOI 257, width grows one code early). A string of the table is a WINDOW OF THE
+// OUTPUT: entry k was defined when the code after string(old) arrived, so its bytes are out[pos(old) .. pos(old) + len(old)]
+// — no prefix / suffix chains, a string is copied 64 bytes per step by the wave's lanes, and len(k) = start(k + 1) - start(k)
+// + 1, so the table is ONE array of 4097 output positions in LDS (16 KB: nine waves per CU). Integer / byte work bound by
+// the latency of dependent loads, not by HBM: a copy whose source may still be in flight waits for the wave's stores
+// (s_waitcnt vmcnt(0)) and reads past the L1 (agent-scope loads); sources known complete are read without waiting.
+#include "common.h"
+
+namespace {
+
+constexpr int LZW_CLEAR = 256, LZW_EOI = 257, LZW_FIRST = 258, LZW_MAX = 4096;
+
+__device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+// status: 0 ok, 1 corrupt stream, 2 more bytes than the block holds
+__global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ block_off,
+                                                             const int64_t* __restrict__ block_nbytes, uint8_t* __restrict__ out,
+                                                             int64_t block_cap, int64_t* __restrict__ decoded,
+                                                             int32_t* __restrict__ status) {
+    __shared__ uint32_t t_start[LZW_MAX + 2];
+    __shared__ uint32_t inbuf[128];                       // two chunks of 64 dwords of the compressed stream
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int64_t n = block_nbytes[b];
+    uint8_t* dst = out + (int64_t)b * block_cap;
+    const uint32_t cap = (uint32_t)block_cap;
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(comp + block_off[b]);
+    const int skip = (int)(a0 & 3);
+    const uint32_t* src32 = reinterpret_cast<const uint32_t*>(a0 - skip);
+    const int64_t ndw = (n + skip + 3) >> 2;              // dwords that hold the stream (the buffer is padded: reading the last one is safe)
+    int64_t loaded = 0, rd = 0;
+    int64_t bits_left = n * 8;
+    uint64_t acc = 0;
+    int have = 0, nbits = 9, next = LZW_FIRST;
+    uint32_t op = 0, old_pos = 0, old_len = 0, safe = 0;   // old_len == 0: no previous code (start, or right after a ClearCode)
+    int err = 0;
+    bool first_word = true;
+    for (;;) {
+        while (have < 32 && rd < ndw) {
+            if (rd >= loaded) {                            // next 256 bytes of the stream, one dword per lane
+                const int64_t idx = loaded + lane;
+                inbuf[idx & 127] = idx < ndw ? src32[idx] : 0u;
+                loaded += 64;
+                __syncthreads();                           // (one wave: orders the LDS writes before the reads below; every store of this wave has completed too)
+                safe = op;
+            }
+            const uint32_t w = bswap32(inbuf[rd & 127]);
+            ++rd;
+            acc = (acc << 32) | w;
+            have += 32;
+            if (first_word) {                              // the stream starts `skip` bytes into its first dword
+                have -= 8 * skip;
+                first_word = false;
+            }
+        }
+        if (bits_left < nbits) break;                      // ran out of input without an EOI: accept what was decoded (host decoder's rule)
+        const int code = (int)((acc >> (have - nbits)) & ((1u << nbits) - 1u));
+        have -= nbits;
+        bits_left -= nbits;
+        if (code == LZW_EOI) break;
+        if (code == LZW_CLEAR) {
+            nbits = 9;
+            next = LZW_FIRST;
+            old_len = 0;
+            continue;
+        }
+        if (old_len == 0) {                                // first code after a clear: a literal
+            if (code > 255) {
+                err = 1;
+                break;
+            }
+            if (lane == 0 && op < cap) dst[op] = (uint8_t)code;
+            old_pos = op;
+            old_len = 1;
+            op += 1;
+            continue;
+        }
+        if (code > next || (code == next && next >= LZW_MAX)) {
+            err = 1;
+            break;
+        }
+        // string(code): a literal, a window of the output, or (code == next) string(old) + its own first byte
+        uint32_t s_start = 0, s_len = 1;
+        const bool kwkwk = code == next;
+        if (kwkwk) {
+            s_start = old_pos;
+            s_len = old_len + 1;
+        } else if (code >= LZW_FIRST) {
+            s_start = t_start[code];
+            s_len = t_start[code + 1] - s_start + 1;
+        }
+        if (next < LZW_MAX) {                              // new entry = string(old) + first byte of string(code): out[old_pos .. op]
+            if (lane == 0) {
+                t_start[next] = old_pos;
+                t_start[next + 1] = op;                    // provisional: becomes the next entry's start (its old_pos is this op)
+            }
+            ++next;
+            if (next > (1 << nbits) - 2 && nbits < 12) ++nbits;
+            __syncthreads();
+        }
+        if (code < 256) {
+            if (lane == 0 && op < cap) dst[op] = (uint8_t)code;
+        } else {
+            if (s_start + s_len > safe) {                  // the source may still be on its way to L2: wait for this wave's stores
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                safe = op;
+            }
+            for (uint32_t k0 = 0; k0 < s_len; k0 += 64) {
+                const uint32_t k = k0 + lane;
+                if (k < s_len) {
+                    const uint32_t sk = (kwkwk && k == s_len - 1) ? 0u : k;
+                    // agent-scope load: served by L2, never by a stale L1 line of bytes this wave stored earlier
+                    const uint8_t v = __hip_atomic_load(dst + s_start + sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (op + k < cap) dst[op + k] = v;
+                }
+            }
+        }
+        old_pos = op;
+        old_len = s_len;
+        op += s_len;
+    }
+    if (lane == 0) {
+        decoded[b] = (int64_t)op;
+        status[b] = err ? 1 : (op > cap ? 2 : 0);
+    }
+}
+
+// Decoded blocks → the raster [height][width][spp] (uint8, pixel-interleaved), undoing predictor 2 (TIFF 6.0 section 14:
+// each sample is the difference to the same sample of the pixel on its left, within the row of its block) on the way. One
+// workgroup per (image row, block column): a block row of bw pixels is a prefix sum per sample — per-thread runs, a scan of
+// the 256 run totals in LDS, then the stores. HBM-bound: one read and one write of the raster.
+constexpr int SC_THREADS = 256, SC_MAX_SPP = 4;
+template <int spp>
+__global__ __launch_bounds__(SC_THREADS) void tiff_blocks_to_image_kernel(const uint8_t* __restrict__ blocks, int64_t block_cap, int bw, int bh,
+                                                                          int blocks_across, int predictor,
+                                                                          uint8_t* __restrict__ image, int width, int height) {
+    __shared__ uint8_t tot[SC_THREADS][SC_MAX_SPP];
+    const int y = blockIdx.x, bx = blockIdx.y, tid = threadIdx.x;
+    const int by = y / bh;
+    const uint8_t* src = blocks + ((int64_t)by * blocks_across + bx) * block_cap + (int64_t)(y - by * bh) * bw * spp;
+    const int x0 = bx * bw;
+    const int valid = min(bw, width - x0);                 // pixels of this block row that lie inside the raster
+    uint8_t* dst = image + ((int64_t)y * width + x0) * spp;
+    const int per = (bw + SC_THREADS - 1) / SC_THREADS;    // pixels per thread (contiguous run)
+    const int p0 = tid * per, p1 = min(p0 + per, bw);
+    if (predictor != 2) {
+        for (int p = p0; p < min(p1, valid); ++p)
+            for (int c = 0; c < spp; ++c) dst[p * spp + c] = src[p * spp + c];
+        return;
+    }
+    uint8_t run[spp];
+#pragma unroll
+    for (int c = 0; c < spp; ++c) run[c] = 0;
+    for (int p = p0; p < p1; ++p)
+        for (int c = 0; c < spp; ++c) run[c] = (uint8_t)(run[c] + src[p * spp + c]);
+    for (int c = 0; c < spp; ++c) tot[tid][c] = run[c];
+    __syncthreads();
+    // inclusive scan of the run totals (Hillis-Steele over 256 entries, all samples at once)
+    for (int off = 1; off < SC_THREADS; off <<= 1) {
+        uint8_t add[spp];
+        for (int c = 0; c < spp; ++c) add[c] = tid >= off ? tot[tid - off][c] : 0;
+        __syncthreads();
+        for (int c = 0; c < spp; ++c) tot[tid][c] = (uint8_t)(tot[tid][c] + add[c]);
+        __syncthreads();
+    }
+    uint8_t base[spp];
+    for (int c = 0; c < spp; ++c) base[c] = tid > 0 ? tot[tid - 1][c] : 0;
+    for (int p = p0; p < p1; ++p)
+        for (int c = 0; c < spp; ++c) {
+            base[c] = (uint8_t)(base[c] + src[p * spp + c]);
+            if (p < valid) dst[p * spp + c] = base[c];
+        }
+}
+
+}  // namespace
+
+extern "C" td_status td_tiff_lzw_decode_dev(const uint8_t* comp, const int64_t* block_off, const int64_t* block_nbytes, int nblocks,
+                                            uint8_t* blocks_out, int64_t block_cap, int64_t* decoded, int32_t* status, void* stream) {
+    TD_REQUIRE(comp && block_off && block_nbytes && blocks_out && decoded && status, "td_tiff_lzw_decode_dev: null pointer");
+    TD_REQUIRE(nblocks >= 0 && block_cap >= 1 && block_cap < ((int64_t)1 << 31), "td_tiff_lzw_decode_dev: %d blocks of %lld bytes", nblocks,
+               (long long)block_cap);
+    if (nblocks == 0) return TD_OK;
+    hipLaunchKernelGGL(tiff_lzw_blocks_kernel, dim3(nblocks), dim3(64), 0, static_cast<hipStream_t>(stream), comp, block_off, block_nbytes,
+                       blocks_out, block_cap, decoded, status);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
+extern "C" td_status td_tiff_blocks_to_image_dev(const uint8_t* blocks, int64_t block_cap, int block_w, int block_h, int blocks_across,
+                                                 int blocks_down, int spp, int predictor, uint8_t* image, int width, int height,
+                                                 void* stream) {
+    TD_REQUIRE(blocks && image, "td_tiff_blocks_to_image_dev: null pointer");
+    TD_REQUIRE(block_w >= 1 && block_h >= 1 && blocks_across >= 1 && blocks_down >= 1 && width >= 1 && height >= 1,
+               "td_tiff_blocks_to_image_dev: bad geometry");
+    TD_REQUIRE(spp >= 1 && spp <= SC_MAX_SPP && (predictor == 1 || predictor == 2), "td_tiff_blocks_to_image_dev: %d samples per pixel, predictor %d",
+               spp, predictor);
+    TD_REQUIRE((int64_t)block_w * block_h * spp <= block_cap, "td_tiff_blocks_to_image_dev: a %d x %d x %d block does not fit %lld bytes", block_w,
+               block_h, spp, (long long)block_cap);
+    TD_REQUIRE((int64_t)blocks_across * block_w >= width && (int64_t)blocks_down * block_h >= height && (int64_t)(blocks_across - 1) * block_w < width &&
+               (int64_t)(blocks_down - 1) * block_h < height, "td_tiff_blocks_to_image_dev: %d x %d blocks of %d x %d do not tile a %d x %d raster",
+               blocks_across, blocks_down, block_w, block_h, width, height);
+    TD_REQUIRE(blocks_across <= 65535, "td_tiff_blocks_to_image_dev: too many block columns");
+    const dim3 grid(height, blocks_across);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define TD_SCATTER(N) hipLaunchKernelGGL(tiff_blocks_to_image_kernel<N>, grid, dim3(SC_THREADS), 0, s, blocks, block_cap, block_w, block_h, \
+                                         blocks_across, predictor, image, width, height)
+    switch (spp) {
+        case 1: TD_SCATTER(1); break;
+        case 2: TD_SCATTER(2); break;
+        case 3: TD_SCATTER(3); break;
+        default: TD_SCATTER(4); break;
+    }
+#undef TD_SCATTER
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}

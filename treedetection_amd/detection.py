@@ -120,6 +120,8 @@ def walk_images(config, predictor, paths, tiles_path, output_path, chain=True, s
             logger.error(f"Error processing {path}: {e}")
 
     try:
+        if chain and paths and hasattr(predictor, "prefetch"):
+            predictor.prefetch(paths[0])
         for n, fp in enumerate(paths):
             cur, prev = int(100 * (n + 1) / total), int(100 * n / total)
             if logger and ((cur // 5) != (prev // 5) or cur == 100 or n == 0):
@@ -128,6 +130,8 @@ def walk_images(config, predictor, paths, tiles_path, output_path, chain=True, s
             handle = None
             try:
                 if chain:
+                    if n + 1 < total and hasattr(predictor, "prefetch"):
+                        predictor.prefetch(paths[n + 1])      # an LZW raster is read and decoded on the GPU while this image predicts
                     handle = predictor.submit(fp, tile_json, whole_image=True)
                 else:
                     predictor(fp, tile_json)
@@ -216,7 +220,8 @@ def predict_on_model(config, model_path, tiles_path, output_path, batch_size=10,
     predictor = Predictor(cfg, device_type=device, max_batch_size=batch_size, output_dir=output_path,
                           exclude_vars=exclude_vars, precision=config.get("precision", "fp32"),
                           return_predictions=False,       # the files are the product; the list is unused here
-                          pipeline=config.get("pipeline", True), device_contours=config.get("device_contours", False),
+                          pipeline=config.get("pipeline", True), device_contours=config.get("device_contours", "auto"),
+                          device_decode=config.get("device_decode", "auto"),
                           sharded_epilogue=epilogue)
     try:
         shard_by = resolve_shard_by(config, W, predictor.sharded_epilogue, len(images_paths))

@@ -314,6 +314,83 @@ class GeoTiff:
                 out[rs - r0:re - r0, cs - c0:ce - c0, :] = piece
         return out
 
+    # -- compressed raster → HBM (tiffdecode.hip) --------------------------------------------------------------------------
+    def device_decodable(self) -> bool:
+        """True when the raster's blocks can be decoded on the GPU: LZW strips or tiles of pixel-interleaved uint8 samples
+        (<= 4 per pixel), predictor 1 or 2. Everything else keeps the host reader (DEFLATE: zlib on the decode threads)."""
+        self._setup_blocks()
+        return (self.compression == 5 and self.planar == 1 and self.dtype == np.uint8 and 1 <= self.count <= 4
+                and self._predictor in (1, 2) and self._counts is not None and self._pil is None
+                and self._bw * self._bh * self.count < (1 << 31))
+
+    def decode_to_device(self, device, stream=None):
+        """The whole raster decoded in HBM: the compressed blocks are read as they lie in the file (one pread of the span that
+        holds them, into pinned memory), copied to the device once, decoded one wave per block (td_tiff_lzw_decode_dev) and
+        laid out as [height, width, bands] uint8 with predictor 2 undone (td_tiff_blocks_to_image_dev). → (image tensor,
+        check) where ``check()`` waits for the kernels and raises ValueError when a block did not decode to its size (the
+        caller then falls back to the host reader). Everything is enqueued on ``stream`` (default: the current one)."""
+        import torch
+        from . import _lib
+        if not self.device_decodable():
+            raise ValueError(f"{self.path}: not decodable on the device (compression {self.compression}, {self.dtype}, {self.count} bands)")
+        lib = _lib.load()
+        dev = torch.device(device)
+        offs = np.asarray(self._offs, dtype=np.int64)
+        cnts = np.asarray(self._counts, dtype=np.int64)
+        nb = self._nx * self._ny
+        assert len(offs) == nb == len(cnts)
+        lo, hi = int(offs.min()), int((offs + cnts).max())
+        span = hi - lo
+        pin = torch.empty((span + 16,), dtype=torch.uint8, pin_memory=True)
+        buf = pin.numpy()
+        fd = os.open(self.path, os.O_RDONLY)
+        try:
+            got = 0
+            while got < span:
+                n = os.preadv(fd, [memoryview(buf)[got:span]], lo + got)
+                if n <= 0:
+                    raise ValueError(f"{self.path}: file ends inside its block data")
+                got += n
+        finally:
+            os.close(fd)
+        buf[span:] = 0
+        block_cap = self._bw * self._bh * self.count
+        expect = np.array([self._block_rows(by) * self._bw * self.count for by in range(self._ny) for _ in range(self._nx)], dtype=np.int64)
+        ctx = torch.cuda.stream(stream) if stream is not None else _NullCtx()
+        with torch.cuda.device(dev), ctx:
+            st = _lib.stream_ptr()
+            comp = pin.to(dev, non_blocking=True)
+            meta = torch.from_numpy(np.stack([offs - lo, cnts])).to(dev, non_blocking=True)
+            blocks = torch.empty((nb, block_cap), dtype=torch.uint8, device=dev)
+            decoded = torch.empty((nb,), dtype=torch.int64, device=dev)
+            status = torch.empty((nb,), dtype=torch.int32, device=dev)
+            _lib.check(lib.td_tiff_lzw_decode_dev(comp.data_ptr(), meta[0].data_ptr(), meta[1].data_ptr(), nb, blocks.data_ptr(), block_cap,
+                                                  decoded.data_ptr(), status.data_ptr(), st), "td_tiff_lzw_decode_dev")
+            image = torch.empty((self.height, self.width, self.count), dtype=torch.uint8, device=dev)
+            _lib.check(lib.td_tiff_blocks_to_image_dev(blocks.data_ptr(), block_cap, self._bw, self._bh, self._nx, self._ny, self.count,
+                                                       self._predictor, image.data_ptr(), self.width, self.height, st), "td_tiff_blocks_to_image_dev")
+            done = torch.cuda.Event()
+            done.record()
+            dec_h = torch.empty((nb,), dtype=torch.int64, pin_memory=True)
+            st_h = torch.empty((nb,), dtype=torch.int32, pin_memory=True)
+            dec_h.copy_(decoded, non_blocking=True)
+            st_h.copy_(status, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record()
+        keep = [pin, comp, meta, blocks, decoded, status]     # alive until check() has run: the kernels read them
+
+        def check():
+            copied.synchronize()
+            keep.clear()
+            bad = np.nonzero((st_h.numpy() != 0) | (dec_h.numpy() != expect))[0]
+            if bad.size:
+                b = int(bad[0])
+                raise ValueError(f"{self.path}: block {b} decodes to {int(dec_h[b])} bytes (status {int(st_h[b])}), expected {int(expect[b])}")
+            return image
+        check.event = done
+        check.compressed_bytes = span
+        return image, check
+
     def _load(self) -> np.ndarray:
         """Whole raster as [bands, rows, cols]."""
         if self._data is None:
@@ -360,6 +437,17 @@ class GeoTiff:
         if not oky.all():
             hwc[~oky, :, :] = 0
 
+    def outside_mask(self, bounds, c0: int, r0: int, w: int, h: int):
+        """The columns / rows of window (c0, r0, w, h) that ``_mask_outside`` keeps, as two boolean arrays — or None when it
+        keeps everything (the usual case: tile bounds lie on pixel edges)."""
+        a, _, c, _, e, f = self.transform
+        minx, miny, maxx, maxy = (float(v) for v in bounds[:4])
+        xs = c + a * (np.arange(c0, c0 + w) + 0.5)
+        ys = f + e * (np.arange(r0, r0 + h) + 0.5)
+        okx = (xs >= minx) & (xs <= maxx)
+        oky = (ys >= miny) & (ys <= maxy)
+        return None if okx.all() and oky.all() else (okx, oky)
+
     def read_bounds_hwc(self, bounds: Sequence[float], out: Optional[np.ndarray] = None, out_off: int = 0) -> np.ndarray:
         """``rasterio.mask.mask(img, [bbox], crop=True)[0]`` as pixel-interleaved [rows, cols, bands] — the layout the
         device resize consumes. With ``out`` (a flat array of the raster's dtype, e.g. pinned staging memory) the window
@@ -378,6 +466,14 @@ class GeoTiff:
         return np.ascontiguousarray(self.read_bounds_hwc(bounds).transpose(2, 0, 1))
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 def write_geotiff(path: str, data: np.ndarray, transform: Sequence[float], epsg: int = 25832, *,
                   tile: Optional[Tuple[int, int]] = None, rows_per_strip: Optional[int] = None,
                   compression: Optional[str] = None, predictor: int = 1, planar: bool = False,
@@ -385,15 +481,15 @@ def write_geotiff(path: str, data: np.ndarray, transform: Sequence[float], epsg:
     """Classic little-endian TIFF with the GeoTIFF tags the reader understands. data: [bands, rows, cols] or
     [rows, cols]; uint8 / uint16 / float32. Defaults: one uncompressed pixel-interleaved strip (what the tile reader
     maps without copying). Options: ``tile=(tile_rows, tile_cols)`` (multiples of 16) or ``rows_per_strip``,
-    ``compression`` None / "deflate", ``predictor`` 1 / 2 (horizontal differencing, integer samples), ``planar``
-    (one block grid per band)."""
+    ``compression`` None / "deflate" / "lzw" (td_tiff_lzw_encode, blocks encoded on host threads), ``predictor`` 1 / 2
+    (horizontal differencing, integer samples), ``planar`` (one block grid per band)."""
     arr = np.asarray(data)
     if arr.ndim == 2:
         arr = arr[None]
     C, H, W = arr.shape
     fmt = {np.dtype(np.uint8): (1, 8), np.dtype(np.uint16): (1, 16), np.dtype(np.float32): (3, 32)}[arr.dtype]
-    if compression not in (None, "deflate"):
-        raise ValueError("compression must be None or 'deflate'")
+    if compression not in (None, "deflate", "lzw"):
+        raise ValueError("compression must be None, 'deflate' or 'lzw'")
     if predictor not in (1, 2) or (predictor == 2 and fmt[0] != 1):
         raise ValueError("predictor 2 needs integer samples")
     hwc = np.ascontiguousarray(arr.transpose(1, 2, 0)).astype(arr.dtype.newbyteorder("<"), copy=False)
@@ -417,6 +513,18 @@ def write_geotiff(path: str, data: np.ndarray, transform: Sequence[float], epsg:
                     blk[:, 1:] = blk[:, 1:] - blk[:, :-1]          # modulo the sample width
                 raw = blk.tobytes()
                 blocks.append(zlib.compress(raw, 6) if compression == "deflate" else raw)
+    if compression == "lzw":
+        from . import _lib
+        lib = _lib.load()
+
+        def enc(raw: bytes) -> bytes:
+            src = np.frombuffer(raw, dtype=np.uint8)
+            dst = np.empty(len(raw) * 3 // 2 + 64, dtype=np.uint8)          # 12-bit codes for single bytes at worst
+            n = lib.td_tiff_lzw_encode(src.ctypes.data, src.size, dst.ctypes.data, dst.size)
+            _lib.check(n, "td_tiff_lzw_encode")
+            return dst[:n].tobytes()
+        with ThreadPoolExecutor(max_workers=max(1, min(16, len(os.sched_getaffinity(0))))) as ex:
+            blocks = list(ex.map(enc, blocks))
     a, _, c, _, e, f = (float(v) for v in transform[:6])
     entries = []   # (tag, type, count, payload bytes)
 
@@ -431,7 +539,7 @@ def write_geotiff(path: str, data: np.ndarray, transform: Sequence[float], epsg:
     add(256, 4, [W])
     add(257, 4, [H])
     add(258, 3, [fmt[1]] * C)
-    add(259, 3, [8 if compression == "deflate" else 1])
+    add(259, 3, [{"deflate": 8, "lzw": 5}.get(compression, 1)])
     add(262, 3, [2 if C >= 3 else 1])
     add(277, 3, [C])
     add(284, 3, [2 if planar else 1])

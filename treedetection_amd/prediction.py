@@ -62,6 +62,7 @@ class _Slot:
         self.out_key = None
         self.event = torch.cuda.Event(blocking=True)
         self.pending = 0
+        self.traced = False         # this batch's borders were followed on the device (Predictor._contour_policy)
         self.lock = threading.Lock()
         self.transient = False      # stand-in for a round that has no real slot (reader failure, _drain): never enters a free list
 
@@ -183,7 +184,8 @@ class Predictor:
     def __init__(self, cfg, device_type="cpu", max_batch_size=5, output_dir="./output", exclude_vars=None,
                  precision: str = "fp32", state_dict: Optional[Dict[str, np.ndarray]] = None,
                  return_predictions: bool = True, host_workers: Optional[int] = None, pipeline: bool = True,
-                 device_contours: bool = False, sharded_epilogue: str = "rank0", schedule: str = "streams"):
+                 device_contours: bool = False, sharded_epilogue: str = "rank0", schedule: str = "streams",
+                 device_decode="auto"):
         """cfg from ``setup_model_cfg``; ``device_type`` = GPU index ("0", 0) as config["device"] carries it.
         ``state_dict`` lets tests and the bench inject weights instead of reading cfg.MODEL.WEIGHTS.
         ``return_predictions=False`` skips rebuilding the Python list ``__call__`` returns (the reference's own caller
@@ -196,6 +198,15 @@ class Predictor:
         the kernel tails of one forward run under the MFMA-bound contractions of the others (bench: 615 vs 554 tiles/s
         fp32, 1868 vs 1550 fp16); "phases" = the phase pipeline described above."""
         self.cfg = cfg
+        # LZW rasters are decoded on the GPU, whole, and their tile windows are cut in HBM (GeoTiff.decode_to_device; images this
+        # process predicts alone: submit). "auto" / True: wherever the raster qualifies; False: the host reader for everything
+        if device_decode not in (True, False, "auto", "true", "false"):
+            raise ValueError(f"device_decode must be true, false or 'auto', got {device_decode!r}")
+        self.device_decode = device_decode in (True, "auto", "true")
+        self._rasters: Dict[str, "object"] = {}
+        self._raster_pool = None
+        self._decode_stream = None
+        self.decode_stats = {"images": 0, "seconds": 0.0, "compressed_bytes": 0, "decoded_bytes": 0}
         if device_type == "cpu" or not torch.cuda.is_available():
             raise RuntimeError("treedetection_amd.Predictor runs on an MI355X only: the HIP path has no CPU fallback "
                                "(config['device'] resolved to 'cpu').")
@@ -218,7 +229,18 @@ class Predictor:
             shared = D.world() < SHARDED_LOCAL_FROM_WORLD or D.single_node() or D.output_is_shared(self.output_dir)
             sharded_epilogue = resolve_sharded_epilogue(D.world(), precision, shared)
         # borders followed on the GPU (td_trace_contours_dev); rank 0's gathered-batch epilogue uses the host tracer
-        self.device_contours = bool(device_contours) and (D.world() == 1 or sharded_epilogue == "local")
+        # "auto" (round 6): the device tracer is switched on while the host epilogue — not the GPU — sets the batch period
+        # (_contour_policy); the files are byte-identical either way, so the switch may happen between any two batches
+        if device_contours not in (True, False, "auto", "true", "false"):
+            raise ValueError(f"device_contours must be true, false or 'auto', got {device_contours!r}")
+        can = D.world() == 1 or sharded_epilogue == "local"
+        self._contours_auto = device_contours == "auto" and can
+        self.device_contours = (device_contours in (True, "true") or self._contours_auto) and can     # buffers for the tracer exist
+        self._contours_on = self.device_contours and not self._contours_auto                          # … and this batch uses it
+        self._late = 0.0                      # running share of epilogue tasks that found their batch finished before they started
+        self._late_n = 0
+        self._on_since = 0
+        self.device_contour_batches = [0, 0]  # batches traced on the host / on the device
         sd = state_dict if state_dict is not None else load_checkpoint(cfg.MODEL.WEIGHTS)
         rh = cfg.MODEL.ROI_HEADS
         eng_args = dict(device=self.device_index, precision=precision, score_thresh=rh.SCORE_THRESH_TEST,
@@ -251,9 +273,53 @@ class Predictor:
             self._free.put(s)
         self._stats_lock = threading.Lock()
         # seconds spent per stage of the last __call__ (reader thread, launcher thread, sum over epilogue workers)
-        self.stats = {"read": 0.0, "launch": 0.0, "launch_wait": 0.0, "epilogue": 0.0, "epilogue_wait": 0.0}
+        # (*_cpu: CPU seconds of the threads that did the stage — time.thread_time — for the host-cores-per-GPU table of DESIGN.md §6)
+        self.stats = {"read": 0.0, "launch": 0.0, "launch_wait": 0.0, "epilogue": 0.0, "epilogue_wait": 0.0, "slot_wait": 0.0,
+                      "read_cpu": 0.0, "launch_cpu": 0.0, "epilogue_cpu": 0.0, "tiles": 0}
         # TD_E2E_TRACE=1: (what, batch / tile index, perf_counter) marks of the last __call__ (tools/e2e_timeline.py)
         self._trace = [] if os.environ.get("TD_E2E_TRACE") else None
+
+    def _roll_stats(self) -> None:
+        """A new image starts: its stage seconds start at zero; what the previous images spent stays in ``totals`` (a chained walk
+        overlaps images, so late epilogue tasks of the previous image land in the new image's counters: only the totals are exact)."""
+        with self._stats_lock:
+            tot = self.__dict__.setdefault("totals", dict.fromkeys(self.stats, 0.0))
+            for k, v in self.stats.items():
+                tot[k] = tot.get(k, 0.0) + v
+            self.stats = dict.fromkeys(self.stats, 0.0)
+
+    def host_totals(self) -> Dict[str, float]:
+        """Stage seconds (wall and CPU) summed over every image since the predictor was built (or since the caller cleared
+        ``totals``), the running image included."""
+        with self._stats_lock:
+            tot = dict(self.__dict__.get("totals") or dict.fromkeys(self.stats, 0.0))
+            for k, v in self.stats.items():
+                tot[k] = tot.get(k, 0.0) + v
+        return tot
+
+    # -- device_contours: "auto" -------------------------------------------------------------------------------------
+    # Signal: an epilogue task that finds its batch's event ALREADY complete when it starts was queued behind other tasks — the
+    # workers are the bottleneck; a task that has to wait for the event means the GPU is. The share of late tasks (exponential
+    # mean over ~64 tasks) switches the device tracer on above 0.5 — from then on the workers only format and write what the
+    # GPU traced — and off again once it stayed below 0.05 for 2 000 tasks (a re-probe: if the backlog returns, so does the tracer).
+    def _note_epilogue_start(self, late: bool) -> None:
+        if not self._contours_auto:
+            return
+        with self._stats_lock:
+            self._late += ((1.0 if late else 0.0) - self._late) / 64.0
+            self._late_n += 1
+            if not self._contours_on and self._late_n >= 32 and self._late > 0.5:
+                self._contours_on, self._on_since, self._late_n = True, 0, 0
+            elif self._contours_on:
+                self._on_since = self._on_since + 1 if self._late < 0.05 else 0
+                if self._on_since >= 2000:
+                    self._contours_on, self._late_n, self._late = False, 0, 0.0
+
+    def _contour_policy(self) -> bool:
+        """Whether the batch being launched is traced on the device."""
+        on = bool(self._contours_on)
+        self.device_contour_batches[1 if on else 0] += 1
+        return on
 
     def _mark(self, what, k=-1) -> None:
         if self._trace is not None:
@@ -267,6 +333,10 @@ class Predictor:
         if getattr(self, "_read_pool", None) is not None:
             self._read_pool.shutdown(wait=True)
             self._read_pool = None
+        if getattr(self, "_raster_pool", None) is not None:
+            self._raster_pool.shutdown(wait=True)
+            self._raster_pool = None
+            self._rasters.clear()
         for eng in getattr(self, "_engines", []) or []:
             eng.close()
 
@@ -275,6 +345,53 @@ class Predictor:
 
     def __exit__(self, *exc):
         self.close()
+
+    # -- compressed rasters decoded on the GPU -------------------------------------------------------------------
+    def prefetch(self, tifpath) -> None:
+        """Starts, on a thread of its own, what the NEXT image needs before its first batch can be cut: an LZW raster's compressed
+        blocks read into pinned memory, copied to the device and decoded there (GeoTiff.decode_to_device) — while the current
+        image predicts. ``detection.walk_images`` calls it with the path after the one it submits. No-op for rasters the host
+        reader serves (uncompressed, DEFLATE, planar, 16-bit) and when ``device_decode`` is off."""
+        if not self.device_decode or tifpath in self._rasters:
+            return
+        if self._raster_pool is None:
+            self._raster_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="td-raster")
+        self._rasters[tifpath] = self._raster_pool.submit(self._decode_raster, tifpath)
+
+    def _decode_raster(self, tifpath):
+        """→ the raster as a device tensor [rows, cols, bands] uint8, or None (not decodable on the device, or a block failed:
+        the host reader then serves the image and reports what is wrong with it, if anything)."""
+        img = None
+        try:
+            img = GeoTiff(tifpath)
+            if not img.device_decodable():
+                return None
+            if self._decode_stream is None:
+                with torch.cuda.device(self.device_index):
+                    self._decode_stream = torch.cuda.Stream()
+            t0 = time.perf_counter()
+            image, check = img.decode_to_device(self.device, self._decode_stream)
+            check()
+            with self._stats_lock:
+                st = self.decode_stats
+                st["images"] += 1
+                st["seconds"] += time.perf_counter() - t0
+                st["compressed_bytes"] += check.compressed_bytes
+                st["decoded_bytes"] += image.numel()
+            return image
+        except Exception as e:
+            print(f"device decode of {tifpath} failed ({e}): using the host reader")
+            return None
+        finally:
+            if img is not None:
+                img.close()
+
+    def _device_raster(self, tifpath):
+        if not self.device_decode:
+            return None
+        self.prefetch(tifpath)
+        fut = self._rasters.pop(tifpath, None)
+        return fut.result() if fut is not None else None
 
     # -- tile metadata ---------------------------------------------------------------------------------------
     def _filter_excluded_vars(self, tiles):
@@ -305,6 +422,15 @@ class Predictor:
         try:
             if _FAULT_TILE and tile["tile_id"] == _FAULT_TILE:      # fault injection (tests): this tile's crop fails
                 raise OSError(f"injected read failure for tile {tile['tile_id']} (TD_FAULT_TILE)")
+            if getattr(img, "_dev", None) is not None:            # the raster lies decoded in HBM: the window is cut there
+                c0, r0, w, h = img.window_of_bounds(tile["bounds"])
+                if w <= 0 or h <= 0:
+                    raise ValueError("Input shapes do not overlap raster.")
+                if img.count < 3:
+                    raise ValueError(f"tile has {img.count} bands, need >= 3")
+                info = {"orig_height": h, "orig_width": w, "height": h, "width": w,
+                        "json_name": tile["json_name"], "tile_id": tile["tile_id"], "meta": tile["meta"]}
+                return {"devwin": (r0, c0, h, w, img.outside_mask(tile["bounds"], c0, r0, w, h))}, info
             if staging is not None and img.dtype == np.uint8:
                 hwc = img.read_bounds_hwc(tile["bounds"], out=staging, out_off=staging_off)
             else:
@@ -332,14 +458,29 @@ class Predictor:
     def _to_model_input(self, batch, slot: Optional[_Slot] = None, engine: Optional[Engine] = None):
         """→ (images tensor on device, format, hw_valid, hw_out)."""
         eng = engine or self.engine
-        if slot is not None and batch and all("staged" in b["data"] for b in batch):
-            used = max(b["data"]["staged"][0] + int(np.prod(b["data"]["staged"][1])) for b in batch)
-            slot.dev_in[:used].copy_(slot.pin_in[:used], non_blocking=True)       # one H2D per batch, from pinned memory
-            tiles = [slot.dev_in[o:o + int(np.prod(shp))].view(*shp) for o, shp in (b["data"]["staged"] for b in batch)]
-            images, hw_valid, hw_out = eng.preprocess_tiles_u8(tiles)
-            return images, INPUT_U8_HWC, hw_valid, hw_out
-        if all("u8" in b["data"] for b in batch):
-            tiles = [b["data"]["u8"].to(self.device, non_blocking=True) for b in batch]
+        if batch and all(("staged" in b["data"] and slot is not None) or "u8" in b["data"] or "devwin" in b["data"] for b in batch):
+            staged = [b["data"]["staged"] for b in batch if "staged" in b["data"]]
+            if staged:
+                used = max(o + int(np.prod(shp)) for o, shp in staged)
+                slot.dev_in[:used].copy_(slot.pin_in[:used], non_blocking=True)       # one H2D per batch, from pinned memory
+            tiles = []
+            for b in batch:
+                d = b["data"]
+                if "staged" in d:
+                    o, shp = d["staged"]
+                    tiles.append(slot.dev_in[o:o + int(np.prod(shp))].view(*shp))
+                elif "devwin" in d:                                 # a window of the raster decoded in HBM
+                    r0, c0, h, w, mask = d["devwin"]
+                    dev = b["raster"]
+                    dev.record_stream(torch.cuda.current_stream())
+                    t = dev[r0:r0 + h, c0:c0 + w, :].contiguous()
+                    if mask is not None:                            # rasterio.mask: pixels whose centre lies outside the bbox are 0
+                        okx, oky = mask
+                        t[:, torch.from_numpy(~okx).to(t.device), :] = 0
+                        t[torch.from_numpy(~oky).to(t.device), :, :] = 0
+                    tiles.append(t)
+                else:
+                    tiles.append(d["u8"].to(self.device, non_blocking=True))
             images, hw_valid, hw_out = eng.preprocess_tiles_u8(tiles)
             return images, INPUT_U8_HWC, hw_valid, hw_out
         planes = []
@@ -361,7 +502,8 @@ class Predictor:
         tile stays in the batch as a black stand-in marked ``failed`` — the gather then carries count = -1 for it and rank 0
         writes no file, so the outcome is the reference's there too."""
         staging = None
-        if img.dtype == np.uint8:
+        raster = getattr(img, "_dev", None)
+        if img.dtype == np.uint8 and raster is None:
             need = 0
             for idx in indices:
                 _, _, w, h = img.window_of_bounds(tiles[idx]["bounds"])
@@ -384,7 +526,13 @@ class Predictor:
                 # side by side: e2e fp16, 400 tiles — 2 threads 1 758 tiles/s (reader-bound), 4: 1 851, 8: 1 905
                 nthreads = int(os.environ.get("TD_READ_THREADS", "0")) or max(2, min(8, host_core_share() // 2))
                 self._read_pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="td-window")
-            results = list(self._read_pool.map(lambda k: self._process_tile(tiles[indices[k]], img, staging, offs[k]), range(len(indices))))
+            def one(k):
+                c0 = time.thread_time()
+                r = self._process_tile(tiles[indices[k]], img, staging, offs[k])
+                with self._stats_lock:
+                    self.stats["read_cpu"] += time.thread_time() - c0
+                return r
+            results = list(self._read_pool.map(one, range(len(indices))))
         else:
             results = [self._process_tile(tiles[idx], img, staging, offs[k]) for k, idx in enumerate(indices)]
         batch = []
@@ -404,7 +552,10 @@ class Predictor:
                 if dropped is not None:
                     dropped.append(idx)
                 continue
-            batch.append({"data": data, **info})
+            entry = {"data": data, **info}
+            if "devwin" in data:
+                entry["raster"] = raster
+            batch.append(entry)
         return batch
 
     def _launch_batch(self, batch, slot: _Slot, pred_subdir, tifpath):
@@ -415,9 +566,10 @@ class Predictor:
             dev_out = slot.outputs(self.engine, len(batch), max(h for h, _ in hw_out), max(w for _, w in hw_out), self.device_contours)
             view = {k: v[: len(batch)] for k, v in dev_out.items()}     # leading-dim slices stay contiguous
             self.engine.forward_raw(images, fmt, hw_valid, hw_out, view)
-            if self.device_contours:
+            slot.traced = self._contour_policy()
+            if slot.traced:
                 self.engine.trace_contours(view, slot.dev_cont, len(batch))
-            slot.copy_results(len(batch), self.device_contours)
+            slot.copy_results(len(batch), slot.traced)
             slot.event.record()
         except BaseException:
             # no epilogue task exists yet that would return the slot: the launcher does (the free list lives as long as the
@@ -431,7 +583,8 @@ class Predictor:
     def _process_and_save_single(self, b, i, slot: _Slot, pred_subdir, tifpath, free: "queue.Queue"):
         """Reference prediction.py:198-266 for one tile: polygons of its instance masks → Prediction_<tile>.json."""
         try:
-            t0 = time.perf_counter()
+            t0, c0 = time.perf_counter(), time.thread_time()
+            self._note_epilogue_start(slot.event.query())
             slot.event.synchronize()
             t1 = time.perf_counter()
             self._mark("epi", i)
@@ -440,7 +593,7 @@ class Predictor:
             host = slot.host
             output_file = os.path.join(pred_subdir, f"Prediction_{os.path.basename(b['tile_id'])}.json")
             n = int(host["count"][i])
-            if self.device_contours:
+            if slot.traced:
                 hc = slot.host_cont
                 args = (hc["points"][i], hc["det_info"][i], hc["contour_info"][i], host["mask_region"][i], host["mask_offset"][i])
                 tail = (host["scores"][i][:n], host["classes"][i], b["meta"]["transform"], tifpath)
@@ -466,6 +619,7 @@ class Predictor:
             with self._stats_lock:
                 self.stats["epilogue_wait"] += t1 - t0
                 self.stats["epilogue"] += time.perf_counter() - t1
+                self.stats["epilogue_cpu"] += time.thread_time() - c0
             return res
         finally:
             with slot.lock:
@@ -479,9 +633,10 @@ class Predictor:
         ctx = torch.cuda.stream(stream) if stream is not None else _null_ctx()
         try:
             with ctx:
-                if self.device_contours:
+                slot.traced = self._contour_policy()
+                if slot.traced:
                     eng.trace_contours({k: v[: len(batch)] for k, v in slot.dev_out.items()}, slot.dev_cont, len(batch))
-                slot.copy_results(len(batch), self.device_contours)
+                slot.copy_results(len(batch), slot.traced)
                 slot.event.record()
         except BaseException:
             self._give_back(slot, self._free)       # no epilogue task will: see _launch_batch
@@ -599,7 +754,7 @@ class Predictor:
             launched += 1
             slot.mark_id = launched - 1
             self._mark("launch", launched - 1)
-            t0 = time.perf_counter()
+            t0, c0 = time.perf_counter(), time.thread_time()
             slot.side = stream               # where finish() enqueues this batch's copies / gather
             if item["batch"] and item["failed"] is None:
                 try:
@@ -614,6 +769,7 @@ class Predictor:
                     item["failed"] = e       # sharded: the round still takes part in its gather, with no detections
             finish(item)
             self.stats["launch"] += time.perf_counter() - t0
+            self.stats["launch_cpu"] += time.thread_time() - c0
             self._mark("launch_done", launched - 1)
 
     @staticmethod
@@ -678,7 +834,7 @@ class Predictor:
         behind these on the engines' streams and its reader takes slots as the epilogue workers return them."""
         B = self.max_batch_size
         rounds = [list(range(r * B, min((r + 1) * B, len(tiles)))) for r in range((len(tiles) + B - 1) // B)]
-        self.stats = dict.fromkeys(self.stats, 0.0)
+        self._roll_stats()
         ready: "queue.Queue" = queue.Queue(maxsize=2)
         stop = threading.Event()
         dropped: List[int] = []
@@ -687,18 +843,23 @@ class Predictor:
             try:
                 for k, indices in enumerate(rounds):
                     self._mark("slot_wait", k)
+                    t0 = time.perf_counter()
                     slot = self._free.get()
+                    self.stats["slot_wait"] += time.perf_counter() - t0
                     if stop.is_set():
                         self._give_back(slot, self._free)
                         return
                     self._mark("read", k)
-                    t0 = time.perf_counter()
+                    t0, c0 = time.perf_counter(), time.thread_time()
                     try:
                         batch = self._read_batch(tiles, indices, img, slot, dropped=dropped)
                     except BaseException:
                         self._give_back(slot, self._free)
                         raise
                     self.stats["read"] += time.perf_counter() - t0
+                    with self._stats_lock:
+                        self.stats["read_cpu"] += time.thread_time() - c0
+                        self.stats["tiles"] += len(batch)
                     self._mark("read_done", k)
                     ready.put((batch, slot))
                 ready.put((None, None))
@@ -971,10 +1132,14 @@ class Predictor:
         self._mark("call")
         tiles = self._load_tiles(tilepath)
         self._mark("tiles_loaded")
+        raster = self._device_raster(tifpath)          # an LZW raster decoded in HBM (prefetched while the previous image ran), or None
         img = GeoTiff(tifpath)
+        img._dev = raster
         self._mark("raster_open")
         try:
-            return self._start_single(tiles, img, pred_subdir, tifpath)
+            pending = self._start_single(tiles, img, pred_subdir, tifpath)
+            pending.keep = raster                      # alive until the image's last forward has read its windows
+            return pending
         finally:
             img.close()
 
@@ -1014,6 +1179,7 @@ class _PendingImage:
     def __init__(self, predictor: "Predictor", futures, dropped=None):
         self._predictor, self._futures, self._done = predictor, futures, None
         self.dropped = dropped if dropped is not None else []      # indices (into the image's tile list) whose crop failed
+        self.keep = None                                           # the image's device-resident raster, if it has one
 
     def result(self):
         if self._done is None:
@@ -1025,6 +1191,7 @@ class _PendingImage:
                     err = err or e
             self._done = (preds, err)
             self._futures = None
+            self.keep = None
         preds, err = self._done
         if err is not None:
             raise err
