@@ -122,6 +122,8 @@ def test_fuse_predictions(tmp_path):
     gpkg.write_polygons(str(urban / "img3.gpkg"), [_crown(30, 30)], {"Confidence_score": [0.6], "filter_index_right": [0]}, 25832)
     gpkg.write_polygons(str(urban / "img4.gpkg"), [_crown(110, 110)], {"Confidence_score": [0.6], "filter_index_right": [0]}, 25833)
     gpkg.write_polygons(str(forest / "img4.gpkg"), [_crown(110, 110)], {"Confidence_score": [0.6], "filter_index_right": [0]}, 25833)
+    gpkg.write_polygons(str(urban / "img5.gpkg"), [_crown(110, 110)], {"Confidence_score": [0.6], "filter_index_right": [0]}, 31467)
+    gpkg.write_polygons(str(forest / "img5.gpkg"), [_crown(110, 110)], {"Confidence_score": [0.6], "filter_index_right": [0]}, 31467)
     log = Log()
     fuse_predictions(str(urban), str(forest), outline, str(out), logger=log)
     rings, cols, srs = gpkg.read_polygons(str(out / "img1.gpkg"))
@@ -131,10 +133,15 @@ def test_fuse_predictions(tmp_path):
     assert cols["Confidence_score"] == pytest.approx(want_scores) and set(cols) == {"Confidence_score", "filter_index_right"}
     assert len(gpkg.read_polygons(str(out / "img2.gpkg"))[0]) == 1               # forest-only image copied
     assert not os.path.exists(out / "img3.gpkg")                                   # no forest layer → skipped, logged
-    assert not os.path.exists(out / "img4.gpkg")                                   # CRS mismatch → error, no output
+    # img4: crowns in EPSG:25833, outline in 25832 → the outline is reprojected (treedetection_amd.crs; reference helpers.py:785-790
+    # to_crs) — in zone 33 it lies elsewhere, so the urban crown survives and the forest one does not
+    r4, _, srs4 = gpkg.read_polygons(str(out / "img4.gpkg"))
+    assert srs4 == 25833 and len(r4) == 1
+    assert any(lvl == "warning" and "CRS mismatch" in m for lvl, m in log.msgs)
+    assert not os.path.exists(out / "img5.gpkg")                                   # DHDN / Gauss-Krüger: not reprojected here → error, no output
     errs = [m for lvl, m in log.msgs if lvl == "error"]
-    assert any("img3.gpkg" in m and "not found" in m for m in errs) and any("CRS mismatch" in m for m in errs)
-    assert yaml.safe_load(open(out / "fusion_recovery.yaml")) == {"completed_files": ["img1", "img2"]}
+    assert any("img3.gpkg" in m and "not found" in m for m in errs) and any("EPSG:31467" in m for m in errs)
+    assert yaml.safe_load(open(out / "fusion_recovery.yaml")) == {"completed_files": ["img1", "img2", "img4"]}
     os.remove(out / "img1.gpkg")
     fuse_predictions(str(urban), str(forest), outline, str(out), logger=log)     # resume: img1 is not rebuilt
     assert not os.path.exists(out / "img1.gpkg")

@@ -77,8 +77,19 @@ def test_gdal_style_bilinear_decimation():
     want = np.einsum("ih,bhw,jw->bij", taps(40, 8), img.astype(np.float64), taps(60, 12))
     assert got.dtype == np.uint8 and np.abs(got.astype(np.float64) - np.floor(want + 0.5)).max() <= 1
     assert (got == np.floor(want + 0.5)).mean() > 0.99
-    with pytest.raises(NotImplementedError):
-        P.resample_bilinear_gdal(img, 80, 60)
+    # magnification (scaling factor above 1): the kernel is NOT stretched — bilinear interpolation between pixel centres; a
+    # constant stays constant, a linear ramp stays linear away from the borders, the borders replicate, 2x of [a, b] = a, (3a+b)/4, (a+3b)/4, b
+    assert (P.resample_bilinear_gdal(const, 100, 70) == 7).all()
+    up = P.resample_bilinear_gdal(ramp, 20, 100)
+    assert up.shape == (1, 20, 100) and np.allclose(up[0, 3, 1:-1], (np.arange(1, 99) + 0.5) / 2 - 0.5, atol=1e-4)
+    assert up[0, 0, 0] == 0.0 and up[0, 0, -1] == 49.0
+    two = np.array([[[10.0, 30.0]]], np.float32)
+    assert np.allclose(P.resample_bilinear_gdal(two, 1, 4), [[[10.0, 15.0, 25.0, 30.0]]])
+    big = P.resample_bilinear_gdal(img, 80, 90)                     # 2x in rows, 1.5x in columns, integers rounded half up
+    assert big.shape == (4, 80, 90) and big.dtype == np.uint8
+    assert np.array_equal(big[:, 0, 0], img[:, 0, 0]) and np.array_equal(big[:, -1, -1], img[:, -1, -1])
+    with pytest.raises(ValueError):
+        P.resample_bilinear_gdal(img, 0, 60)
 
 
 def _scene(tmp_path, rng, same_grid):
@@ -232,6 +243,7 @@ def test_containment_rules_as_in_the_reference(tmp_path):
     assert got["two_a"]["is_contained"] == "True" and got["alone"]["is_contained"] == "False" and got["alone"]["num_contained"] == 0
     assert all(p["TreeHeight"] == 12.0 for p in got.values()) and got["alone"]["Area"] == pytest.approx(36.0)
     # the config above has no scaling keys: the NDVI raster was decimated by the documented default 0.2 (400 → 80 px);
-    # magnification is not restated
-    with pytest.raises(NotImplementedError):
-        P.process_layer([crowns["alone"]], [0.9], dict(config, ndvi_scaling_factor=2.0), str(tmp_path / "ndsm" / "7.tif"), str(tmp_path / "img" / "7.tif"))
+    # a factor above 1 magnifies it (GDAL's bilinear interpolation): the same crown survives with the same attributes
+    up = P.process_layer([crowns["alone"]], [0.9], dict(config, ndvi_scaling_factor=2.0, height_scaling_factor=2.0), str(tmp_path / "ndsm" / "7.tif"),
+                         str(tmp_path / "img" / "7.tif"))
+    assert len(up) == 1 and up[0]["properties"]["TreeHeight"] == 12.0 and up[0]["properties"]["Area"] == pytest.approx(36.0)

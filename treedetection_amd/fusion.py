@@ -5,9 +5,10 @@ Per stitched image: keep the forest model's crowns that *intersect* the forest, 
 not *within* it; either layer alone passes through unchanged when the other is empty. The reference evaluates the two
 predicates against ``unary_union`` of the outline polygons near the image (geopandas/shapely, absent here); this
 module evaluates them against the polygons themselves with ``td_region_relate`` (libtreedet_hip.so, host code), which
-gives the same answers without building the union. Not reproduced: ``to_crs`` (no PROJ — layers in different EPSG
-codes are refused with an error instead of reprojected) and the ``buffer(0)`` / ``make_valid`` repair of invalid
-rings (crowns come from border following + simplification and are written as they are).
+gives the same answers without building the union. ``to_crs``: treedetection_amd.crs moves the OUTLINE into the crowns' CRS
+(geographic / UTM / Web Mercator codes; any other pair is refused with an error instead of guessed). Not reproduced: the
+``buffer(0)`` / ``make_valid`` repair of invalid rings (crowns come from border following + simplification and are written
+as they are).
 """
 from __future__ import annotations
 
@@ -52,6 +53,7 @@ def fuse_predictions(urban_fold, forrest_fold, forrest_path, output_dir, logger=
         if forest_polys else np.zeros((0, 4))
 
     fused: List[str] = []
+    forest_polys_in = {}          # the outline reprojected per crown CRS (normally none: same code, or a file without one)
     for name in todo:
         urban_path, forest_path_ = os.path.join(urban_fold, name), os.path.join(forrest_fold, name)
         if not os.path.exists(urban_path):
@@ -77,10 +79,19 @@ def fuse_predictions(urban_fold, forrest_fold, forrest_path, output_dir, logger=
                     logger.debug(f"Only urban file saved to {out_path}")
                 fused.append(out_path)
                 continue
-            codes = {urban.srs_id, forest.srs_id} | ({forest_epsg} if forest_epsg else set())
-            if len(codes) > 1:
-                raise ValueError(f"CRS mismatch {sorted(codes)}: reprojection is not available in this package — "
-                                 f"store the forest outline in the rasters' CRS")
+            if urban.srs_id != forest.srs_id:
+                raise ValueError(f"CRS mismatch between the urban (EPSG:{urban.srs_id}) and the forest (EPSG:{forest.srs_id}) crowns of one image")
+            if forest_epsg and forest_epsg != urban.srs_id and forest_polys_in.get(urban.srs_id) is None:
+                # reference helpers.py:785-790 aligns the crowns with the outline's CRS; here the OUTLINE goes to the crowns' CRS
+                # (vertex by vertex, as to_crs does) and the fused layer stays in the rasters' CRS
+                from .crs import to_crs
+                if logger:
+                    logger.warning("CRS mismatch detected. Aligning the forest boundary with the crowns' CRS.")
+                moved = to_crs(forest_polys, forest_epsg, urban.srs_id)
+                forest_polys_in[urban.srs_id] = (moved, np.array([[p[0][:, 0].min(), p[0][:, 1].min(), p[0][:, 0].max(), p[0][:, 1].max()] for p in moved])
+                                                 if moved else np.zeros((0, 4)))
+            if forest_epsg and forest_epsg != urban.srs_id:
+                forest_polys, boxes = forest_polys_in[urban.srs_id]
             ue, fe = urban.envelopes(), forest.envelopes()          # [n,4] minx, maxx, miny, maxy
             cb = (min(ue[:, 0].min(), fe[:, 0].min()), min(ue[:, 2].min(), fe[:, 2].min()),
                   max(ue[:, 1].max(), fe[:, 1].max()), max(ue[:, 3].max(), fe[:, 3].max()))
@@ -130,9 +141,11 @@ def exclude_outlines(config, logger=None):
                 crowns = read_layer(path)
                 if len(crowns) == 0:
                     continue
-                if epsg and crowns.srs_id != epsg:
-                    raise ValueError(f"CRS mismatch (crowns EPSG:{crowns.srs_id}, outline EPSG:{epsg}); reprojection is not available")
-                keep = ~Region(polys).relate(crowns.rings())[1]
+                outline = polys
+                if epsg and crowns.srs_id != epsg:          # reference helpers.py:55: exclude_outline.to_crs(crowns.crs)
+                    from .crs import to_crs
+                    outline = to_crs(polys, epsg, crowns.srs_id)
+                keep = ~Region(outline).relate(crowns.rings())[1]
                 env = crowns.envelopes()[keep]
                 extent = (float(env[:, 0].min()), float(env[:, 2].min()), float(env[:, 1].max()), float(env[:, 3].max())) if len(env) else None
                 idx = np.nonzero(keep)[0]

@@ -8,7 +8,7 @@ are one launch of ``td_crown_stats`` per raster (libtreedet_hip.so; a workgroup 
 box, same membership arithmetic); the N x N box filters and the selection rules are small host numpy, written to follow
 the reference line by line *including* its quirks, which are listed in DESIGN.md §7 and marked ``# ref:`` below.
 GDAL's bilinear decimation of the rasters (``ndvi_scaling_factor`` 0.2 in the example config) is restated from its
-published algorithm (:func:`resample_bilinear_gdal`). Not reproduced: magnification (factors above 1 raise), fiona's
+published algorithm (:func:`resample_bilinear_gdal`, both directions). Not reproduced: fiona's
 schema handling (the layer is written by
 :mod:`treedetection_amd.gpkg`), and cupy's float32 reduction order for mean / variance / centroid (accumulated in
 float64, rounded once). The reference holds no fixture for this stage: parity is unpinned (oracle/postprocess_ref.py).
@@ -69,28 +69,36 @@ def _decimation_weights(n_src: int, n_dst: int):
     (gcore/overview.cpp GDALResampleChunk_Convolution: kernel radius 1 stretched by the decimation ratio, weights
     1 - |d| with d in destination-pixel units, normalised over the taps that fall inside the raster)."""
     scale = n_dst / n_src
-    radius = 1.0 / scale
+    # the same routine magnifies: its kernel is stretched only when shrinking (dfXScaleWeight = min(scale, 1)), so for n_dst > n_src
+    # the radius stays ONE source pixel — plain bilinear interpolation between pixel centres, taps outside the raster dropped and
+    # the rest renormalised (the border rows / columns replicate)
+    sw = min(scale, 1.0)
+    radius = 1.0 / sw
     rows = []
     for j in range(n_dst):
         centre = (j + 0.5) / scale
         start = max(int(math.floor(centre - radius + 0.5)), 0)
         stop = min(int(centre + radius + 0.5), n_src)
         idx = np.arange(start, stop)
-        w = np.maximum(0.0, 1.0 - np.abs(scale * (idx - centre + 0.5)))
+        w = np.maximum(0.0, 1.0 - np.abs(sw * (idx - centre + 0.5)))
+        if w.sum() <= 0.0:                       # a tap exactly one radius away on both sides: the nearest source pixel
+            idx = np.array([min(max(int(centre), 0), n_src - 1)])
+            w = np.ones(1)
         rows.append((idx, w / w.sum()))
     return rows
 
 
 def resample_bilinear_gdal(arr: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
-    """``src.read(out_shape=(bands, out_h, out_w), resampling=Resampling.bilinear)`` for a SMALLER out_shape
-    (reference postprocessing.py:781-797 with a scaling factor below 1): separable triangle-filter decimation as GDAL's
-    RasterIO performs it, float32 working type, integer rasters rounded half up and clamped. Same shape = plain copy.
-    GDAL is not available here: restated from its published source, unpinned."""
+    """``src.read(out_shape=(bands, out_h, out_w), resampling=Resampling.bilinear)`` (reference postprocessing.py:781-797):
+    the separable triangle filter of GDAL's RasterIO — stretched by the ratio when the out_shape is SMALLER (scaling factor below
+    1: decimation), one source pixel wide when it is LARGER (factor above 1: interpolation between pixel centres) — float32
+    working type, integer rasters rounded half up and clamped. Same shape = plain copy. GDAL is not available here: restated
+    from its published source, unpinned."""
     bands, h, w = arr.shape
     if (out_h, out_w) == (h, w):
         return arr
-    if out_h > h or out_w > w or out_h < 1 or out_w < 1:
-        raise NotImplementedError("scaling factors above 1 (GDAL bilinear magnification) are not restated")
+    if out_h < 1 or out_w < 1:
+        raise ValueError(f"cannot resample a {h} x {w} raster to {out_h} x {out_w}")
     work = arr.astype(np.float32)
     tmp = np.empty((bands, h, out_w), np.float32)
     for j, (idx, wgt) in enumerate(_decimation_weights(w, out_w)):

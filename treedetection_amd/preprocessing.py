@@ -21,13 +21,16 @@ import yaml
 from .geotiff import GeoTiff
 
 
-def _load_outline(path: Optional[str]):
-    """Forest outline → list of polygons (each a list of closed rings, shell first) — reference preprocessing.py:153-163
-    (``gpd.read_file(forest_shapefile)``; GeoJSON, GeoPackage and Shapefile are read here)."""
+def _load_outline(path: Optional[str], target_epsg: Optional[int] = None):
+    """Forest outline → list of polygons (each a list of closed rings, shell first) in the CRS of the rasters — reference
+    preprocessing.py:153-163 (``gpd.read_file(forest_shapefile)`` then ``to_crs(crs of the first raster)``; GeoJSON, GeoPackage
+    and Shapefile are read here, treedetection_amd.crs reprojects between geographic, UTM and Web Mercator codes)."""
     if not path:
         return None
+    from .crs import to_crs
     from .vector import read_polygon_layer
-    polys, _ = read_polygon_layer(path)
+    polys, epsg = read_polygon_layer(path)
+    polys = to_crs(polys, epsg, target_epsg)
     polys = [p for p in polys if p and len(p[0]) >= 4]
     if not polys:
         raise ValueError(f"No valid geometries found in the forest shapefile {path}.")
@@ -110,7 +113,11 @@ def tile_data(file_list: Sequence[str], out_dir: str, buffer: int = 30, tile_wid
     if not file_list:
         (logger.info if logger else print)("All files have already been processed. Exiting Tiling.")
         return
-    polys = _load_outline(forest_shapefile)
+    target = None
+    if forest_shapefile:
+        with GeoTiff(file_list[0]) as first:          # the reference aligns the outline with the FIRST raster's CRS (preprocessing.py:157-158)
+            target = first.epsg
+    polys = _load_outline(forest_shapefile, target)
 
     def one(p):
         try:
