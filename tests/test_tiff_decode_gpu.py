@@ -98,7 +98,8 @@ def test_a_corrupt_block_is_reported_and_the_predictor_falls_back(tmp_path, caps
 
 def test_prediction_files_are_identical_with_the_device_decoder_on_or_off(tmp_path):
     """An LZW raster (4 bands, tiles with predictor 2) through the Predictor: windows cut in HBM (device_decode auto) against the
-    host reader (false), plus the same pixels stored uncompressed — byte-identical Prediction_*.json; bounds that do not lie on
+    host reader (false), plus the same pixels stored uncompressed (uploaded whole to HBM, or read window by window on the host) —
+    byte-identical Prediction_*.json; bounds that do not lie on
     pixel edges go through rasterio.mask's centre rule on the device as on the host."""
     import treedetection_amd as TD
     from treedetection_amd.preprocessing import tile_single_file
@@ -107,7 +108,7 @@ def test_prediction_files_are_identical_with_the_device_decoder_on_or_off(tmp_pa
     sd = make_synthetic_state_dict(50, seed=3, width_div=2)
     cfg = TD.setup_model_cfg(update_model="x", device="0")
     outs = {}
-    for tag, kw, dd in (("raw", {}, "auto"), ("lzw_dev", {"compression": "lzw", "tile": (128, 128), "predictor": 2}, "auto"),
+    for tag, kw, dd in (("raw", {}, "auto"), ("raw_host", {}, False), ("raw_strips", {"rows_per_strip": 16}, "auto"), ("lzw_dev", {"compression": "lzw", "tile": (128, 128), "predictor": 2}, "auto"),
                         ("lzw_host", {"compression": "lzw", "tile": (128, 128), "predictor": 2}, False),
                         ("lzw_strips_dev", {"compression": "lzw", "rows_per_strip": 3}, True)):
         d = tmp_path / tag
@@ -126,8 +127,10 @@ def test_prediction_files_are_identical_with_the_device_decoder_on_or_off(tmp_pa
                 pred.prefetch(tif)
                 pred(tif, str(d / "tiles" / "9.json"))
             assert pred.decode_stats["images"] == (2 if tag in ("lzw_dev", "lzw_strips_dev") else 0), (tag, pred.decode_stats)
+            # an uncompressed raster is kept whole in HBM as well (uploaded in large pieces), unless device_decode is off
+            assert pred.upload_stats["images"] == (2 if tag in ("raw", "raw_strips") else 0), (tag, pred.upload_stats)
         files = sorted(os.listdir(d / "out" / "9"))
         outs[tag] = {f: open(d / "out" / "9" / f, "rb").read().replace(tif.encode(), b"IMG") for f in files}
         assert len(files) == 9
-    assert outs["raw"] == outs["lzw_dev"] == outs["lzw_host"] == outs["lzw_strips_dev"]
+    assert outs["raw"] == outs["raw_host"] == outs["raw_strips"] == outs["lzw_dev"] == outs["lzw_host"] == outs["lzw_strips_dev"]
     assert sum(len(json.loads(v)) for v in outs["raw"].values()) > 5

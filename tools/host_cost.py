@@ -1,6 +1,7 @@
 """What ONE GPU costs the host on the files-to-files path: CPU seconds per tile, split by stage.
 
-    python tools/host_cost.py [fp16|fp32] [images=4] [side=20] [contours=host|dev|auto] [stitch=1|0] [batch=8]
+    python tools/host_cost.py [fp16|fp32] [images=4] [side=20] [contours=host|dev|auto] [stitch=1|0] [batch=8] [raster=raw|lzw]
+                              [device_raster=auto|false]
 
 Fixture = bench.py's e2e raster (side x side tiles of 1000 x 1000 px, 4-band RGBI uint8 on tmpfs, 16 distinct generator tiles
 cycled), compact-crown weights (weights.blob_mask_head: ~20 contours per tile). One warm-up image, then ``images`` images through
@@ -48,6 +49,7 @@ def main():
     precision = next((a for a in sys.argv[1:] if a in ("fp16", "fp32")), "fp16")
     n_img, side, B = int(args.get("images", 4)), int(args.get("side", 20)), int(args.get("batch", 8))
     contours, stitch = args.get("contours", "host"), args.get("stitch", "1") != "0"
+    raster, dd = args.get("raster", "raw"), {"auto": "auto", "false": False}[args.get("device_raster", "auto")]
     S = 1000
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     root = tempfile.mkdtemp(prefix="td_hostcost_", dir=base)
@@ -61,7 +63,8 @@ def main():
                 img[:3, r * S:(r + 1) * S, c * S:(c + 1) * S] = t.transpose(2, 0, 1)
                 img[3, r * S:(r + 1) * S, c * S:(c + 1) * S] = t[..., 1]
         tif0 = f"{root}/base.tif"
-        write_geotiff(tif0, img, (0.2, 0.0, 412000.0, 0.0, -0.2, 5318000.0 + side * S * 0.2), 25832)
+        kw = {"compression": "lzw", "tile": (256, 256), "predictor": 2} if raster == "lzw" else {}
+        write_geotiff(tif0, img, (0.2, 0.0, 412000.0, 0.0, -0.2, 5318000.0 + side * S * 0.2), 25832, **kw)
         del img
         tile_data([tif0], f"{root}/tiles0", buffer=0, tile_width=200, tile_height=200)
         names = [str(324125400 + k) for k in range(n_img)] + ["warm"]
@@ -74,13 +77,14 @@ def main():
         cfg = T.setup_model_cfg(update_model="synthetic", device="0")
         dc = {"host": False, "dev": True, "auto": "auto"}[contours]
         pred = T.Predictor(cfg, device_type="0", max_batch_size=B, output_dir=f"{root}/pred", precision=precision, state_dict=sd,
-                           return_predictions=False, device_contours=dc)
+                           return_predictions=False, device_contours=dc, device_decode=dd)
         logger = logging.getLogger("td-hostcost")
         logger.setLevel(logging.ERROR)
         config = {"logger": logger, "simplify_tolerance": 0.2}
         paths = [f"{root}/rgb/{nm}.tif" for nm in names[:-1]]
         pred.submit(f"{root}/rgb/warm.tif", f"{root}/tiles/warm.json", whole_image=True).result()
-        out = {"precision": precision, "images": n_img, "tiles_per_image": ntiles, "batch": B, "contours": contours,
+        out = {"precision": precision, "images": n_img, "tiles_per_image": ntiles, "batch": B, "contours": contours, "raster": raster,
+               "device_raster": str(dd), "file_bytes": os.path.getsize(tif0),
                "host_cores": len(os.sched_getaffinity(0)), "epilogue_workers": pred._pool._max_workers}
         for label, st in (("walk", f"{root}/gpkg" if stitch else None), ("walk_again", f"{root}/gpkg2" if stitch else None)):
             pred.totals = dict.fromkeys(pred.stats, 0.0)
@@ -104,6 +108,7 @@ def main():
                                                "reader_waiting_for_a_slot": ms(tot["slot_wait"]), "epilogue_workers": ms(tot["epilogue"]),
                                                "epilogue_waiting_for_the_gpu": ms(tot["epilogue_wait"]), "stitch_threads": ms(rep["stitch_seconds"])},
                           "cores_busy": round((u1 - u0 + s1 - s0) / dt, 2),
+                          "raster_upload": dict(pred.upload_stats), "raster_decode": dict(pred.decode_stats),
                           "device_contours_batches": getattr(pred, "device_contour_batches", None)}
         shutil.rmtree(f"{root}/pred", ignore_errors=True)
         pred.close()

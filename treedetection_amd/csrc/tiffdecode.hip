@@ -9,9 +9,8 @@
 // MSB-first 9..12-bit codes, ClearCode 256, EOI 257, width grows one code early). A string of the table is a WINDOW OF THE
 // OUTPUT: entry k was defined when the code after string(old) arrived, so its bytes are out[pos(old) .. pos(old) + len(old)]
 // — no prefix / suffix chains, a string is copied 64 bytes per step by the wave's lanes, and len(k) = start(k + 1) - start(k)
-// + 1, so the table is ONE array of 4097 output positions in LDS (16 KB: nine waves per CU). Integer / byte work bound by
-// the latency of dependent loads, not by HBM: a copy whose source may still be in flight waits for the wave's stores
-// (s_waitcnt vmcnt(0)) and reads past the L1 (agent-scope loads); sources known complete are read without waiting.
+// + 1, so the table is ONE array of 4097 output positions in LDS (16 KB). Integer / byte work bound by the latency of dependent
+// LDS reads (two per code), not by HBM: 1 byte written per byte decoded, the compressed bytes read once.
 #include "common.h"
 
 namespace {
@@ -21,12 +20,21 @@ constexpr int LZW_CLEAR = 256, LZW_EOI = 257, LZW_FIRST = 258, LZW_MAX = 4096;
 __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
 // status: 0 ok, 1 corrupt stream, 2 more bytes than the block holds
+//
+// Where a string's bytes come from: every source lies in the output of the current table epoch (since the last ClearCode),
+// and on imagery an epoch is a few KB (3 800 codes of 1 - 3 bytes) — so the wave keeps the last RING bytes of its output in
+// LDS and copies from there: LDS operations of one wave execute in order, a copy can follow the write it depends on without
+// any wait, and a code costs two dependent LDS reads (table, ring) instead of a round trip to L2 per code (the first
+// version of this kernel: 2.7 GB/s per raster; profiles/r06_lzw.txt). Sources older than the ring (long runs of flat
+// pixels: strings of thousands of bytes) are read from the block's output in memory, behind a wait for this wave's stores.
+constexpr int LZW_RING = 16384;                            // bytes of recent output kept in LDS (16 + 16 KB: four waves per CU)
 __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ block_off,
                                                              const int64_t* __restrict__ block_nbytes, uint8_t* __restrict__ out,
                                                              int64_t block_cap, int64_t* __restrict__ decoded,
                                                              int32_t* __restrict__ status) {
     __shared__ uint32_t t_start[LZW_MAX + 2];
     __shared__ uint32_t inbuf[128];                       // two chunks of 64 dwords of the compressed stream
+    __shared__ uint8_t ring[LZW_RING];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int64_t n = block_nbytes[b];
     uint8_t* dst = out + (int64_t)b * block_cap;
@@ -76,7 +84,11 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
                 err = 1;
                 break;
             }
-            if (lane == 0 && op < cap) dst[op] = (uint8_t)code;
+            if (lane == 0) {
+                ring[op & (LZW_RING - 1)] = (uint8_t)code;
+                if (op < cap) dst[op] = (uint8_t)code;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             old_pos = op;
             old_len = 1;
             op += 1;
@@ -103,11 +115,22 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
             }
             ++next;
             if (next > (1 << nbits) - 2 && nbits < 12) ++nbits;
-            __syncthreads();
         }
         if (code < 256) {
-            if (lane == 0 && op < cap) dst[op] = (uint8_t)code;
+            if (lane == 0) {
+                ring[op & (LZW_RING - 1)] = (uint8_t)code;
+                if (op < cap) dst[op] = (uint8_t)code;
+            }
+        } else if (op - s_start + 64 <= (uint32_t)LZW_RING && s_len <= 64) {
+            // the usual case: a short string whose source is still in the ring. One step: read, then write (in-order LDS)
+            if ((uint32_t)lane < s_len) {
+                const uint32_t sk = (kwkwk && (uint32_t)lane == s_len - 1) ? 0u : (uint32_t)lane;
+                const uint8_t v = ring[(s_start + sk) & (LZW_RING - 1)];
+                ring[(op + lane) & (LZW_RING - 1)] = v;
+                if (op + lane < cap) dst[op + lane] = v;
+            }
         } else {
+            // long strings and sources that have left the ring: through the block's output in memory
             if (s_start + s_len > safe) {                  // the source may still be on its way to L2: wait for this wave's stores
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 safe = op;
@@ -118,10 +141,14 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
                     const uint32_t sk = (kwkwk && k == s_len - 1) ? 0u : k;
                     // agent-scope load: served by L2, never by a stale L1 line of bytes this wave stored earlier
                     const uint8_t v = __hip_atomic_load(dst + s_start + sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ring[(op + k) & (LZW_RING - 1)] = v;
                     if (op + k < cap) dst[op + k] = v;
                 }
             }
         }
+        // (one wave: its LDS operations execute in program order — the fence keeps the compiler from moving the table / ring
+        // reads of the next code above these writes; no barrier instruction is needed)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         old_pos = op;
         old_len = s_len;
         op += s_len;

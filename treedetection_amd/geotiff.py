@@ -391,6 +391,69 @@ class GeoTiff:
         check.compressed_bytes = span
         return image, check
 
+    def device_uploadable(self) -> bool:
+        """True when the raster's pixels lie in the file as ONE dense [rows, cols, bands] uint8 array (uncompressed contiguous
+        strips, pixel-interleaved): it can be copied to the GPU in large sequential pieces and its tile windows cut there."""
+        self._setup_blocks()
+        return self._flat is not None and getattr(self, "_fd", None) is not None and self.dtype == np.uint8 and self._pil is None
+
+    def upload_to_device(self, device, stream=None, staging=None, pool=None, piece: int = 16 << 20):
+        """The whole uncompressed raster in HBM: the file's pixel bytes are read in large sequential pieces (pread of ``piece``
+        bytes, several side by side on ``pool``) into pinned staging buffers and copied to the device as they arrive — per tile
+        one memcpy of its bytes out of the page cache, no system call per window row and no per-batch H2D of windows later.
+        ``staging``: list of >= 2 pinned uint8 tensors to rotate through (created here when None). → (image tensor [rows,
+        cols, bands] uint8, check) as :meth:`decode_to_device`."""
+        import torch
+        if not self.device_uploadable():
+            raise ValueError(f"{self.path}: not one dense uint8 array in the file")
+        dev = torch.device(device)
+        total = self.height * self.width * self.count
+        if staging is None:
+            staging = [torch.empty((4 * piece,), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        cap = min(t.numel() for t in staging)
+        ctx = torch.cuda.stream(stream) if stream is not None else _NullCtx()
+        fd, base = self._fd, self._flat_off
+
+        def read_into(view: memoryview, off: int) -> None:
+            got = 0
+            while got < len(view):
+                n = os.preadv(fd, [view[got:]], base + off + got)
+                if n <= 0:
+                    raise ValueError(f"{self.path}: file ends inside its pixel data")
+                got += n
+
+        with torch.cuda.device(dev), ctx:
+            image = torch.empty((self.height, self.width, self.count), dtype=torch.uint8, device=dev)
+            flat = image.view(-1)
+            events = [None] * len(staging)
+            k = 0
+            for o in range(0, total, cap):
+                n = min(cap, total - o)
+                buf = staging[k % len(staging)]
+                if events[k % len(staging)] is not None:
+                    events[k % len(staging)].synchronize()          # the copy that last used this staging buffer has finished
+                mv = memoryview(buf.numpy())
+                parts = [(p, min(piece, n - p)) for p in range(0, n, piece)]
+                if pool is not None and len(parts) > 1:
+                    list(pool.map(lambda pr: read_into(mv[pr[0]:pr[0] + pr[1]], o + pr[0]), parts))
+                else:
+                    for p0, pn in parts:
+                        read_into(mv[p0:p0 + pn], o + p0)
+                flat[o:o + n].copy_(buf[:n], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                events[k % len(staging)] = ev
+                k += 1
+            done = torch.cuda.Event()
+            done.record()
+
+        def check():
+            done.synchronize()
+            return image
+        check.event = done
+        check.compressed_bytes = total
+        return image, check
+
     def _load(self) -> np.ndarray:
         """Whole raster as [bands, rows, cols]."""
         if self._data is None:

@@ -63,6 +63,7 @@ class _Slot:
         self.event = torch.cuda.Event(blocking=True)
         self.pending = 0
         self.traced = False         # this batch's borders were followed on the device (Predictor._contour_policy)
+        self.submitted = 0.0        # when the batch's epilogue tasks were queued
         self.lock = threading.Lock()
         self.transient = False      # stand-in for a round that has no real slot (reader failure, _drain): never enters a free list
 
@@ -207,6 +208,11 @@ class Predictor:
         self._raster_pool = None
         self._decode_stream = None
         self.decode_stats = {"images": 0, "seconds": 0.0, "compressed_bytes": 0, "decoded_bytes": 0}
+        self.upload_stats = {"images": 0, "seconds": 0.0, "compressed_bytes": 0, "decoded_bytes": 0}
+        self._upload_staging = self._upload_pool = None
+        # uncompressed rasters up to this size are kept whole in HBM too (TD_DEVICE_RASTER_MAX_GB, default 24): beyond it the host
+        # window reader serves them
+        self.device_raster_max_bytes = int(float(os.environ.get("TD_DEVICE_RASTER_MAX_GB", "24")) * (1 << 30))
         if device_type == "cpu" or not torch.cuda.is_available():
             raise RuntimeError("treedetection_amd.Predictor runs on an MI355X only: the HIP path has no CPU fallback "
                                "(config['device'] resolved to 'cpu').")
@@ -298,10 +304,14 @@ class Predictor:
         return tot
 
     # -- device_contours: "auto" -------------------------------------------------------------------------------------
-    # Signal: an epilogue task that finds its batch's event ALREADY complete when it starts was queued behind other tasks — the
-    # workers are the bottleneck; a task that has to wait for the event means the GPU is. The share of late tasks (exponential
-    # mean over ~64 tasks) switches the device tracer on above 0.5 — from then on the workers only format and write what the
-    # GPU traced — and off again once it stayed below 0.05 for 2 000 tasks (a re-probe: if the backlog returns, so does the tracer).
+    # Signal: an epilogue task is LATE when it sat in the worker pool's queue for more than a millisecond (every worker was busy)
+    # AND its batch had left the GPU by the time it started — the workers, not the GPU and not the reader, set the pace. (A
+    # finished event alone says nothing: when the READER is the slow stage the GPU idles, every event is complete at once and
+    # the workers are idle too — measured on a box with slow page-cache reads, where that signal switched the tracer on and cost
+    # 20 %.) The share of late tasks (exponential mean over ~64 tasks) switches the device tracer on above 0.5 — from then on the
+    # workers only format and write what the GPU traced — and off again once it stayed below 0.05 for 2 000 tasks (a re-probe).
+    # Measured on the compact-crown fixture (tools/host_cost.py, profiles/r06_host_cost.txt): the device tracer is SLOWER there
+    # than 16 host workers (one wave follows a crown's border serially); it is for hosts with few cores per GPU.
     def _note_epilogue_start(self, late: bool) -> None:
         if not self._contours_auto:
             return
@@ -337,6 +347,9 @@ class Predictor:
             self._raster_pool.shutdown(wait=True)
             self._raster_pool = None
             self._rasters.clear()
+        if getattr(self, "_upload_pool", None) is not None:
+            self._upload_pool.shutdown(wait=True)
+            self._upload_pool = self._upload_staging = None
         for eng in getattr(self, "_engines", []) or []:
             eng.close()
 
@@ -349,9 +362,10 @@ class Predictor:
     # -- compressed rasters decoded on the GPU -------------------------------------------------------------------
     def prefetch(self, tifpath) -> None:
         """Starts, on a thread of its own, what the NEXT image needs before its first batch can be cut: an LZW raster's compressed
-        blocks read into pinned memory, copied to the device and decoded there (GeoTiff.decode_to_device) — while the current
-        image predicts. ``detection.walk_images`` calls it with the path after the one it submits. No-op for rasters the host
-        reader serves (uncompressed, DEFLATE, planar, 16-bit) and when ``device_decode`` is off."""
+        blocks read into pinned memory, copied to the device and decoded there (GeoTiff.decode_to_device), or an uncompressed
+        raster's bytes copied to the device in large sequential pieces (GeoTiff.upload_to_device) — while the current image
+        predicts. ``detection.walk_images`` calls it with the path after the one it submits. No-op for rasters the host reader
+        serves (DEFLATE, PackBits, planar, 16-bit) and when ``device_decode`` is off."""
         if not self.device_decode or tifpath in self._rasters:
             return
         if self._raster_pool is None:
@@ -364,18 +378,29 @@ class Predictor:
         img = None
         try:
             img = GeoTiff(tifpath)
-            if not img.device_decodable():
+            decode = img.device_decodable()
+            if not decode and not (img.device_uploadable() and img.height * img.width * img.count <= self.device_raster_max_bytes):
                 return None
             if self._decode_stream is None:
                 with torch.cuda.device(self.device_index):
                     self._decode_stream = torch.cuda.Stream()
             t0 = time.perf_counter()
-            image, check = img.decode_to_device(self.device, self._decode_stream)
+            c0 = time.thread_time()
+            if decode:
+                image, check = img.decode_to_device(self.device, self._decode_stream)
+            else:
+                # an uncompressed raster: its bytes go to HBM in large sequential pieces (GeoTiff.upload_to_device), the windows
+                # are cut there — one memcpy per byte out of the page cache instead of a pread per window row + an H2D per batch
+                if self._upload_staging is None:
+                    self._upload_staging = [torch.empty((64 << 20,), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+                    self._upload_pool = ThreadPoolExecutor(max_workers=max(1, min(8, host_core_share() // 4)), thread_name_prefix="td-upload")
+                image, check = img.upload_to_device(self.device, self._decode_stream, self._upload_staging, self._upload_pool)
             check()
             with self._stats_lock:
-                st = self.decode_stats
+                st = self.decode_stats if decode else self.upload_stats
                 st["images"] += 1
                 st["seconds"] += time.perf_counter() - t0
+                st["thread_cpu"] = st.get("thread_cpu", 0.0) + time.thread_time() - c0
                 st["compressed_bytes"] += check.compressed_bytes
                 st["decoded_bytes"] += image.numel()
             return image
@@ -577,6 +602,7 @@ class Predictor:
             self._give_back(slot, self._free)
             raise
         slot.pending = len(batch)
+        slot.submitted = time.perf_counter()
         return [self._pool.submit(self._process_and_save_single, b, i, slot, pred_subdir, tifpath, self._free)
                 for i, b in enumerate(batch)]
 
@@ -584,7 +610,7 @@ class Predictor:
         """Reference prediction.py:198-266 for one tile: polygons of its instance masks → Prediction_<tile>.json."""
         try:
             t0, c0 = time.perf_counter(), time.thread_time()
-            self._note_epilogue_start(slot.event.query())
+            self._note_epilogue_start(t0 - slot.submitted > 1e-3 and slot.event.query())
             slot.event.synchronize()
             t1 = time.perf_counter()
             self._mark("epi", i)
@@ -598,8 +624,13 @@ class Predictor:
                 args = (hc["points"][i], hc["det_info"][i], hc["contour_info"][i], host["mask_region"][i], host["mask_offset"][i])
                 tail = (host["scores"][i][:n], host["classes"][i], b["meta"]["transform"], tifpath)
                 text = tile_polygons_json_dev(*args, None, *tail)
-                if text is None:        # a detection too large / too fragmented for the device tracer: fetch this tile's rows
-                    text = tile_polygons_json_dev(*args, slot.dev_out["mask_bits"][i].cpu().numpy(), *tail)
+                if text is None:
+                    # a detection too large / too fragmented for the device tracer (its region exceeds the 56-KB label image): this
+                    # tile goes through the host path — only the words the paste wrote are fetched, not the worst-case buffer
+                    # (12.8 MB per 1000 x 1000 tile: on the compact-crown fixture most tiles hold one such crown)
+                    tile_prediction_file(self.device_index, host["mask_region"][i], host["mask_offset"][i], slot.bits_ptr(i),
+                                         host["mask_bits"][i], host["scores"][i][:n], host["classes"][i], b["meta"]["transform"],
+                                         tifpath, output_file)
             else:
                 # rows fetched (only the words written), traced, formatted and written by one call without the GIL
                 text = None
@@ -642,6 +673,7 @@ class Predictor:
             self._give_back(slot, self._free)       # no epilogue task will: see _launch_batch
             raise
         slot.pending = len(batch)
+        slot.submitted = time.perf_counter()
         futures.extend(self._pool.submit(self._process_and_save_single, b, i, slot, pred_subdir, tifpath, self._free)
                        for i, b in enumerate(batch))
 
