@@ -19,41 +19,52 @@ constexpr int LZW_CLEAR = 256, LZW_EOI = 257, LZW_FIRST = 258, LZW_MAX = 4096;
 
 __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
-// status: 0 ok, 1 corrupt stream, 2 more bytes than the block holds
+// status: 0 ok, 1 corrupt stream, 2 more bytes than the block holds, 3 left to the wide-table pass
 //
 // Where a string's bytes come from: every source lies in the output of the current table epoch (since the last ClearCode),
 // and on imagery an epoch is a few KB (3 800 codes of 1 - 3 bytes) — so the wave keeps the last RING bytes of its output in
 // LDS and copies from there: LDS operations of one wave execute in order, a copy can follow the write it depends on without
-// any wait, and a code costs two dependent LDS reads (table, ring) instead of a round trip to L2 per code (the first
-// version of this kernel: 2.7 GB/s per raster; profiles/r06_lzw.txt). Sources older than the ring (long runs of flat
-// pixels: strings of thousands of bytes) are read from the block's output in memory, behind a wait for this wave's stores.
-constexpr int LZW_RING = 16384;                            // bytes of recent output kept in LDS (16 + 16 KB: four waves per CU)
+// any wait, and a code costs two dependent LDS reads (table, ring) instead of a round trip to L2. Sources older than the ring
+// (long runs of flat pixels: strings of thousands of bytes) are read from the block's output in memory, behind a wait for
+// this wave's stores. What bounds the kernel is the instruction latency of ONE wave walking a sequential stream (~100
+// dependent instructions per code), so everything is done to keep many waves resident: the table holds positions relative to
+// the epoch's start as uint16 (8 KB; an epoch whose output outgrows 16 bits — flat rasters — flags its block for the second
+// launch, the same kernel with a uint32 table), literals are strings of a 256-byte identity table so that every code takes the
+// same copy path, and the common case is one branch-free stretch: profiles/r06_lzw.txt has the measured rates of each step.
+constexpr int LZW_RING = 16384;                            // bytes of recent output kept in LDS
+constexpr int LZW_LIT = LZW_RING;                          // the identity table follows the ring: ring_lit[LZW_LIT + c] = c
+template <typename TableT, bool SECOND>
 __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ block_off,
                                                              const int64_t* __restrict__ block_nbytes, uint8_t* __restrict__ out,
                                                              int64_t block_cap, int64_t* __restrict__ decoded,
                                                              int32_t* __restrict__ status) {
-    __shared__ uint32_t t_start[LZW_MAX + 2];
+    __shared__ TableT t_start[LZW_MAX + 2];               // start of entry k relative to the epoch's start; len(k) = t[k + 1] - t[k] + 1
     __shared__ uint32_t inbuf[128];                       // two chunks of 64 dwords of the compressed stream
-    __shared__ uint8_t ring[LZW_RING];
+    __shared__ uint8_t ring_lit[LZW_RING + 256];
     const int b = blockIdx.x, lane = threadIdx.x;
+    if (SECOND && status[b] != 3) return;                  // the second launch only takes the blocks the narrow table gave up on
+    constexpr uint32_t REL_MAX = sizeof(TableT) == 2 ? 65535u - 4096u : 0xffffffffu;
     const int64_t n = block_nbytes[b];
     uint8_t* dst = out + (int64_t)b * block_cap;
     const uint32_t cap = (uint32_t)block_cap;
     const uintptr_t a0 = reinterpret_cast<uintptr_t>(comp + block_off[b]);
     const int skip = (int)(a0 & 3);
     const uint32_t* src32 = reinterpret_cast<const uint32_t*>(a0 - skip);
-    const int64_t ndw = (n + skip + 3) >> 2;              // dwords that hold the stream (the buffer is padded: reading the last one is safe)
-    int64_t loaded = 0, rd = 0;
+    const int ndw = (int)((n + skip + 3) >> 2);            // dwords that hold the stream (the buffer is padded: reading the last one is safe)
+    for (int c = lane; c < 256; c += 64) ring_lit[LZW_LIT + c] = (uint8_t)c;
+    for (int c = lane; c < LZW_FIRST + 1; c += 64) t_start[c] = 0;      // literals: len = t[c + 1] - t[c] + 1 = 1
+    int loaded = 0, rd = 0;
     int64_t bits_left = n * 8;
     uint64_t acc = 0;
     int have = 0, nbits = 9, next = LZW_FIRST;
-    uint32_t op = 0, old_pos = 0, old_len = 0, safe = 0;   // old_len == 0: no previous code (start, or right after a ClearCode)
+    uint32_t op = 0, old_pos = 0, old_len = 0, safe = 0, epoch = 0;      // old_len == 0: no previous code (start, or right after a ClearCode)
     int err = 0;
     bool first_word = true;
+    __syncthreads();
     for (;;) {
         while (have < 32 && rd < ndw) {
             if (rd >= loaded) {                            // next 256 bytes of the stream, one dword per lane
-                const int64_t idx = loaded + lane;
+                const int idx = loaded + lane;
                 inbuf[idx & 127] = idx < ndw ? src32[idx] : 0u;
                 loaded += 64;
                 __syncthreads();                           // (one wave: orders the LDS writes before the reads below; every store of this wave has completed too)
@@ -72,61 +83,53 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
         const int code = (int)((acc >> (have - nbits)) & ((1u << nbits) - 1u));
         have -= nbits;
         bits_left -= nbits;
-        if (code == LZW_EOI) break;
-        if (code == LZW_CLEAR) {
-            nbits = 9;
-            next = LZW_FIRST;
-            old_len = 0;
-            continue;
-        }
-        if (old_len == 0) {                                // first code after a clear: a literal
-            if (code > 255) {
+        // the rare cases first, behind ONE test: EOI / ClearCode, the literal after a clear, a code beyond the table
+        if (__builtin_expect((unsigned)(code - LZW_CLEAR) < 2u || old_len == 0 || code > next || (code == next && next >= LZW_MAX), 0)) {
+            if (code == LZW_EOI) break;
+            if (code == LZW_CLEAR) {
+                nbits = 9;
+                next = LZW_FIRST;
+                old_len = 0;
+                continue;
+            }
+            if (old_len != 0 || code > 255) {              // beyond the table, or not a literal right after a clear
                 err = 1;
                 break;
             }
             if (lane == 0) {
-                ring[op & (LZW_RING - 1)] = (uint8_t)code;
+                ring_lit[op & (LZW_RING - 1)] = (uint8_t)code;
                 if (op < cap) dst[op] = (uint8_t)code;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            epoch = op;                                    // table positions are relative to the first byte of the epoch
             old_pos = op;
             old_len = 1;
             op += 1;
             continue;
         }
-        if (code > next || (code == next && next >= LZW_MAX)) {
-            err = 1;
-            break;
-        }
-        // string(code): a literal, a window of the output, or (code == next) string(old) + its own first byte
-        uint32_t s_start = 0, s_len = 1;
+        // string(code) = out[s_start .. s_start + s_len): a window of the output — for a literal a window of the identity table
         const bool kwkwk = code == next;
-        if (kwkwk) {
-            s_start = old_pos;
-            s_len = old_len + 1;
-        } else if (code >= LZW_FIRST) {
-            s_start = t_start[code];
-            s_len = t_start[code + 1] - s_start + 1;
-        }
+        const uint32_t t0 = t_start[code], t1 = t_start[code + 1];
+        uint32_t s_start = kwkwk ? old_pos : epoch + t0;
+        const uint32_t s_len = kwkwk ? old_len + 1 : (code < 256 ? 1u : t1 - t0 + 1);
         if (next < LZW_MAX) {                              // new entry = string(old) + first byte of string(code): out[old_pos .. op]
+            if (op - epoch > REL_MAX) {                    // (uint16 table only) this epoch's output no longer fits: the wide pass decodes the block
+                err = 3;
+                break;
+            }
             if (lane == 0) {
-                t_start[next] = old_pos;
-                t_start[next + 1] = op;                    // provisional: becomes the next entry's start (its old_pos is this op)
+                t_start[next] = (TableT)(old_pos - epoch);
+                t_start[next + 1] = (TableT)(op - epoch);  // provisional: becomes the next entry's start (its old_pos is this op)
             }
             ++next;
-            if (next > (1 << nbits) - 2 && nbits < 12) ++nbits;
+            nbits += (next > (1 << nbits) - 2 && nbits < 12) ? 1 : 0;
         }
-        if (code < 256) {
-            if (lane == 0) {
-                ring[op & (LZW_RING - 1)] = (uint8_t)code;
-                if (op < cap) dst[op] = (uint8_t)code;
-            }
-        } else if (op - s_start + 64 <= (uint32_t)LZW_RING && s_len <= 64) {
-            // the usual case: a short string whose source is still in the ring. One step: read, then write (in-order LDS)
+        if (__builtin_expect(s_len <= 64 && (code < 256 || op - s_start + 64 <= (uint32_t)LZW_RING), 1)) {
+            // one step: read (ring or identity table), then write ring + memory; LDS operations of a wave execute in order
             if ((uint32_t)lane < s_len) {
                 const uint32_t sk = (kwkwk && (uint32_t)lane == s_len - 1) ? 0u : (uint32_t)lane;
-                const uint8_t v = ring[(s_start + sk) & (LZW_RING - 1)];
-                ring[(op + lane) & (LZW_RING - 1)] = v;
+                const uint32_t a = code < 256 ? (uint32_t)(LZW_LIT + code) : ((s_start + sk) & (LZW_RING - 1));
+                const uint8_t v = ring_lit[a];
+                ring_lit[(op + lane) & (LZW_RING - 1)] = v;
                 if (op + lane < cap) dst[op + lane] = v;
             }
         } else {
@@ -141,21 +144,18 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
                     const uint32_t sk = (kwkwk && k == s_len - 1) ? 0u : k;
                     // agent-scope load: served by L2, never by a stale L1 line of bytes this wave stored earlier
                     const uint8_t v = __hip_atomic_load(dst + s_start + sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ring[(op + k) & (LZW_RING - 1)] = v;
+                    ring_lit[(op + k) & (LZW_RING - 1)] = v;
                     if (op + k < cap) dst[op + k] = v;
                 }
             }
         }
-        // (one wave: its LDS operations execute in program order — the fence keeps the compiler from moving the table / ring
-        // reads of the next code above these writes; no barrier instruction is needed)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         old_pos = op;
         old_len = s_len;
         op += s_len;
     }
     if (lane == 0) {
         decoded[b] = (int64_t)op;
-        status[b] = err ? 1 : (op > cap ? 2 : 0);
+        status[b] = err ? err : (op > cap ? 2 : 0);
     }
 }
 
@@ -214,8 +214,12 @@ extern "C" td_status td_tiff_lzw_decode_dev(const uint8_t* comp, const int64_t* 
     TD_REQUIRE(nblocks >= 0 && block_cap >= 1 && block_cap < ((int64_t)1 << 31), "td_tiff_lzw_decode_dev: %d blocks of %lld bytes", nblocks,
                (long long)block_cap);
     if (nblocks == 0) return TD_OK;
-    hipLaunchKernelGGL(tiff_lzw_blocks_kernel, dim3(nblocks), dim3(64), 0, static_cast<hipStream_t>(stream), comp, block_off, block_nbytes,
-                       blocks_out, block_cap, decoded, status);
+    // narrow table first (six waves per CU); blocks whose epochs outgrow it (flat rasters) are decoded again with the wide one
+    hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint16_t, false>), dim3(nblocks), dim3(64), 0, static_cast<hipStream_t>(stream), comp, block_off,
+                       block_nbytes, blocks_out, block_cap, decoded, status);
+    TD_KERNEL_CHECK();
+    hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint32_t, true>), dim3(nblocks), dim3(64), 0, static_cast<hipStream_t>(stream), comp, block_off,
+                       block_nbytes, blocks_out, block_cap, decoded, status);
     TD_KERNEL_CHECK();
     return TD_OK;
 }

@@ -375,7 +375,7 @@ class GeoTiff:
             st_h = torch.empty((nb,), dtype=torch.int32, pin_memory=True)
             dec_h.copy_(decoded, non_blocking=True)
             st_h.copy_(status, non_blocking=True)
-            copied = torch.cuda.Event()
+            copied = torch.cuda.Event(blocking=True)
             copied.record()
         keep = [pin, comp, meta, blocks, decoded, status]     # alive until check() has run: the kernels read them
 
@@ -397,7 +397,7 @@ class GeoTiff:
         self._setup_blocks()
         return self._flat is not None and getattr(self, "_fd", None) is not None and self.dtype == np.uint8 and self._pil is None
 
-    def upload_to_device(self, device, stream=None, staging=None, pool=None, piece: int = 16 << 20):
+    def upload_to_device(self, device, stream=None, staging=None, pool=None, piece: int = 4 << 20):
         """The whole uncompressed raster in HBM: the file's pixel bytes are read in large sequential pieces (pread of ``piece``
         bytes, several side by side on ``pool``) into pinned staging buffers and copied to the device as they arrive — per tile
         one memcpy of its bytes out of the page cache, no system call per window row and no per-batch H2D of windows later.
@@ -434,17 +434,19 @@ class GeoTiff:
                     events[k % len(staging)].synchronize()          # the copy that last used this staging buffer has finished
                 mv = memoryview(buf.numpy())
                 parts = [(p, min(piece, n - p)) for p in range(0, n, piece)]
-                if pool is not None and len(parts) > 1:
-                    list(pool.map(lambda pr: read_into(mv[pr[0]:pr[0] + pr[1]], o + pr[0]), parts))
-                else:
-                    for p0, pn in parts:
-                        read_into(mv[p0:p0 + pn], o + p0)
-                flat[o:o + n].copy_(buf[:n], non_blocking=True)
+
+                def one(pr, mv=mv, o=o):
+                    read_into(mv[pr[0]:pr[0] + pr[1]], o + pr[0])
+                    return pr
+                # every piece goes to the device as soon as it (and the pieces before it) has been read: copies of a few MB keep
+                # the DMA queue short for the small result copies of the running forwards (64-MB copies delayed them by a millisecond)
+                for p0, pn in (pool.map(one, parts) if pool is not None and len(parts) > 1 else map(one, parts)):
+                    flat[o + p0:o + p0 + pn].copy_(buf[p0:p0 + pn], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
                 events[k % len(staging)] = ev
                 k += 1
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(blocking=True)
             done.record()
 
         def check():
