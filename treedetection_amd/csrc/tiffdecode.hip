@@ -59,6 +59,7 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
     int have = 0, nbits = 9, next = LZW_FIRST;
     uint32_t op = 0, old_pos = 0, old_len = 0, safe = 0, epoch = 0;      // old_len == 0: no previous code (start, or right after a ClearCode)
     int err = 0;
+    uint32_t slow = 0;                                      // codes that went through memory instead of the ring (diagnostic: decoded[b] >> 32)
     bool first_word = true;
     __syncthreads();
     for (;;) {
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
             }
         } else {
             // long strings and sources that have left the ring: through the block's output in memory
+            ++slow;
             if (s_start + s_len > safe) {                  // the source may still be on its way to L2: wait for this wave's stores
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 safe = op;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
         op += s_len;
     }
     if (lane == 0) {
-        decoded[b] = (int64_t)op;
+        decoded[b] = (int64_t)op | ((int64_t)slow << 32);
         status[b] = err ? err : (op > cap ? 2 : 0);
     }
 }

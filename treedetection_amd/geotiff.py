@@ -323,12 +323,14 @@ class GeoTiff:
                 and self._predictor in (1, 2) and self._counts is not None and self._pil is None
                 and self._bw * self._bh * self.count < (1 << 31))
 
-    def decode_to_device(self, device, stream=None):
+    def decode_to_device(self, device, stream=None, pinned=None, pool=None):
         """The whole raster decoded in HBM: the compressed blocks are read as they lie in the file (one pread of the span that
         holds them, into pinned memory), copied to the device once, decoded one wave per block (td_tiff_lzw_decode_dev) and
         laid out as [height, width, bands] uint8 with predictor 2 undone (td_tiff_blocks_to_image_dev). → (image tensor,
         check) where ``check()`` waits for the kernels and raises ValueError when a block did not decode to its size (the
-        caller then falls back to the host reader). Everything is enqueued on ``stream`` (default: the current one)."""
+        caller then falls back to the host reader). Everything is enqueued on ``stream`` (default: the current one). ``pinned``:
+        a one-element list holding a pinned uint8 tensor to read the file into (grown and put back when too small — pinning
+        hundreds of MB per image costs as much as reading them); ``pool``: threads the file read is spread over."""
         import torch
         from . import _lib
         if not self.device_decodable():
@@ -341,16 +343,31 @@ class GeoTiff:
         assert len(offs) == nb == len(cnts)
         lo, hi = int(offs.min()), int((offs + cnts).max())
         span = hi - lo
-        pin = torch.empty((span + 16,), dtype=torch.uint8, pin_memory=True)
+        if pinned is not None and pinned and pinned[0] is not None and pinned[0].numel() >= span + 16:
+            pin = pinned[0]
+        else:
+            pin = torch.empty((span + 16 + (span >> 3),), dtype=torch.uint8, pin_memory=True)
+            if pinned is not None:
+                pinned[:] = [pin]
         buf = pin.numpy()
         fd = os.open(self.path, os.O_RDONLY)
-        try:
+
+        def read_piece(pr):
             got = 0
-            while got < span:
-                n = os.preadv(fd, [memoryview(buf)[got:span]], lo + got)
+            view = memoryview(buf)[pr[0]:pr[0] + pr[1]]
+            while got < pr[1]:
+                n = os.preadv(fd, [view[got:]], lo + pr[0] + got)
                 if n <= 0:
                     raise ValueError(f"{self.path}: file ends inside its block data")
                 got += n
+        try:
+            piece = 8 << 20
+            parts = [(p, min(piece, span - p)) for p in range(0, span, piece)]
+            if pool is not None and len(parts) > 1:
+                list(pool.map(read_piece, parts))
+            else:
+                for pr in parts:
+                    read_piece(pr)
         finally:
             os.close(fd)
         buf[span:] = 0
@@ -359,16 +376,19 @@ class GeoTiff:
         ctx = torch.cuda.stream(stream) if stream is not None else _NullCtx()
         with torch.cuda.device(dev), ctx:
             st = _lib.stream_ptr()
-            comp = pin.to(dev, non_blocking=True)
+            comp = pin[:span + 16].to(dev, non_blocking=True)
             meta = torch.from_numpy(np.stack([offs - lo, cnts])).to(dev, non_blocking=True)
             blocks = torch.empty((nb, block_cap), dtype=torch.uint8, device=dev)
             decoded = torch.empty((nb,), dtype=torch.int64, device=dev)
             status = torch.empty((nb,), dtype=torch.int32, device=dev)
+            k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            k0.record()
             _lib.check(lib.td_tiff_lzw_decode_dev(comp.data_ptr(), meta[0].data_ptr(), meta[1].data_ptr(), nb, blocks.data_ptr(), block_cap,
                                                   decoded.data_ptr(), status.data_ptr(), st), "td_tiff_lzw_decode_dev")
             image = torch.empty((self.height, self.width, self.count), dtype=torch.uint8, device=dev)
             _lib.check(lib.td_tiff_blocks_to_image_dev(blocks.data_ptr(), block_cap, self._bw, self._bh, self._nx, self._ny, self.count,
                                                        self._predictor, image.data_ptr(), self.width, self.height, st), "td_tiff_blocks_to_image_dev")
+            k1.record()
             done = torch.cuda.Event()
             done.record()
             dec_h = torch.empty((nb,), dtype=torch.int64, pin_memory=True)
@@ -381,11 +401,14 @@ class GeoTiff:
 
         def check():
             copied.synchronize()
+            check.kernel_ms = k0.elapsed_time(k1)          # the two decode launches + the scatter / predictor kernel
             keep.clear()
-            bad = np.nonzero((st_h.numpy() != 0) | (dec_h.numpy() != expect))[0]
+            produced = dec_h.numpy() & 0xffffffff
+            check.slow_codes = int((dec_h.numpy() >> 32).sum())     # strings copied through memory (sources older than the LDS ring)
+            bad = np.nonzero((st_h.numpy() != 0) | (produced != expect))[0]
             if bad.size:
                 b = int(bad[0])
-                raise ValueError(f"{self.path}: block {b} decodes to {int(dec_h[b])} bytes (status {int(st_h[b])}), expected {int(expect[b])}")
+                raise ValueError(f"{self.path}: block {b} decodes to {int(produced[b])} bytes (status {int(st_h[b])}), expected {int(expect[b])}")
             return image
         check.event = done
         check.compressed_bytes = span

@@ -210,6 +210,7 @@ class Predictor:
         self.decode_stats = {"images": 0, "seconds": 0.0, "compressed_bytes": 0, "decoded_bytes": 0}
         self.upload_stats = {"images": 0, "seconds": 0.0, "compressed_bytes": 0, "decoded_bytes": 0}
         self._upload_staging = self._upload_pool = None
+        self._decode_pinned = [None]
         # uncompressed rasters up to this size are kept whole in HBM too (TD_DEVICE_RASTER_MAX_GB, default 24): beyond it the host
         # window reader serves them
         self.device_raster_max_bytes = int(float(os.environ.get("TD_DEVICE_RASTER_MAX_GB", "24")) * (1 << 30))
@@ -386,14 +387,15 @@ class Predictor:
                     self._decode_stream = torch.cuda.Stream()
             t0 = time.perf_counter()
             c0 = time.thread_time()
+            if self._upload_pool is None:
+                self._upload_pool = ThreadPoolExecutor(max_workers=max(1, min(8, host_core_share() // 4)), thread_name_prefix="td-upload")
             if decode:
-                image, check = img.decode_to_device(self.device, self._decode_stream)
+                image, check = img.decode_to_device(self.device, self._decode_stream, self._decode_pinned, self._upload_pool)
             else:
                 # an uncompressed raster: its bytes go to HBM in large sequential pieces (GeoTiff.upload_to_device), the windows
                 # are cut there — one memcpy per byte out of the page cache instead of a pread per window row + an H2D per batch
                 if self._upload_staging is None:
                     self._upload_staging = [torch.empty((64 << 20,), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
-                    self._upload_pool = ThreadPoolExecutor(max_workers=max(1, min(8, host_core_share() // 4)), thread_name_prefix="td-upload")
                 image, check = img.upload_to_device(self.device, self._decode_stream, self._upload_staging, self._upload_pool)
             check()
             with self._stats_lock:
@@ -403,6 +405,7 @@ class Predictor:
                 st["thread_cpu"] = st.get("thread_cpu", 0.0) + time.thread_time() - c0
                 st["compressed_bytes"] += check.compressed_bytes
                 st["decoded_bytes"] += image.numel()
+                st["kernel_ms"] = st.get("kernel_ms", 0.0) + getattr(check, "kernel_ms", 0.0)
             return image
         except Exception as e:
             print(f"device decode of {tifpath} failed ({e}): using the host reader")
