@@ -85,7 +85,7 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end region: warm Predictor.__call__ over a synthetic GeoTIFF on tmpfs "
                     "(window reads → device → Prediction_*.json files)")
     ap.add_argument("--no-lzw", action="store_true", help="skip the LZW-raster region (device decode of compressed rasters, files to files)")
-    ap.add_argument("--lzw-side", type=int, default=10, help="the LZW raster is side x side tiles of --tile pixels")
+    ap.add_argument("--lzw-side", type=int, default=20, help="the LZW raster is side x side tiles of 450 x 450 pixels")
     ap.add_argument("--e2e-side", type=int, default=20, help="the e2e raster is side x side tiles of --tile pixels")
     ap.add_argument("--streams", type=int, default=0, help="engines / HIP streams the batches alternate over (default 3 for "
                     "--schedule streams, 1 for plain): the HBM-bound kernels and the kernel tails of one forward run under the "
@@ -249,7 +249,8 @@ def compact_line(full):
             "e2e_crowns_json_kb_per_tile": _r((full.get("e2e_crowns", {}).get("f32", {}).get("json_bytes_per_tile") or 0) / 1e3) or None,
             "e2e_lzw_f16": val("lzw", "f16", "device", "value"), "e2e_lzw_f16_ratio": val("lzw", "f16", "device", "ratio_to_model_stage"),
             "e2e_lzw_host_reader_f16": val("lzw", "f16", "host_reader", "value"),
-            "lzw_decode_windows_450_per_s": val("lzw", "f16", "decode_windows_450x450x4_per_s"), "lzw_decode_gb_per_s": val("lzw", "f16", "decode_gbytes_per_s")}
+            "lzw_decode_windows_450_per_s": val("lzw", "f16", "decode_windows_450x450x4_per_s"), "lzw_decode_gb_per_s": val("lzw", "f16", "decode_gbytes_per_s"),
+            "lzw_kernel_gb_per_s": val("lzw", "f16", "kernel_gbytes_per_s")}
     c["regions"] = {k: v for k, v in scal.items() if v is not None}
     c["regions_unit"] = "tiles/s (two_model: tile visits/s; *_frac: executed FLOPs / MFMA peak; *_ratio: e2e / model stage; predict_tiles_*: files to GeoPackage layers = predict + stitch, image-sharded at N > 1; *_per_tile: counts / kB)"
     c["detail"] = full.get("detail_file")
@@ -783,7 +784,7 @@ def main():
 
     def run_lzw(precision, sd_w, side):
         """SURVEY §8f-2's leftover: the raster as real orthophotos are stored — LZW, 256 x 256 tiles, predictor 2
-        (GDAL: TILED=YES COMPRESS=LZW PREDICTOR=2) — files to files. The compressed blocks cross PCIe once and are decoded on the GPU
+        (GDAL: TILED=YES COMPRESS=LZW PREDICTOR=2) — cut into the REFERENCE's tiles (450 x 450 px, 400 per image) — files to files. The compressed blocks cross PCIe once and are decoded on the GPU
         (tiffdecode.hip, one wave per block), the tile windows are cut in HBM; the next image is decoded while the current one
         predicts (Predictor.prefetch). Reported: the decode alone (raster bytes/s, also as 450 x 450 x 4 windows/s, the reference's
         tile size), the chained files-to-files rate, and the same walk through the HOST reader's decode threads on a few tiles."""
@@ -796,38 +797,48 @@ def main():
         root = tempfile.mkdtemp(prefix="td_lzw_", dir=base)
         try:
             os.makedirs(f"{root}/rgb")
-            img = np.zeros((4, side * S, side * S), np.uint8)
-            for r in range(side):
-                for c in range(side):
-                    t = rgb_np[(r * side + c) % len(rgb_np)]
+            TP = 450                                      # the reference's tile: 90 m x 90 m at 0.2 m (example/config.yml:26-28) → 800 x 800 network input
+            px = side * TP
+            nb = -(-px // S)
+            img = np.zeros((4, nb * S, nb * S), np.uint8)
+            for r in range(nb):
+                for c in range(nb):
+                    t = rgb_np[(r * nb + c) % len(rgb_np)]
                     img[:3, r * S:(r + 1) * S, c * S:(c + 1) * S] = t.transpose(2, 0, 1)
                     img[3, r * S:(r + 1) * S, c * S:(c + 1) * S] = t[..., 1]
+            img = np.ascontiguousarray(img[:, :px, :px])
             tif = f"{root}/rgb/324125000.tif"
             t0 = time.perf_counter()
-            write_geotiff(tif, img, (0.2, 0.0, 412000.0, 0.0, -0.2, 5318000.0 + side * S * 0.2), 25832, compression="lzw", tile=(256, 256), predictor=2)
+            write_geotiff(tif, img, (0.2, 0.0, 412000.0, 0.0, -0.2, 5318000.0 + px * 0.2), 25832, compression="lzw", tile=(256, 256), predictor=2)
             t_enc = time.perf_counter() - t0
             raw_bytes, file_bytes = img.nbytes, os.path.getsize(tif)
             del img
-            tile_data([tif], f"{root}/tiles", buffer=0, tile_width=int(S * 0.2), tile_height=int(S * 0.2))
+            tile_data([tif], f"{root}/tiles", buffer=0, tile_width=int(TP * 0.2), tile_height=int(TP * 0.2))
             tjson = f"{root}/tiles/324125000.json"
             ntiles = len(json.load(open(tjson)))
             # (a) the decode alone: file → pinned memory → device → decoded raster in HBM
+            from concurrent.futures import ThreadPoolExecutor
             g = GeoTiff(tif)
-            times = []
+            times, ktimes = [], []
+            pinned, rpool = [None], ThreadPoolExecutor(max_workers=8)
             for _ in range(4):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                image, check = g.decode_to_device(f"cuda:{local_rank}")
+                image, check = g.decode_to_device(f"cuda:{local_rank}", None, pinned, rpool)
                 check()
                 times.append(time.perf_counter() - t0)
+                ktimes.append(check.kernel_ms * 1e-3)
                 del image
-            t_dec = min(times[1:])
+            rpool.shutdown()
+            del pinned
+            t_dec, t_ker = min(times[1:]), min(ktimes[1:])
             cfg = T.setup_model_cfg(update_model="synthetic", device=str(local_rank))
             names = [str(324125001 + k) for k in range(5)]
             for nm in names:
                 os.link(tif, f"{root}/rgb/{nm}.tif")
                 os.link(tjson, f"{root}/tiles/{nm}.json")
-            res = {"raster": f"{side * S}x{side * S}x4 uint8, LZW, 256x256 tiles, predictor 2, on {'tmpfs' if base else 'disk'}",
+            res = {"raster": f"{px}x{px}x4 uint8, LZW, 256x256 tiles, predictor 2, on {'tmpfs' if base else 'disk'}; {ntiles} tiles of {TP}x{TP} px per image",
+                   "kernel_seconds": t_ker, "kernel_gbytes_per_s": raw_bytes / t_ker / 1e9,
                    "raw_bytes": raw_bytes, "file_bytes": file_bytes, "compression_ratio": raw_bytes / file_bytes, "encode_seconds": t_enc,
                    "decode_seconds": t_dec, "decode_calls_s": times, "decode_gbytes_per_s": raw_bytes / t_dec / 1e9,
                    "decode_windows_450x450x4_per_s": raw_bytes / t_dec / (450 * 450 * 4), "tiles_per_image": ntiles}

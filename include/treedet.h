@@ -297,7 +297,8 @@ int64_t td_tiff_lzw_encode(const uint8_t* src, int64_t n, uint8_t* dst, int64_t 
  * host (prediction.py:164 → GDAL → libtiff); here the compressed blocks of a raster cross PCIe once and are decoded by one wave
  * each. comp: DEVICE copy of the file's compressed bytes (padded by >= 8 bytes); block_off / block_nbytes: DEVICE int64
  * [nblocks], position and size of every LZW strip / tile in comp; blocks_out: DEVICE [nblocks][block_cap] bytes, block b decoded
- * at b * block_cap (block_cap = bytes of a full block); decoded / status: DEVICE [nblocks] — bytes produced (low 32 bits; the high 32
+ * at b * block_cap (block_cap = bytes of a full block); decoded: DEVICE int64 [nblocks], status: DEVICE int32 [2 * nblocks + 1] (the
+ * first nblocks entries are the blocks' status, the rest is scratch for the second pass) — bytes produced (low 32 bits; the high 32
  * bits count the strings that were copied through memory instead of the LDS ring: a diagnostic), and 0 = ok,
  * 1 = corrupt stream, 2 = more than block_cap bytes (the rules of td_tiff_lzw_decode). Asynchronous on `stream`. */
 td_status td_tiff_lzw_decode_dev(const uint8_t* comp, const int64_t* block_off, const int64_t* block_nbytes, int nblocks,

@@ -37,53 +37,50 @@ template <typename TableT, bool SECOND>
 __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ block_off,
                                                              const int64_t* __restrict__ block_nbytes, uint8_t* __restrict__ out,
                                                              int64_t block_cap, int64_t* __restrict__ decoded,
-                                                             int32_t* __restrict__ status) {
+                                                             int32_t* __restrict__ status, int nblocks, int* __restrict__ wide_list) {
     __shared__ TableT t_start[LZW_MAX + 2];               // start of entry k relative to the epoch's start; len(k) = t[k + 1] - t[k] + 1
-    __shared__ uint32_t inbuf[128];                       // two chunks of 64 dwords of the compressed stream
+    __shared__ uint32_t inbuf[128];                       // two chunks of 64 big-endian dwords of the compressed stream
     __shared__ uint8_t ring_lit[LZW_RING + 256];
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (SECOND && status[b] != 3) return;                  // the second launch only takes the blocks the narrow table gave up on
+    const int lane = threadIdx.x;
     constexpr uint32_t REL_MAX = sizeof(TableT) == 2 ? 65535u - 4096u : 0xffffffffu;
+    // first launch: block = blockIdx.x. Second launch (wide table): a few resident waves walk the list of blocks the first one
+    // gave up on (wide_list[0] = their number) — nothing to do on imagery, so its cost must be that of an empty kernel
+    for (int item = blockIdx.x; item < (SECOND ? wide_list[0] : nblocks); item += gridDim.x) {
+    const int b = SECOND ? wide_list[1 + item] : item;
     const int64_t n = block_nbytes[b];
     uint8_t* dst = out + (int64_t)b * block_cap;
     const uint32_t cap = (uint32_t)block_cap;
     const uintptr_t a0 = reinterpret_cast<uintptr_t>(comp + block_off[b]);
-    const int skip = (int)(a0 & 3);
+    const uint32_t skip = (uint32_t)(a0 & 3);
     const uint32_t* src32 = reinterpret_cast<const uint32_t*>(a0 - skip);
-    const int ndw = (int)((n + skip + 3) >> 2);            // dwords that hold the stream (the buffer is padded: reading the last one is safe)
+    const uint32_t ndw = (uint32_t)((n + skip + 3) >> 2); // dwords that hold the stream (the buffer is padded: reading the last one is safe)
+    const uint32_t end_bit = (uint32_t)(n + skip) * 8u;    // (blocks are < 512 MB: bit positions fit 32 bits)
+    __syncthreads();                                       // (second launch: the previous item's LDS reads are done)
     for (int c = lane; c < 256; c += 64) ring_lit[LZW_LIT + c] = (uint8_t)c;
     for (int c = lane; c < LZW_FIRST + 1; c += 64) t_start[c] = 0;      // literals: len = t[c + 1] - t[c] + 1 = 1
-    int loaded = 0, rd = 0;
-    int64_t bits_left = n * 8;
-    uint64_t acc = 0;
-    int have = 0, nbits = 9, next = LZW_FIRST;
+    // the first two chunks of the stream; afterwards chunk k + 1 is loaded when the reader enters chunk k
+    inbuf[lane] = (uint32_t)lane < ndw ? bswap32(src32[lane]) : 0u;
+    inbuf[64 + lane] = (uint32_t)(64 + lane) < ndw ? bswap32(src32[64 + lane]) : 0u;
+    uint32_t loaded = 128;                                 // dwords [loaded - 128, loaded) are in inbuf
+    uint32_t bitpos = skip * 8u;                           // next unread bit, counted from the aligned base, MSB first
+    int nbits = 9, next = LZW_FIRST;
     uint32_t op = 0, old_pos = 0, old_len = 0, safe = 0, epoch = 0;      // old_len == 0: no previous code (start, or right after a ClearCode)
     int err = 0;
     uint32_t slow = 0;                                      // codes that went through memory instead of the ring (diagnostic: decoded[b] >> 32)
-    bool first_word = true;
     __syncthreads();
     for (;;) {
-        while (have < 32 && rd < ndw) {
-            if (rd >= loaded) {                            // next 256 bytes of the stream, one dword per lane
-                const int idx = loaded + lane;
-                inbuf[idx & 127] = idx < ndw ? src32[idx] : 0u;
-                loaded += 64;
-                __syncthreads();                           // (one wave: orders the LDS writes before the reads below; every store of this wave has completed too)
-                safe = op;
-            }
-            const uint32_t w = bswap32(inbuf[rd & 127]);
-            ++rd;
-            acc = (acc << 32) | w;
-            have += 32;
-            if (first_word) {                              // the stream starts `skip` bytes into its first dword
-                have -= 8 * skip;
-                first_word = false;
-            }
+        if (bitpos + (uint32_t)nbits > end_bit) break;     // ran out of input without an EOI: accept what was decoded (host decoder's rule)
+        const uint32_t dw = bitpos >> 5;
+        if (__builtin_expect(dw + 1 >= loaded, 0)) {       // the reader enters the last loaded chunk: bring in the next one over the older
+            const uint32_t idx = loaded + lane;
+            inbuf[idx & 127] = idx < ndw ? bswap32(src32[idx]) : 0u;
+            loaded += 64;
+            __syncthreads();                               // (one wave: orders the LDS write before the reads below; every store of this wave has completed too)
+            safe = op;
         }
-        if (bits_left < nbits) break;                      // ran out of input without an EOI: accept what was decoded (host decoder's rule)
-        const int code = (int)((acc >> (have - nbits)) & ((1u << nbits) - 1u));
-        have -= nbits;
-        bits_left -= nbits;
+        const uint64_t two = ((uint64_t)inbuf[dw & 127] << 32) | inbuf[(dw + 1) & 127];
+        const int code = (int)((two >> (64 - (bitpos & 31) - nbits)) & ((1u << nbits) - 1u));
+        bitpos += nbits;
         // the rare cases first, behind ONE test: EOI / ClearCode, the literal after a clear, a code beyond the table
         if (__builtin_expect((unsigned)(code - LZW_CLEAR) < 2u || old_len == 0 || code > next || (code == next && next >= LZW_MAX), 0)) {
             if (code == LZW_EOI) break;
@@ -157,7 +154,9 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
     }
     if (lane == 0) {
         decoded[b] = (int64_t)op | ((int64_t)slow << 32);
-        status[b] = err ? err : (op > cap ? 2 : 0);
+        status[b] = err == 3 && !SECOND ? 3 : (err ? 1 : (op > cap ? 2 : 0));
+        if (!SECOND && err == 3) wide_list[1 + atomicAdd(wide_list, 1)] = b;
+    }
     }
 }
 
@@ -216,12 +215,16 @@ extern "C" td_status td_tiff_lzw_decode_dev(const uint8_t* comp, const int64_t* 
     TD_REQUIRE(nblocks >= 0 && block_cap >= 1 && block_cap < ((int64_t)1 << 31), "td_tiff_lzw_decode_dev: %d blocks of %lld bytes", nblocks,
                (long long)block_cap);
     if (nblocks == 0) return TD_OK;
-    // narrow table first (six waves per CU); blocks whose epochs outgrow it (flat rasters) are decoded again with the wide one
-    hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint16_t, false>), dim3(nblocks), dim3(64), 0, static_cast<hipStream_t>(stream), comp, block_off,
-                       block_nbytes, blocks_out, block_cap, decoded, status);
+    // narrow table first (six waves per CU); blocks whose epochs outgrow it (flat rasters) are listed in wide_list and decoded again
+    // by a few resident waves with the wide table — an empty loop on imagery
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int* wide_list = reinterpret_cast<int*>(status) + nblocks;      // status has room for 2 * nblocks + 1 ints (include/treedet.h)
+    TD_HIP_CHECK(hipMemsetAsync(wide_list, 0, sizeof(int), s));
+    hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint16_t, false>), dim3(nblocks), dim3(64), 0, s, comp, block_off, block_nbytes, blocks_out,
+                       block_cap, decoded, status, nblocks, wide_list);
     TD_KERNEL_CHECK();
-    hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint32_t, true>), dim3(nblocks), dim3(64), 0, static_cast<hipStream_t>(stream), comp, block_off,
-                       block_nbytes, blocks_out, block_cap, decoded, status);
+    hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint32_t, true>), dim3(nblocks < 1024 ? nblocks : 1024), dim3(64), 0, s, comp, block_off,
+                       block_nbytes, blocks_out, block_cap, decoded, status, nblocks, wide_list);
     TD_KERNEL_CHECK();
     return TD_OK;
 }

@@ -380,7 +380,7 @@ class GeoTiff:
             meta = torch.from_numpy(np.stack([offs - lo, cnts])).to(dev, non_blocking=True)
             blocks = torch.empty((nb, block_cap), dtype=torch.uint8, device=dev)
             decoded = torch.empty((nb,), dtype=torch.int64, device=dev)
-            status = torch.empty((nb,), dtype=torch.int32, device=dev)
+            status = torch.empty((2 * nb + 1,), dtype=torch.int32, device=dev)      # [nb] status + scratch of the wide-table pass
             k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             k0.record()
             _lib.check(lib.td_tiff_lzw_decode_dev(comp.data_ptr(), meta[0].data_ptr(), meta[1].data_ptr(), nb, blocks.data_ptr(), block_cap,
@@ -394,7 +394,7 @@ class GeoTiff:
             dec_h = torch.empty((nb,), dtype=torch.int64, pin_memory=True)
             st_h = torch.empty((nb,), dtype=torch.int32, pin_memory=True)
             dec_h.copy_(decoded, non_blocking=True)
-            st_h.copy_(status, non_blocking=True)
+            st_h.copy_(status[:nb], non_blocking=True)
             copied = torch.cuda.Event(blocking=True)
             copied.record()
         keep = [pin, comp, meta, blocks, decoded, status]     # alive until check() has run: the kernels read them
