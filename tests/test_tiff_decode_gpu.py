@@ -108,7 +108,7 @@ def test_prediction_files_are_identical_with_the_device_decoder_on_or_off(tmp_pa
     sd = make_synthetic_state_dict(50, seed=3, width_div=2)
     cfg = TD.setup_model_cfg(update_model="x", device="0")
     outs = {}
-    for tag, kw, dd in (("raw", {}, "auto"), ("raw_host", {}, False), ("raw_strips", {"rows_per_strip": 16}, "auto"), ("lzw_dev", {"compression": "lzw", "tile": (128, 128), "predictor": 2}, "auto"),
+    for tag, kw, dd in (("raw", {}, "all"), ("raw_host", {}, "auto"), ("raw_strips", {"rows_per_strip": 16}, "all"), ("lzw_dev", {"compression": "lzw", "tile": (128, 128), "predictor": 2}, "auto"),
                         ("lzw_host", {"compression": "lzw", "tile": (128, 128), "predictor": 2}, False),
                         ("lzw_strips_dev", {"compression": "lzw", "rows_per_strip": 3}, True)):
         d = tmp_path / tag
@@ -127,7 +127,7 @@ def test_prediction_files_are_identical_with_the_device_decoder_on_or_off(tmp_pa
                 pred.prefetch(tif)
                 pred(tif, str(d / "tiles" / "9.json"))
             assert pred.decode_stats["images"] == (2 if tag in ("lzw_dev", "lzw_strips_dev") else 0), (tag, pred.decode_stats)
-            # an uncompressed raster is kept whole in HBM as well (uploaded in large pieces), unless device_decode is off
+            # device_decode "all": an uncompressed raster is kept whole in HBM as well (uploaded in 4-MB pieces); "auto" leaves it to the host reader
             assert pred.upload_stats["images"] == (2 if tag in ("raw", "raw_strips") else 0), (tag, pred.upload_stats)
         files = sorted(os.listdir(d / "out" / "9"))
         outs[tag] = {f: open(d / "out" / "9" / f, "rb").read().replace(tif.encode(), b"IMG") for f in files}

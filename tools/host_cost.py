@@ -1,7 +1,7 @@
 """What ONE GPU costs the host on the files-to-files path: CPU seconds per tile, split by stage.
 
     python tools/host_cost.py [fp16|fp32] [images=4] [side=20] [contours=host|dev|auto] [stitch=1|0] [batch=8] [raster=raw|lzw]
-                              [device_raster=auto|false]
+                              [device_raster=auto|all|false]
 
 Fixture = bench.py's e2e raster (side x side tiles of 1000 x 1000 px, 4-band RGBI uint8 on tmpfs, 16 distinct generator tiles
 cycled), compact-crown weights (weights.blob_mask_head: ~20 contours per tile). One warm-up image, then ``images`` images through
@@ -49,7 +49,7 @@ def main():
     precision = next((a for a in sys.argv[1:] if a in ("fp16", "fp32")), "fp16")
     n_img, side, B = int(args.get("images", 4)), int(args.get("side", 20)), int(args.get("batch", 8))
     contours, stitch = args.get("contours", "host"), args.get("stitch", "1") != "0"
-    raster, dd = args.get("raster", "raw"), {"auto": "auto", "false": False}[args.get("device_raster", "auto")]
+    raster, dd = args.get("raster", "raw"), {"auto": "auto", "all": "all", "false": False}[args.get("device_raster", "auto")]
     S = 1000
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     root = tempfile.mkdtemp(prefix="td_hostcost_", dir=base)

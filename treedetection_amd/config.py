@@ -10,8 +10,8 @@ Optional extra keys (defaults preserve the reference's behaviour): ``precision``
 are at least as many images as ranks, detection.resolve_shard_by), ``eager_stitch`` (true: every image is stitched as soon as
 its tile files are complete, while the next one predicts), ``fp16_min_batch`` (0 = off: a larger batch for the fp16 engine only,
 detection.engine_batch_size), ``device_contours`` ("auto" | true | false: mask borders followed on the GPU while the host epilogue,
-not the GPU, sets the batch period; same files), ``device_decode`` ("auto" | false: LZW rasters decoded on the GPU, tile windows cut
-in HBM; same pixels).
+not the GPU, sets the batch period; same files), ``device_decode`` ("auto" | false | "all": LZW rasters decoded on the GPU, tile windows cut
+in HBM — "all": uncompressed rasters are kept in HBM too; same pixels).
 """
 from __future__ import annotations
 

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
                                                              const int64_t* __restrict__ block_nbytes, uint8_t* __restrict__ out,
                                                              int64_t block_cap, int64_t* __restrict__ decoded,
                                                              int32_t* __restrict__ status, int nblocks, int* __restrict__ wide_list) {
-    __shared__ TableT t_start[LZW_MAX + 2];               // start of entry k relative to the epoch's start; len(k) = t[k + 1] - t[k] + 1
+    __shared__ __attribute__((aligned(8))) TableT t_start[LZW_MAX + 4];               // start of entry k relative to the epoch's start; len(k) = t[k + 1] - t[k] + 1
     __shared__ uint32_t inbuf[128];                       // two chunks of 64 big-endian dwords of the compressed stream
     __shared__ uint8_t ring_lit[LZW_RING + 256];
     const int lane = threadIdx.x;
@@ -106,9 +106,19 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
         }
         // string(code) = out[s_start .. s_start + s_len): a window of the output — for a literal a window of the identity table
         const bool kwkwk = code == next;
-        const uint32_t t0 = t_start[code], t1 = t_start[code + 1];
-        uint32_t s_start = kwkwk ? old_pos : epoch + t0;
-        const uint32_t s_len = kwkwk ? old_len + 1 : (code < 256 ? 1u : t1 - t0 + 1);
+        uint32_t t0, t1;
+        if (sizeof(TableT) == 2) {                         // t[code] and t[code + 1] in ONE LDS round trip: the two dwords around them
+            const uint32_t* t32 = reinterpret_cast<const uint32_t*>(t_start);
+            const uint64_t both = ((uint64_t)t32[(code >> 1) + 1] << 32) | t32[code >> 1];
+            const uint32_t pair = (uint32_t)(both >> ((code & 1) * 16));
+            t0 = pair & 0xffffu;
+            t1 = pair >> 16;
+        } else {
+            t0 = t_start[code];
+            t1 = t_start[code + 1];
+        }
+        const uint32_t s_start = kwkwk ? old_pos : epoch + t0;
+        const uint32_t s_len = kwkwk ? old_len + 1 : t1 - t0 + 1;     // (a literal's entries are all 0: length 1)
         if (next < LZW_MAX) {                              // new entry = string(old) + first byte of string(code): out[old_pos .. op]
             if (op - epoch > REL_MAX) {                    // (uint16 table only) this epoch's output no longer fits: the wide pass decodes the block
                 err = 3;

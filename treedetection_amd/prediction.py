@@ -200,10 +200,15 @@ class Predictor:
         fp32, 1868 vs 1550 fp16); "phases" = the phase pipeline described above."""
         self.cfg = cfg
         # LZW rasters are decoded on the GPU, whole, and their tile windows are cut in HBM (GeoTiff.decode_to_device; images this
-        # process predicts alone: submit). "auto" / True: wherever the raster qualifies; False: the host reader for everything
-        if device_decode not in (True, False, "auto", "true", "false"):
-            raise ValueError(f"device_decode must be true, false or 'auto', got {device_decode!r}")
-        self.device_decode = device_decode in (True, "auto", "true")
+        # process predicts alone: submit). "auto" / True: every LZW raster that qualifies; False: the host reader for everything
+        if device_decode not in (True, False, "auto", "true", "false", "all"):
+            raise ValueError(f"device_decode must be true, false, 'auto' or 'all', got {device_decode!r}")
+        self.device_decode = device_decode in (True, "auto", "true", "all")
+        # "all": uncompressed uint8 rasters are kept whole in HBM too (uploaded in 4-MB pieces). Measured both ways (round 6,
+        # tools/host_cost.py, profiles/r06_host_cost.txt): on a 256-thread host with slow page-cache reads +10 % tiles/s and -30 % host CPU
+        # per tile; on a 16-core host -20 % (the upload's reader threads compete with the epilogue workers, and an image that was not
+        # prefetched waits for its whole raster before its first batch) — so the default keeps the per-window host reader for them
+        self.device_upload = device_decode == "all"
         self._rasters: Dict[str, "object"] = {}
         self._raster_pool = None
         self._decode_stream = None
@@ -380,7 +385,8 @@ class Predictor:
         try:
             img = GeoTiff(tifpath)
             decode = img.device_decodable()
-            if not decode and not (img.device_uploadable() and img.height * img.width * img.count <= self.device_raster_max_bytes):
+            if not decode and not (self.device_upload and img.device_uploadable()
+                                   and img.height * img.width * img.count <= self.device_raster_max_bytes):
                 return None
             if self._decode_stream is None:
                 with torch.cuda.device(self.device_index):
