@@ -303,6 +303,13 @@ int64_t td_tiff_lzw_encode(const uint8_t* src, int64_t n, uint8_t* dst, int64_t 
  * 1 = corrupt stream, 2 = more than block_cap bytes (the rules of td_tiff_lzw_decode). Asynchronous on `stream`. */
 td_status td_tiff_lzw_decode_dev(const uint8_t* comp, const int64_t* block_off, const int64_t* block_nbytes, int nblocks,
                                  uint8_t* blocks_out, int64_t block_cap, int64_t* decoded, int32_t* status, void* stream);
+/* The same for DEFLATE blocks (TIFF compression 8 / 32946: zlib streams; inflate_core.h): status int32 [nblocks], decoded int64
+ * [nblocks]; the Adler-32 trailer is not checked. */
+td_status td_tiff_inflate_dev(const uint8_t* comp, const int64_t* block_off, const int64_t* block_nbytes, int nblocks,
+                              uint8_t* blocks_out, int64_t block_cap, int64_t* decoded, int32_t* status, void* stream);
+/* The decoder td_tiff_inflate_dev runs, instantiated for one lane on the host (parity tests against zlib without a GPU): one zlib
+ * stream → dst; returns the bytes produced or a negative status (TD_ERR_INVALID corrupt stream, TD_ERR_CAPACITY). */
+int64_t td_tiff_inflate(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap);
 /* Decoded blocks (strips: block_w = width; tiles: full padded tiles, row-major grid blocks_across x blocks_down) → the raster
  * image [height][width][spp] uint8 (DEVICE), predictor 2 undone per block row on the way (td_tiff_unpredict's arithmetic).
  * spp <= 4. Asynchronous on `stream`. */

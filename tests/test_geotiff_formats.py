@@ -232,3 +232,34 @@ def test_lzw_encoder_streams_are_what_libtiff_reads(tmp_path):
         assert os.path.getsize(path) < img.nbytes
         assert np.array_equal(np.asarray(Image.open(path)).transpose(2, 0, 1), img), kw       # libtiff's decoder
         assert np.array_equal(GeoTiff(path).read(), img), kw                                   # ours
+
+
+def test_the_gpu_inflate_source_on_the_host_against_zlib():
+    """td_tiff_inflate = csrc/inflate_core.h instantiated for ONE lane — the same source the GPU runs with 64 (tiffdecode.hip) — against
+    zlib's own streams: stored / fixed / dynamic blocks, every level and strategy, empty and one-byte inputs, odd buffer alignment;
+    corrupt and too-long streams are refused with the statuses of the LZW decoder."""
+    import zlib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    img = _image(rng, 4, 200, 300, np.uint8).transpose(1, 2, 0).tobytes()
+    far = rng.integers(0, 256, 32768, dtype=np.uint8).tobytes()
+    for raw in (b"", b"a", bytes(100000), rng.integers(0, 256, 70000, dtype=np.uint8).tobytes(), img, b"the quick brown fox " * 4000,
+                far + far[:300] + far[7:500]):
+        for level in (0, 1, 6, 9):
+            for strategy in (0, zlib.Z_FIXED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY):
+                c = zlib.compressobj(level, zlib.DEFLATED, 15, 9, strategy)
+                comp = c.compress(raw) + c.flush()
+                buf = np.zeros(len(comp) + 3, np.uint8)
+                for shift in (0, 1, 3):
+                    buf[shift:shift + len(comp)] = np.frombuffer(comp, dtype=np.uint8)
+                    out = np.empty(len(raw) + 8, np.uint8)
+                    n = lib.td_tiff_inflate(buf[shift:].ctypes.data, len(comp), out.ctypes.data, out.size)
+                    assert n == len(raw) and out[:n].tobytes() == raw, (len(raw), level, strategy, shift)
+    comp = bytearray(zlib.compress(img, 6))
+    out = np.empty(len(img) + 8, np.uint8)
+    assert lib.td_tiff_inflate(np.frombuffer(bytes(comp), dtype=np.uint8).ctypes.data, len(comp), out.ctypes.data, 100) == _lib.ERR_CAPACITY
+    comp[60] ^= 0xff
+    bad = np.frombuffer(bytes(comp), dtype=np.uint8)
+    n = lib.td_tiff_inflate(bad.ctypes.data, len(comp), out.ctypes.data, out.size)
+    assert n == _lib.ERR_INVALID or out[:max(n, 0)].tobytes() != img          # a flipped byte: refused, or at least not the image
+    assert lib.td_tiff_inflate(bad.ctypes.data, 3, out.ctypes.data, out.size) == _lib.ERR_INVALID

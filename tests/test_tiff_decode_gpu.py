@@ -26,13 +26,14 @@ def _raster(bands, h, w, seed=0):
     return img
 
 
+@pytest.mark.parametrize("codec", ["lzw", "deflate"])
 @pytest.mark.parametrize("bands", [3, 4, 1])
 @pytest.mark.parametrize("kw", [{"tile": (128, 128)}, {"tile": (64, 256), "predictor": 2}, {"rows_per_strip": 7}, {"rows_per_strip": 1, "predictor": 2},
                                 {"rows_per_strip": 64, "predictor": 2}, {}])
-def test_device_decode_equals_the_host_reader(tmp_path, kw, bands):
+def test_device_decode_equals_the_host_reader(tmp_path, kw, bands, codec):
     img = _raster(bands, 517, 683, seed=bands)
     path = str(tmp_path / "r.tif")
-    write_geotiff(path, img, T, 25832, compression="lzw", **kw)
+    write_geotiff(path, img, T, 25832, compression=codec, **kw)
     g = GeoTiff(path)
     assert g.device_decodable()
     image, check = g.decode_to_device("cuda:0")
@@ -53,6 +54,68 @@ def test_device_decode_of_a_file_written_by_libtiff(tmp_path):
     assert g.compression == 5 and g.device_decodable()
     image, check = g.decode_to_device("cuda:0")
     assert np.array_equal(check().cpu().numpy().transpose(2, 0, 1), img)
+
+
+def test_deflate_streams_of_every_block_type_on_the_device(tmp_path):
+    """zlib streams as libtiff / GDAL write them at any setting: stored blocks (level 0, and what zlib emits for noise), fixed Huffman
+    codes (tiny strips), dynamic codes (levels 1 / 6 / 9), run-length and Huffman-only strategies, matches at the far end of the 32-KB
+    window, a file written by libtiff (through Pillow: 'tiff_adobe_deflate'). The device decoder (inflate_core.h, one wave per block)
+    against zlib's own output, byte for byte; the same source runs on the host as td_tiff_inflate (tests/test_geotiff_formats.py)."""
+    import struct
+    import zlib
+    from PIL import Image
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    img = _raster(4, 300, 1100, seed=2)
+    raws = [img.transpose(1, 2, 0).tobytes(), bytes(200000), rng.integers(0, 256, 150000, dtype=np.uint8).tobytes(), b"x",
+            (b"abcdefghijklmnopqrstuvwxyz0123456789" * 3000), rng.integers(0, 3, 250000, dtype=np.uint8).tobytes()]
+    # a match that reaches back exactly 32 768 bytes
+    far = rng.integers(0, 256, 32768, dtype=np.uint8).tobytes()
+    raws.append(far + far[:300] + far[5:400])
+    streams, expect = [], []
+    for raw in raws:
+        for level, strategy in ((0, 0), (1, 0), (6, 0), (9, 0), (6, zlib.Z_FIXED), (6, zlib.Z_RLE), (6, zlib.Z_HUFFMAN_ONLY)):
+            c = zlib.compressobj(level, zlib.DEFLATED, 15, 9, strategy)
+            streams.append(c.compress(raw) + c.flush())
+            expect.append(raw)
+    cap = max(len(r) for r in raws) + 64
+    offs, blob = [], bytearray()
+    for st in streams:
+        blob += b"\0" * ((-len(blob)) % 3)                      # odd alignments on purpose
+        offs.append(len(blob))
+        blob += st
+    blob += b"\0" * 16
+    comp = torch.from_numpy(np.frombuffer(bytes(blob), dtype=np.uint8).copy()).cuda()
+    d_off = torch.tensor(offs, dtype=torch.int64, device="cuda")
+    d_n = torch.tensor([len(st) for st in streams], dtype=torch.int64, device="cuda")
+    out = torch.zeros((len(streams), cap), dtype=torch.uint8, device="cuda")
+    dec = torch.zeros((len(streams),), dtype=torch.int64, device="cuda")
+    status = torch.full((len(streams),), -1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.td_tiff_inflate_dev(comp.data_ptr(), d_off.data_ptr(), d_n.data_ptr(), len(streams), out.data_ptr(), cap, dec.data_ptr(),
+                                       status.data_ptr(), _lib.stream_ptr()), "td_tiff_inflate_dev")
+    torch.cuda.synchronize()
+    assert (status == 0).all(), status.cpu().tolist()
+    got = out.cpu().numpy()
+    for k, raw in enumerate(expect):
+        assert int(dec[k]) == len(raw), (k, int(dec[k]), len(raw))
+        assert got[k, :len(raw)].tobytes() == raw, k
+    # corrupt streams are reported per block, the others still decode
+    bad = bytearray(blob)
+    bad[offs[2] + 40] ^= 0x5a
+    comp2 = torch.from_numpy(np.frombuffer(bytes(bad), dtype=np.uint8).copy()).cuda()
+    _lib.check(lib.td_tiff_inflate_dev(comp2.data_ptr(), d_off.data_ptr(), d_n.data_ptr(), len(streams), out.data_ptr(), cap, dec.data_ptr(),
+                                       status.data_ptr(), _lib.stream_ptr()), "td_tiff_inflate_dev")
+    torch.cuda.synchronize()
+    st = status.cpu().numpy()
+    assert (st[:2] == 0).all() and (st[3:] == 0).all() and (st[2] != 0 or int(dec[2]) != len(expect[2]) or out[2, :len(expect[2])].cpu().numpy().tobytes() != expect[2])
+    # a file libtiff wrote
+    path = str(tmp_path / "pil_deflate.tif")
+    rgb = _raster(3, 700, 900, seed=5)
+    Image.fromarray(rgb.transpose(1, 2, 0)).save(path, compression="tiff_adobe_deflate")
+    g = GeoTiff(path)
+    assert g.compression in (8, 32946) and g.device_decodable()
+    image, check = g.decode_to_device("cuda:0")
+    assert np.array_equal(check().cpu().numpy().transpose(2, 0, 1), rgb)
 
 
 def test_large_blocks_with_many_table_clears_and_incompressible_data(tmp_path):
@@ -110,7 +173,8 @@ def test_prediction_files_are_identical_with_the_device_decoder_on_or_off(tmp_pa
     outs = {}
     for tag, kw, dd in (("raw", {}, "all"), ("raw_host", {}, "auto"), ("raw_strips", {"rows_per_strip": 16}, "all"), ("lzw_dev", {"compression": "lzw", "tile": (128, 128), "predictor": 2}, "auto"),
                         ("lzw_host", {"compression": "lzw", "tile": (128, 128), "predictor": 2}, False),
-                        ("lzw_strips_dev", {"compression": "lzw", "rows_per_strip": 3}, True)):
+                        ("lzw_strips_dev", {"compression": "lzw", "rows_per_strip": 3}, True),
+                        ("deflate_dev", {"compression": "deflate", "tile": (128, 128), "predictor": 2}, "auto")):
         d = tmp_path / tag
         (d / "rgb").mkdir(parents=True)
         tif = str(d / "rgb" / "9.tif")
@@ -126,11 +190,11 @@ def test_prediction_files_are_identical_with_the_device_decoder_on_or_off(tmp_pa
             for _ in range(2):                                      # twice: the second image is prefetched by the first's walk
                 pred.prefetch(tif)
                 pred(tif, str(d / "tiles" / "9.json"))
-            assert pred.decode_stats["images"] == (2 if tag in ("lzw_dev", "lzw_strips_dev") else 0), (tag, pred.decode_stats)
+            assert pred.decode_stats["images"] == (2 if tag in ("lzw_dev", "lzw_strips_dev", "deflate_dev") else 0), (tag, pred.decode_stats)
             # device_decode "all": an uncompressed raster is kept whole in HBM as well (uploaded in 4-MB pieces); "auto" leaves it to the host reader
             assert pred.upload_stats["images"] == (2 if tag in ("raw", "raw_strips") else 0), (tag, pred.upload_stats)
         files = sorted(os.listdir(d / "out" / "9"))
         outs[tag] = {f: open(d / "out" / "9" / f, "rb").read().replace(tif.encode(), b"IMG") for f in files}
         assert len(files) == 9
-    assert outs["raw"] == outs["raw_host"] == outs["raw_strips"] == outs["lzw_dev"] == outs["lzw_host"] == outs["lzw_strips_dev"]
+    assert outs["raw"] == outs["raw_host"] == outs["raw_strips"] == outs["lzw_dev"] == outs["lzw_host"] == outs["lzw_strips_dev"] == outs["deflate_dev"]
     assert sum(len(json.loads(v)) for v in outs["raw"].values()) > 5

@@ -1,7 +1,8 @@
-"""Decode rate of LZW rasters on the GPU (tiffdecode.hip): python tools/lzw_decode_bench.py [side=9000] [tile=256|strip=N] [predictor=2] [data=tiles|noise|flat]
+"""Decode rate of LZW / DEFLATE rasters on the GPU (tiffdecode.hip): python tools/raster_decode_bench.py [codec=lzw|deflate] [side=9000] [tile=256|strip=N]
+[predictor=2] [data=tiles|noise|flat]
 Raster side x side x 4 uint8 (default 9000: the 400 windows of 450 x 450 px the reference cuts from one image, twice over); prints per
 call file → pinned → device → decoded raster in HBM, and the kernels alone (HIP events). Under rocprofv3 --kernel-trace --stats the
-per-kernel durations land in profiles/r06_lzw_kernel_stats.csv."""
+per-kernel durations land in profiles/r06_decode_kernel_stats.csv."""
 import json
 import os
 import sys
@@ -17,7 +18,7 @@ from treedetection_amd.geotiff import GeoTiff, write_geotiff      # noqa: E402
 from treedetection_amd.synth import make_tile                      # noqa: E402
 
 args = dict(a.split("=", 1) for a in sys.argv[1:] if "=" in a)
-side, pred, data = int(args.get("side", 9000)), int(args.get("predictor", 2)), args.get("data", "tiles")
+side, pred, data, codec = int(args.get("side", 9000)), int(args.get("predictor", 2)), args.get("data", "tiles"), args.get("codec", "lzw")
 kw = {"rows_per_strip": int(args["strip"])} if "strip" in args else {"tile": (int(args.get("tile", 256)),) * 2}
 base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
 path = os.path.join(base, f"td_lzwbench_{os.getpid()}.tif")
@@ -38,7 +39,7 @@ else:
     img = np.ascontiguousarray(img[:, :side, :side])
 try:
     t0 = time.perf_counter()
-    write_geotiff(path, img, (0.2, 0, 412000.0, 0, -0.2, 5318000.0 + side * 0.2), 25832, compression="lzw", predictor=pred, **kw)
+    write_geotiff(path, img, (0.2, 0, 412000.0, 0, -0.2, 5318000.0 + side * 0.2), 25832, compression=codec, predictor=pred, **kw)
     t_enc = time.perf_counter() - t0
     g = GeoTiff(path)
     g._setup_blocks()
@@ -53,13 +54,13 @@ try:
         got = check()
         times.append(time.perf_counter() - t0)
         ktimes.append(check.kernel_ms)
-        slow = check.slow_codes
+        slow = getattr(check, "slow_codes", 0)
         if k == 0:
             assert np.array_equal(got.cpu().numpy().transpose(2, 0, 1), img), "decoded raster differs from what was written"
         del image, got
     raw = img.nbytes
     best = min(times[1:])
-    print(json.dumps({"raster": f"{side}x{side}x4", "layout": kw, "predictor": pred, "data": data, "blocks": g._nx * g._ny, "raw_mb": raw / 1e6,
+    print(json.dumps({"codec": codec, "raster": f"{side}x{side}x4", "layout": kw, "predictor": pred, "data": data, "blocks": g._nx * g._ny, "raw_mb": raw / 1e6,
                       "file_mb": os.path.getsize(path) / 1e6, "ratio": raw / os.path.getsize(path), "encode_s": round(t_enc, 2),
                       "decode_ms": [round(t * 1e3, 1) for t in times], "kernel_ms": [round(t, 1) for t in ktimes],
                       "kernel_gb_per_s": raw / (min(ktimes) * 1e-3) / 1e9, "strings_through_memory": slow, "decode_gb_per_s": raw / best / 1e9,

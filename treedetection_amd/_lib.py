@@ -87,6 +87,8 @@ SIGNATURES = {
     "td_tiff_lzw_decode": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
     "td_tiff_packbits_decode": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
     "td_tiff_lzw_encode": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
+    "td_tiff_inflate": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
+    "td_tiff_inflate_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "td_tiff_lzw_decode_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "td_tiff_blocks_to_image_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "td_tiff_unpredict": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]),

@@ -1,0 +1,317 @@
+// DEFLATE (RFC 1951) inside a zlib wrapper (RFC 1950) — the stream of TIFF compression 8 / 32946 strips and tiles — decoded by
+// ONE 64-lane wave per block on the GPU (tiffdecode.hip) and, from the same source, by one host thread (tiffcodec.cpp:
+// td_tiff_inflate, NL = 1): the reference reads such rasters through rasterio → GDAL → zlib on the host, one tile window at
+// a time (TreeDetection/prediction.py:61,164). Symbols are decoded by every lane alike (a DEFLATE stream is sequential);
+// matches are copied 64 bytes per step out of a 32-KB ring of the output — DEFLATE's window — so no copy ever reads memory;
+// the Huffman tables of a block are built by lane 0 (a few thousand operations per 16 - 64 KB of output).
+// Tables: a 10-bit lookup for literal / length codes and an 8-bit one for distance codes (entry = length << 9 | symbol, 0 =
+// longer code), canonical count / symbol arrays for the codes that are longer (decoded bit by bit, as zlib's `puff` does).
+#pragma once
+#include <cstdint>
+
+#ifdef __HIP_DEVICE_COMPILE__
+#define TD_INF_SYNC() __syncthreads()
+#else
+#define TD_INF_SYNC() ((void)0)
+#endif
+#ifdef __HIPCC__
+#define TD_INF_HD __host__ __device__ inline
+#else
+#define TD_INF_HD static inline
+#endif
+
+constexpr int INF_RING = 32768;          // DEFLATE's window
+constexpr int INF_LIT_FAST = 10, INF_DIST_FAST = 8;
+
+struct InflateScratch {                  // LDS on the device (~38 KB: four waves per CU), a plain struct on the host
+    uint8_t ring[INF_RING];
+    uint32_t inbuf[128];                 // two chunks of 64 little-endian dwords of the stream
+    uint16_t lit_fast[1 << INF_LIT_FAST];
+    uint16_t dist_fast[1 << INF_DIST_FAST];
+    uint16_t lit_sym[288], dist_sym[32]; // symbols in canonical order
+    uint16_t lit_count[16], dist_count[16];
+    uint8_t lens[384];                   // code lengths of the block being set up (19 of the code-length code, then 32 .. 348: literal / length + distance)
+};
+
+// status: 0 ok, 1 corrupt stream, 2 more bytes than the block holds
+struct InflateResult {
+    uint32_t produced;
+    int status;
+};
+
+namespace inflate_detail {
+
+struct Reader {
+    const uint32_t* src32;               // aligned base of the stream
+    uint32_t ndw, loaded, rd;            // dwords in the stream / loaded into inbuf so far / consumed into acc
+    uint64_t acc;
+    int have;
+    uint32_t end_bit;                    // first bit past the stream (from the aligned base)
+};
+
+template <int NL>
+TD_INF_HD void load_chunk(InflateScratch& S, Reader& r, int lane) {
+    for (int k = lane; k < 64; k += NL) {
+        const uint32_t idx = r.loaded + k;
+        S.inbuf[idx & 127] = idx < r.ndw ? r.src32[idx] : 0u;
+    }
+    r.loaded += 64;
+    TD_INF_SYNC();
+}
+
+// make at least n <= 32 bits available in acc (zeros past the end of the stream: the callers check `overrun`)
+template <int NL>
+TD_INF_HD void ensure(InflateScratch& S, Reader& r, int n, int lane) {
+    if (r.have < n) {
+        if (r.rd >= r.loaded) load_chunk<NL>(S, r, lane);
+        r.acc |= (uint64_t)S.inbuf[r.rd & 127] << r.have;
+        ++r.rd;
+        r.have += 32;
+    }
+}
+TD_INF_HD uint32_t take(Reader& r, int n) {
+    const uint32_t v = (uint32_t)(r.acc & ((1ull << n) - 1ull));
+    r.acc >>= n;
+    r.have -= n;
+    return v;
+}
+TD_INF_HD uint32_t bitpos(const Reader& r) { return r.rd * 32u - (uint32_t)r.have; }
+
+// restart the reader at an absolute bit position (after a stored block)
+template <int NL>
+TD_INF_HD void seek(InflateScratch& S, Reader& r, uint32_t bit, int lane) {
+    TD_INF_SYNC();
+    r.rd = bit >> 5;
+    r.loaded = r.rd & ~63u;
+    load_chunk<NL>(S, r, lane);
+    load_chunk<NL>(S, r, lane);
+    r.acc = 0;
+    r.have = 0;
+    ensure<NL>(S, r, 1, lane);
+    take(r, (int)(bit & 31));
+}
+
+TD_INF_HD uint32_t reverse_bits(uint32_t v, int n) {
+    uint32_t o = 0;
+    for (int i = 0; i < n; ++i) {
+        o = (o << 1) | (v & 1u);
+        v >>= 1;
+    }
+    return o;
+}
+
+// canonical Huffman tables from code lengths lens[0..n): counts per length, symbols in canonical order, the fast lookup.
+// Returns false for an over-subscribed set (an incomplete one is allowed only for a single distance code, as zlib allows).
+TD_INF_HD bool build(const uint8_t* lens, int n, uint16_t* count, uint16_t* sym, uint16_t* fast, int fast_bits) {
+    for (int l = 0; l < 16; ++l) count[l] = 0;
+    for (int s = 0; s < n; ++s) ++count[lens[s]];
+    int left = 1;
+    for (int l = 1; l < 16; ++l) {
+        left <<= 1;
+        left -= count[l];
+        if (left < 0) return false;
+    }
+    uint16_t offs[16];
+    offs[1] = 0;
+    for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
+    for (int s = 0; s < n; ++s)
+        if (lens[s]) sym[offs[lens[s]]++] = (uint16_t)s;
+    for (int i = 0; i < (1 << fast_bits); ++i) fast[i] = 0;
+    uint32_t code = 0;
+    int index = 0;
+    for (int l = 1; l <= fast_bits; ++l) {
+        for (int k = 0; k < count[l]; ++k) {
+            const uint32_t rev = reverse_bits(code, l);
+            const uint16_t e = (uint16_t)((l << 9) | sym[index]);
+            for (uint32_t f = rev; f < (1u << fast_bits); f += 1u << l) fast[f] = e;
+            ++code;
+            ++index;
+        }
+        code <<= 1;
+    }
+    return true;
+}
+
+// one symbol: the fast table, else bit by bit over the canonical arrays (codes longer than the table's index)
+template <int NL>
+TD_INF_HD int decode_sym(InflateScratch& S, Reader& r, const uint16_t* fast, int fast_bits, const uint16_t* count, const uint16_t* sym, int lane) {
+    ensure<NL>(S, r, 15, lane);
+    const uint16_t e = fast[r.acc & ((1u << fast_bits) - 1u)];
+    if (e) {
+        take(r, e >> 9);
+        return e & 511;
+    }
+    int code = 0, first = 0, index = 0;
+    uint64_t bits = r.acc;
+    for (int l = 1; l <= 15; ++l) {
+        code |= (int)(bits & 1u);
+        bits >>= 1;
+        const int c = count[l];
+        if (code - c < first) {
+            take(r, l);
+            return sym[index + (code - first)];
+        }
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
+}  // namespace inflate_detail
+
+// src: the zlib stream (n bytes); dst: the block's output (cap bytes); every lane of the wave calls this with its lane id
+// (host: NL = 1, lane = 0). The result is the same on every lane.
+template <int NL>
+TD_INF_HD InflateResult inflate_block(InflateScratch& S, const uint8_t* src, int64_t n, uint8_t* dst, uint32_t cap, int lane) {
+    using namespace inflate_detail;
+    constexpr uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    constexpr uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    constexpr uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    constexpr uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    constexpr uint8_t ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    InflateResult res{0, 1};
+    if (n < 6) return res;                                  // header + at least an empty block + trailer
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(src);
+    const uint32_t skip = (uint32_t)(a0 & 3);
+    Reader r{};
+    r.src32 = reinterpret_cast<const uint32_t*>(a0 - skip);
+    r.ndw = (uint32_t)((n + skip + 3) >> 2);
+    r.end_bit = (uint32_t)(n + skip) * 8u;
+    seek<NL>(S, r, skip * 8u, lane);
+    ensure<NL>(S, r, 16, lane);
+    const uint32_t cmf = take(r, 8), flg = take(r, 8);
+    if ((cmf & 15) != 8 || ((cmf << 8) | flg) % 31 != 0 || (flg & 32)) return res;      // not deflate / bad check / preset dictionary
+    uint32_t op = 0;
+    for (;;) {
+        ensure<NL>(S, r, 3, lane);
+        const uint32_t last = take(r, 1), type = take(r, 2);
+        if (type == 3) return res;
+        if (type == 0) {                                    // stored: LEN, ~LEN, bytes — copied straight from the stream in memory
+            take(r, r.have & 7);
+            ensure<NL>(S, r, 32, lane);
+            const uint32_t len = take(r, 16), nlen = take(r, 16);
+            if ((len ^ nlen) != 0xffffu) return res;
+            const uint32_t byte0 = bitpos(r) >> 3;          // from the aligned base
+            if ((uint64_t)byte0 + len > (uint64_t)n + skip) return res;
+            const uint8_t* from = reinterpret_cast<const uint8_t*>(r.src32) + byte0;
+            for (uint32_t k0 = 0; k0 < len; k0 += NL) {
+                const uint32_t k = k0 + lane;
+                if (k < len) {
+                    const uint8_t v = from[k];
+                    S.ring[(op + k) & (INF_RING - 1)] = v;
+                    if (op + k < cap) dst[op + k] = v;
+                }
+            }
+            op += len;
+            seek<NL>(S, r, (byte0 + len) * 8u, lane);
+        } else {
+            TD_INF_SYNC();
+            bool ok = true;
+            if (type == 1) {                                // fixed codes
+                if (lane == 0) {
+                    for (int s = 0; s < 288; ++s) S.lens[s] = s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8));
+                    ok = build(S.lens, 288, S.lit_count, S.lit_sym, S.lit_fast, INF_LIT_FAST);
+                    for (int s = 0; s < 30; ++s) S.lens[s] = 5;
+                    ok = ok && build(S.lens, 30, S.dist_count, S.dist_sym, S.dist_fast, INF_DIST_FAST);
+                }
+            } else {                                        // dynamic codes: the code-length code first, then the two tables
+                ensure<NL>(S, r, 14, lane);
+                const int hlit = (int)take(r, 5) + 257, hdist = (int)take(r, 5) + 1, hclen = (int)take(r, 4) + 4;
+                if (hlit > 286 || hdist > 30) return res;
+                uint8_t cl[19];
+                for (int i = 0; i < 19; ++i) cl[i] = 0;
+                for (int i = 0; i < hclen; ++i) {
+                    ensure<NL>(S, r, 3, lane);
+                    cl[ORDER[i]] = (uint8_t)take(r, 3);
+                }
+                TD_INF_SYNC();
+                if (lane == 0) {
+                    for (int i = 0; i < 19; ++i) S.lens[i] = cl[i];
+                    ok = build(S.lens, 19, S.lit_count, S.lit_sym, S.lit_fast, 7);       // (the code-length code uses the literal table's arrays for a moment)
+                }
+                TD_INF_SYNC();
+#ifdef __HIP_DEVICE_COMPILE__
+                ok = __shfl((int)ok, 0) != 0;
+#endif
+                if (!ok) return res;
+                // the hlit + hdist code lengths, run-length coded; every lane decodes them (uniform), lane 0 keeps them
+                uint8_t prev = 0;
+                int idx = 0;
+                uint8_t* L = S.lens + 32;                   // (past the 19 entries still in use by nothing: the tables above are built)
+                while (idx < hlit + hdist) {
+                    const int s = decode_sym<NL>(S, r, S.lit_fast, 7, S.lit_count, S.lit_sym, lane);
+                    if (s < 0 || bitpos(r) > r.end_bit) return res;
+                    int rep = 1;
+                    uint8_t v = (uint8_t)s;
+                    if (s == 16) {
+                        if (idx == 0) return res;
+                        ensure<NL>(S, r, 2, lane);
+                        rep = 3 + (int)take(r, 2);
+                        v = prev;
+                    } else if (s == 17) {
+                        ensure<NL>(S, r, 3, lane);
+                        rep = 3 + (int)take(r, 3);
+                        v = 0;
+                    } else if (s == 18) {
+                        ensure<NL>(S, r, 7, lane);
+                        rep = 11 + (int)take(r, 7);
+                        v = 0;
+                    }
+                    if (idx + rep > hlit + hdist) return res;
+                    if (lane == 0)
+                        for (int k = 0; k < rep; ++k) L[idx + k] = v;
+                    idx += rep;
+                    prev = v;
+                }
+                TD_INF_SYNC();
+                if (lane == 0) {
+                    ok = L[256] != 0;                        // no end-of-block code
+                    ok = ok && build(L, hlit, S.lit_count, S.lit_sym, S.lit_fast, INF_LIT_FAST);
+                    ok = ok && build(L + hlit, hdist, S.dist_count, S.dist_sym, S.dist_fast, INF_DIST_FAST);
+                }
+            }
+            TD_INF_SYNC();
+#ifdef __HIP_DEVICE_COMPILE__
+            ok = __shfl((int)ok, 0) != 0;
+#endif
+            if (!ok) return res;
+            for (;;) {                                      // the block's symbols
+                const int s = decode_sym<NL>(S, r, S.lit_fast, INF_LIT_FAST, S.lit_count, S.lit_sym, lane);
+                if (s < 0 || bitpos(r) > r.end_bit) return res;
+                if (s < 256) {
+                    if (lane == 0) {
+                        S.ring[op & (INF_RING - 1)] = (uint8_t)s;
+                        if (op < cap) dst[op] = (uint8_t)s;
+                    }
+                    ++op;
+                    continue;
+                }
+                if (s == 256) break;
+                if (s > 285) return res;
+                ensure<NL>(S, r, 5, lane);
+                const uint32_t len = LBASE[s - 257] + take(r, LEXT[s - 257]);
+                const int ds = decode_sym<NL>(S, r, S.dist_fast, INF_DIST_FAST, S.dist_count, S.dist_sym, lane);
+                if (ds < 0 || ds > 29) return res;
+                ensure<NL>(S, r, 13, lane);
+                const uint32_t dist = DBASE[ds] + take(r, DEXT[ds]);
+                if (dist > op || bitpos(r) > r.end_bit) return res;
+                // out[op + k] = out[op - dist + (k mod dist)]: every source byte was written before this match began
+                for (uint32_t k0 = 0; k0 < len; k0 += NL) {
+                    const uint32_t k = k0 + lane;
+                    if (k < len) {
+                        const uint8_t v = S.ring[(op - dist + (k % dist)) & (INF_RING - 1)];
+                        S.ring[(op + k) & (INF_RING - 1)] = v;
+                        if (op + k < cap) dst[op + k] = v;
+                    }
+                }
+                op += len;
+            }
+        }
+        if (last) break;
+    }
+    res.produced = op;
+    res.status = op > cap ? 2 : 0;
+    return res;
+}

@@ -164,6 +164,32 @@ extern "C" int64_t td_tiff_lzw_encode(const uint8_t* src, int64_t n, uint8_t* ds
     return op;
 }
 
+// DEFLATE in a zlib wrapper (TIFF compression 8 / 32946): the decoder the GPU runs (inflate_core.h, one wave per block), instantiated
+// for ONE lane — the same source on the host, so its parity with zlib is tested without a GPU (tests/test_geotiff_formats.py). The
+// tile reader itself keeps Python's zlib for DEFLATE blocks (it also checks the Adler-32 trailer, which this decoder skips).
+#include "inflate_core.h"
+extern "C" int64_t td_tiff_inflate(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap) {
+    if (!src || !dst || n < 0 || cap < 0 || cap >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 28)) {
+        td_set_error("td_tiff_inflate: bad argument");
+        return TD_ERR_INVALID;
+    }
+    static thread_local InflateScratch scratch;
+    // the core reads whole dwords from the 4-byte-aligned address below src up to the dword that holds the stream's last byte: copy
+    // the stream into a padded, aligned buffer so that a caller's tight buffer is never over-read
+    std::vector<uint32_t> padded((size_t)(n + 8) / 4 + 2, 0u);
+    std::memcpy(padded.data(), src, (size_t)n);
+    const InflateResult r = inflate_block<1>(scratch, reinterpret_cast<const uint8_t*>(padded.data()), n, dst, (uint32_t)cap, 0);
+    if (r.status == 1) {
+        td_set_error("td_tiff_inflate: corrupt stream");
+        return TD_ERR_INVALID;
+    }
+    if (r.status == 2) {
+        td_set_error("td_tiff_inflate: %lld bytes decoded, capacity %lld", (long long)r.produced, (long long)cap);
+        return TD_ERR_CAPACITY;
+    }
+    return (int64_t)r.produced;
+}
+
 // PackBits (TIFF 6.0 section 9): header byte h: 0..127 → copy h+1 literal bytes; -127..-1 → repeat the next byte
 // 1-h times; -128 → no operation.
 extern "C" int64_t td_tiff_packbits_decode(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap) {

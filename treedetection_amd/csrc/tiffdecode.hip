@@ -12,6 +12,7 @@
 // + 1, so the table is ONE array of 4097 output positions in LDS (16 KB). Integer / byte work bound by the latency of dependent
 // LDS reads (two per code), not by HBM: 1 byte written per byte decoded, the compressed bytes read once.
 #include "common.h"
+#include "inflate_core.h"
 
 namespace {
 
@@ -170,6 +171,22 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
     }
 }
 
+// DEFLATE blocks (TIFF compression 8 / 32946: zlib streams), one wave per block: inflate_core.h. LDS: the 32-KB window + tables
+// (38 KB: four waves per CU); every match is copied out of the window in LDS, literals and matches go to memory as byte stores.
+__global__ __launch_bounds__(64) void tiff_inflate_blocks_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ block_off,
+                                                                 const int64_t* __restrict__ block_nbytes, uint8_t* __restrict__ out,
+                                                                 int64_t block_cap, int64_t* __restrict__ decoded,
+                                                                 int32_t* __restrict__ status) {
+    __shared__ InflateScratch S;
+    const int b = blockIdx.x;
+    const InflateResult r = inflate_block<64>(S, comp + block_off[b], block_nbytes[b], out + (int64_t)b * block_cap, (uint32_t)block_cap,
+                                              (int)threadIdx.x);
+    if (threadIdx.x == 0) {
+        decoded[b] = (int64_t)r.produced;
+        status[b] = r.status;
+    }
+}
+
 // Decoded blocks → the raster [height][width][spp] (uint8, pixel-interleaved), undoing predictor 2 (TIFF 6.0 section 14:
 // each sample is the difference to the same sample of the pixel on its left, within the row of its block) on the way. One
 // workgroup per (image row, block column): a block row of bw pixels is a prefix sum per sample — per-thread runs, a scan of
@@ -235,6 +252,18 @@ extern "C" td_status td_tiff_lzw_decode_dev(const uint8_t* comp, const int64_t* 
     TD_KERNEL_CHECK();
     hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint32_t, true>), dim3(nblocks < 1024 ? nblocks : 1024), dim3(64), 0, s, comp, block_off,
                        block_nbytes, blocks_out, block_cap, decoded, status, nblocks, wide_list);
+    TD_KERNEL_CHECK();
+    return TD_OK;
+}
+
+extern "C" td_status td_tiff_inflate_dev(const uint8_t* comp, const int64_t* block_off, const int64_t* block_nbytes, int nblocks,
+                                         uint8_t* blocks_out, int64_t block_cap, int64_t* decoded, int32_t* status, void* stream) {
+    TD_REQUIRE(comp && block_off && block_nbytes && blocks_out && decoded && status, "td_tiff_inflate_dev: null pointer");
+    TD_REQUIRE(nblocks >= 0 && block_cap >= 1 && block_cap < ((int64_t)1 << 31), "td_tiff_inflate_dev: %d blocks of %lld bytes", nblocks,
+               (long long)block_cap);
+    if (nblocks == 0) return TD_OK;
+    hipLaunchKernelGGL(tiff_inflate_blocks_kernel, dim3(nblocks), dim3(64), 0, static_cast<hipStream_t>(stream), comp, block_off, block_nbytes,
+                       blocks_out, block_cap, decoded, status);
     TD_KERNEL_CHECK();
     return TD_OK;
 }

@@ -316,16 +316,17 @@ class GeoTiff:
 
     # -- compressed raster → HBM (tiffdecode.hip) --------------------------------------------------------------------------
     def device_decodable(self) -> bool:
-        """True when the raster's blocks can be decoded on the GPU: LZW strips or tiles of pixel-interleaved uint8 samples
-        (<= 4 per pixel), predictor 1 or 2. Everything else keeps the host reader (DEFLATE: zlib on the decode threads)."""
+        """True when the raster's blocks can be decoded on the GPU: LZW or DEFLATE (zlib) strips or tiles of pixel-interleaved
+        uint8 samples (<= 4 per pixel), predictor 1 or 2. Everything else keeps the host reader."""
         self._setup_blocks()
-        return (self.compression == 5 and self.planar == 1 and self.dtype == np.uint8 and 1 <= self.count <= 4
+        return (self.compression in (5, 8, 32946) and self.planar == 1 and self.dtype == np.uint8 and 1 <= self.count <= 4
                 and self._predictor in (1, 2) and self._counts is not None and self._pil is None
                 and self._bw * self._bh * self.count < (1 << 31))
 
     def decode_to_device(self, device, stream=None, pinned=None, pool=None):
         """The whole raster decoded in HBM: the compressed blocks are read as they lie in the file (one pread of the span that
-        holds them, into pinned memory), copied to the device once, decoded one wave per block (td_tiff_lzw_decode_dev) and
+        holds them, into pinned memory), copied to the device once, decoded one wave per block (td_tiff_lzw_decode_dev /
+        td_tiff_inflate_dev) and
         laid out as [height, width, bands] uint8 with predictor 2 undone (td_tiff_blocks_to_image_dev). → (image tensor,
         check) where ``check()`` waits for the kernels and raises ValueError when a block did not decode to its size (the
         caller then falls back to the host reader). Everything is enqueued on ``stream`` (default: the current one). ``pinned``:
@@ -383,8 +384,9 @@ class GeoTiff:
             status = torch.empty((2 * nb + 1,), dtype=torch.int32, device=dev)      # [nb] status + scratch of the wide-table pass
             k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             k0.record()
-            _lib.check(lib.td_tiff_lzw_decode_dev(comp.data_ptr(), meta[0].data_ptr(), meta[1].data_ptr(), nb, blocks.data_ptr(), block_cap,
-                                                  decoded.data_ptr(), status.data_ptr(), st), "td_tiff_lzw_decode_dev")
+            fn, fname = (lib.td_tiff_lzw_decode_dev, "td_tiff_lzw_decode_dev") if self.compression == 5 else (lib.td_tiff_inflate_dev, "td_tiff_inflate_dev")
+            _lib.check(fn(comp.data_ptr(), meta[0].data_ptr(), meta[1].data_ptr(), nb, blocks.data_ptr(), block_cap,
+                          decoded.data_ptr(), status.data_ptr(), st), fname)
             image = torch.empty((self.height, self.width, self.count), dtype=torch.uint8, device=dev)
             _lib.check(lib.td_tiff_blocks_to_image_dev(blocks.data_ptr(), block_cap, self._bw, self._bh, self._nx, self._ny, self.count,
                                                        self._predictor, image.data_ptr(), self.width, self.height, st), "td_tiff_blocks_to_image_dev")
@@ -404,7 +406,7 @@ class GeoTiff:
             check.kernel_ms = k0.elapsed_time(k1)          # the two decode launches + the scatter / predictor kernel
             keep.clear()
             produced = dec_h.numpy() & 0xffffffff
-            check.slow_codes = int((dec_h.numpy() >> 32).sum())     # strings copied through memory (sources older than the LDS ring)
+            check.slow_codes = int((dec_h.numpy() >> 32).sum())     # LZW: strings copied through memory (sources older than the LDS ring)
             bad = np.nonzero((st_h.numpy() != 0) | (produced != expect))[0]
             if bad.size:
                 b = int(bad[0])
