@@ -1,7 +1,7 @@
 # Regenerates the judged artefacts of profiles/ on the GPU box: bash tools/profile_round.sh [round tag, default r02]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r05}
+TAG=${1:-r06}
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
 export TD_TUNE_CACHE=$O/tune.txt
@@ -34,3 +34,10 @@ cp $O/bench_plain_profiled.json $O/${TAG}_plain_profiled_run.json
 cp $O/bench_plain_profiled_detail.json $O/${TAG}_plain_profiled_detail.json
 python3 -c "import json;d=json.load(open('$O/${TAG}_pmc_conv_fp32.json'));print('fp32 conv family', d['conv_family'])"
 python3 -c "import json;d=json.load(open('$O/${TAG}_pmc_conv_fp16.json'));print('fp16 conv family', d['conv_family'])"
+# (round 6) the raster decode kernels: per-kernel durations of an LZW and a DEFLATE raster (256 x 256 tiles, predictor 2) decoded five times
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $O/decode_lzw -o s --output-format csv -- python3 $R/tools/raster_decode_bench.py codec=lzw side=20000 > $O/${TAG}_decode_lzw.json 2> $O/decode_lzw.err || exit 1
+rocprofv3 --kernel-trace --stats -d $O/decode_deflate -o s --output-format csv -- python3 $R/tools/raster_decode_bench.py codec=deflate side=9000 > $O/${TAG}_decode_deflate.json 2> $O/decode_deflate.err || exit 1
+cp $(find $O/decode_lzw -name "*kernel_stats.csv" | head -1) $O/${TAG}_decode_lzw_kernel_stats.csv
+cp $(find $O/decode_deflate -name "*kernel_stats.csv" | head -1) $O/${TAG}_decode_deflate_kernel_stats.csv
+echo decode stats done
