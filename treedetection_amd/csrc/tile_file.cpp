@@ -9,7 +9,6 @@
 #include <atomic>
 #include <cstdio>
 #include <mutex>
-#include <time.h>
 
 namespace {
 
@@ -62,23 +61,9 @@ extern "C" int td_tile_prediction_file(int device, const int32_t* mask_region, c
         TD_HIP_CHECK(cs.err);
         hipStream_t st = cs.s[cs.next.fetch_add(1, std::memory_order_relaxed) % kCopyStreams];
         TD_HIP_CHECK(hipMemcpyAsync(rows_host, mask_bits_dev, (size_t)used * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        // wait without spinning: hipStreamSynchronize burns the core while the copy queues behind the running forwards (measured: 5 CPU ms
-        // per tile in the fp32 engine's epilogue workers, sixteen of them). One event per worker thread, query + 50-us naps.
-        static thread_local hipEvent_t ev = nullptr;
-        static thread_local int ev_device = -1;
-        if (ev == nullptr || ev_device != device) {
-            TD_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            ev_device = device;
-        }
-        TD_HIP_CHECK(hipEventRecord(ev, st));
-        for (;;) {
-            const hipError_t q = hipEventQuery(ev);
-            if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) TD_HIP_CHECK(q);
-            (void)hipGetLastError();                       // hipErrorNotReady is sticky in hipGetLastError: clear it
-            struct timespec nap = {0, 50000};
-            nanosleep(&nap, nullptr);
-        }
+        // (an event-query loop with 50-us naps instead of this call was measured in round 6: the epilogue workers' CPU time fell, but every
+        // image took 5 batch periods longer — queries do not push the runtime's queued copies out the way a synchronisation does)
+        TD_HIP_CHECK(hipStreamSynchronize(st));
     }
     std::string text;
     const int entries = td_polygons_json_text(mask_region, mask_offset, rows_host, used, scores, classes, n, transform, image_id, text,
