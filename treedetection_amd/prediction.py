@@ -208,6 +208,8 @@ class Predictor:
         self.cfg = cfg
         # LZW rasters are decoded on the GPU, whole, and their tile windows are cut in HBM (GeoTiff.decode_to_device; images this
         # process predicts alone: submit). "auto" / True: every LZW raster that qualifies; False: the host reader for everything
+        if device_decode == "auto" and os.environ.get("TD_DEVICE_DECODE"):       # diagnostics: override the default
+            device_decode = {"0": False, "false": False, "all": "all"}.get(os.environ["TD_DEVICE_DECODE"], "auto")
         if device_decode not in (True, False, "auto", "true", "false", "all"):
             raise ValueError(f"device_decode must be true, false, 'auto' or 'all', got {device_decode!r}")
         self.device_decode = device_decode in (True, "auto", "true", "all")
