@@ -284,6 +284,16 @@ int td_tile_prediction_file(int device, const int32_t* mask_region, const int64_
                             uint32_t* rows_host, int64_t mask_words, const float* scores, const int32_t* classes, int n,
                             const double* transform, const char* image_id, const char* path, int64_t* bytes_written);
 
+/* The tile files of a whole batch in ONE call: tile i reads its records at mask_region + i * D * 4, mask_offset + i * D, scores /
+ * classes + i * D (D = dets_per_image), counts[i] detections (count < 0: the tile is skipped, as a dropped tile is), its device rows
+ * at mask_bits_dev + i * bits_stride_words, uses the pinned rows_host + i * bits_stride_words, the affine at transforms + 6 * i and
+ * writes paths[i]; status[i] / bytes_written[i] receive td_tile_prediction_file's result per tile. The tiles are spread over
+ * `threads` host threads. Returns TD_OK or the first failing tile's status (the other tiles are still written). */
+int td_batch_prediction_files(int device, int n_tiles, int dets_per_image, const int32_t* mask_region, const int64_t* mask_offset,
+                              const uint32_t* mask_bits_dev, uint32_t* rows_host, int64_t bits_stride_words, const float* scores,
+                              const int32_t* classes, const int32_t* counts, const double* transforms, const char* image_id,
+                              const char* const* paths, int threads, int32_t* status, int64_t* bytes_written);
+
 /* ---- raster input (reference prediction.py:61,164: rasterio.open / rasterio.mask.mask → GDAL → libtiff) ---- */
 /* Decompress one TIFF strip or tile: LZW (compression 5) and PackBits (32773) per TIFF 6.0; DEFLATE strips go
  * through zlib on the host side. Return the number of bytes written to dst (capacity cap), or a negative status

@@ -309,6 +309,33 @@ def test_device_contours_auto_switches_between_batches_with_identical_files(tmp_
         T.Predictor(cfg, device_type="0", output_dir=str(tmp_path / "c"), state_dict=sd, device_contours="sometimes")
 
 
+def test_batch_epilogue_writes_the_same_files_as_a_task_per_tile(tmp_path, monkeypatch):
+    """Where only the files are wanted (return_predictions=False: what predict_on_model runs) a batch's host epilogue is ONE task and ONE
+    library call (td_batch_prediction_files); with return_predictions=True, or TD_BATCH_EPILOGUE=0, it is a task per tile
+    (td_tile_prediction_file). Same files byte for byte — also for a batch that holds an unreadable tile (dropped by the reader)."""
+    import treedetection_amd as T
+    from treedetection_amd.preprocessing import tile_single_file
+    sd = make_synthetic_state_dict(50, seed=3, width_div=2)
+    rgb, _ = make_tile(300, 500)
+    rgbi = np.ascontiguousarray(np.concatenate([rgb, rgb[..., 1:2]], axis=2).transpose(2, 0, 1))
+    tif = str(tmp_path / "9.tif")
+    write_geotiff(tif, rgbi, (0.2, 0.0, 412000.0, 0.0, -0.2, 5318100.0), 25832)
+    tile_single_file(tif, str(tmp_path / "tiles"), buffer=10, tile_width=40, tile_height=40)
+    meta = str(tmp_path / "tiles" / "9.json")
+    cfg = T.setup_model_cfg(update_model="x", device="0")
+    outs = {}
+    for tag, env, ret in (("batch", "1", False), ("per_tile", "0", False), ("with_predictions", "1", True)):
+        monkeypatch.setenv("TD_BATCH_EPILOGUE", env)
+        with T.Predictor(cfg, device_type="0", max_batch_size=4, output_dir=str(tmp_path / tag), state_dict=sd, return_predictions=ret) as pred:
+            assert pred._batch_epilogue == (env == "1")
+            res = pred(tif, meta)
+            assert (len(res) > 5) == ret
+        outs[tag] = {f: open(tmp_path / tag / "9" / f, "rb").read() for f in sorted(os.listdir(tmp_path / tag / "9"))}
+        assert len(outs[tag]) == 9
+    assert outs["batch"] == outs["per_tile"] == outs["with_predictions"]
+    assert sum(len(json.loads(v)) for v in outs["batch"].values()) > 5
+
+
 def test_predictor_fp16_engine_end_to_end(tmp_path):
     """config ``precision: fp16``: the same Predictor flow on the fp16 engine; per tile about the same crowns as fp32
     (engine-level tolerances: tests/test_engine_fp16_gpu.py)."""

@@ -37,6 +37,7 @@ def cpu_seconds():
 
 
 def main():
+    os.environ["TD_HOST_STATS"] = "1"          # per-stage CPU accounting in the Predictor (off by default: it costs rate)
     import torch
     import treedetection_amd as T
     from treedetection_amd import detection as DT

@@ -84,6 +84,8 @@ SIGNATURES = {
     "td_trace_contours_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "td_find_contours": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "td_batch_prediction_files": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_void_p, C.c_void_p]),
     "td_tiff_lzw_decode": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
     "td_tiff_packbits_decode": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
     "td_tiff_lzw_encode": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),

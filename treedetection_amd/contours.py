@@ -85,6 +85,27 @@ def tile_prediction_file(device: int, regions: np.ndarray, offsets: np.ndarray, 
     return int(wrote.value)
 
 
+def batch_prediction_files(device: int, host: dict, n_tiles: int, bits_dev_ptr: int, transforms: np.ndarray, image_id: str,
+                           paths: Sequence[str], threads: int = 4):
+    """All tile files of one batch in ONE library call (td_batch_prediction_files): ``host`` = the slot's pinned numpy views of the
+    engine outputs (count / mask_region / mask_offset / mask_bits / scores / classes, batch-major), ``bits_dev_ptr`` the device
+    address of the batch's packed mask rows. → (status per tile, bytes per tile); raises on the first failing tile."""
+    lib = _lib.load()
+    D = int(host["scores"].shape[1])
+    words = host["mask_bits"].view(np.uint32)
+    stride = int(words.shape[1])
+    status = np.zeros(n_tiles, np.int32)
+    wrote = np.zeros(n_tiles, np.int64)
+    arr = (C.c_char_p * n_tiles)(*[os.fsencode(p) for p in paths])
+    tr = np.ascontiguousarray(transforms, dtype=np.float64).reshape(n_tiles, 6)
+    st = lib.td_batch_prediction_files(int(device), int(n_tiles), D, host["mask_region"].ctypes.data, host["mask_offset"].ctypes.data,
+                                       int(bits_dev_ptr), words.ctypes.data, stride, host["scores"].ctypes.data, host["classes"].ctypes.data,
+                                       host["count"].ctypes.data, tr.ctypes.data, image_id.encode("utf-8", "surrogateescape"), arr, int(threads),
+                                       status.ctypes.data, wrote.ctypes.data)
+    _lib.check(st, "td_batch_prediction_files")
+    return status, wrote
+
+
 def tile_polygons_json_dev(points: np.ndarray, det_info: np.ndarray, contour_info: np.ndarray, regions: np.ndarray,
                            offsets: np.ndarray, bits, scores: np.ndarray, classes: np.ndarray, transform: Sequence[float],
                            image_id: str):

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cstdio>
 #include <mutex>
+#include <thread>
 
 namespace {
 
@@ -82,4 +83,44 @@ extern "C" int td_tile_prediction_file(int device, const int32_t* mask_region, c
     }
     *bytes_written = (int64_t)text.size();
     return entries;
+}
+
+// A whole batch's tile files in ONE call (round 6): the files-to-files path is bound, at the fp16 rate, by the Python work per tile —
+// every worker thread's Python runs under one interpreter lock — so the per-tile call above costs the rate more than its C part does.
+// Tile i of the batch: records at mask_region + i * D * 4, mask_offset + i * D, scores / classes + i * D, count[i] detections,
+// device rows at mask_bits_dev + i * bits_stride_words, pinned host rows at rows_host + i * bits_stride_words, transform at
+// transforms + 6 * i, file paths[i]. status[i] receives the entry count or the negative status of tile i (a tile with count < 0 is
+// skipped: status 0, no file); the tiles are spread over `threads` threads. Returns TD_OK, or the first failing tile's status.
+extern "C" int td_batch_prediction_files(int device, int n_tiles, int dets_per_image, const int32_t* mask_region, const int64_t* mask_offset,
+                                         const uint32_t* mask_bits_dev, uint32_t* rows_host, int64_t bits_stride_words, const float* scores,
+                                         const int32_t* classes, const int32_t* counts, const double* transforms, const char* image_id,
+                                         const char* const* paths, int threads, int32_t* status, int64_t* bytes_written) {
+    if (n_tiles < 0 || dets_per_image < 1 || !counts || !transforms || !image_id || !paths || !status || !bytes_written ||
+        (n_tiles > 0 && (!mask_region || !mask_offset || !mask_bits_dev || !rows_host || !scores || !classes)) || bits_stride_words < 0) {
+        td_set_error("td_batch_prediction_files: bad argument");
+        return TD_ERR_INVALID;
+    }
+    std::atomic<int> next{0};
+    auto work = [&] {
+        for (int i = next.fetch_add(1); i < n_tiles; i = next.fetch_add(1)) {
+            bytes_written[i] = 0;
+            if (counts[i] < 0) {
+                status[i] = 0;
+                continue;
+            }
+            const size_t D = (size_t)dets_per_image;
+            status[i] = td_tile_prediction_file(device, mask_region + i * D * 4, mask_offset + i * D, mask_bits_dev + (size_t)i * bits_stride_words,
+                                                rows_host + (size_t)i * bits_stride_words, bits_stride_words, scores + i * D, classes + i * D,
+                                                counts[i] > dets_per_image ? dets_per_image : counts[i], transforms + 6 * (size_t)i, image_id, paths[i],
+                                                bytes_written + i);
+        }
+    };
+    const int nt = threads < 1 ? 1 : (threads > n_tiles ? (n_tiles > 0 ? n_tiles : 1) : threads);
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    for (int i = 0; i < n_tiles; ++i)
+        if (status[i] < 0) return status[i];
+    return TD_OK;
 }

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import distributed as D
-from .contours import find_contours, tile_polygons_json, tile_polygons_json_dev, tile_prediction_file, xy
+from .contours import batch_prediction_files, find_contours, tile_polygons_json, tile_polygons_json_dev, tile_prediction_file, xy
 from .engine import Engine, INPUT_F32_CHW, INPUT_U8_HWC
 from .geotiff import GeoTiff
 from .weights import load_checkpoint
@@ -48,13 +48,6 @@ def _tune_cache_path(device_index: int) -> str:
         import tempfile
         base = tempfile.mkdtemp(prefix="td_tune_")
     return os.path.join(base, f"tile_choices_v{TILE_TABLE_VERSION}_{name}.txt")
-
-
-def _wait_event(event) -> None:
-    """Waits for a batch's results. (Round 6 measured a query + 0.2-ms-nap loop here to keep sixteen workers from spinning inside HIP's
-    synchronisation: worker CPU time fell from 1.4 to 1.0 ms per tile, but the fp16 files-to-files rate fell by 8 % on the same box — a
-    query does not flush the runtime's queued work the way a synchronisation does, and late epilogues hold buffer slots. Reverted.)"""
-    event.synchronize()
 
 
 class _Slot:
@@ -293,6 +286,13 @@ class Predictor:
         for s in self._slots:
             self._free.put(s)
         self._stats_lock = threading.Lock()
+        # per-stage CPU accounting (time.thread_time per tile and stage) is for tools/host_cost.py only: the files-to-files path is
+        # bound by the Python work per tile at the fp16 rate (every thread's Python runs under one interpreter lock), and a few
+        # extra calls per tile cost 10 - 30 % of the rate on the same box (round 6, gpurun_out/r6_j … r6_l)
+        self._cpu_stats = bool(os.environ.get("TD_HOST_STATS"))
+        # one epilogue task per BATCH where only the files are wanted (_submit_epilogue); TD_BATCH_EPILOGUE=0 = a task per tile
+        self._batch_epilogue = os.environ.get("TD_BATCH_EPILOGUE", "1") != "0"
+        self._epilogue_threads = max(1, min(4, workers // 3))
         # seconds spent per stage of the last __call__ (reader thread, launcher thread, sum over epilogue workers)
         # (*_cpu: CPU seconds of the threads that did the stage — time.thread_time — for the host-cores-per-GPU table of DESIGN.md §6)
         self.stats = {"read": 0.0, "launch": 0.0, "launch_wait": 0.0, "epilogue": 0.0, "epilogue_wait": 0.0, "slot_wait": 0.0,
@@ -575,7 +575,10 @@ class Predictor:
                 with self._stats_lock:
                     self.stats["read_cpu"] += time.thread_time() - c0
                 return r
-            results = list(self._read_pool.map(one, range(len(indices))))
+            if self._cpu_stats:
+                results = list(self._read_pool.map(one, range(len(indices))))
+            else:
+                results = list(self._read_pool.map(lambda k: self._process_tile(tiles[indices[k]], img, staging, offs[k]), range(len(indices))))
         else:
             results = [self._process_tile(tiles[idx], img, staging, offs[k]) for k, idx in enumerate(indices)]
         batch = []
@@ -619,17 +622,54 @@ class Predictor:
             # Predictor; predict_on_model logs the image's error and walks on, so a slot lost here would be lost for good)
             self._give_back(slot, self._free)
             raise
-        slot.pending = len(batch)
+        return self._submit_epilogue(batch, slot, pred_subdir, tifpath)
+
+    def _submit_epilogue(self, batch, slot: _Slot, pred_subdir, tifpath) -> list:
+        """Queues the host epilogue of a launched batch → its futures. Where only the files are wanted (``return_predictions=False``:
+        what predict_on_model runs) and the host traces the borders, the whole batch is ONE task and ONE library call
+        (td_batch_prediction_files, its tiles spread over a few C threads): the files-to-files path is bound by the Python work per
+        tile at the fp16 rate — every thread's Python runs under one interpreter lock — and a task per tile costs eight times the
+        Python of a task per batch. Otherwise one task per tile (:meth:`_process_and_save_single`)."""
         slot.submitted = time.perf_counter()
-        return [self._pool.submit(self._process_and_save_single, b, i, slot, pred_subdir, tifpath, self._free)
-                for i, b in enumerate(batch)]
+        if self._batch_epilogue and not self.return_predictions and not slot.traced:
+            slot.pending = 1
+            return [self._pool.submit(self._save_batch, batch, slot, pred_subdir, tifpath, self._free)]
+        slot.pending = len(batch)
+        return [self._pool.submit(self._process_and_save_single, b, i, slot, pred_subdir, tifpath, self._free) for i, b in enumerate(batch)]
+
+    def _save_batch(self, batch, slot: _Slot, pred_subdir, tifpath, free: "queue.Queue"):
+        try:
+            t0 = time.perf_counter()
+            c0 = time.thread_time() if self._cpu_stats else 0.0
+            slot.event.synchronize()
+            t1 = time.perf_counter()
+            self._mark("epi", 0)
+            self._mark("batch_done", getattr(slot, "mark_id", -1))
+            n = len(batch)
+            paths = [os.path.join(pred_subdir, f"Prediction_{os.path.basename(b['tile_id'])}.json") for b in batch]
+            tr = np.array([b["meta"]["transform"][:6] for b in batch], dtype=np.float64)
+            batch_prediction_files(self.device_index, slot.host, n, slot.bits_ptr(0), tr, tifpath, paths, threads=self._epilogue_threads)
+            self._mark("epi_done", n - 1)
+            with self._stats_lock:
+                self.stats["epilogue_wait"] += t1 - t0
+                self.stats["epilogue"] += time.perf_counter() - t1
+                if self._cpu_stats:
+                    self.stats["epilogue_cpu"] += time.thread_time() - c0      # (this thread only: the call's C threads are in the process total)
+            return []
+        finally:
+            with slot.lock:
+                slot.pending -= 1
+                if slot.pending == 0:
+                    self._give_back(slot, free)
 
     def _process_and_save_single(self, b, i, slot: _Slot, pred_subdir, tifpath, free: "queue.Queue"):
         """Reference prediction.py:198-266 for one tile: polygons of its instance masks → Prediction_<tile>.json."""
         try:
-            t0, c0 = time.perf_counter(), time.thread_time()
-            self._note_epilogue_start(t0 - slot.submitted > 1e-3 and slot.event.query())
-            _wait_event(slot.event)
+            t0 = time.perf_counter()
+            c0 = time.thread_time() if self._cpu_stats else 0.0
+            if self._contours_auto:
+                self._note_epilogue_start(t0 - slot.submitted > 1e-3 and slot.event.query())
+            slot.event.synchronize()
             t1 = time.perf_counter()
             self._mark("epi", i)
             if i == 0:
@@ -668,7 +708,8 @@ class Predictor:
             with self._stats_lock:
                 self.stats["epilogue_wait"] += t1 - t0
                 self.stats["epilogue"] += time.perf_counter() - t1
-                self.stats["epilogue_cpu"] += time.thread_time() - c0
+                if self._cpu_stats:
+                    self.stats["epilogue_cpu"] += time.thread_time() - c0
             return res
         finally:
             with slot.lock:
@@ -690,10 +731,7 @@ class Predictor:
         except BaseException:
             self._give_back(slot, self._free)       # no epilogue task will: see _launch_batch
             raise
-        slot.pending = len(batch)
-        slot.submitted = time.perf_counter()
-        futures.extend(self._pool.submit(self._process_and_save_single, b, i, slot, pred_subdir, tifpath, self._free)
-                       for i, b in enumerate(batch))
+        futures.extend(self._submit_epilogue(batch, slot, pred_subdir, tifpath))
 
     def _launch_pipelined(self, ready, prepare, finish, total_rounds: Optional[int] = None) -> None:
         """Launcher loop of a pipelined run. Tick t enqueues, on the main stream, the trunk of batch t, the mask-head
@@ -804,7 +842,8 @@ class Predictor:
             launched += 1
             slot.mark_id = launched - 1
             self._mark("launch", launched - 1)
-            t0, c0 = time.perf_counter(), time.thread_time()
+            t0 = time.perf_counter()
+            c0 = time.thread_time() if self._cpu_stats else 0.0
             slot.side = stream               # where finish() enqueues this batch's copies / gather
             if item["batch"] and item["failed"] is None:
                 try:
@@ -819,7 +858,8 @@ class Predictor:
                     item["failed"] = e       # sharded: the round still takes part in its gather, with no detections
             finish(item)
             self.stats["launch"] += time.perf_counter() - t0
-            self.stats["launch_cpu"] += time.thread_time() - c0
+            if self._cpu_stats:
+                self.stats["launch_cpu"] += time.thread_time() - c0
             self._mark("launch_done", launched - 1)
 
     @staticmethod
@@ -900,16 +940,18 @@ class Predictor:
                         self._give_back(slot, self._free)
                         return
                     self._mark("read", k)
-                    t0, c0 = time.perf_counter(), time.thread_time()
+                    t0 = time.perf_counter()
+                    c0 = time.thread_time() if self._cpu_stats else 0.0
                     try:
                         batch = self._read_batch(tiles, indices, img, slot, dropped=dropped)
                     except BaseException:
                         self._give_back(slot, self._free)
                         raise
                     self.stats["read"] += time.perf_counter() - t0
-                    with self._stats_lock:
-                        self.stats["read_cpu"] += time.thread_time() - c0
-                        self.stats["tiles"] += len(batch)
+                    if self._cpu_stats:
+                        with self._stats_lock:
+                            self.stats["read_cpu"] += time.thread_time() - c0
+                            self.stats["tiles"] += len(batch)
                     self._mark("read_done", k)
                     ready.put((batch, slot))
                 ready.put((None, None))
@@ -1139,13 +1181,13 @@ class Predictor:
             free.put(slot)
 
     def _release_when_done(self, slot: _Slot, free: "queue.Queue"):
-        _wait_event(slot.event)
+        slot.event.synchronize()
         self._give_back(slot, free)
         return []
 
     def _save_gathered(self, slot: _Slot, pin, j, tile, pred_subdir, tifpath, free: "queue.Queue"):
         try:
-            _wait_event(slot.event)
+            slot.event.synchronize()
             n = int(pin["count"][j])
             if n < 0:           # the owning rank could not crop this tile: dropped, as the reference drops it (prediction.py:174-176)
                 return []
