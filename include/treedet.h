@@ -330,6 +330,11 @@ td_status td_tiff_blocks_to_image_dev(const uint8_t* blocks, int64_t block_cap, 
  * from `file_off` on, read with pread(2) into the dense buffer dst (e.g. pinned staging memory). Returns the bytes read or
  * TD_ERR_INVALID (bad argument, read error, file shorter than the window). Thread-safe (no file position is used). */
 int64_t td_read_window(int fd, int64_t file_off, int64_t row_stride, int64_t row_bytes, int64_t rows, uint8_t* dst);
+/* The windows of a whole batch in one call: window i = rows[i] pieces of row_bytes[i] bytes lying row_stride apart from file_off[i],
+ * read into dst + dst_off[i]; the windows are cut into row bands and spread over `threads` host threads. Returns the bytes read or
+ * TD_ERR_INVALID. */
+int64_t td_read_windows(int fd, int n, const int64_t* file_off, int64_t row_stride, const int64_t* row_bytes, const int64_t* rows,
+                        uint8_t* dst, const int64_t* dst_off, int threads);
 /* Undo TIFF predictor 2 (horizontal differencing) in place on one decoded block of rows x cols pixels with
  * `samples` interleaved samples of 1, 2 or 4 bytes (host byte order). */
 int td_tiff_unpredict(void* data, int64_t rows, int64_t cols, int samples, int bytes_per_sample);

@@ -263,3 +263,28 @@ def test_the_gpu_inflate_source_on_the_host_against_zlib():
     n = lib.td_tiff_inflate(bad.ctypes.data, len(comp), out.ctypes.data, out.size)
     assert n == _lib.ERR_INVALID or out[:max(n, 0)].tobytes() != img          # a flipped byte: refused, or at least not the image
     assert lib.td_tiff_inflate(bad.ctypes.data, 3, out.ctypes.data, out.size) == _lib.ERR_INVALID
+
+
+def test_a_batch_of_windows_in_one_call(tmp_path):
+    """GeoTiff.read_windows_flat (td_read_windows): the windows of a whole batch of an uncompressed raster in one library call, row bands
+    spread over C threads — the same bytes as window-by-window reads; a compressed raster says it cannot (the caller reads per window);
+    a window past the end of the file is an error, not a short read."""
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 255, (4, 300, 500), dtype=np.uint8)
+    path = str(tmp_path / "a.tif")
+    write_geotiff(path, img, T, 25832)
+    g = GeoTiff(path)
+    wins = [(0, 0, 100, 100), (400, 200, 100, 100), (37, 11, 250, 289), (499, 299, 1, 1), (0, 0, 500, 300)]
+    sizes = [w * h * 4 for _, _, w, h in wins]
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).tolist()
+    for threads in (1, 3, 16):
+        out = np.zeros(sum(sizes) + 5, np.uint8)
+        assert g.read_windows_flat(wins, out, offs, threads)
+        for (c0, r0, w, h), o in zip(wins, offs):
+            assert np.array_equal(out[o:o + w * h * 4].reshape(h, w, 4), img[:, r0:r0 + h, c0:c0 + w].transpose(1, 2, 0))
+        assert (out[-5:] == 0).all()
+    with pytest.raises(_lib.TreeDetError if hasattr(_lib, "TreeDetError") else Exception):
+        g.read_windows_flat([(0, 290, 500, 30)], np.zeros(500 * 30 * 4, np.uint8), [0], 2)          # rows 300 .. 319 do not exist
+    packed = str(tmp_path / "b.tif")
+    write_geotiff(packed, img, T, 25832, compression="deflate", tile=(64, 64))
+    assert GeoTiff(packed).read_windows_flat(wins[:1], np.zeros(sizes[0], np.uint8), [0], 2) is False

@@ -93,6 +93,7 @@ SIGNATURES = {
     "td_tiff_inflate_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "td_tiff_lzw_decode_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "td_tiff_blocks_to_image_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "td_read_windows": (C.c_int64, [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "td_tiff_unpredict": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "td_region_relate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "td_simplify_ring": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int]),

@@ -278,3 +278,46 @@ extern "C" int64_t td_read_window(int fd, int64_t file_off, int64_t row_stride, 
     }
     return rows * row_bytes;
 }
+
+// The windows of a whole batch in one call (round 6): window i = rows[i] pieces of row_bytes[i] bytes, row_stride apart from file_off[i],
+// into dst + dst_off[i] — spread over `threads` threads (each window is cut into row bands so that a batch of few, tall windows
+// still fills them). The files-to-files path is bound by the Python work per tile at the fp16 rate; one call per batch replaces
+// eight Python tasks on a thread pool. Returns the bytes read or TD_ERR_INVALID.
+#include <atomic>
+#include <thread>
+extern "C" int64_t td_read_windows(int fd, int n, const int64_t* file_off, int64_t row_stride, const int64_t* row_bytes, const int64_t* rows,
+                                   uint8_t* dst, const int64_t* dst_off, int threads) {
+    if (fd < 0 || n < 0 || (n > 0 && (!file_off || !row_bytes || !rows || !dst || !dst_off)) || row_stride < 0) {
+        td_set_error("td_read_windows: bad argument");
+        return TD_ERR_INVALID;
+    }
+    struct Band { int w; int64_t r0, r1; };
+    std::vector<Band> bands;
+    const int64_t band_rows = 128;
+    for (int i = 0; i < n; ++i) {
+        if (file_off[i] < 0 || row_bytes[i] < 0 || rows[i] < 0 || row_stride < row_bytes[i] || dst_off[i] < 0) {
+            td_set_error("td_read_windows: window %d is malformed", i);
+            return TD_ERR_INVALID;
+        }
+        for (int64_t r = 0; r < rows[i]; r += band_rows) bands.push_back({i, r, r + band_rows < rows[i] ? r + band_rows : rows[i]});
+    }
+    std::atomic<size_t> next{0};
+    std::atomic<int64_t> total{0};
+    std::atomic<int> failed{0};
+    auto work = [&] {
+        for (size_t k = next.fetch_add(1); k < bands.size(); k = next.fetch_add(1)) {
+            const Band& b = bands[k];
+            const int64_t got = td_read_window(fd, file_off[b.w] + b.r0 * row_stride, row_stride, row_bytes[b.w], b.r1 - b.r0,
+                                               dst + dst_off[b.w] + b.r0 * row_bytes[b.w]);
+            if (got < 0) failed.store(1);
+            else total.fetch_add(got);
+        }
+    };
+    const int nt = threads < 1 ? 1 : (threads > (int)bands.size() ? (bands.empty() ? 1 : (int)bands.size()) : threads);
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    if (failed.load()) return TD_ERR_INVALID;          // td_read_window has set the message
+    return total.load();
+}

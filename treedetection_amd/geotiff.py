@@ -551,6 +551,25 @@ class GeoTiff:
         self._mask_outside(hwc, bounds, c0, r0)
         return hwc
 
+    def read_windows_flat(self, windows, out: np.ndarray, out_offs, threads: int = 8) -> bool:
+        """The windows (col_off, row_off, width, height) of a whole batch of an uncompressed, pixel-interleaved raster in ONE library
+        call (td_read_windows: pread per window row, row bands spread over ``threads`` C threads) into the flat array ``out`` at
+        ``out_offs`` (elements). → False when the raster is not of that kind (the caller reads window by window)."""
+        self._setup_blocks()
+        if self._flat is None or getattr(self, "_fd", None) is None or out.dtype != self.dtype or not out.flags.c_contiguous:
+            return False
+        from . import _lib
+        px = self.count * self.dtype.itemsize
+        n = len(windows)
+        foff = np.array([self._flat_off + (r0 * self.width + c0) * px for c0, r0, w, h in windows], dtype=np.int64)
+        rbytes = np.array([w * px for c0, r0, w, h in windows], dtype=np.int64)
+        rows = np.array([h for c0, r0, w, h in windows], dtype=np.int64)
+        doff = np.asarray(out_offs, dtype=np.int64) * self.dtype.itemsize
+        got = _lib.load().td_read_windows(self._fd, n, foff.ctypes.data, self.width * px, rbytes.ctypes.data, rows.ctypes.data, out.ctypes.data,
+                                          doff.ctypes.data, int(threads))
+        _lib.check(got, "td_read_windows")
+        return True
+
     def read_bounds(self, bounds: Sequence[float]) -> np.ndarray:
         """Same window as [bands, rows, cols] (rasterio's axis order)."""
         return np.ascontiguousarray(self.read_bounds_hwc(bounds).transpose(2, 0, 1))
