@@ -26,11 +26,19 @@ def _raster(bands, h, w, seed=0):
     return img
 
 
+@pytest.fixture(params=["large", "small"])
+def ring(request, monkeypatch):
+    """Both LDS footprints of the block decoders (tiffdecode.hip: the ring of recent output — 16 KB / 4 KB for LZW, 32 KB / 8 KB for
+    DEFLATE; the library takes the small one by itself once a raster has more blocks than fit the chip in one round)."""
+    monkeypatch.setenv("TD_DECODE_RING", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("codec", ["lzw", "deflate"])
 @pytest.mark.parametrize("bands", [3, 4, 1])
 @pytest.mark.parametrize("kw", [{"tile": (128, 128)}, {"tile": (64, 256), "predictor": 2}, {"rows_per_strip": 7}, {"rows_per_strip": 1, "predictor": 2},
                                 {"rows_per_strip": 64, "predictor": 2}, {}])
-def test_device_decode_equals_the_host_reader(tmp_path, kw, bands, codec):
+def test_device_decode_equals_the_host_reader(tmp_path, kw, bands, codec, ring):
     img = _raster(bands, 517, 683, seed=bands)
     path = str(tmp_path / "r.tif")
     write_geotiff(path, img, T, 25832, compression=codec, **kw)
@@ -56,7 +64,7 @@ def test_device_decode_of_a_file_written_by_libtiff(tmp_path):
     assert np.array_equal(check().cpu().numpy().transpose(2, 0, 1), img)
 
 
-def test_deflate_streams_of_every_block_type_on_the_device(tmp_path):
+def test_deflate_streams_of_every_block_type_on_the_device(tmp_path, ring):
     """zlib streams as libtiff / GDAL write them at any setting: stored blocks (level 0, and what zlib emits for noise), fixed Huffman
     codes (tiny strips), dynamic codes (levels 1 / 6 / 9), run-length and Huffman-only strategies, matches at the far end of the 32-KB
     window, a file written by libtiff (through Pillow: 'tiff_adobe_deflate'). The device decoder (inflate_core.h, one wave per block)
@@ -118,17 +126,32 @@ def test_deflate_streams_of_every_block_type_on_the_device(tmp_path):
     assert np.array_equal(check().cpu().numpy().transpose(2, 0, 1), rgb)
 
 
-def test_large_blocks_with_many_table_clears_and_incompressible_data(tmp_path):
+def test_large_blocks_with_many_table_clears_and_incompressible_data(tmp_path, ring):
     """One strip = the whole raster (4 MB decoded: hundreds of table clears in one stream), noise (mostly literal codes) and a raster of
     one value (strings up to thousands of bytes, copied 64 bytes per step)."""
     rng = np.random.default_rng(3)
     noise = rng.integers(0, 256, (4, 1000, 1000), dtype=np.uint8)
     flat = np.full((3, 900, 1100), 201, np.uint8)
-    for name, img, kw in (("noise", noise, {}), ("flat", flat, {}), ("flat_tiles", flat, {"tile": (512, 512), "predictor": 2})):
-        path = str(tmp_path / f"{name}.tif")
-        write_geotiff(path, img, T, 25832, compression="lzw", **kw)
+    # a pattern that repeats every 20 000 bytes: every string / match points further back than the small rings hold
+    period = rng.integers(0, 256, 20000, dtype=np.uint8)
+    far = np.resize(period, 3 * 600 * 700).reshape(600, 700, 3).transpose(2, 0, 1).copy()
+    for name, img, kw in (("noise", noise, {}), ("flat", flat, {}), ("flat_tiles", flat, {"tile": (512, 512), "predictor": 2}), ("far", far, {})):
+        for codec in ("lzw", "deflate"):
+            path = str(tmp_path / f"{name}_{codec}.tif")
+            write_geotiff(path, img, T, 25832, compression=codec, **kw)
+            image, check = GeoTiff(path).decode_to_device("cuda:0")
+            assert np.array_equal(check().cpu().numpy().transpose(2, 0, 1), img), (name, codec)
+
+
+def test_rasters_with_more_blocks_than_one_round_take_the_small_ring_by_themselves(tmp_path, monkeypatch):
+    """No override: 1 700 one-row strips (beyond 256 CUs x 6 LZW waves / x 4 DEFLATE waves) → the library picks the small rings."""
+    monkeypatch.delenv("TD_DECODE_RING", raising=False)
+    img = _raster(4, 1700, 640, seed=9)
+    for codec in ("lzw", "deflate"):
+        path = str(tmp_path / f"many_{codec}.tif")
+        write_geotiff(path, img, T, 25832, compression=codec, rows_per_strip=1, predictor=2)
         image, check = GeoTiff(path).decode_to_device("cuda:0")
-        assert np.array_equal(check().cpu().numpy().transpose(2, 0, 1), img), name
+        assert np.array_equal(check().cpu().numpy().transpose(2, 0, 1), img), codec
 
 
 def test_a_corrupt_block_is_reported_and_the_predictor_falls_back(tmp_path, capsys):

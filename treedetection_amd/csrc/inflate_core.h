@@ -2,8 +2,11 @@
 // ONE 64-lane wave per block on the GPU (tiffdecode.hip) and, from the same source, by one host thread (tiffcodec.cpp:
 // td_tiff_inflate, NL = 1): the reference reads such rasters through rasterio → GDAL → zlib on the host, one tile window at
 // a time (TreeDetection/prediction.py:61,164). Symbols are decoded by every lane alike (a DEFLATE stream is sequential);
-// matches are copied 64 bytes per step out of a 32-KB ring of the output — DEFLATE's window — so no copy ever reads memory;
-// the Huffman tables of a block are built by lane 0 (a few thousand operations per 16 - 64 KB of output).
+// matches are copied 64 bytes per step out of a ring of the last RING bytes of the output in LDS (RING = 32 KB = DEFLATE's
+// whole window: no copy ever reads memory; RING = 8 KB: 13 KB per wave, twelve waves per CU instead of four, and the rare match
+// that reaches further back reads the block's output in memory behind a wait for this wave's stores — on imagery matches
+// point at the neighbouring pixels or the row above); the Huffman tables of a block are built by lane 0 (a few thousand
+// operations per 16 - 64 KB of output).
 // Tables: a 10-bit lookup for literal / length codes and an 8-bit one for distance codes (entry = length << 9 | symbol, 0 =
 // longer code), canonical count / symbol arrays for the codes that are longer (decoded bit by bit, as zlib's `puff` does).
 #pragma once
@@ -11,8 +14,13 @@
 
 #ifdef __HIP_DEVICE_COMPILE__
 #define TD_INF_SYNC() __syncthreads()
+// this wave's stores have reached L2; an agent-scope load is served there, never by a stale L1 line
+#define TD_INF_STORES_DONE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define TD_INF_LOAD_OUT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #else
 #define TD_INF_SYNC() ((void)0)
+#define TD_INF_STORES_DONE() ((void)0)
+#define TD_INF_LOAD_OUT(p) (*(p))
 #endif
 #ifdef __HIPCC__
 #define TD_INF_HD __host__ __device__ inline
@@ -20,11 +28,13 @@
 #define TD_INF_HD static inline
 #endif
 
-constexpr int INF_RING = 32768;          // DEFLATE's window
+constexpr int INF_WINDOW = 32768;        // DEFLATE's window
 constexpr int INF_LIT_FAST = 10, INF_DIST_FAST = 8;
 
-struct InflateScratch {                  // LDS on the device (~38 KB: four waves per CU), a plain struct on the host
-    uint8_t ring[INF_RING];
+template <int RING>
+struct InflateScratchT {                 // LDS on the device (RING + 4.6 KB), a plain struct on the host
+    static_assert(RING >= 1024 && (RING & (RING - 1)) == 0 && RING <= INF_WINDOW, "ring size");
+    uint8_t ring[RING];
     uint32_t inbuf[128];                 // two chunks of 64 little-endian dwords of the stream
     uint16_t lit_fast[1 << INF_LIT_FAST];
     uint16_t dist_fast[1 << INF_DIST_FAST];
@@ -32,6 +42,7 @@ struct InflateScratch {                  // LDS on the device (~38 KB: four wave
     uint16_t lit_count[16], dist_count[16];
     uint8_t lens[384];                   // code lengths of the block being set up (19 of the code-length code, then 32 .. 348: literal / length + distance)
 };
+using InflateScratch = InflateScratchT<INF_WINDOW>;
 
 // status: 0 ok, 1 corrupt stream, 2 more bytes than the block holds
 struct InflateResult {
@@ -49,8 +60,8 @@ struct Reader {
     uint32_t end_bit;                    // first bit past the stream (from the aligned base)
 };
 
-template <int NL>
-TD_INF_HD void load_chunk(InflateScratch& S, Reader& r, int lane) {
+template <int NL, typename Scratch>
+TD_INF_HD void load_chunk(Scratch& S, Reader& r, int lane) {
     for (int k = lane; k < 64; k += NL) {
         const uint32_t idx = r.loaded + k;
         S.inbuf[idx & 127] = idx < r.ndw ? r.src32[idx] : 0u;
@@ -60,8 +71,8 @@ TD_INF_HD void load_chunk(InflateScratch& S, Reader& r, int lane) {
 }
 
 // make at least n <= 32 bits available in acc (zeros past the end of the stream: the callers check `overrun`)
-template <int NL>
-TD_INF_HD void ensure(InflateScratch& S, Reader& r, int n, int lane) {
+template <int NL, typename Scratch>
+TD_INF_HD void ensure(Scratch& S, Reader& r, int n, int lane) {
     if (r.have < n) {
         if (r.rd >= r.loaded) load_chunk<NL>(S, r, lane);
         r.acc |= (uint64_t)S.inbuf[r.rd & 127] << r.have;
@@ -78,8 +89,8 @@ TD_INF_HD uint32_t take(Reader& r, int n) {
 TD_INF_HD uint32_t bitpos(const Reader& r) { return r.rd * 32u - (uint32_t)r.have; }
 
 // restart the reader at an absolute bit position (after a stored block)
-template <int NL>
-TD_INF_HD void seek(InflateScratch& S, Reader& r, uint32_t bit, int lane) {
+template <int NL, typename Scratch>
+TD_INF_HD void seek(Scratch& S, Reader& r, uint32_t bit, int lane) {
     TD_INF_SYNC();
     r.rd = bit >> 5;
     r.loaded = r.rd & ~63u;
@@ -133,8 +144,8 @@ TD_INF_HD bool build(const uint8_t* lens, int n, uint16_t* count, uint16_t* sym,
 }
 
 // one symbol: the fast table, else bit by bit over the canonical arrays (codes longer than the table's index)
-template <int NL>
-TD_INF_HD int decode_sym(InflateScratch& S, Reader& r, const uint16_t* fast, int fast_bits, const uint16_t* count, const uint16_t* sym, int lane) {
+template <int NL, typename Scratch>
+TD_INF_HD int decode_sym(Scratch& S, Reader& r, const uint16_t* fast, int fast_bits, const uint16_t* count, const uint16_t* sym, int lane) {
     ensure<NL>(S, r, 15, lane);
     const uint16_t e = fast[r.acc & ((1u << fast_bits) - 1u)];
     if (e) {
@@ -163,8 +174,8 @@ TD_INF_HD int decode_sym(InflateScratch& S, Reader& r, const uint16_t* fast, int
 
 // src: the zlib stream (n bytes); dst: the block's output (cap bytes); every lane of the wave calls this with its lane id
 // (host: NL = 1, lane = 0). The result is the same on every lane.
-template <int NL>
-TD_INF_HD InflateResult inflate_block(InflateScratch& S, const uint8_t* src, int64_t n, uint8_t* dst, uint32_t cap, int lane) {
+template <int NL, int RING>
+TD_INF_HD InflateResult inflate_block(InflateScratchT<RING>& S, const uint8_t* src, int64_t n, uint8_t* dst, uint32_t cap, int lane) {
     using namespace inflate_detail;
     constexpr uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     constexpr uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -200,7 +211,7 @@ TD_INF_HD InflateResult inflate_block(InflateScratch& S, const uint8_t* src, int
                 const uint32_t k = k0 + lane;
                 if (k < len) {
                     const uint8_t v = from[k];
-                    S.ring[(op + k) & (INF_RING - 1)] = v;
+                    S.ring[(op + k) & (RING - 1)] = v;
                     if (op + k < cap) dst[op + k] = v;
                 }
             }
@@ -282,7 +293,7 @@ TD_INF_HD InflateResult inflate_block(InflateScratch& S, const uint8_t* src, int
                 if (s < 0 || bitpos(r) > r.end_bit) return res;
                 if (s < 256) {
                     if (lane == 0) {
-                        S.ring[op & (INF_RING - 1)] = (uint8_t)s;
+                        S.ring[op & (RING - 1)] = (uint8_t)s;
                         if (op < cap) dst[op] = (uint8_t)s;
                     }
                     ++op;
@@ -298,12 +309,25 @@ TD_INF_HD InflateResult inflate_block(InflateScratch& S, const uint8_t* src, int
                 const uint32_t dist = DBASE[ds] + take(r, DEXT[ds]);
                 if (dist > op || bitpos(r) > r.end_bit) return res;
                 // out[op + k] = out[op - dist + (k mod dist)]: every source byte was written before this match began
-                for (uint32_t k0 = 0; k0 < len; k0 += NL) {
-                    const uint32_t k = k0 + lane;
-                    if (k < len) {
-                        const uint8_t v = S.ring[(op - dist + (k % dist)) & (INF_RING - 1)];
-                        S.ring[(op + k) & (INF_RING - 1)] = v;
-                        if (op + k < cap) dst[op + k] = v;
+                if (RING == INF_WINDOW || dist + len + 64 <= (uint32_t)RING) {       // the sources outlive this match's own writes to the ring
+                    for (uint32_t k0 = 0; k0 < len; k0 += NL) {
+                        const uint32_t k = k0 + lane;
+                        if (k < len) {
+                            const uint8_t v = S.ring[(op - dist + (k % dist)) & (RING - 1)];
+                            S.ring[(op + k) & (RING - 1)] = v;
+                            if (op + k < cap) dst[op + k] = v;
+                        }
+                    }
+                } else {                                    // sources that have left the ring: the block's output in memory
+                    TD_INF_STORES_DONE();
+                    for (uint32_t k0 = 0; k0 < len; k0 += NL) {
+                        const uint32_t k = k0 + lane;
+                        if (k < len) {
+                            const uint32_t from = op - dist + (k % dist);
+                            const uint8_t v = from < cap ? TD_INF_LOAD_OUT(dst + from) : (uint8_t)0;     // (past cap: the block fails with status 2 anyway)
+                            S.ring[(op + k) & (RING - 1)] = v;
+                            if (op + k < cap) dst[op + k] = v;
+                        }
                     }
                 }
                 op += len;

@@ -173,7 +173,7 @@ extern "C" int64_t td_tiff_inflate(const uint8_t* src, int64_t n, uint8_t* dst, 
         td_set_error("td_tiff_inflate: bad argument");
         return TD_ERR_INVALID;
     }
-    static thread_local InflateScratch scratch;
+    static thread_local InflateScratchT<8192> scratch;       // (the ring the device uses on large rasters: its far-match path runs here too)
     // the core reads whole dwords from the 4-byte-aligned address below src up to the dword that holds the stream's last byte: copy
     // the stream into a padded, aligned buffer so that a caller's tight buffer is never over-read
     std::vector<uint32_t> padded((size_t)(n + 8) / 4 + 2, 0u);

@@ -13,6 +13,8 @@
 // LDS reads (two per code), not by HBM: 1 byte written per byte decoded, the compressed bytes read once.
 #include "common.h"
 #include "inflate_core.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -32,9 +34,9 @@ __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap
 // the epoch's start as uint16 (8 KB; an epoch whose output outgrows 16 bits — flat rasters — flags its block for the second
 // launch, the same kernel with a uint32 table), literals are strings of a 256-byte identity table so that every code takes the
 // same copy path, and the common case is one branch-free stretch: profiles/r06_lzw.txt has the measured rates of each step.
-constexpr int LZW_RING = 16384;                            // bytes of recent output kept in LDS
-constexpr int LZW_LIT = LZW_RING;                          // the identity table follows the ring: ring_lit[LZW_LIT + c] = c
-template <typename TableT, bool SECOND>
+// LZW_RING bytes of recent output are kept in LDS: 16 KB (25 KB per wave: six waves per CU) while a raster's blocks fit the chip
+// in one round, 4 KB (13 KB: twelve waves per CU) beyond — a block's latency is the same, so a launch lasts rounds x latency.
+template <typename TableT, bool SECOND, int LZW_RING>
 __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ block_off,
                                                              const int64_t* __restrict__ block_nbytes, uint8_t* __restrict__ out,
                                                              int64_t block_cap, int64_t* __restrict__ decoded,
@@ -42,6 +44,7 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
     __shared__ __attribute__((aligned(8))) TableT t_start[LZW_MAX + 4];               // start of entry k relative to the epoch's start; len(k) = t[k + 1] - t[k] + 1
     __shared__ uint32_t inbuf[128];                       // two chunks of 64 big-endian dwords of the compressed stream
     __shared__ uint8_t ring_lit[LZW_RING + 256];
+    constexpr int LZW_LIT = LZW_RING;                      // the identity table follows the ring: ring_lit[LZW_LIT + c] = c
     const int lane = threadIdx.x;
     constexpr uint32_t REL_MAX = sizeof(TableT) == 2 ? 65535u - 4096u : 0xffffffffu;
     // first launch: block = blockIdx.x. Second launch (wide table): a few resident waves walk the list of blocks the first one
@@ -171,13 +174,15 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
     }
 }
 
-// DEFLATE blocks (TIFF compression 8 / 32946: zlib streams), one wave per block: inflate_core.h. LDS: the 32-KB window + tables
-// (38 KB: four waves per CU); every match is copied out of the window in LDS, literals and matches go to memory as byte stores.
+// DEFLATE blocks (TIFF compression 8 / 32946: zlib streams), one wave per block: inflate_core.h. LDS: a ring of the output +
+// tables — the whole 32-KB window (37 KB: four waves per CU) while the blocks fit the chip in one round, 8 KB (13 KB: twelve
+// waves per CU) beyond; literals and matches go to memory as byte stores.
+template <int RING>
 __global__ __launch_bounds__(64) void tiff_inflate_blocks_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ block_off,
                                                                  const int64_t* __restrict__ block_nbytes, uint8_t* __restrict__ out,
                                                                  int64_t block_cap, int64_t* __restrict__ decoded,
                                                                  int32_t* __restrict__ status) {
-    __shared__ InflateScratch S;
+    __shared__ InflateScratchT<RING> S;
     const int b = blockIdx.x;
     const InflateResult r = inflate_block<64>(S, comp + block_off[b], block_nbytes[b], out + (int64_t)b * block_cap, (uint32_t)block_cap,
                                               (int)threadIdx.x);
@@ -234,6 +239,21 @@ __global__ __launch_bounds__(SC_THREADS) void tiff_blocks_to_image_kernel(const 
         }
 }
 
+// Which ring: the small one as soon as the blocks no longer fit the chip in one round with the large one (256 CUs x the waves
+// the large footprint allows). TD_DECODE_RING = small | large overrides (measurements: tools/raster_decode_bench.py).
+int ring_override() {
+    const char* e = getenv("TD_DECODE_RING");
+    return !e ? -1 : (!strcmp(e, "small") ? 1 : (!strcmp(e, "large") ? 0 : -1));
+}
+int lzw_ring_choice(int nblocks) {
+    const int o = ring_override();
+    return o >= 0 ? o : nblocks > 256 * 6;
+}
+int inflate_ring_choice(int nblocks) {
+    const int o = ring_override();
+    return o >= 0 ? o : nblocks > 256 * 4;
+}
+
 }  // namespace
 
 extern "C" td_status td_tiff_lzw_decode_dev(const uint8_t* comp, const int64_t* block_off, const int64_t* block_nbytes, int nblocks,
@@ -247,10 +267,15 @@ extern "C" td_status td_tiff_lzw_decode_dev(const uint8_t* comp, const int64_t* 
     hipStream_t s = static_cast<hipStream_t>(stream);
     int* wide_list = reinterpret_cast<int*>(status) + nblocks;      // status has room for 2 * nblocks + 1 ints (include/treedet.h)
     TD_HIP_CHECK(hipMemsetAsync(wide_list, 0, sizeof(int), s));
-    hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint16_t, false>), dim3(nblocks), dim3(64), 0, s, comp, block_off, block_nbytes, blocks_out,
-                       block_cap, decoded, status, nblocks, wide_list);
+    const int small_ring = lzw_ring_choice(nblocks);
+    if (small_ring)
+        hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint16_t, false, 4096>), dim3(nblocks), dim3(64), 0, s, comp, block_off, block_nbytes,
+                           blocks_out, block_cap, decoded, status, nblocks, wide_list);
+    else
+        hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint16_t, false, 16384>), dim3(nblocks), dim3(64), 0, s, comp, block_off, block_nbytes,
+                           blocks_out, block_cap, decoded, status, nblocks, wide_list);
     TD_KERNEL_CHECK();
-    hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint32_t, true>), dim3(nblocks < 1024 ? nblocks : 1024), dim3(64), 0, s, comp, block_off,
+    hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint32_t, true, 16384>), dim3(nblocks < 1024 ? nblocks : 1024), dim3(64), 0, s, comp, block_off,
                        block_nbytes, blocks_out, block_cap, decoded, status, nblocks, wide_list);
     TD_KERNEL_CHECK();
     return TD_OK;
@@ -262,8 +287,12 @@ extern "C" td_status td_tiff_inflate_dev(const uint8_t* comp, const int64_t* blo
     TD_REQUIRE(nblocks >= 0 && block_cap >= 1 && block_cap < ((int64_t)1 << 31), "td_tiff_inflate_dev: %d blocks of %lld bytes", nblocks,
                (long long)block_cap);
     if (nblocks == 0) return TD_OK;
-    hipLaunchKernelGGL(tiff_inflate_blocks_kernel, dim3(nblocks), dim3(64), 0, static_cast<hipStream_t>(stream), comp, block_off, block_nbytes,
-                       blocks_out, block_cap, decoded, status);
+    if (inflate_ring_choice(nblocks))
+        hipLaunchKernelGGL(tiff_inflate_blocks_kernel<8192>, dim3(nblocks), dim3(64), 0, static_cast<hipStream_t>(stream), comp, block_off,
+                           block_nbytes, blocks_out, block_cap, decoded, status);
+    else
+        hipLaunchKernelGGL(tiff_inflate_blocks_kernel<INF_WINDOW>, dim3(nblocks), dim3(64), 0, static_cast<hipStream_t>(stream), comp, block_off,
+                           block_nbytes, blocks_out, block_cap, decoded, status);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
