@@ -4,7 +4,9 @@ The reference reads rasters through rasterio/GDAL (``rasterio.open`` + ``rasteri
 TreeDetection/prediction.py:61,164); neither is installed here. The tile loader needs windowed reads of classic or
 BigTIFF rasters — strips or tiles, pixel-interleaved or planar, 8/16/32-bit integer or float samples, uncompressed or
 DEFLATE (zlib) / LZW / PackBits (td_tiff_*_decode in libtreedet_hip.so), horizontal-differencing predictor — plus the
-three geo tags (ModelPixelScale / ModelTiepoint / GeoKeyDirectory). Other codecs (JPEG, ...) fall back to Pillow.
+three geo tags (ModelPixelScale / ModelTiepoint / GeoKeyDirectory). JPEG-in-TIFF (compression 7, 8-bit, one or three bands)
+is windowed too: a block's abbreviated stream + the JPEGTables tag form one JPEG stream, decoded by Pillow's libjpeg block by
+block (GDAL does the same through libtiff). Other codecs (old-style JPEG, floating-point predictor, ...): whole image through Pillow.
 """
 from __future__ import annotations
 
@@ -164,9 +166,42 @@ class GeoTiff:
                     # windows are read with pread (td_read_window): no page fault per window row, no munmap of a touched
                     # mapping at close; the map stays for whole-raster reads and foreign byte orders
                     self._fd, self._flat_off = os.open(self.path, os.O_RDONLY), offs[0]
-        if self.compression not in (1, 5, 8, 32946, 32773) or self._predictor not in (1, 2):
+        if self.compression == 7 and self._jpeg_blocks_ok():
+            tb = bytes(bytearray(int(v) for v in t.get(347, [])))
+            self._jpeg_tables = tb if len(tb) >= 4 and tb[:2] == b"\xff\xd8" and tb[-2:] == b"\xff\xd9" else b""
+        elif self.compression not in (1, 5, 8, 32946, 32773) or self._predictor not in (1, 2):
             self._pil_fallback()
         self._blocks_ready = True
+
+    def _jpeg_blocks_ok(self) -> bool:
+        """New-style JPEG blocks this reader decodes one by one: 8-bit chunky samples, grey or three bands (RGB or YCbCr)."""
+        return (self.dtype == np.uint8 and self.planar == 1 and self.count in (1, 3) and self._predictor == 1
+                and int(self.tags.get(262, [2 if self.count == 3 else 1])[0]) in (1, 2, 6))
+
+    def _decode_jpeg_block(self, raw: bytes, rows: int) -> np.ndarray:
+        """One strip / tile of a compression-7 raster → uint8 [rows, bw, bands]. TIFF Technical Note 2: the block is an abbreviated JPEG
+        stream (SOI, frame and scan headers, entropy-coded data, EOI); the quantisation / Huffman tables it leaves out are in the
+        JPEGTables tag (SOI, DQT / DHT segments, EOI) — tables minus its EOI + block minus its SOI is a complete stream. The colour
+        space is NOT in the stream (no JFIF header): libtiff tells libjpeg from PhotometricInterpretation; here an Adobe APP14 segment
+        (transform 0 = as stored, 1 = YCbCr) says the same thing to Pillow's libjpeg."""
+        import io
+        from PIL import Image
+        data = bytes(raw)
+        if data[:2] != b"\xff\xd8":
+            raise ValueError(f"{self.path}: a JPEG block does not start with SOI")
+        head = b"\xff\xd8"
+        if self.count == 3 and b"JFIF\0" not in data[:32]:
+            ycc = int(self.tags.get(262, [2])[0]) == 6
+            head += b"\xff\xee\x00\x0eAdobe\x00\x64\x00\x00\x00\x00" + (b"\x01" if ycc else b"\x00")
+        stream = head + self._jpeg_tables[2:-2] + data[2:]
+        with Image.open(io.BytesIO(stream)) as im:
+            if im.format != "JPEG" or im.mode not in ("L", "RGB"):
+                raise ValueError(f"{self.path}: a JPEG block decodes to mode {im.mode}")
+            arr = np.asarray(im)
+        arr = arr[:, :, None] if arr.ndim == 2 else arr
+        if arr.shape[0] < rows or arr.shape[1] != self._bw or arr.shape[2] != self.count:
+            raise ValueError(f"{self.path}: a JPEG block decodes to {arr.shape}, expected at least ({rows}, {self._bw}, {self.count})")
+        return arr[:rows]
 
     def _pil_fallback(self) -> None:
         """Codecs this reader does not implement (JPEG, floating-point predictor, ...): whole image through Pillow."""
@@ -227,6 +262,8 @@ class GeoTiff:
         cnt = self._counts[idx] if self._counts is not None else nbytes
         raw = self._mm[off:off + cnt]
         comp = self.compression
+        if comp == 7:
+            return self._decode_jpeg_block(raw, rows)
         if comp == 1:
             buf = np.asarray(raw[:nbytes])
         elif comp in (8, 32946):
@@ -583,6 +620,16 @@ class _NullCtx:
         return False
 
 
+def _jpeg_block(blk: np.ndarray, quality: int = 90) -> bytes:
+    """One strip / tile as a COMPLETE JPEG stream (its own tables: the JPEGTables tag is optional, TIFF Technical Note 2), YCbCr 4:2:0
+    for three bands — Pillow's libjpeg encoder. Lossy: a test fixture for the windowed JPEG reader, not an archive format."""
+    import io
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(blk[:, :, 0] if blk.shape[2] == 1 else blk).save(buf, "JPEG", quality=quality, subsampling=2 if blk.shape[2] == 3 else 0)
+    return buf.getvalue()
+
+
 def write_geotiff(path: str, data: np.ndarray, transform: Sequence[float], epsg: int = 25832, *,
                   tile: Optional[Tuple[int, int]] = None, rows_per_strip: Optional[int] = None,
                   compression: Optional[str] = None, predictor: int = 1, planar: bool = False,
@@ -590,15 +637,16 @@ def write_geotiff(path: str, data: np.ndarray, transform: Sequence[float], epsg:
     """Classic little-endian TIFF with the GeoTIFF tags the reader understands. data: [bands, rows, cols] or
     [rows, cols]; uint8 / uint16 / float32. Defaults: one uncompressed pixel-interleaved strip (what the tile reader
     maps without copying). Options: ``tile=(tile_rows, tile_cols)`` (multiples of 16) or ``rows_per_strip``,
-    ``compression`` None / "deflate" / "lzw" (td_tiff_lzw_encode, blocks encoded on host threads), ``predictor`` 1 / 2
+    ``compression`` None / "deflate" / "lzw" (td_tiff_lzw_encode, blocks encoded on host threads) / "jpeg" (lossy; Pillow's encoder per
+    block), ``predictor`` 1 / 2
     (horizontal differencing, integer samples), ``planar`` (one block grid per band)."""
     arr = np.asarray(data)
     if arr.ndim == 2:
         arr = arr[None]
     C, H, W = arr.shape
     fmt = {np.dtype(np.uint8): (1, 8), np.dtype(np.uint16): (1, 16), np.dtype(np.float32): (3, 32)}[arr.dtype]
-    if compression not in (None, "deflate", "lzw"):
-        raise ValueError("compression must be None, 'deflate' or 'lzw'")
+    if compression not in (None, "deflate", "lzw", "jpeg"):
+        raise ValueError("compression must be None, 'deflate', 'lzw' or 'jpeg'")
     if predictor not in (1, 2) or (predictor == 2 and fmt[0] != 1):
         raise ValueError("predictor 2 needs integer samples")
     hwc = np.ascontiguousarray(arr.transpose(1, 2, 0)).astype(arr.dtype.newbyteorder("<"), copy=False)
@@ -608,6 +656,8 @@ def write_geotiff(path: str, data: np.ndarray, transform: Sequence[float], epsg:
             raise ValueError("tile sides must be multiples of 16")
     else:
         bh, bw = int(rows_per_strip or H), W
+    if compression == "jpeg" and (planar or predictor != 1 or arr.dtype != np.uint8 or C not in (1, 3) or bh % 16):
+        raise ValueError("jpeg: uint8 grey / three-band chunky rasters, no predictor, block heights in multiples of 16")
     ny, nx = (H + bh - 1) // bh, (W + bw - 1) // bw
     blocks = []
     for p in range(C if planar else 1):
@@ -620,6 +670,9 @@ def write_geotiff(path: str, data: np.ndarray, transform: Sequence[float], epsg:
                 blk[:piece.shape[0], :piece.shape[1]] = piece
                 if predictor == 2:
                     blk[:, 1:] = blk[:, 1:] - blk[:, :-1]          # modulo the sample width
+                if compression == "jpeg":
+                    blocks.append(_jpeg_block(blk))
+                    continue
                 raw = blk.tobytes()
                 blocks.append(zlib.compress(raw, 6) if compression == "deflate" else raw)
     if compression == "lzw":
@@ -648,8 +701,8 @@ def write_geotiff(path: str, data: np.ndarray, transform: Sequence[float], epsg:
     add(256, 4, [W])
     add(257, 4, [H])
     add(258, 3, [fmt[1]] * C)
-    add(259, 3, [{"deflate": 8, "lzw": 5}.get(compression, 1)])
-    add(262, 3, [2 if C >= 3 else 1])
+    add(259, 3, [{"deflate": 8, "lzw": 5, "jpeg": 7}.get(compression, 1)])
+    add(262, 3, [(6 if compression == "jpeg" else 2) if C >= 3 else 1])
     add(277, 3, [C])
     add(284, 3, [2 if planar else 1])
     if predictor == 2:
@@ -666,6 +719,8 @@ def write_geotiff(path: str, data: np.ndarray, transform: Sequence[float], epsg:
     if C > 3:
         add(338, 3, [0] * (C - 3))
     add(339, 3, [fmt[0]] * C)
+    if compression == "jpeg" and C == 3:
+        add(530, 3, [2, 2])                    # YCbCrSubSampling: 4:2:0, what _jpeg_block encodes
     add(33550, 12, [a, -e, 0.0])
     add(33922, 12, [0.0, 0.0, 0.0, c, f, 0.0])
     add(34735, 3, [1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, int(epsg)])
