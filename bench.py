@@ -249,6 +249,7 @@ def compact_line(full):
             "e2e_crowns_json_kb_per_tile": _r((full.get("e2e_crowns", {}).get("f32", {}).get("json_bytes_per_tile") or 0) / 1e3) or None,
             "e2e_lzw_f16": val("lzw", "f16", "device", "value"), "e2e_lzw_f16_ratio": val("lzw", "f16", "device", "ratio_to_model_stage"),
             "e2e_lzw_host_reader_f16": val("lzw", "f16", "host_reader", "value"),
+            "e2e_lzw_same_raster_uncompressed_f16": val("lzw", "f16", "uncompressed", "value"),
             "lzw_decode_windows_450_per_s": val("lzw", "f16", "decode_windows_450x450x4_per_s"), "lzw_decode_gb_per_s": val("lzw", "f16", "decode_gbytes_per_s"),
             "lzw_kernel_gb_per_s": val("lzw", "f16", "kernel_gbytes_per_s")}
     c["regions"] = {k: v for k, v in scal.items() if v is not None}
@@ -842,19 +843,27 @@ def main():
                    "raw_bytes": raw_bytes, "file_bytes": file_bytes, "compression_ratio": raw_bytes / file_bytes, "encode_seconds": t_enc,
                    "decode_seconds": t_dec, "decode_calls_s": times, "decode_gbytes_per_s": raw_bytes / t_dec / 1e9,
                    "decode_windows_450x450x4_per_s": raw_bytes / t_dec / (450 * 450 * 4), "tiles_per_image": ntiles}
-            for mode, dd, imgs in (("device", "auto", names), ("host_reader", False, names[:1])):
+            # the same pixels stored uncompressed (one strip): what the 450-px walk does when no decode is in the way
+            raw_tif = f"{root}/raw/324125000.tif"
+            os.makedirs(f"{root}/raw")
+            write_geotiff(raw_tif, GeoTiff(tif).read(), (0.2, 0.0, 412000.0, 0.0, -0.2, 5318000.0 + px * 0.2), 25832)
+            for nm in names:
+                os.link(raw_tif, f"{root}/raw/{nm}.tif")
+            for mode, dd, imgs in (("device", "auto", names), ("host_reader", False, names[:1]), ("uncompressed", "auto", names)):
+                src_dir = "raw" if mode == "uncompressed" else "rgb"
+                tif_w = raw_tif if mode == "uncompressed" else tif
                 pred = T.Predictor(cfg, device_type=str(local_rank), max_batch_size=B, output_dir=f"{root}/out_{mode}", precision=precision,
                                    state_dict=sd_w, return_predictions=False, device_decode=dd)
                 try:
-                    pred.prefetch(tif)
-                    pred(tif, tjson)                   # warm-up image
+                    pred.prefetch(tif_w)
+                    pred(tif_w, tjson)                 # warm-up image
                     t0 = time.perf_counter()
                     pending = None
-                    pred.prefetch(f"{root}/rgb/{imgs[0]}.tif")
+                    pred.prefetch(f"{root}/{src_dir}/{imgs[0]}.tif")
                     for k, nm in enumerate(imgs):
                         if k + 1 < len(imgs):
-                            pred.prefetch(f"{root}/rgb/{imgs[k + 1]}.tif")
-                        h = pred.submit(f"{root}/rgb/{nm}.tif", f"{root}/tiles/{nm}.json")
+                            pred.prefetch(f"{root}/{src_dir}/{imgs[k + 1]}.tif")
+                        h = pred.submit(f"{root}/{src_dir}/{nm}.tif", f"{root}/tiles/{nm}.json")
                         if pending is not None:
                             pending.result()
                         pending = h
@@ -868,7 +877,8 @@ def main():
                     pred.close()
                     shutil.rmtree(f"{root}/out_{mode}", ignore_errors=True)
             log(f"lzw region ({precision}): decode {t_dec * 1e3:.1f} ms per {raw_bytes / 1e6:.0f} MB raster ({res['decode_windows_450x450x4_per_s']:.0f} windows of 450x450x4 per s), "
-                f"files to files {res['device']['value']:.0f} tiles/s on the device decoder, {res['host_reader']['value']:.0f} through the host reader")
+                f"files to files {res['device']['value']:.0f} tiles/s on the device decoder, {res['host_reader']['value']:.0f} through the host reader, "
+                f"{res['uncompressed']['value']:.0f} on the same raster stored uncompressed")
             return res
         finally:
             shutil.rmtree(root, ignore_errors=True)

@@ -354,6 +354,11 @@ int td_tile_polygons_json_dev(const int16_t* points, int64_t points_cap, const i
  * first == last for a ring; writes the kept vertices (a subsequence, closed again) to out_xy (capacity out_cap
  * pairs) and returns their number (>= 4 for a ring of >= 4 points), or a negative status. Host code only. */
 int td_simplify_ring(const double* xy, int n, double tolerance, double* out_xy, int out_cap);
+
+/* OGC validity of one closed polygon shell (n points, first == last) as GEOS decides it: 1 valid, 0 invalid (self-touching,
+ * self-crossing, spikes, fewer than three distinct points, non-finite coordinates), < 0 error. Replaces `geom.is_valid` on the
+ * fused crowns, reference TreeDetection/helpers.py:816,819. Host code. */
+int td_ring_is_valid(const double* xy, int n);
 /* One tile's prediction file → the features it contributes to the image's layer (helpers.py:436-470,
  * process_prediction_file_sync): parse the JSON array the predictor wrote (`json` / `len`, UTF-8 text), take
  * "score" and "polygon_coords" of every entry (coordinates flattened and paired like reshape(-1, 2); fewer than 4

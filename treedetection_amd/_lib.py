@@ -97,6 +97,7 @@ SIGNATURES = {
     "td_tiff_unpredict": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "td_region_relate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "td_simplify_ring": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int]),
+    "td_ring_is_valid": (C.c_int, [C.c_void_p, C.c_int]),
     "td_stitch_tile_json": (C.c_int, [C.c_char_p, C.c_int64, C.POINTER(C.c_double), C.c_double, C.c_int32, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "td_stitch_tile_files": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int64,

@@ -156,6 +156,52 @@ struct Simplifier {
 
 }  // namespace
 
+// OGC validity of a polygon shell as GEOS' IsValidOp decides it for one ring (reference helpers.py:816 `geom.is_valid` on every
+// fused crown): finite coordinates, closed, at least four points of which three are distinct, and no two segments meeting
+// anywhere but at the shared end point of consecutive ones — a ring that touches itself at a vertex, crosses itself, or runs
+// back over itself (a spike) is invalid. Repeated consecutive points are allowed. Exact-sign orientation tests; O(n^2) pairs
+// behind an envelope test (crowns have tens of vertices).
+extern "C" int td_ring_is_valid(const double* xy, int n) {
+    using namespace tdgeom;
+    if (!xy || n < 0) {
+        td_set_error("td_ring_is_valid: bad argument");
+        return TD_ERR_INVALID;
+    }
+    if (n < 4) return 0;
+    for (int i = 0; i < 2 * n; ++i)
+        if (!std::isfinite(xy[i])) return 0;
+    if (xy[0] != xy[2 * (n - 1)] || xy[1] != xy[2 * (n - 1) + 1]) return 0;
+    std::vector<Pt> p;                                   // the ring without its closing point and without repeated points
+    for (int i = 0; i + 1 < n; ++i) {
+        const Pt q{xy[2 * i], xy[2 * i + 1]};
+        if (p.empty() || !(p.back() == q)) p.push_back(q);
+    }
+    while (p.size() > 1 && p.back() == p.front()) p.pop_back();
+    const int m = (int)p.size();
+    if (m < 3) return 0;
+    auto at = [&](int i) -> const Pt& { return p[(i % m + m) % m]; };
+    for (int i = 0; i < m; ++i) {
+        const Pt &a = at(i), &b = at(i + 1);
+        // consecutive segments share b: they may not overlap (c back on the line a - b, towards a)
+        const Pt& c = at(i + 2);
+        if (orientation(a.x, a.y, b.x, b.y, c.x, c.y) == 0) {
+            const double dot = (a.x - b.x) * (c.x - b.x) + (a.y - b.y) * (c.y - b.y);
+            if (dot > 0) return 0;
+        }
+        for (int j = i + 2; j < m; ++j) {
+            if (i == 0 && j == m - 1) continue;          // the closing segment is consecutive to the first
+            const Pt &q1 = at(j), &q2 = at(j + 1);
+            if (!env_overlap(a, b, q1, q2)) continue;
+            const int o1 = orientation(a.x, a.y, b.x, b.y, q1.x, q1.y), o2 = orientation(a.x, a.y, b.x, b.y, q2.x, q2.y);
+            if (o1 * o2 > 0) continue;
+            const int o3 = orientation(q1.x, q1.y, q2.x, q2.y, a.x, a.y), o4 = orientation(q1.x, q1.y, q2.x, q2.y, b.x, b.y);
+            if (o3 * o4 > 0) continue;
+            return 0;                                    // they meet: crossing, touching, or collinear overlap (envelopes overlap)
+        }
+    }
+    return 1;
+}
+
 extern "C" int td_simplify_ring(const double* xy, int n, double tolerance, double* out_xy, int out_cap) {
     if (!xy || !out_xy || n < 0 || out_cap < 0 || !(tolerance >= 0.0)) {
         td_set_error("td_simplify_ring: bad argument");

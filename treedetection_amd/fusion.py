@@ -6,9 +6,14 @@ not *within* it; either layer alone passes through unchanged when the other is e
 predicates against ``unary_union`` of the outline polygons near the image (geopandas/shapely, absent here); this
 module evaluates them against the polygons themselves with ``td_region_relate`` (libtreedet_hip.so, host code), which
 gives the same answers without building the union. ``to_crs``: treedetection_amd.crs moves the OUTLINE into the crowns' CRS
-(geographic / UTM / Web Mercator codes; any other pair is refused with an error instead of guessed). Not reproduced: the
-``buffer(0)`` / ``make_valid`` repair of invalid rings (crowns come from border following + simplification and are written
-as they are).
+(geographic / UTM / Web Mercator codes; any other pair is refused with an error instead of guessed).
+
+Invalid geometries. The reference repairs an invalid OUTLINE with ``make_valid`` (helpers.py:740-751): GEOS rebuilds the area from
+the noded linework, i.e. a point is inside when a ray from it crosses the polygon's rings an odd number of times — which is how
+``td_region_relate`` decides membership in the first place (odd crossing count over ALL rings of a polygon), so a bow-tie or an
+overlapping-hole outline answers as its repaired form would. Every fused CROWN that is not valid goes through ``buffer(0)``
+(helpers.py:815-817): treedetection_amd.validity restates both (td_ring_is_valid; the depth-labelled arrangement of BufferOp) —
+a crown with a one-pixel neck comes out as a MultiPolygon, a spike disappears.
 """
 from __future__ import annotations
 
@@ -20,6 +25,7 @@ import numpy as np
 
 from .gpkg import read_layer, write_blobs
 from .recoveries import load_fusion_recovery, save_fusion_recovery
+from .validity import buffer0, geometry_blob, ring_is_valid
 from .vector import Region, read_polygon_layer
 
 
@@ -107,11 +113,28 @@ def fuse_predictions(urban_fold, forrest_fold, forrest_path, output_dir, logger=
                 keep_f = np.zeros(len(forest), bool)
                 keep_u = np.ones(len(urban), bool)
             blobs = [forest.blob(i) for i in np.nonzero(keep_f)[0]] + [urban.blob(i) for i in np.nonzero(keep_u)[0]]
+            env = np.concatenate([fe[keep_f], ue[keep_u]])
+            # reference helpers.py:815-817: `geom.buffer(0) if not geom.is_valid else geom` on every fused crown
+            f_rings, u_rings = forest.rings(), urban.rings()
+            kept_rings = [f_rings[i] for i in np.nonzero(keep_f)[0]] + [u_rings[i] for i in np.nonzero(keep_u)[0]]
+            repaired = 0
+            for k, ring in enumerate(kept_rings):
+                if len(ring) and not ring_is_valid(ring):
+                    polys = buffer0(ring)
+                    blobs[k] = geometry_blob(polys, forest.srs_id)
+                    if polys:
+                        pts = np.concatenate([r for p_ in polys for r in p_])
+                        env[k] = (pts[:, 0].min(), pts[:, 0].max(), pts[:, 1].min(), pts[:, 1].max())
+                    else:
+                        env[k] = np.nan
+                    repaired += 1
+            if repaired and logger:
+                logger.debug(f"{repaired} invalid crown geometries repaired (buffer(0)) in {name}")
             cols = {}
             for c in forest.columns:
                 if c in urban.columns:
                     cols[c] = [forest.columns[c][i] for i in np.nonzero(keep_f)[0]] + [urban.columns[c][i] for i in np.nonzero(keep_u)[0]]
-            env = np.concatenate([fe[keep_f], ue[keep_u]])
+            env = env[~np.isnan(env[:, 0])]
             extent = (float(env[:, 0].min()), float(env[:, 2].min()), float(env[:, 1].max()), float(env[:, 3].max())) if len(env) else None
             write_blobs(out_path, blobs, cols, forest.srs_id, extent)
             if logger:
