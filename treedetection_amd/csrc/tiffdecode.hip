@@ -36,7 +36,7 @@ __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap
 // same copy path, and the common case is one branch-free stretch: profiles/r06_lzw.txt has the measured rates of each step.
 // LZW_RING bytes of recent output are kept in LDS: 16 KB (25 KB per wave: six waves per CU) while a raster's blocks fit the chip
 // in one round, 4 KB (13 KB: twelve waves per CU) beyond — a block's latency is the same, so a launch lasts rounds x latency.
-template <typename TableT, bool SECOND, int LZW_RING>
+template <typename TableT, bool SECOND, int LZW_RING, bool FAST>
 __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ block_off,
                                                              const int64_t* __restrict__ block_nbytes, uint8_t* __restrict__ out,
                                                              int64_t block_cap, int64_t* __restrict__ decoded,
@@ -72,7 +72,98 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
     int err = 0;
     uint32_t slow = 0;                                      // codes that went through memory instead of the ring (diagnostic: decoded[b] >> 32)
     __syncthreads();
+    uint32_t hold = 0;                                     // codes left to the one-by-one path before the next chunk attempt
     for (;;) {
+        if (FAST && hold == 0 && old_len != 0 && next + 64 < LZW_MAX && op - epoch <= REL_MAX) {
+            // ---- 64 codes at once -------------------------------------------------------------------------------------------
+            // Between two ClearCodes the WIDTH of a code depends only on how many codes came before it (the table grows by one
+            // entry per code), so the 64 lanes cut the next 64 codes out of the stream at once; a string's length is the
+            // distance of two table positions, its start a prefix sum over the lanes — the table arithmetic of 64 codes costs
+            // what one code costs in the loop below. What stays sequential is the copying (a string may begin in the bytes
+            // its predecessor just wrote), but with everything it needs already in registers: four lane reads, one LDS read,
+            // one LDS write, one store per code. The chunk ends early at a ClearCode / EOI / the end of the input / a code the
+            // table cannot hold yet, at a string the one-step copy does not take (longer than 64 bytes, or from beyond the
+            // ring), and where lengths inside the chunk depend on each other more than three deep; those codes take the loop
+            // below, one by one.
+            while (((bitpos + 64u * 12u) >> 5) + 1u >= loaded) {
+                const uint32_t idx = loaded + lane;
+                inbuf[idx & 127] = idx < ndw ? bswap32(src32[idx]) : 0u;
+                loaded += 64;
+                __syncthreads();
+                safe = op;
+            }
+            const uint32_t c0 = (uint32_t)next - 257u;     // this chunk's first code is the c0-th since the ClearCode (c0 >= 1)
+            const uint32_t idx = c0 + lane;
+            auto bits_before = [](uint32_t i) {            // bits of the codes 0 .. i - 1 of a table epoch: 9 each, one more from the 254th, 766th, 1790th on
+                return 9u * i + (i > 254u ? i - 254u : 0u) + (i > 766u ? i - 766u : 0u) + (i > 1790u ? i - 1790u : 0u);
+            };
+            const uint32_t my_bits = 9u + (idx >= 254u) + (idx >= 766u) + (idx >= 1790u);
+            const uint32_t off = bitpos + bits_before(idx) - bits_before(c0);
+            const uint32_t dwl = off >> 5;
+            const uint64_t twol = ((uint64_t)inbuf[dwl & 127] << 32) | inbuf[(dwl + 1) & 127];
+            const uint32_t code = (uint32_t)((twol >> (64 - (off & 31) - my_bits)) & ((1u << my_bits) - 1u));
+            const bool stop = (code - (uint32_t)LZW_CLEAR) < 2u || off + my_bits > end_bit || code > 257u + idx;
+            const uint64_t stops = __ballot(stop);
+            uint32_t n = stops ? (uint32_t)__builtin_ctzll(stops) : 64u;
+            const bool lit = code < 256u;
+            const uint32_t e = code - 258u;                // the table entry: string(e-th code) + first byte of the (e + 1)-th
+            const bool inchunk = !lit && e >= c0 && (uint32_t)lane < n;
+            uint32_t L = 0, src = 0;
+            if (lane == 0) t_start[LZW_FIRST + c0] = (TableT)(op - epoch);       // where the chunk's first string will begin: the end of entry c0 - 1
+            if ((uint32_t)lane < n && !inchunk) {
+                const uint32_t t0 = t_start[code], t1 = t_start[code + 1];      // (literals: both 0)
+                L = t1 - t0 + 1u;
+                src = epoch + t0;
+            }
+            for (int r = 0; r < 3; ++r) {                  // lengths that hang on a code of this chunk: L = L(that code) + 1
+                const uint32_t Lm = (uint32_t)__shfl((int)L, (int)((e - c0) & 63u));
+                if (inchunk && L == 0 && Lm != 0) L = Lm + 1u;
+            }
+            const uint64_t open = __ballot((uint32_t)lane < n && L == 0);
+            if (open) n = min(n, (uint32_t)__builtin_ctzll(open));
+            uint32_t incl = (uint32_t)lane < n ? L : 0u;   // inclusive prefix sum over the lanes
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+                if (lane >= d) incl += up;
+            }
+            const uint32_t pos = op + incl - L;            // where this lane's string begins
+            const uint32_t pos_m = (uint32_t)__shfl((int)pos, (int)((e - c0) & 63u));      // (every lane takes part: a lane read inside a branch returns 0 for the lanes outside it)
+            if (inchunk) src = pos_m;
+            const bool hard = (uint32_t)lane < n && (L > 64u || (!lit && pos - src + 64u > (uint32_t)LZW_RING) || pos + L - epoch > REL_MAX);
+            const uint64_t hards = __ballot(hard);
+            if (hards) n = min(n, (uint32_t)__builtin_ctzll(hards));
+            if (n == 0) {
+                hold = 1;
+            } else {
+                const uint32_t last_pos = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)(n - 1));        // (lane reads: the wave's state stays in scalar registers)
+                const uint32_t last_len = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(n - 1));
+                if ((uint32_t)lane < n) t_start[LZW_FIRST + idx] = (TableT)(pos - epoch);
+                if (lane == 0) t_start[LZW_FIRST + c0 + n] = (TableT)(last_pos + last_len - epoch);
+                for (uint32_t k = 0; k < n; ++k) {
+                    const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)code, (int)k), sk = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)k);
+                    const uint32_t lk = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)k), pk = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)k);
+                    if ((uint32_t)lane < lk) {
+                        // (a string that runs into its own first byte — the code names the entry being defined — repeats that byte)
+                        const uint32_t from = (sk + lane == pk) ? sk : sk + lane;
+                        const uint32_t a = ck < 256u ? (uint32_t)LZW_LIT + ck : (from & (LZW_RING - 1));
+                        const uint8_t v = ring_lit[a];
+                        ring_lit[(pk + lane) & (LZW_RING - 1)] = v;
+                        if (pk + lane < cap) dst[pk + lane] = v;
+                    }
+                }
+                bitpos += bits_before(c0 + n) - bits_before(c0);
+                next += (int)n;
+                nbits = 9 + (next >= 511) + (next >= 1023) + (next >= 2047);
+                old_pos = last_pos;
+                old_len = last_len;
+                op = last_pos + last_len;
+                if (n < 8) hold = 32;                      // hard going (long runs, far sources): a stretch of single codes before the next attempt
+                __syncthreads();
+                continue;
+            }
+        }
+        if (hold) --hold;
         if (bitpos + (uint32_t)nbits > end_bit) break;     // ran out of input without an EOI: accept what was decoded (host decoder's rule)
         const uint32_t dw = bitpos >> 5;
         if (__builtin_expect(dw + 1 >= loaded, 0)) {       // the reader enters the last loaded chunk: bring in the next one over the older
@@ -268,14 +359,17 @@ extern "C" td_status td_tiff_lzw_decode_dev(const uint8_t* comp, const int64_t* 
     int* wide_list = reinterpret_cast<int*>(status) + nblocks;      // status has room for 2 * nblocks + 1 ints (include/treedet.h)
     TD_HIP_CHECK(hipMemsetAsync(wide_list, 0, sizeof(int), s));
     const int small_ring = lzw_ring_choice(nblocks);
-    if (small_ring)
-        hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint16_t, false, 4096>), dim3(nblocks), dim3(64), 0, s, comp, block_off, block_nbytes,
-                           blocks_out, block_cap, decoded, status, nblocks, wide_list);
-    else
-        hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint16_t, false, 16384>), dim3(nblocks), dim3(64), 0, s, comp, block_off, block_nbytes,
-                           blocks_out, block_cap, decoded, status, nblocks, wide_list);
+    const char* one = getenv("TD_LZW_ONE_BY_ONE");          // measurements: the code-by-code loop alone (tools/raster_decode_bench.py)
+    const bool chunks = !(one && one[0] == '1');
+#define TD_LZW(RING, FAST) hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint16_t, false, RING, FAST>), dim3(nblocks), dim3(64), 0, s, comp, block_off, \
+                                              block_nbytes, blocks_out, block_cap, decoded, status, nblocks, wide_list)
+    if (small_ring && chunks) TD_LZW(4096, true);
+    else if (small_ring) TD_LZW(4096, false);
+    else if (chunks) TD_LZW(16384, true);
+    else TD_LZW(16384, false);
+#undef TD_LZW
     TD_KERNEL_CHECK();
-    hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint32_t, true, 16384>), dim3(nblocks < 1024 ? nblocks : 1024), dim3(64), 0, s, comp, block_off,
+    hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint32_t, true, 16384, false>), dim3(nblocks < 1024 ? nblocks : 1024), dim3(64), 0, s, comp, block_off,
                        block_nbytes, blocks_out, block_cap, decoded, status, nblocks, wide_list);
     TD_KERNEL_CHECK();
     return TD_OK;
