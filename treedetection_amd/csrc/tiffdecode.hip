@@ -74,17 +74,18 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
     __syncthreads();
     uint32_t hold = 0;                                     // codes left to the one-by-one path before the next chunk attempt
     for (;;) {
-        if (FAST && hold == 0 && old_len != 0 && next + 64 < LZW_MAX && op - epoch <= REL_MAX) {
+        if (FAST && hold == 0 && old_len != 0 && next < LZW_MAX - 1 && op - epoch <= REL_MAX) {
             // ---- 64 codes at once -------------------------------------------------------------------------------------------
             // Between two ClearCodes the WIDTH of a code depends only on how many codes came before it (the table grows by one
             // entry per code), so the 64 lanes cut the next 64 codes out of the stream at once; a string's length is the
-            // distance of two table positions, its start a prefix sum over the lanes — the table arithmetic of 64 codes costs
-            // what one code costs in the loop below. What stays sequential is the copying (a string may begin in the bytes
-            // its predecessor just wrote), but with everything it needs already in registers: four lane reads, one LDS read,
-            // one LDS write, one store per code. The chunk ends early at a ClearCode / EOI / the end of the input / a code the
-            // table cannot hold yet, at a string the one-step copy does not take (longer than 64 bytes, or from beyond the
-            // ring), and where lengths inside the chunk depend on each other more than three deep; those codes take the loop
-            // below, one by one.
+            // distance of two table positions (or one more than the length of an earlier code of this chunk), its start a
+            // prefix sum over the lanes — the table arithmetic of 64 codes costs what one code costs in the loop below. Then the
+            // bytes, in three steps: (A) literals: every lane stores its own; (B) strings whose source ends before this chunk's
+            // output begins (the table holds thousands of older entries: on imagery nearly all of them): every lane copies
+            // its own string out of the ring, one byte per step; (C) what is left — strings that begin in bytes this chunk
+            // writes, or beyond the ring — one after the other in code order, everything they need already in registers.
+            // The chunk ends early at a ClearCode / EOI / the end of the input / a code the table cannot hold yet / the last
+            // table entry; those codes take the loop below, one by one.
             while (((bitpos + 64u * 12u) >> 5) + 1u >= loaded) {
                 const uint32_t idx = loaded + lane;
                 inbuf[idx & 127] = idx < ndw ? bswap32(src32[idx]) : 0u;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
             const uint32_t dwl = off >> 5;
             const uint64_t twol = ((uint64_t)inbuf[dwl & 127] << 32) | inbuf[(dwl + 1) & 127];
             const uint32_t code = (uint32_t)((twol >> (64 - (off & 31) - my_bits)) & ((1u << my_bits) - 1u));
-            const bool stop = (code - (uint32_t)LZW_CLEAR) < 2u || off + my_bits > end_bit || code > 257u + idx;
+            const bool stop = (code - (uint32_t)LZW_CLEAR) < 2u || off + my_bits > end_bit || code > 257u + idx || 257u + idx >= (uint32_t)LZW_MAX - 1u;
             const uint64_t stops = __ballot(stop);
             uint32_t n = stops ? (uint32_t)__builtin_ctzll(stops) : 64u;
             const bool lit = code < 256u;
@@ -115,12 +116,13 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
                 L = t1 - t0 + 1u;
                 src = epoch + t0;
             }
-            for (int r = 0; r < 3; ++r) {                  // lengths that hang on a code of this chunk: L = L(that code) + 1
+            // lengths that hang on a code of this chunk: L = L(that code) + 1. Every round settles at least the lowest open lane
+            // (it points at a lower one); runs of one value take many rounds, imagery one or two. (Lane reads stay outside
+            // branches: inside one they return 0 for the lanes that did not take it.)
+            while (__ballot(inchunk && L == 0)) {
                 const uint32_t Lm = (uint32_t)__shfl((int)L, (int)((e - c0) & 63u));
                 if (inchunk && L == 0 && Lm != 0) L = Lm + 1u;
             }
-            const uint64_t open = __ballot((uint32_t)lane < n && L == 0);
-            if (open) n = min(n, (uint32_t)__builtin_ctzll(open));
             uint32_t incl = (uint32_t)lane < n ? L : 0u;   // inclusive prefix sum over the lanes
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
@@ -128,28 +130,65 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
                 if (lane >= d) incl += up;
             }
             const uint32_t pos = op + incl - L;            // where this lane's string begins
-            const uint32_t pos_m = (uint32_t)__shfl((int)pos, (int)((e - c0) & 63u));      // (every lane takes part: a lane read inside a branch returns 0 for the lanes outside it)
+            const uint32_t pos_m = (uint32_t)__shfl((int)pos, (int)((e - c0) & 63u));
             if (inchunk) src = pos_m;
-            const bool hard = (uint32_t)lane < n && (L > 64u || (!lit && pos - src + 64u > (uint32_t)LZW_RING) || pos + L - epoch > REL_MAX);
-            const uint64_t hards = __ballot(hard);
+            // the chunk's output stays well inside the ring (step B reads old bytes while younger lanes write ahead), and inside the table's range
+            const uint64_t hards = __ballot((uint32_t)lane < n && (incl > (uint32_t)LZW_RING / 2u || pos + L - epoch > REL_MAX));
             if (hards) n = min(n, (uint32_t)__builtin_ctzll(hards));
             if (n == 0) {
                 hold = 1;
             } else {
                 const uint32_t last_pos = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)(n - 1));        // (lane reads: the wave's state stays in scalar registers)
                 const uint32_t last_len = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(n - 1));
-                if ((uint32_t)lane < n) t_start[LZW_FIRST + idx] = (TableT)(pos - epoch);
-                if (lane == 0) t_start[LZW_FIRST + c0 + n] = (TableT)(last_pos + last_len - epoch);
-                for (uint32_t k = 0; k < n; ++k) {
-                    const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)code, (int)k), sk = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)k);
-                    const uint32_t lk = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)k), pk = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)k);
-                    if ((uint32_t)lane < lk) {
-                        // (a string that runs into its own first byte — the code names the entry being defined — repeats that byte)
-                        const uint32_t from = (sk + lane == pk) ? sk : sk + lane;
-                        const uint32_t a = ck < 256u ? (uint32_t)LZW_LIT + ck : (from & (LZW_RING - 1));
-                        const uint8_t v = ring_lit[a];
-                        ring_lit[(pk + lane) & (LZW_RING - 1)] = v;
-                        if (pk + lane < cap) dst[pk + lane] = v;
+                const uint32_t op_end = last_pos + last_len;
+                const bool mine = (uint32_t)lane < n;
+                if (mine) t_start[LZW_FIRST + idx] = (TableT)(pos - epoch);
+                // (A) literals
+                if (mine && lit) {
+                    ring_lit[pos & (LZW_RING - 1)] = (uint8_t)code;
+                    if (pos < cap) dst[pos] = (uint8_t)code;
+                }
+                // (B) sources that end before this chunk's first byte and are still in the ring when its last byte is written
+                const bool early = mine && !lit && src + L <= op && op_end - src <= (uint32_t)LZW_RING;
+                for (uint32_t t = 0;; ++t) {
+                    const bool act = early && t < L;
+                    if (!__ballot(act)) break;
+                    if (act) {
+                        const uint8_t v = ring_lit[(src + t) & (LZW_RING - 1)];
+                        ring_lit[(pos + t) & (LZW_RING - 1)] = v;
+                        if (pos + t < cap) dst[pos + t] = v;
+                    }
+                }
+                // (C) the rest, in code order
+                uint64_t late = __ballot(mine && !lit && !early);
+                while (late) {
+                    const int k = __builtin_ctzll(late);
+                    late &= late - 1;
+                    const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src, k), lk = (uint32_t)__builtin_amdgcn_readlane((int)L, k);
+                    const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pos, k);
+                    if (lk <= 64u && op_end - sk <= (uint32_t)LZW_RING) {       // (steps A and B have already written up to op_end: the source must have survived that)
+                        if ((uint32_t)lane < lk) {
+                            // (a string that runs into its own first byte — the code names the entry being defined — repeats that byte)
+                            const uint32_t from = (sk + lane == pk) ? sk : sk + lane;
+                            const uint8_t v = ring_lit[from & (LZW_RING - 1)];
+                            ring_lit[(pk + lane) & (LZW_RING - 1)] = v;
+                            if (pk + lane < cap) dst[pk + lane] = v;
+                        }
+                    } else {                               // long strings and sources that have left the ring: through the block's output in memory
+                        ++slow;
+                        if (sk + lk > safe) {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            safe = pk;                     // every byte before this string has been stored (steps A, B and the earlier strings of C)
+                        }
+                        for (uint32_t k0 = 0; k0 < lk; k0 += 64) {
+                            const uint32_t kk = k0 + lane;
+                            if (kk < lk) {
+                                const uint32_t from = (sk + kk == pk) ? sk : sk + kk;
+                                const uint8_t v = __hip_atomic_load(dst + from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                ring_lit[(pk + kk) & (LZW_RING - 1)] = v;
+                                if (pk + kk < cap) dst[pk + kk] = v;
+                            }
+                        }
                     }
                 }
                 bitpos += bits_before(c0 + n) - bits_before(c0);
@@ -157,8 +196,7 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
                 nbits = 9 + (next >= 511) + (next >= 1023) + (next >= 2047);
                 old_pos = last_pos;
                 old_len = last_len;
-                op = last_pos + last_len;
-                if (n < 8) hold = 32;                      // hard going (long runs, far sources): a stretch of single codes before the next attempt
+                op = op_end;
                 __syncthreads();
                 continue;
             }
@@ -369,7 +407,7 @@ extern "C" td_status td_tiff_lzw_decode_dev(const uint8_t* comp, const int64_t* 
     else TD_LZW(16384, false);
 #undef TD_LZW
     TD_KERNEL_CHECK();
-    hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint32_t, true, 16384, false>), dim3(nblocks < 1024 ? nblocks : 1024), dim3(64), 0, s, comp, block_off,
+    hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint32_t, true, 16384, true>), dim3(nblocks < 1024 ? nblocks : 1024), dim3(64), 0, s, comp, block_off,
                        block_nbytes, blocks_out, block_cap, decoded, status, nblocks, wide_list);
     TD_KERNEL_CHECK();
     return TD_OK;
