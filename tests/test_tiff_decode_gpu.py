@@ -144,7 +144,7 @@ def test_large_blocks_with_many_table_clears_and_incompressible_data(tmp_path, r
 
 
 def test_rasters_with_more_blocks_than_one_round_take_the_small_ring_by_themselves(tmp_path, monkeypatch):
-    """No override: 1 700 one-row strips (beyond 256 CUs x 6 LZW waves / x 4 DEFLATE waves) → the library picks the small rings."""
+    """No override: 1 700 one-row strips (beyond 256 CUs x 4 DEFLATE waves → the library picks the small DEFLATE ring by itself)."""
     monkeypatch.delenv("TD_DECODE_RING", raising=False)
     img = _raster(4, 1700, 640, seed=9)
     for codec in ("lzw", "deflate"):

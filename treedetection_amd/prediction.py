@@ -399,17 +399,7 @@ class Predictor:
                 return None
             if self._decode_stream is None:
                 with torch.cuda.device(self.device_index):
-                    if os.environ.get("TD_DECODE_PRIORITY") == "low":      # experiment
-                        import ctypes
-                        hip = ctypes.CDLL("libamdhip64.so")
-                        lo, hi = ctypes.c_int(0), ctypes.c_int(0)
-                        hip.hipDeviceGetStreamPriorityRange(ctypes.byref(lo), ctypes.byref(hi))
-                        h = ctypes.c_void_p()
-                        rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, lo.value)
-                        print(f"decode stream: priority range least {lo.value} greatest {hi.value}, created rc {rc}", flush=True)
-                        self._decode_stream = torch.cuda.ExternalStream(h.value)
-                    else:
-                        self._decode_stream = torch.cuda.Stream()
+                    self._decode_stream = torch.cuda.Stream()
             t0 = time.perf_counter()
             c0 = time.thread_time()
             if self._upload_pool is None:
