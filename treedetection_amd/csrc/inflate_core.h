@@ -289,24 +289,86 @@ TD_INF_HD InflateResult inflate_block(InflateScratchT<RING>& S, const uint8_t* s
 #endif
             if (!ok) return res;
             for (;;) {                                      // the block's symbols
-                const int s = decode_sym<NL>(S, r, S.lit_fast, INF_LIT_FAST, S.lit_count, S.lit_sym, lane);
-                if (s < 0 || bitpos(r) > r.end_bit) return res;
-                if (s < 256) {
-                    if (lane == 0) {
-                        S.ring[op & (RING - 1)] = (uint8_t)s;
-                        if (op < cap) dst[op] = (uint8_t)s;
+                uint32_t len = 0, dist = 0;                 // the match this step ends with (len == 0: none)
+#ifdef __HIP_DEVICE_COMPILE__
+                if (NL == 64) {
+                    // Several symbols per step: every lane looks up the literal / length code AND the distance code that WOULD start
+                    // at its bit of the 64-bit reservoir (two LDS accesses for all 64 candidates), then the wave follows the chain
+                    // code → next code through those answers with lane reads — a few scalar instructions per symbol instead of a
+                    // table round trip each. The lanes on the chain store their literals together; a length code that ends the
+                    // chain takes its extra bits, its distance code (the other lookup, at the bit where it starts) and that one's
+                    // extra bits out of the same reservoir when they are all there. The chain also ends at the end-of-block code,
+                    // at a code longer than a table's index, or where the reservoir runs out; the one-symbol path below takes over.
+                    ensure<NL>(S, r, 33, lane);             // 33 .. 64 bits in the reservoir
+                    const int avail = r.have - INF_LIT_FAST;                 // a code may start at bits 0 .. avail: its index bits are all there
+                    const uint64_t here = r.acc >> lane;
+                    const int el = (int)S.lit_fast[(uint32_t)here & ((1u << INF_LIT_FAST) - 1u)];
+                    const int dl = (int)S.dist_fast[(uint32_t)here & ((1u << INF_DIST_FAST) - 1u)];
+                    int cur = 0, cnt = 0, rank = -1;
+                    while (cur <= avail) {
+                        const int ec = __builtin_amdgcn_readlane(el, cur);
+                        if ((ec >> 9) == 0 || (ec & 511) >= 256) break;
+                        if (lane == cur) rank = cnt;
+                        cur += ec >> 9;
+                        ++cnt;
                     }
-                    ++op;
-                    continue;
+                    int used = cur;
+                    if (cur <= avail) {
+                        const int ec = __builtin_amdgcn_readlane(el, cur);
+                        const int sy = ec & 511;
+                        if ((ec >> 9) != 0 && sy > 256 && sy <= 285) {
+                            int p = cur + (ec >> 9);
+                            const int xb = LEXT[sy - 257];
+                            if (p + xb + INF_DIST_FAST <= r.have) {          // the length's extra bits and the distance code's index bits
+                                const uint32_t l0 = LBASE[sy - 257] + ((uint32_t)(r.acc >> p) & ((1u << xb) - 1u));
+                                p += xb;
+                                const int dc = __builtin_amdgcn_readlane(dl, p);
+                                const int ds = dc & 511;
+                                if ((dc >> 9) != 0 && ds <= 29) {
+                                    p += dc >> 9;
+                                    const int db = DEXT[ds];
+                                    if (p + db <= r.have) {
+                                        dist = DBASE[ds] + (db ? (uint32_t)(r.acc >> p) & ((1u << db) - 1u) : 0u);      // (p <= 63 whenever db > 0)
+                                        len = l0;
+                                        used = p + db;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (cnt || len) {
+                        if (rank >= 0) {
+                            S.ring[(op + rank) & (RING - 1)] = (uint8_t)el;
+                            if (op + rank < cap) dst[op + rank] = (uint8_t)el;
+                        }
+                        r.acc = used < 64 ? r.acc >> used : 0;                // (used <= have)
+                        r.have -= used;
+                        op += (uint32_t)cnt;
+                        if (bitpos(r) > r.end_bit) return res;
+                        if (!len) continue;
+                    }
                 }
-                if (s == 256) break;
-                if (s > 285) return res;
-                ensure<NL>(S, r, 5, lane);
-                const uint32_t len = LBASE[s - 257] + take(r, LEXT[s - 257]);
-                const int ds = decode_sym<NL>(S, r, S.dist_fast, INF_DIST_FAST, S.dist_count, S.dist_sym, lane);
-                if (ds < 0 || ds > 29) return res;
-                ensure<NL>(S, r, 13, lane);
-                const uint32_t dist = DBASE[ds] + take(r, DEXT[ds]);
+#endif
+                if (!len) {                                 // one symbol, any code length
+                    const int s = decode_sym<NL>(S, r, S.lit_fast, INF_LIT_FAST, S.lit_count, S.lit_sym, lane);
+                    if (s < 0 || bitpos(r) > r.end_bit) return res;
+                    if (s < 256) {
+                        if (lane == 0) {
+                            S.ring[op & (RING - 1)] = (uint8_t)s;
+                            if (op < cap) dst[op] = (uint8_t)s;
+                        }
+                        ++op;
+                        continue;
+                    }
+                    if (s == 256) break;
+                    if (s > 285) return res;
+                    ensure<NL>(S, r, 5, lane);
+                    len = LBASE[s - 257] + take(r, LEXT[s - 257]);
+                    const int ds = decode_sym<NL>(S, r, S.dist_fast, INF_DIST_FAST, S.dist_count, S.dist_sym, lane);
+                    if (ds < 0 || ds > 29) return res;
+                    ensure<NL>(S, r, 13, lane);
+                    dist = DBASE[ds] + take(r, DEXT[ds]);
+                }
                 if (dist > op || bitpos(r) > r.end_bit) return res;
                 // out[op + k] = out[op - dist + (k mod dist)]: every source byte was written before this match began
                 if (RING == INF_WINDOW || dist + len + 64 <= (uint32_t)RING) {       // the sources outlive this match's own writes to the ring
