@@ -32,7 +32,7 @@ Polygon = List[np.ndarray]          # [shell, hole, ...] closed rings
 
 
 def ring_is_valid(ring: np.ndarray) -> bool:
-    r = np.ascontiguousarray(ring, dtype=np.float64).reshape(-1, 2)
+    r = np.require(ring, dtype=np.float64, requirements=["C", "A"]).reshape(-1, 2)      # (rings cut out of a geometry blob start at odd addresses)
     st = _lib.load().td_ring_is_valid(r.ctypes.data, int(r.shape[0]))
     _lib.check(st, "td_ring_is_valid")
     return bool(st)
