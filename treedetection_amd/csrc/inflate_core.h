@@ -17,10 +17,15 @@
 // this wave's stores have reached L2; an agent-scope load is served there, never by a stale L1 line
 #define TD_INF_STORES_DONE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define TD_INF_LOAD_OUT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// Values read from LDS at a wave-uniform address ARE uniform; telling the compiler so keeps the decoder's whole state (bit
+// reservoir, positions, table entries) in scalar registers and its control flow in scalar branches — left alone it carried the
+// state in vector registers, ran the loops under exec masks and fetched the length / distance base tables with per-lane loads.
+#define TD_INF_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #else
 #define TD_INF_SYNC() ((void)0)
 #define TD_INF_STORES_DONE() ((void)0)
 #define TD_INF_LOAD_OUT(p) (*(p))
+#define TD_INF_UNIFORM(x) ((uint32_t)(x))
 #endif
 #ifdef __HIPCC__
 #define TD_INF_HD __host__ __device__ inline
@@ -75,7 +80,7 @@ template <int NL, typename Scratch>
 TD_INF_HD void ensure(Scratch& S, Reader& r, int n, int lane) {
     if (r.have < n) {
         if (r.rd >= r.loaded) load_chunk<NL>(S, r, lane);
-        r.acc |= (uint64_t)S.inbuf[r.rd & 127] << r.have;
+        r.acc |= (uint64_t)TD_INF_UNIFORM(S.inbuf[r.rd & 127]) << r.have;
         ++r.rd;
         r.have += 32;
     }
@@ -147,7 +152,7 @@ TD_INF_HD bool build(const uint8_t* lens, int n, uint16_t* count, uint16_t* sym,
 template <int NL, typename Scratch>
 TD_INF_HD int decode_sym(Scratch& S, Reader& r, const uint16_t* fast, int fast_bits, const uint16_t* count, const uint16_t* sym, int lane) {
     ensure<NL>(S, r, 15, lane);
-    const uint16_t e = fast[r.acc & ((1u << fast_bits) - 1u)];
+    const uint32_t e = TD_INF_UNIFORM(fast[r.acc & ((1u << fast_bits) - 1u)]);
     if (e) {
         take(r, e >> 9);
         return e & 511;
@@ -157,10 +162,10 @@ TD_INF_HD int decode_sym(Scratch& S, Reader& r, const uint16_t* fast, int fast_b
     for (int l = 1; l <= 15; ++l) {
         code |= (int)(bits & 1u);
         bits >>= 1;
-        const int c = count[l];
+        const int c = (int)TD_INF_UNIFORM(count[l]);
         if (code - c < first) {
             take(r, l);
-            return sym[index + (code - first)];
+            return (int)TD_INF_UNIFORM(sym[index + (code - first)]);
         }
         index += c;
         first += c;
@@ -177,10 +182,14 @@ TD_INF_HD int decode_sym(Scratch& S, Reader& r, const uint16_t* fast, int fast_b
 template <int NL, int RING>
 TD_INF_HD InflateResult inflate_block(InflateScratchT<RING>& S, const uint8_t* src, int64_t n, uint8_t* dst, uint32_t cap, int lane) {
     using namespace inflate_detail;
-    constexpr uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-    constexpr uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    constexpr uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-    constexpr uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    // length / distance codes: base value | extra bits << 16 (dwords: a scalar load on the device; byte tables would be per-lane loads)
+    constexpr uint32_t LEN_CODE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11 | 1 << 16, 13 | 1 << 16, 15 | 1 << 16, 17 | 1 << 16, 19 | 2 << 16, 23 | 2 << 16, 27 | 2 << 16,
+                                       31 | 2 << 16, 35 | 3 << 16, 43 | 3 << 16, 51 | 3 << 16, 59 | 3 << 16, 67 | 4 << 16, 83 | 4 << 16, 99 | 4 << 16,
+                                       115 | 4 << 16, 131 | 5 << 16, 163 | 5 << 16, 195 | 5 << 16, 227 | 5 << 16, 258};
+    constexpr uint32_t DIST_CODE[30] = {1, 2, 3, 4, 5 | 1 << 16, 7 | 1 << 16, 9 | 2 << 16, 13 | 2 << 16, 17 | 3 << 16, 25 | 3 << 16, 33 | 4 << 16, 49 | 4 << 16,
+                                        65 | 5 << 16, 97 | 5 << 16, 129 | 6 << 16, 193 | 6 << 16, 257 | 7 << 16, 385 | 7 << 16, 513 | 8 << 16, 769 | 8 << 16,
+                                        1025 | 9 << 16, 1537 | 9 << 16, 2049 | 10 << 16, 3073 | 10 << 16, 4097 | 11 << 16, 6145 | 11 << 16, 8193 | 12 << 16,
+                                        12289 | 12 << 16, 16385 | 13 << 16, 24577 | 13 << 16};
     constexpr uint8_t ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     InflateResult res{0, 1};
     if (n < 6) return res;                                  // header + at least an empty block + trailer
@@ -244,7 +253,7 @@ TD_INF_HD InflateResult inflate_block(InflateScratchT<RING>& S, const uint8_t* s
                 }
                 TD_INF_SYNC();
 #ifdef __HIP_DEVICE_COMPILE__
-                ok = __shfl((int)ok, 0) != 0;
+                ok = TD_INF_UNIFORM(__shfl((int)ok, 0)) != 0;
 #endif
                 if (!ok) return res;
                 // the hlit + hdist code lengths, run-length coded; every lane decodes them (uniform), lane 0 keeps them
@@ -285,13 +294,18 @@ TD_INF_HD InflateResult inflate_block(InflateScratchT<RING>& S, const uint8_t* s
             }
             TD_INF_SYNC();
 #ifdef __HIP_DEVICE_COMPILE__
-            ok = __shfl((int)ok, 0) != 0;
+            ok = TD_INF_UNIFORM(__shfl((int)ok, 0)) != 0;
 #endif
             if (!ok) return res;
             for (;;) {                                      // the block's symbols
                 uint32_t len = 0, dist = 0;                 // the match this step ends with (len == 0: none)
 #ifdef __HIP_DEVICE_COMPILE__
                 if (NL == 64) {
+                    r.have = (int)TD_INF_UNIFORM(r.have);
+                    r.acc = ((uint64_t)TD_INF_UNIFORM(r.acc >> 32) << 32) | TD_INF_UNIFORM((uint32_t)r.acc);
+                    r.rd = TD_INF_UNIFORM(r.rd);
+                    r.loaded = TD_INF_UNIFORM(r.loaded);
+                    op = TD_INF_UNIFORM(op);
                     // Several symbols per step: every lane looks up the literal / length code AND the distance code that WOULD start
                     // at its bit of the 64-bit reservoir (two LDS accesses for all 64 candidates), then the wave follows the chain
                     // code → next code through those answers with lane reads — a few scalar instructions per symbol instead of a
@@ -318,17 +332,22 @@ TD_INF_HD InflateResult inflate_block(InflateScratchT<RING>& S, const uint8_t* s
                         const int sy = ec & 511;
                         if ((ec >> 9) != 0 && sy > 256 && sy <= 285) {
                             int p = cur + (ec >> 9);
-                            const int xb = LEXT[sy - 257];
+                            // base and extra bits of a length code by arithmetic (RFC 1951 3.2.5: groups of four codes per extra bit) — a
+                            // table in memory is a scalar load of ~200 cycles on the chain's critical path
+                            const int c = sy - 257;
+                            const int xb = c < 8 || c == 28 ? 0 : (c >> 2) - 1;
+                            const uint32_t lbase = c < 8 ? 3u + (uint32_t)c : (c == 28 ? 258u : 3u + ((4u + ((uint32_t)c & 3u)) << xb));
                             if (p + xb + INF_DIST_FAST <= r.have) {          // the length's extra bits and the distance code's index bits
-                                const uint32_t l0 = LBASE[sy - 257] + ((uint32_t)(r.acc >> p) & ((1u << xb) - 1u));
+                                const uint32_t l0 = lbase + ((uint32_t)(r.acc >> p) & ((1u << xb) - 1u));
                                 p += xb;
                                 const int dc = __builtin_amdgcn_readlane(dl, p);
                                 const int ds = dc & 511;
                                 if ((dc >> 9) != 0 && ds <= 29) {
                                     p += dc >> 9;
-                                    const int db = DEXT[ds];
+                                    const int db = ds < 4 ? 0 : (ds >> 1) - 1;                // (pairs of codes per extra bit)
+                                    const uint32_t dbase = ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1u)) << db);
                                     if (p + db <= r.have) {
-                                        dist = DBASE[ds] + (db ? (uint32_t)(r.acc >> p) & ((1u << db) - 1u) : 0u);      // (p <= 63 whenever db > 0)
+                                        dist = dbase + (db ? (uint32_t)(r.acc >> p) & ((1u << db) - 1u) : 0u);      // (p <= 63 whenever db > 0)
                                         len = l0;
                                         used = p + db;
                                     }
@@ -363,19 +382,23 @@ TD_INF_HD InflateResult inflate_block(InflateScratchT<RING>& S, const uint8_t* s
                     if (s == 256) break;
                     if (s > 285) return res;
                     ensure<NL>(S, r, 5, lane);
-                    len = LBASE[s - 257] + take(r, LEXT[s - 257]);
+                    const uint32_t lc = TD_INF_UNIFORM(LEN_CODE[s - 257]);
+                    len = (lc & 0xffffu) + take(r, (int)(lc >> 16));
                     const int ds = decode_sym<NL>(S, r, S.dist_fast, INF_DIST_FAST, S.dist_count, S.dist_sym, lane);
                     if (ds < 0 || ds > 29) return res;
                     ensure<NL>(S, r, 13, lane);
-                    dist = DBASE[ds] + take(r, DEXT[ds]);
+                    const uint32_t dcode = TD_INF_UNIFORM(DIST_CODE[ds]);
+                    dist = (dcode & 0xffffu) + take(r, (int)(dcode >> 16));
                 }
                 if (dist > op || bitpos(r) > r.end_bit) return res;
-                // out[op + k] = out[op - dist + (k mod dist)]: every source byte was written before this match began
+                // out[op + k] = out[op - dist + (k mod dist)]: every source byte was written before this match began. Nearly every
+                // match is shorter than its distance (k mod dist = k): the division runs only for the overlapping ones (runs).
+                const bool wraps = dist < len;
                 if (RING == INF_WINDOW || dist + len + 64 <= (uint32_t)RING) {       // the sources outlive this match's own writes to the ring
                     for (uint32_t k0 = 0; k0 < len; k0 += NL) {
                         const uint32_t k = k0 + lane;
                         if (k < len) {
-                            const uint8_t v = S.ring[(op - dist + (k % dist)) & (RING - 1)];
+                            const uint8_t v = S.ring[(op - dist + (wraps ? k % dist : k)) & (RING - 1)];
                             S.ring[(op + k) & (RING - 1)] = v;
                             if (op + k < cap) dst[op + k] = v;
                         }
@@ -385,7 +408,7 @@ TD_INF_HD InflateResult inflate_block(InflateScratchT<RING>& S, const uint8_t* s
                     for (uint32_t k0 = 0; k0 < len; k0 += NL) {
                         const uint32_t k = k0 + lane;
                         if (k < len) {
-                            const uint32_t from = op - dist + (k % dist);
+                            const uint32_t from = op - dist + (wraps ? k % dist : k);
                             const uint8_t v = from < cap ? TD_INF_LOAD_OUT(dst + from) : (uint8_t)0;     // (past cap: the block fails with status 2 anyway)
                             S.ring[(op + k) & (RING - 1)] = v;
                             if (op + k < cap) dst[op + k] = v;

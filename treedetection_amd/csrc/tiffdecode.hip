@@ -371,6 +371,40 @@ __global__ __launch_bounds__(SC_THREADS) void tiff_blocks_to_image_kernel(const 
         }
 }
 
+// The same for four samples per pixel (RGBI, the reference's rasters): one WAVE per block row, a pixel is one dword, the four
+// byte-wise running sums ride in it (carry-less packed add), 64 pixels per step: a scan across the lanes by lane reads, no LDS,
+// no barrier. 4 rows per workgroup.
+__device__ __forceinline__ uint32_t add_bytes(uint32_t a, uint32_t b) {
+    return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
+}
+__global__ __launch_bounds__(256) void tiff_blocks_to_image_rgbi_kernel(const uint8_t* __restrict__ blocks, int64_t block_cap, int bw, int bh,
+                                                                        int blocks_across, int predictor, uint8_t* __restrict__ image, int width,
+                                                                        int height) {
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6), bx = blockIdx.y;
+    if (y >= height) return;
+    const int by = y / bh;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(blocks + ((int64_t)by * blocks_across + bx) * block_cap) + (int64_t)(y - by * bh) * bw;
+    const int x0 = bx * bw;
+    const int valid = min(bw, width - x0);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(image) + (int64_t)y * width + x0;
+    uint32_t carry = 0;
+    for (int p0 = 0; p0 < valid; p0 += 64) {
+        const int p = p0 + lane;
+        uint32_t v = p < bw ? src[p] : 0u;
+        if (predictor == 2) {
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)v, d);
+                if (lane >= d) v = add_bytes(v, up);
+            }
+            v = add_bytes(v, carry);
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+        }
+        if (p < valid) dst[p] = v;
+    }
+}
+
 // Which ring. DEFLATE: the small one as soon as the blocks no longer fit the chip in one round with the large one (256 CUs x
 // four waves). TD_DECODE_RING = small | large overrides (tests, measurements: tools/raster_decode_bench.py).
 int ring_override() {
@@ -448,6 +482,12 @@ extern "C" td_status td_tiff_blocks_to_image_dev(const uint8_t* blocks, int64_t 
     TD_REQUIRE(blocks_across <= 65535, "td_tiff_blocks_to_image_dev: too many block columns");
     const dim3 grid(height, blocks_across);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (spp == 4 && block_cap % 4 == 0 && reinterpret_cast<uintptr_t>(blocks) % 4 == 0 && reinterpret_cast<uintptr_t>(image) % 4 == 0) {
+        hipLaunchKernelGGL(tiff_blocks_to_image_rgbi_kernel, dim3((height + 3) / 4, blocks_across), dim3(256), 0, s, blocks, block_cap, block_w, block_h,
+                           blocks_across, predictor, image, width, height);
+        TD_KERNEL_CHECK();
+        return TD_OK;
+    }
 #define TD_SCATTER(N) hipLaunchKernelGGL(tiff_blocks_to_image_kernel<N>, grid, dim3(SC_THREADS), 0, s, blocks, block_cap, block_w, block_h, \
                                          blocks_across, predictor, image, width, height)
     switch (spp) {
