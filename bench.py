@@ -251,7 +251,9 @@ def compact_line(full):
             "e2e_lzw_host_reader_f16": val("lzw", "f16", "host_reader", "value"),
             "e2e_lzw_same_raster_uncompressed_f16": val("lzw", "f16", "uncompressed", "value"),
             "lzw_decode_windows_450_per_s": val("lzw", "f16", "decode_windows_450x450x4_per_s"), "lzw_decode_gb_per_s": val("lzw", "f16", "decode_gbytes_per_s"),
-            "lzw_kernel_gb_per_s": val("lzw", "f16", "kernel_gbytes_per_s")}
+            "lzw_kernel_gb_per_s": val("lzw", "f16", "kernel_gbytes_per_s"),
+            "e2e_deflate_f16": val("deflate", "f16", "device", "value"), "e2e_deflate_f16_ratio": val("deflate", "f16", "device", "ratio_to_model_stage"),
+            "deflate_decode_windows_450_per_s": val("deflate", "f16", "decode_windows_450x450x4_per_s"), "deflate_kernel_gb_per_s": val("deflate", "f16", "kernel_gbytes_per_s")}
     c["regions"] = {k: v for k, v in scal.items() if v is not None}
     c["regions_unit"] = "tiles/s (two_model: tile visits/s; *_frac: executed FLOPs / MFMA peak; *_ratio: e2e / model stage; predict_tiles_*: files to GeoPackage layers = predict + stitch, image-sharded at N > 1; *_per_tile: counts / kB)"
     c["detail"] = full.get("detail_file")
@@ -783,7 +785,7 @@ def main():
                                               "note": "images back to back as detection.predict_on_model walks them: image i+1 submitted while image i drains"}}
             return out
 
-    def run_lzw(precision, sd_w, side):
+    def run_lzw(precision, sd_w, side, codec="lzw"):
         """SURVEY §8f-2's leftover: the raster as real orthophotos are stored — LZW, 256 x 256 tiles, predictor 2
         (GDAL: TILED=YES COMPRESS=LZW PREDICTOR=2) — cut into the REFERENCE's tiles (450 x 450 px, 400 per image) — files to files. The compressed blocks cross PCIe once and are decoded on the GPU
         (tiffdecode.hip, one wave per block), the tile windows are cut in HBM; the next image is decoded while the current one
@@ -810,7 +812,7 @@ def main():
             img = np.ascontiguousarray(img[:, :px, :px])
             tif = f"{root}/rgb/324125000.tif"
             t0 = time.perf_counter()
-            write_geotiff(tif, img, (0.2, 0.0, 412000.0, 0.0, -0.2, 5318000.0 + px * 0.2), 25832, compression="lzw", tile=(256, 256), predictor=2)
+            write_geotiff(tif, img, (0.2, 0.0, 412000.0, 0.0, -0.2, 5318000.0 + px * 0.2), 25832, compression=codec, tile=(256, 256), predictor=2)
             t_enc = time.perf_counter() - t0
             raw_bytes, file_bytes = img.nbytes, os.path.getsize(tif)
             del img
@@ -838,20 +840,23 @@ def main():
             for nm in names:
                 os.link(tif, f"{root}/rgb/{nm}.tif")
                 os.link(tjson, f"{root}/tiles/{nm}.json")
-            res = {"raster": f"{px}x{px}x4 uint8, LZW, 256x256 tiles, predictor 2, on {'tmpfs' if base else 'disk'}; {ntiles} tiles of {TP}x{TP} px per image",
+            res = {"raster": f"{px}x{px}x4 uint8, {codec.upper()}, 256x256 tiles, predictor 2, on {'tmpfs' if base else 'disk'}; {ntiles} tiles of {TP}x{TP} px per image",
                    "kernel_seconds": t_ker, "kernel_gbytes_per_s": raw_bytes / t_ker / 1e9,
                    "raw_bytes": raw_bytes, "file_bytes": file_bytes, "compression_ratio": raw_bytes / file_bytes, "encode_seconds": t_enc,
                    "decode_seconds": t_dec, "decode_calls_s": times, "decode_gbytes_per_s": raw_bytes / t_dec / 1e9,
                    "decode_windows_450x450x4_per_s": raw_bytes / t_dec / (450 * 450 * 4), "tiles_per_image": ntiles}
-            # the same pixels stored uncompressed (one strip): what the 450-px walk does when no decode is in the way
-            raw_tif = f"{root}/raw/324125000.tif"
-            os.makedirs(f"{root}/raw")
-            write_geotiff(raw_tif, GeoTiff(tif).read(), (0.2, 0.0, 412000.0, 0.0, -0.2, 5318000.0 + px * 0.2), 25832)
-            for nm in names:
-                os.link(raw_tif, f"{root}/raw/{nm}.tif")
-            for mode, dd, imgs in (("device", "auto", names), ("host_reader", False, names[:1]), ("uncompressed", "auto", names)):
+            modes = [("device", "auto", names)]
+            if codec == "lzw":
+                # the same pixels stored uncompressed (one strip): what the 450-px walk does when no decode is in the way
+                raw_tif = f"{root}/raw/324125000.tif"
+                os.makedirs(f"{root}/raw")
+                write_geotiff(raw_tif, GeoTiff(tif).read(), (0.2, 0.0, 412000.0, 0.0, -0.2, 5318000.0 + px * 0.2), 25832)
+                for nm in names:
+                    os.link(raw_tif, f"{root}/raw/{nm}.tif")
+                modes += [("host_reader", False, names[:1]), ("uncompressed", "auto", names)]
+            for mode, dd, imgs in modes:
                 src_dir = "raw" if mode == "uncompressed" else "rgb"
-                tif_w = raw_tif if mode == "uncompressed" else tif
+                tif_w = f"{root}/raw/324125000.tif" if mode == "uncompressed" else tif
                 pred = T.Predictor(cfg, device_type=str(local_rank), max_batch_size=B, output_dir=f"{root}/out_{mode}", precision=precision,
                                    state_dict=sd_w, return_predictions=False, device_decode=dd)
                 try:
@@ -876,9 +881,9 @@ def main():
                 finally:
                     pred.close()
                     shutil.rmtree(f"{root}/out_{mode}", ignore_errors=True)
-            log(f"lzw region ({precision}): decode {t_dec * 1e3:.1f} ms per {raw_bytes / 1e6:.0f} MB raster ({res['decode_windows_450x450x4_per_s']:.0f} windows of 450x450x4 per s), "
-                f"files to files {res['device']['value']:.0f} tiles/s on the device decoder, {res['host_reader']['value']:.0f} through the host reader, "
-                f"{res['uncompressed']['value']:.0f} on the same raster stored uncompressed")
+            log(f"{codec} region ({precision}): decode {t_dec * 1e3:.1f} ms per {raw_bytes / 1e6:.0f} MB raster ({res['decode_windows_450x450x4_per_s']:.0f} windows of 450x450x4 per s), "
+                f"files to files {res['device']['value']:.0f} tiles/s on the device decoder" +
+                (f", {res['host_reader']['value']:.0f} through the host reader, {res['uncompressed']['value']:.0f} on the same raster stored uncompressed" if codec == "lzw" else ""))
             return res
         finally:
             shutil.rmtree(root, ignore_errors=True)
@@ -935,7 +940,7 @@ def main():
             b32 = go("fp16", not args.no_profile, "fp16_batch32") + (nsteps,)
             B, nsteps = args.batch, args.steps
     two = e2e = e2e_c = None
-    pt = pt_n = lzw = None
+    pt = pt_n = lzw = deflate = None
     if args.depth == 50 and args.schedule == "streams" and not args.no_e2e:
         import shutil
         from treedetection_amd.weights import blob_mask_head
@@ -968,6 +973,8 @@ def main():
                     pk = "fp16" if "fp16" in precs else precs[0]
                     lzw = {pk: run_lzw(pk, sd_c, args.lzw_side)}
                     lzw[pk]["model_stage_same_weights"] = e2e_c[pk]["model_stage_same_weights"]
+                    deflate = {pk: run_lzw(pk, sd_c, args.lzw_side, codec="deflate")}
+                    deflate[pk]["model_stage_same_weights"] = e2e_c[pk]["model_stage_same_weights"]
             else:
                 # N > 1: predict_tiles files to GeoPackage layers with WHOLE IMAGES sharded over the ranks (the structure
                 # detection.predict_on_model runs), compact-crown fixture
@@ -1264,6 +1271,13 @@ def main():
                 r["device"]["ratio_to_model_stage"] = r["device"]["value"] / ref_rate if ref_rate else None
                 o["f32" if pk == "fp32" else "f16"] = r
             line["lzw"] = o
+        if deflate:
+            o = {"note": "the same region on a DEFLATE-compressed raster (zlib level 6, 256 x 256 tiles, predictor 2): tiff_inflate_blocks_kernel"}
+            for pk, r in deflate.items():
+                ref_rate = max((line["value"] if pk == args.precision else (line.get("fp16") or {}).get("value")) or 0.0, r.get("model_stage_same_weights") or 0.0) or None
+                r["device"]["ratio_to_model_stage"] = r["device"]["value"] / ref_rate if ref_rate else None
+                o["f32" if pk == "fp32" else "f16"] = r
+            line["deflate"] = o
         if world == 1 and not args.no_cpu_baseline:
             sd101 = None
             if args.depth == 50 and not args.no_r101:
