@@ -221,3 +221,44 @@ def test_prediction_files_are_identical_with_the_device_decoder_on_or_off(tmp_pa
         assert len(files) == 9
     assert outs["raw"] == outs["raw_host"] == outs["raw_strips"] == outs["lzw_dev"] == outs["lzw_host"] == outs["lzw_strips_dev"] == outs["deflate_dev"]
     assert sum(len(json.loads(v)) for v in outs["raw"].values()) > 5
+
+
+def test_streams_longer_than_their_block_are_reported_and_stay_inside_it(ring):
+    """A block whose stream decodes to more bytes than the block holds (a corrupt byte count, a wrong tile size) ends with status 2; nothing
+    is written or read past the block's capacity: the bytes behind it keep their pattern (LZW and DEFLATE, flat / noisy / repeating data)."""
+    import zlib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    raws = [bytes(60000), rng.integers(0, 256, 50000, dtype=np.uint8).tobytes(), (bytes(range(251)) * 300)[:70000], rng.integers(0, 4, 90000, dtype=np.uint8).tobytes()]
+    cap = 5000
+    for codec in ("lzw", "deflate"):
+        streams = []
+        for raw in raws:
+            if codec == "deflate":
+                streams.append(zlib.compress(raw, 6))
+            else:
+                src = np.frombuffer(raw, np.uint8)
+                enc = np.empty(len(raw) * 2 + 64, np.uint8)
+                n = lib.td_tiff_lzw_encode(src.ctypes.data, src.size, enc.ctypes.data, enc.size)
+                streams.append(enc[:n].tobytes())
+        offs, blob = [], bytearray()
+        for st in streams:
+            offs.append(len(blob))
+            blob += st
+        blob += b"\0" * 16
+        comp = torch.from_numpy(np.frombuffer(bytes(blob), dtype=np.uint8).copy()).cuda()
+        d_off = torch.tensor(offs, dtype=torch.int64, device="cuda")
+        d_n = torch.tensor([len(st) for st in streams], dtype=torch.int64, device="cuda")
+        out = torch.full((len(streams) + 1, cap), 0xA5, dtype=torch.uint8, device="cuda")          # one block of guard bytes behind the last
+        dec = torch.zeros((len(streams),), dtype=torch.int64, device="cuda")
+        status = torch.full((2 * len(streams) + 1,), -1, dtype=torch.int32, device="cuda")
+        fn = lib.td_tiff_lzw_decode_dev if codec == "lzw" else lib.td_tiff_inflate_dev
+        _lib.check(fn(comp.data_ptr(), d_off.data_ptr(), d_n.data_ptr(), len(streams), out.data_ptr(), cap, dec.data_ptr(), status.data_ptr(),
+                      _lib.stream_ptr()), codec)
+        torch.cuda.synchronize()
+        assert status[:len(streams)].tolist() == [2] * len(streams), (codec, status.tolist())
+        got = out.cpu().numpy()
+        for k, raw in enumerate(raws):
+            assert (int(dec[k]) & 0xffffffff) == len(raw), (codec, k)
+            assert got[k].tobytes() == raw[:cap], (codec, k)                                    # the part that fits is right
+        assert (got[-1] == 0xA5).all(), codec

@@ -187,7 +187,8 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
                             const uint32_t kk = k0 + lane;
                             if (kk < lk) {
                                 const uint32_t from = (sk + kk == pk) ? sk : sk + kk;
-                                const uint8_t v = __hip_atomic_load(dst + from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                // (a source past the block's capacity exists only in a stream that decodes to too many bytes: status 2 either way)
+                                const uint8_t v = from < cap ? __hip_atomic_load(dst + from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)0;
                                 ring_lit[(pk + kk) & (LZW_RING - 1)] = v;
                                 if (pk + kk < cap) dst[pk + kk] = v;
                             }
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
                 if (k < s_len) {
                     const uint32_t sk = (kwkwk && k == s_len - 1) ? 0u : k;
                     // agent-scope load: served by L2, never by a stale L1 line of bytes this wave stored earlier
-                    const uint8_t v = __hip_atomic_load(dst + s_start + sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint8_t v = s_start + sk < cap ? __hip_atomic_load(dst + s_start + sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)0;
                     ring_lit[(op + k) & (LZW_RING - 1)] = v;
                     if (op + k < cap) dst[op + k] = v;
                 }
