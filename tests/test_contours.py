@@ -72,3 +72,48 @@ def test_xy_is_corner_based_affine():
     x, y = xy(t, rows=[0, 10, 5], cols=[0, 0, 20])
     assert np.allclose(x, [412000.0, 412000.0, 412004.0]) and np.allclose(y, [5319000.0, 5318998.0, 5318999.0])
     assert x.dtype == np.float64
+
+
+def _pixels_on(contour):
+    """Every pixel of a CHAIN_APPROX_SIMPLE contour: consecutive vertices are joined by runs in one of the 8 directions."""
+    pts = set()
+    n = len(contour)
+    for i in range(n):
+        (x0, y0), (x1, y1) = contour[i], contour[(i + 1) % n]
+        dx, dy = int(np.sign(x1 - x0)), int(np.sign(y1 - y0))
+        steps = max(abs(int(x1 - x0)), abs(int(y1 - y0)))
+        assert steps == 0 or (abs(int(x1 - x0)) in (0, steps) and abs(int(y1 - y0)) in (0, steps)), (contour[i], contour[(i + 1) % n])
+        for s in range(steps + 1):
+            pts.add((int(x0) + s * dx, int(y0) + s * dy))
+    return pts
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_borders_and_counts_against_scipy_ndimage(seed):
+    """Independent of both tracers (scipy.ndimage, not written by this build). Suzuki & Abe 1985, the algorithm behind
+    cv2.findContours: with 8-connected foreground a border point is a 1-pixel with a 0-pixel among its FOUR neighbours (the
+    frame counts as 0), every border point lies on a followed border, and RETR_TREE returns one contour per 8-connected
+    foreground component plus one per hole (a 4-connected background component that does not reach the frame)."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(1000 + seed)
+    h, w = int(rng.integers(10, 60)), int(rng.integers(10, 60))
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    m = np.zeros((h, w), bool)
+    for _ in range(int(rng.integers(1, 7))):
+        cy, cx, r = rng.uniform(0, h), rng.uniform(0, w), rng.uniform(2, 12)
+        m |= (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+    if seed % 3:
+        m ^= rng.uniform(0, 1, (h, w)) < 0.06
+    cross = ndi.generate_binary_structure(2, 1)
+    border = m & ~ndi.binary_erosion(m, structure=cross, border_value=0)
+    n_fg = ndi.label(m, structure=np.ones((3, 3), int))[1]
+    padded = np.pad(~m, 1, constant_values=True)                      # the frame joins every outside region
+    n_holes = ndi.label(padded, structure=cross)[1] - 1
+    for tracer in (find_contours, ref_contours):
+        cs = tracer(m)
+        assert len(cs) == n_fg + n_holes, (len(cs), n_fg, n_holes)
+        got = set()
+        for c in cs:
+            got |= _pixels_on(np.asarray(c).reshape(-1, 2))
+        want = {(int(x), int(y)) for y, x in zip(*np.nonzero(border))}
+        assert got == want
