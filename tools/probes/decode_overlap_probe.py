@@ -68,11 +68,8 @@ del img
 g = GeoTiff(tif)
 prio = args.get("priority", "normal")
 if prio == "low":
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    h = ctypes.c_void_p()
-    hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, 1)
-    dstream = torch.cuda.ExternalStream(h.value)
+    from treedetection_amd import _lib
+    dstream = _lib.low_priority_stream(0)
 else:
     dstream = torch.cuda.Stream()
 pinned = [None]

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -156,3 +157,35 @@ def stream_ptr() -> int:
     import torch
 
     return int(torch.cuda.current_stream().cuda_stream)
+
+
+_low_priority_streams: dict = {}
+_low_priority_lock = threading.Lock()
+
+
+def low_priority_stream(device_index: int):
+    """→ a torch stream wrapping a HIP stream with the LOWEST priority the device offers (torch itself only creates normal and
+    higher). Background work that shares the chip with the forwards — the raster decode of the NEXT image — goes there: HIP gives
+    every priority level its own hardware queues, so the long decode kernel never sits in front of a model stream's kernels in
+    one queue (with the default four queues and five or more streams it did: tools/probes/decode_overlap_probe.py, 763 vs 1 732
+    tiles/s while a DEFLATE raster decodes), and the dispatcher serves the forwards' workgroups first. The HIP entry points are
+    taken from the runtime libtreedet_hip.so is bound to — the one torch loaded. ONE stream per device for the life of the
+    process, never destroyed: torch's allocators remember the streams a block was used on and record events on them when the
+    block is freed, long after a Predictor is closed (destroying the stream at close() ended in a segmentation fault there)."""
+    import torch
+
+    with _low_priority_lock:
+        if device_index in _low_priority_streams:
+            return _low_priority_streams[device_index]
+        lib = load()
+        least, greatest, handle = C.c_int(0), C.c_int(0), C.c_void_p()
+        with torch.cuda.device(device_index):
+            torch.cuda.current_stream()                                    # the device's context exists before the raw calls
+            err = lib.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest))
+            if err == 0:
+                err = lib.hipStreamCreateWithPriority(C.byref(handle), C.c_uint(1), C.c_int(least.value))    # 1 = hipStreamNonBlocking
+            if err != 0 or not handle.value:
+                raise TdError(f"hipStreamCreateWithPriority(priority {least.value}) failed: hipError {err}")
+            stream = torch.cuda.ExternalStream(handle.value, device=device_index)
+        _low_priority_streams[device_index] = stream
+        return stream

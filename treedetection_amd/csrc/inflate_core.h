@@ -13,7 +13,10 @@
 #include <cstdint>
 
 #ifdef __HIP_DEVICE_COMPILE__
-#define TD_INF_SYNC() __syncthreads()
+// orders this WAVE's LDS writes before its later LDS reads (the fences of __syncthreads without its s_barrier): a block is decoded by
+// one wave, and several such waves share a workgroup (tiffdecode.hip), each inside its own loops — a workgroup barrier would hang
+#define TD_INF_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); \
+                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 // this wave's stores have reached L2; an agent-scope load is served there, never by a stale L1 line
 #define TD_INF_STORES_DONE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define TD_INF_LOAD_OUT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -29,8 +32,11 @@
 #endif
 #ifdef __HIPCC__
 #define TD_INF_HD __host__ __device__ inline
+// the decoder's loop belongs INSIDE each kernel that runs it (several instantiate it: called out of line it cost 13 % and 70 registers)
+#define TD_INF_INLINE __attribute__((always_inline))
 #else
 #define TD_INF_HD static inline
+#define TD_INF_INLINE
 #endif
 
 constexpr int INF_WINDOW = 32768;        // DEFLATE's window
@@ -180,7 +186,7 @@ TD_INF_HD int decode_sym(Scratch& S, Reader& r, const uint16_t* fast, int fast_b
 // src: the zlib stream (n bytes); dst: the block's output (cap bytes); every lane of the wave calls this with its lane id
 // (host: NL = 1, lane = 0). The result is the same on every lane.
 template <int NL, int RING>
-TD_INF_HD InflateResult inflate_block(InflateScratchT<RING>& S, const uint8_t* src, int64_t n, uint8_t* dst, uint32_t cap, int lane) {
+TD_INF_HD TD_INF_INLINE InflateResult inflate_block(InflateScratchT<RING>& S, const uint8_t* src, int64_t n, uint8_t* dst, uint32_t cap, int lane) {
     using namespace inflate_detail;
     // length / distance codes: base value | extra bits << 16 (dwords: a scalar load on the device; byte tables would be per-lane loads)
     constexpr uint32_t LEN_CODE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11 | 1 << 16, 13 | 1 << 16, 15 | 1 << 16, 17 | 1 << 16, 19 | 2 << 16, 23 | 2 << 16, 27 | 2 << 16,

@@ -39,20 +39,33 @@ __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap
 // of a 256-byte identity table so that every code of that loop takes the same copy path.
 // LZW_RING bytes of recent output are kept in LDS: 16 KB (25 KB per wave: six waves per CU); a 4-KB variant (13 KB: twelve waves
 // per CU) exists for measurements and to exercise the through-memory paths in the tests.
-template <typename TableT, bool SECOND, int LZW_RING, bool FAST>
-__global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ block_off,
+// this wave's LDS writes before its later LDS reads: the fences of __syncthreads() without the s_barrier (waves of one workgroup
+// decode different blocks, each in its own loops)
+#define TD_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); \
+                           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+template <typename TableT, bool SECOND, int LZW_RING, bool FAST, int WPB>
+__global__ __launch_bounds__(64 * WPB) void tiff_lzw_blocks_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ block_off,
                                                              const int64_t* __restrict__ block_nbytes, uint8_t* __restrict__ out,
                                                              int64_t block_cap, int64_t* __restrict__ decoded,
                                                              int32_t* __restrict__ status, int nblocks, int* __restrict__ wide_list) {
-    __shared__ __attribute__((aligned(8))) TableT t_start[LZW_MAX + 4];               // start of entry k relative to the epoch's start; len(k) = t[k + 1] - t[k] + 1
-    __shared__ uint32_t inbuf[128];                       // two chunks of 64 big-endian dwords of the compressed stream
-    __shared__ uint8_t ring_lit[LZW_RING + 256];
+    // WPB waves share a workgroup, each with its own tables and its own block (why: tiff_inflate_blocks_kernel below); nothing in
+    // here meets a workgroup barrier — the waves run their own loops
+    struct Lds {
+        TableT t_start[LZW_MAX + 4];                       // start of entry k relative to the epoch's start; len(k) = t[k + 1] - t[k] + 1
+        uint32_t inbuf[128];                               // two chunks of 64 big-endian dwords of the compressed stream
+        uint8_t ring_lit[LZW_RING + 256];
+    };
+    __shared__ __attribute__((aligned(8))) Lds lds[WPB];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    TableT* const t_start = lds[wave].t_start;
+    uint32_t* const inbuf = lds[wave].inbuf;
+    uint8_t* const ring_lit = lds[wave].ring_lit;
     constexpr int LZW_LIT = LZW_RING;                      // the identity table follows the ring: ring_lit[LZW_LIT + c] = c
-    const int lane = threadIdx.x;
+    const int lane = (int)threadIdx.x & 63;
     constexpr uint32_t REL_MAX = sizeof(TableT) == 2 ? 65535u - 4096u : 0xffffffffu;
     // first launch: block = blockIdx.x. Second launch (wide table): a few resident waves walk the list of blocks the first one
     // gave up on (wide_list[0] = their number) — nothing to do on imagery, so its cost must be that of an empty kernel
-    for (int item = blockIdx.x; item < (SECOND ? wide_list[0] : nblocks); item += gridDim.x) {
+    for (int item = blockIdx.x * WPB + wave; item < (SECOND ? wide_list[0] : nblocks); item += gridDim.x * WPB) {
     const int b = SECOND ? wide_list[1 + item] : item;
     const int64_t n = block_nbytes[b];
     uint8_t* dst = out + (int64_t)b * block_cap;
@@ -62,7 +75,7 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
     const uint32_t* src32 = reinterpret_cast<const uint32_t*>(a0 - skip);
     const uint32_t ndw = (uint32_t)((n + skip + 3) >> 2); // dwords that hold the stream (the buffer is padded: reading the last one is safe)
     const uint32_t end_bit = (uint32_t)(n + skip) * 8u;    // (blocks are < 512 MB: bit positions fit 32 bits)
-    __syncthreads();                                       // (second launch: the previous item's LDS reads are done)
+    TD_WAVE_SYNC();                                       // (second launch: the previous item's LDS reads are done)
     for (int c = lane; c < 256; c += 64) ring_lit[LZW_LIT + c] = (uint8_t)c;
     for (int c = lane; c < LZW_FIRST + 1; c += 64) t_start[c] = 0;      // literals: len = t[c + 1] - t[c] + 1 = 1
     // the first two chunks of the stream; afterwards chunk k + 1 is loaded when the reader enters chunk k
@@ -74,7 +87,7 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
     uint32_t op = 0, old_pos = 0, old_len = 0, safe = 0, epoch = 0;      // old_len == 0: no previous code (start, or right after a ClearCode)
     int err = 0;
     uint32_t slow = 0;                                      // codes that went through memory instead of the ring (diagnostic: decoded[b] >> 32)
-    __syncthreads();
+    TD_WAVE_SYNC();
     uint32_t hold = 0;                                     // codes left to the one-by-one path before the next chunk attempt
     for (;;) {
         if (FAST && hold == 0 && old_len != 0 && next < LZW_MAX - 1 && op - epoch <= REL_MAX) {
@@ -93,7 +106,7 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
                 const uint32_t idx = loaded + lane;
                 inbuf[idx & 127] = idx < ndw ? bswap32(src32[idx]) : 0u;
                 loaded += 64;
-                __syncthreads();
+                TD_WAVE_SYNC();
                 safe = op;
             }
             const uint32_t c0 = (uint32_t)next - 257u;     // this chunk's first code is the c0-th since the ClearCode (c0 >= 1)
@@ -201,7 +214,7 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
                 old_pos = last_pos;
                 old_len = last_len;
                 op = op_end;
-                __syncthreads();
+                TD_WAVE_SYNC();
                 continue;
             }
         }
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
             const uint32_t idx = loaded + lane;
             inbuf[idx & 127] = idx < ndw ? bswap32(src32[idx]) : 0u;
             loaded += 64;
-            __syncthreads();                               // (one wave: orders the LDS write before the reads below; every store of this wave has completed too)
+            TD_WAVE_SYNC();                               // (one wave: orders the LDS write before the reads below; every store of this wave has completed too)
             safe = op;
         }
         const uint64_t two = ((uint64_t)inbuf[dw & 127] << 32) | inbuf[(dw + 1) & 127];
@@ -308,18 +321,23 @@ __global__ __launch_bounds__(64) void tiff_lzw_blocks_kernel(const uint8_t* __re
 }
 
 // DEFLATE blocks (TIFF compression 8 / 32946: zlib streams), one wave per block: inflate_core.h. LDS: a ring of the output +
-// tables — the whole 32-KB window (37 KB: four waves per CU) while the blocks fit the chip in one round, 8 KB (13 KB: twelve
-// waves per CU) beyond; literals and matches go to memory as byte stores.
-template <int RING>
-__global__ __launch_bounds__(64) void tiff_inflate_blocks_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ block_off,
-                                                                 const int64_t* __restrict__ block_nbytes, uint8_t* __restrict__ out,
-                                                                 int64_t block_cap, int64_t* __restrict__ decoded,
-                                                                 int32_t* __restrict__ status) {
-    __shared__ InflateScratchT<RING> S;
-    const int b = blockIdx.x;
-    const InflateResult r = inflate_block<64>(S, comp + block_off[b], block_nbytes[b], out + (int64_t)b * block_cap, (uint32_t)block_cap,
-                                              (int)threadIdx.x);
-    if (threadIdx.x == 0) {
+// tables — the whole 32-KB window (37 KB per wave) while the blocks fit the chip in one round, 8 KB (12 KB per wave) beyond; literals
+// and matches go to memory as byte stores. WPB waves (= blocks of the raster) share a workgroup, so that the long-lived decoder
+// waves sit TOGETHER on few CUs (twelve per CU with the small ring) instead of a few on every CU: a decoder wave holds 104
+// vector registers and 12 KB of LDS for the whole 60 ms, and one such wave per SIMD is enough to keep the model's large tiles
+// (256 registers x 2 waves per SIMD, > 100 KB of LDS) off that CU — spread one per workgroup they stalled the forward of the
+// image that predicts meanwhile on every CU of the chip.
+template <int RING, int WPB>
+__global__ __launch_bounds__(64 * WPB) void tiff_inflate_blocks_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ block_off,
+                                                                       const int64_t* __restrict__ block_nbytes, uint8_t* __restrict__ out,
+                                                                       int64_t block_cap, int64_t* __restrict__ decoded,
+                                                                       int32_t* __restrict__ status, int nblocks) {
+    __shared__ InflateScratchT<RING> S[WPB];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;      // the wave's number as a scalar: its LDS base stays one
+    const int b = blockIdx.x * WPB + wave;
+    if (b >= nblocks) return;                              // whole waves leave; nothing below meets a workgroup barrier
+    const InflateResult r = inflate_block<64>(S[wave], comp + block_off[b], block_nbytes[b], out + (int64_t)b * block_cap, (uint32_t)block_cap, lane);
+    if (lane == 0) {
         decoded[b] = (int64_t)r.produced;
         status[b] = r.status;
     }
@@ -437,15 +455,17 @@ extern "C" td_status td_tiff_lzw_decode_dev(const uint8_t* comp, const int64_t* 
     const int small_ring = lzw_ring_choice(nblocks);
     const char* one = getenv("TD_LZW_ONE_BY_ONE");          // measurements: the code-by-code loop alone (tools/raster_decode_bench.py)
     const bool chunks = !(one && one[0] == '1');
-#define TD_LZW(RING, FAST) hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint16_t, false, RING, FAST>), dim3(nblocks), dim3(64), 0, s, comp, block_off, \
-                                              block_nbytes, blocks_out, block_cap, decoded, status, nblocks, wide_list)
-    if (small_ring && chunks) TD_LZW(4096, true);
-    else if (small_ring) TD_LZW(4096, false);
-    else if (chunks) TD_LZW(16384, true);
-    else TD_LZW(16384, false);
+    // waves per workgroup: as many as 160 KB of LDS hold (13 / 25 / 33 KB per wave)
+#define TD_LZW(RING, FAST, WPB) hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint16_t, false, RING, FAST, WPB>), dim3((nblocks + WPB - 1) / WPB), dim3(64 * WPB), 0, s, comp, \
+                                                   block_off, block_nbytes, blocks_out, block_cap, decoded, status, nblocks, wide_list)
+    if (small_ring && chunks) TD_LZW(4096, true, 12);
+    else if (small_ring) TD_LZW(4096, false, 12);
+    else if (chunks) TD_LZW(16384, true, 6);
+    else TD_LZW(16384, false, 6);
 #undef TD_LZW
     TD_KERNEL_CHECK();
-    hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint32_t, true, 16384, true>), dim3(nblocks < 1024 ? nblocks : 1024), dim3(64), 0, s, comp, block_off,
+    const int second_groups = (nblocks + 3) / 4 < 256 ? (nblocks + 3) / 4 : 256;
+    hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint32_t, true, 16384, true, 4>), dim3(second_groups), dim3(64 * 4), 0, s, comp, block_off,
                        block_nbytes, blocks_out, block_cap, decoded, status, nblocks, wide_list);
     TD_KERNEL_CHECK();
     return TD_OK;
@@ -457,12 +477,20 @@ extern "C" td_status td_tiff_inflate_dev(const uint8_t* comp, const int64_t* blo
     TD_REQUIRE(nblocks >= 0 && block_cap >= 1 && block_cap < ((int64_t)1 << 31), "td_tiff_inflate_dev: %d blocks of %lld bytes", nblocks,
                (long long)block_cap);
     if (nblocks == 0) return TD_OK;
-    if (inflate_ring_choice(nblocks))
-        hipLaunchKernelGGL(tiff_inflate_blocks_kernel<8192>, dim3(nblocks), dim3(64), 0, static_cast<hipStream_t>(stream), comp, block_off,
-                           block_nbytes, blocks_out, block_cap, decoded, status);
-    else
-        hipLaunchKernelGGL(tiff_inflate_blocks_kernel<INF_WINDOW>, dim3(nblocks), dim3(64), 0, static_cast<hipStream_t>(stream), comp, block_off,
-                           block_nbytes, blocks_out, block_cap, decoded, status);
+    constexpr int WPB_SMALL = 12, WPB_WINDOW = 4;          // 148 KB of LDS per workgroup either way
+    static const char* wpb_env = getenv("TD_INFLATE_WPB");  // measurements: 1 = a workgroup per block, 8 (tools/probes/decode_overlap_probe.py)
+    const int wpb = wpb_env ? atoi(wpb_env) : 0;
+#define TD_INFLATE(RING, WPB) hipLaunchKernelGGL((tiff_inflate_blocks_kernel<RING, WPB>), dim3((nblocks + WPB - 1) / WPB), dim3(64 * WPB), 0, \
+                                                 static_cast<hipStream_t>(stream), comp, block_off, block_nbytes, blocks_out, block_cap, decoded, status, nblocks)
+    if (inflate_ring_choice(nblocks)) {
+        if (wpb == 1) TD_INFLATE(8192, 1);
+        else if (wpb == 8) TD_INFLATE(8192, 8);
+        else TD_INFLATE(8192, WPB_SMALL);
+    } else {
+        if (wpb == 1) TD_INFLATE(INF_WINDOW, 1);
+        else TD_INFLATE(INF_WINDOW, WPB_WINDOW);
+    }
+#undef TD_INFLATE
     TD_KERNEL_CHECK();
     return TD_OK;
 }

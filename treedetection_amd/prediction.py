@@ -20,6 +20,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
+from . import _lib
 from . import distributed as D
 from .contours import batch_prediction_files, find_contours, tile_polygons_json, tile_polygons_json_dev, tile_prediction_file, xy
 from .engine import Engine, INPUT_F32_CHW, INPUT_U8_HWC
@@ -398,8 +399,8 @@ class Predictor:
                                    and img.height * img.width * img.count <= self.device_raster_max_bytes):
                 return None
             if self._decode_stream is None:
-                with torch.cuda.device(self.device_index):
-                    self._decode_stream = torch.cuda.Stream()
+                # lowest priority: its own hardware queue, and the forwards' workgroups are served first (_lib.low_priority_stream)
+                self._decode_stream = _lib.low_priority_stream(self.device_index)
             t0 = time.perf_counter()
             c0 = time.thread_time()
             if self._upload_pool is None:
