@@ -16,12 +16,27 @@
 // 0.65 us per code for the code-by-code loop, 12 x less with the chunks (324 MB raster: 109.5 -> 9.1 ms).
 #include "common.h"
 #include "inflate_core.h"
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <cstring>
 
 namespace {
 
 constexpr int LZW_CLEAR = 256, LZW_EOI = 257, LZW_FIRST = 258, LZW_MAX = 4096;
+
+// Which block a decoder wave takes next: a counter per launch (one of kTickets slots, zeroed on the launch's stream). The waves of a
+// workgroup share its LDS for the whole launch, so a raster of more blocks than the chip holds waves is NOT left to the dispatcher
+// (a workgroup's slot is only refilled when its slowest wave is done: 20000 x 20000 px took 28 ms instead of 22 that way): one
+// workgroup per CU at most, every wave fetching blocks until the counter passes the last one.
+constexpr int kTickets = 64;
+__device__ int g_block_ticket[kTickets];
+
+__device__ __forceinline__ int take_block(int* ticket, int lane) {
+    int v = 0;
+    if (lane == 0) v = atomicAdd(ticket, 1);
+    return __builtin_amdgcn_readfirstlane(v);
+}
 
 __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
@@ -47,7 +62,8 @@ template <typename TableT, bool SECOND, int LZW_RING, bool FAST, int WPB>
 __global__ __launch_bounds__(64 * WPB) void tiff_lzw_blocks_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ block_off,
                                                              const int64_t* __restrict__ block_nbytes, uint8_t* __restrict__ out,
                                                              int64_t block_cap, int64_t* __restrict__ decoded,
-                                                             int32_t* __restrict__ status, int nblocks, int* __restrict__ wide_list) {
+                                                             int32_t* __restrict__ status, int nblocks, int* __restrict__ wide_list,
+                                                             int* __restrict__ ticket) {
     // WPB waves share a workgroup, each with its own tables and its own block (why: tiff_inflate_blocks_kernel below); nothing in
     // here meets a workgroup barrier — the waves run their own loops
     struct Lds {
@@ -63,9 +79,10 @@ __global__ __launch_bounds__(64 * WPB) void tiff_lzw_blocks_kernel(const uint8_t
     constexpr int LZW_LIT = LZW_RING;                      // the identity table follows the ring: ring_lit[LZW_LIT + c] = c
     const int lane = (int)threadIdx.x & 63;
     constexpr uint32_t REL_MAX = sizeof(TableT) == 2 ? 65535u - 4096u : 0xffffffffu;
-    // first launch: block = blockIdx.x. Second launch (wide table): a few resident waves walk the list of blocks the first one
+    // first launch: blocks by ticket. Second launch (wide table): a few resident waves walk the list of blocks the first one
     // gave up on (wide_list[0] = their number) — nothing to do on imagery, so its cost must be that of an empty kernel
-    for (int item = blockIdx.x * WPB + wave; item < (SECOND ? wide_list[0] : nblocks); item += gridDim.x * WPB) {
+    for (int item = SECOND ? (int)blockIdx.x * WPB + wave : take_block(ticket, lane); item < (SECOND ? wide_list[0] : nblocks);
+         item = SECOND ? item + (int)gridDim.x * WPB : take_block(ticket, lane)) {
     const int b = SECOND ? wide_list[1 + item] : item;
     const int64_t n = block_nbytes[b];
     uint8_t* dst = out + (int64_t)b * block_cap;
@@ -331,15 +348,16 @@ template <int RING, int WPB>
 __global__ __launch_bounds__(64 * WPB) void tiff_inflate_blocks_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ block_off,
                                                                        const int64_t* __restrict__ block_nbytes, uint8_t* __restrict__ out,
                                                                        int64_t block_cap, int64_t* __restrict__ decoded,
-                                                                       int32_t* __restrict__ status, int nblocks) {
+                                                                       int32_t* __restrict__ status, int nblocks, int* __restrict__ ticket) {
     __shared__ InflateScratchT<RING> S[WPB];
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;      // the wave's number as a scalar: its LDS base stays one
-    const int b = blockIdx.x * WPB + wave;
-    if (b >= nblocks) return;                              // whole waves leave; nothing below meets a workgroup barrier
-    const InflateResult r = inflate_block<64>(S[wave], comp + block_off[b], block_nbytes[b], out + (int64_t)b * block_cap, (uint32_t)block_cap, lane);
-    if (lane == 0) {
-        decoded[b] = (int64_t)r.produced;
-        status[b] = r.status;
+    for (int b = take_block(ticket, lane); b < nblocks; b = take_block(ticket, lane)) {      // whole waves leave; nothing in here meets a workgroup barrier
+        const InflateResult r = inflate_block<64>(S[wave], comp + block_off[b], block_nbytes[b], out + (int64_t)b * block_cap, (uint32_t)block_cap, lane);
+        if (lane == 0) {
+            decoded[b] = (int64_t)r.produced;
+            status[b] = r.status;
+        }
+        TD_INF_SYNC();                                     // the next block's set-up writes follow this block's last LDS reads
     }
 }
 
@@ -424,6 +442,33 @@ __global__ __launch_bounds__(256) void tiff_blocks_to_image_rgbi_kernel(const ui
     }
 }
 
+struct Tickets {
+    std::once_flag once;
+    int* base = nullptr;
+    int cus = 0;
+    hipError_t err = hipSuccess;
+};
+Tickets g_tickets[16];
+std::atomic<unsigned> g_ticket_next{0};
+
+// → a zeroed block counter for one launch on `s` (a slot is reused 64 launches later: long after its launch has ended) and the
+// number of CUs (= the most workgroups worth launching: one fills a CU's LDS)
+td_status next_ticket(hipStream_t s, int** ticket, int* cus) {
+    int dev = 0;
+    TD_HIP_CHECK(hipGetDevice(&dev));
+    TD_REQUIRE(dev >= 0 && dev < 16, "raster decode: device %d", dev);
+    Tickets& t = g_tickets[dev];
+    std::call_once(t.once, [&] {
+        t.err = hipGetSymbolAddress(reinterpret_cast<void**>(&t.base), HIP_SYMBOL(g_block_ticket));
+        if (t.err == hipSuccess) t.err = hipDeviceGetAttribute(&t.cus, hipDeviceAttributeMultiprocessorCount, dev);
+    });
+    TD_HIP_CHECK(t.err);
+    *ticket = t.base + g_ticket_next.fetch_add(1, std::memory_order_relaxed) % kTickets;
+    *cus = t.cus > 0 ? t.cus : 256;
+    TD_HIP_CHECK(hipMemsetAsync(*ticket, 0, sizeof(int), s));
+    return TD_OK;
+}
+
 // Which ring. DEFLATE: the small one as soon as the blocks no longer fit the chip in one round with the large one (256 CUs x
 // four waves). TD_DECODE_RING = small | large overrides (tests, measurements: tools/raster_decode_bench.py).
 int ring_override() {
@@ -455,9 +500,14 @@ extern "C" td_status td_tiff_lzw_decode_dev(const uint8_t* comp, const int64_t* 
     const int small_ring = lzw_ring_choice(nblocks);
     const char* one = getenv("TD_LZW_ONE_BY_ONE");          // measurements: the code-by-code loop alone (tools/raster_decode_bench.py)
     const bool chunks = !(one && one[0] == '1');
-    // waves per workgroup: as many as 160 KB of LDS hold (13 / 25 / 33 KB per wave)
-#define TD_LZW(RING, FAST, WPB) hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint16_t, false, RING, FAST, WPB>), dim3((nblocks + WPB - 1) / WPB), dim3(64 * WPB), 0, s, comp, \
-                                                   block_off, block_nbytes, blocks_out, block_cap, decoded, status, nblocks, wide_list)
+    // waves per workgroup: as many as 160 KB of LDS hold (13 / 25 / 33 KB per wave); one workgroup per CU at most, blocks by ticket
+    int* ticket = nullptr;
+    int cus = 0;
+    const td_status tst = next_ticket(s, &ticket, &cus);
+    if (tst < 0) return tst;
+#define TD_LZW(RING, FAST, WPB) hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint16_t, false, RING, FAST, WPB>), \
+                                                   dim3((nblocks + WPB - 1) / WPB < cus ? (nblocks + WPB - 1) / WPB : cus), dim3(64 * WPB), 0, s, comp, \
+                                                   block_off, block_nbytes, blocks_out, block_cap, decoded, status, nblocks, wide_list, ticket)
     if (small_ring && chunks) TD_LZW(4096, true, 12);
     else if (small_ring) TD_LZW(4096, false, 12);
     else if (chunks) TD_LZW(16384, true, 6);
@@ -466,7 +516,7 @@ extern "C" td_status td_tiff_lzw_decode_dev(const uint8_t* comp, const int64_t* 
     TD_KERNEL_CHECK();
     const int second_groups = (nblocks + 3) / 4 < 256 ? (nblocks + 3) / 4 : 256;
     hipLaunchKernelGGL((tiff_lzw_blocks_kernel<uint32_t, true, 16384, true, 4>), dim3(second_groups), dim3(64 * 4), 0, s, comp, block_off,
-                       block_nbytes, blocks_out, block_cap, decoded, status, nblocks, wide_list);
+                       block_nbytes, blocks_out, block_cap, decoded, status, nblocks, wide_list, ticket);
     TD_KERNEL_CHECK();
     return TD_OK;
 }
@@ -480,8 +530,15 @@ extern "C" td_status td_tiff_inflate_dev(const uint8_t* comp, const int64_t* blo
     constexpr int WPB_SMALL = 12, WPB_WINDOW = 4;          // 148 KB of LDS per workgroup either way
     static const char* wpb_env = getenv("TD_INFLATE_WPB");  // measurements: 1 = a workgroup per block, 8 (tools/probes/decode_overlap_probe.py)
     const int wpb = wpb_env ? atoi(wpb_env) : 0;
-#define TD_INFLATE(RING, WPB) hipLaunchKernelGGL((tiff_inflate_blocks_kernel<RING, WPB>), dim3((nblocks + WPB - 1) / WPB), dim3(64 * WPB), 0, \
-                                                 static_cast<hipStream_t>(stream), comp, block_off, block_nbytes, blocks_out, block_cap, decoded, status, nblocks)
+    int* ticket = nullptr;
+    int cus = 0;
+    const td_status tst = next_ticket(static_cast<hipStream_t>(stream), &ticket, &cus);
+    if (tst < 0) return tst;
+    // one workgroup per CU at most (WPB = 1: as many single waves as CUs hold: twelve each)
+#define TD_INFLATE(RING, WPB) hipLaunchKernelGGL((tiff_inflate_blocks_kernel<RING, WPB>), \
+                                                 dim3((nblocks + WPB - 1) / WPB < cus * (WPB == 1 ? 12 : 1) ? (nblocks + WPB - 1) / WPB : cus * (WPB == 1 ? 12 : 1)), \
+                                                 dim3(64 * WPB), 0, static_cast<hipStream_t>(stream), comp, block_off, block_nbytes, blocks_out, block_cap, \
+                                                 decoded, status, nblocks, ticket)
     if (inflate_ring_choice(nblocks)) {
         if (wpb == 1) TD_INFLATE(8192, 1);
         else if (wpb == 8) TD_INFLATE(8192, 8);
