@@ -154,6 +154,47 @@ def test_rasters_with_more_blocks_than_one_round_take_the_small_ring_by_themselv
         assert np.array_equal(check().cpu().numpy().transpose(2, 0, 1), img), codec
 
 
+def test_more_blocks_than_decoder_waves_go_by_ticket(tmp_path, monkeypatch):
+    """3 300 one-row strips: more blocks than the chip holds decoder waves (256 CUs x 12 DEFLATE / x 6 LZW waves, one workgroup per
+    CU) — every wave fetches several blocks from the launch's counter (tiffdecode.hip: take_block); two decodes in a row reuse
+    the waves' LDS and take fresh counters."""
+    monkeypatch.delenv("TD_DECODE_RING", raising=False)
+    img = _raster(4, 3300, 96, seed=4)
+    for codec in ("lzw", "deflate"):
+        path = str(tmp_path / f"ticket_{codec}.tif")
+        write_geotiff(path, img, T, 25832, compression=codec, rows_per_strip=1, predictor=2)
+        for _ in range(2):
+            image, check = GeoTiff(path).decode_to_device("cuda:0")
+            assert np.array_equal(check().cpu().numpy().transpose(2, 0, 1), img), codec
+
+
+def test_decode_on_the_low_priority_stream_beside_other_work(tmp_path):
+    """The Predictor decodes the NEXT image on a stream of the lowest HIP priority (_lib.low_priority_stream: its own hardware queue,
+    one per device for the life of the process) while forwards run on other streams: same bytes, and the stream is what it says."""
+    import ctypes as C
+    low = _lib.low_priority_stream(0)
+    assert _lib.low_priority_stream(0) is low
+    lib = _lib.load()
+    least, greatest, prio = C.c_int(0), C.c_int(0), C.c_int(123)
+    assert lib.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) == 0
+    assert lib.hipStreamGetPriority(C.c_void_p(low.cuda_stream), C.byref(prio)) == 0
+    assert prio.value == least.value and least.value >= greatest.value
+    img = _raster(4, 1500, 1100, seed=6)
+    paths = {}
+    for codec in ("lzw", "deflate"):
+        paths[codec] = str(tmp_path / f"low_{codec}.tif")
+        write_geotiff(paths[codec], img, T, 25832, compression=codec, tile=(128, 128), predictor=2)
+    a = torch.randn((4096, 4096), device="cuda")
+    pinned = [None]
+    for codec in ("lzw", "deflate"):
+        busy = torch.tanh(a * 1.0001) + a              # other work on the current stream while the decode runs
+        image, check = GeoTiff(paths[codec]).decode_to_device("cuda:0", low, pinned)
+        busy = torch.tanh(busy) * a
+        assert np.array_equal(check().cpu().numpy().transpose(2, 0, 1), img), codec
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(busy).any())
+
+
 def test_a_corrupt_block_is_reported_and_the_predictor_falls_back(tmp_path, capsys):
     import treedetection_amd as TD
     from treedetection_amd.preprocessing import tile_single_file
