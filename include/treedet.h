@@ -310,7 +310,9 @@ int64_t td_tiff_lzw_encode(const uint8_t* src, int64_t n, uint8_t* dst, int64_t 
  * at b * block_cap (block_cap = bytes of a full block); decoded: DEVICE int64 [nblocks], status: DEVICE int32 [2 * nblocks + 1] (the
  * first nblocks entries are the blocks' status, the rest is scratch for the second pass) — bytes produced (low 32 bits; the high 32
  * bits count the strings that were copied through memory instead of the LDS ring: a diagnostic), and 0 = ok,
- * 1 = corrupt stream, 2 = more than block_cap bytes (the rules of td_tiff_lzw_decode). Asynchronous on `stream`. */
+ * 1 = corrupt stream, 2 = more than block_cap bytes (the rules of td_tiff_lzw_decode). Asynchronous on `stream`, whose device must be
+ * the calling thread's current one. The decoder waves share workgroups (6 - 12 each, one workgroup per CU at most) and take their blocks
+ * from a per-launch counter, so a raster that decodes while forwards run on other streams leaves whole CUs to them. */
 td_status td_tiff_lzw_decode_dev(const uint8_t* comp, const int64_t* block_off, const int64_t* block_nbytes, int nblocks,
                                  uint8_t* blocks_out, int64_t block_cap, int64_t* decoded, int32_t* status, void* stream);
 /* The same for DEFLATE blocks (TIFF compression 8 / 32946: zlib streams; inflate_core.h): status int32 [nblocks], decoded int64
